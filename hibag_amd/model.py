@@ -1,0 +1,172 @@
+"""In-memory form of HIBAG's model and genotype objects.
+
+``HlaAttrBagObj`` mirrors the R list of class ``hlaAttrBagObj`` that
+``hlaModelToObj()`` writes and ``hlaModelFromObj()`` reads (reference:
+``R/HIBAG.R:1041-1062`` / ``:1135-1178``; field meaning in
+``man/hlaAttrBagObj.Rd:9-38``), so that pre-fit public models load unchanged.
+``HlaSNPGeno`` mirrors ``hlaSNPGenoClass`` (``R/DataUtilities.R:236-244``).
+
+Index conventions are the C side's, not R's: ``Classifier.snpidx`` and
+``Classifier.hla`` are 0-based here, exactly what ``hlaModelFromObj`` passes to
+``HIBAG_NewClassifierHaplo`` (``tree$snpidx - 1L``, ``match(hla, allele) - 1L``,
+``R/HIBAG.R:1147-1163``).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, List, Optional, Sequence
+
+import numpy as np
+
+from . import rdata
+
+NA_INTEGER = rdata.NA_INTEGER
+MAX_SNP_IN_CLASSIFIER = 128  # inst/include/LibHLA_ext.h:223
+
+
+@dataclass
+class Classifier:
+    """One individual classifier of the ensemble (``man/hlaAttrBagObj.Rd:25-38``)."""
+    snpidx: np.ndarray            # int32, 0-based indices into the model's SNP list
+    freq: np.ndarray              # float64 haplotype frequencies
+    hla: np.ndarray               # int32 allele index of each haplotype, ascending
+    haplo: List[str]              # '0'/'1' strings, char s <-> SNP snpidx[s]
+    samp_num: Optional[np.ndarray] = None   # bootstrap counts of the training samples
+    outofbag_acc: float = 0.0
+
+    def __post_init__(self):
+        self.snpidx = np.ascontiguousarray(self.snpidx, np.int32)
+        self.freq = np.ascontiguousarray(self.freq, np.float64)
+        self.hla = np.ascontiguousarray(self.hla, np.int32)
+        self.haplo = list(self.haplo)
+        if not (len(self.freq) == len(self.hla) == len(self.haplo)):
+            raise ValueError("haplotype columns 'freq', 'hla', 'haplo' differ in length")
+
+
+@dataclass
+class HlaAttrBagObj:
+    n_samp: int
+    n_snp: int
+    hla_allele: List[str]
+    classifiers: List[Classifier]
+    hla_locus: str = ""
+    sample_id: List[str] = field(default_factory=list)
+    snp_id: List[str] = field(default_factory=list)
+    snp_position: Optional[np.ndarray] = None
+    snp_allele: List[str] = field(default_factory=list)
+    snp_allele_freq: Optional[np.ndarray] = None
+    hla_freq: Optional[np.ndarray] = None
+    assembly: str = "unknown"
+    matching: Optional[np.ndarray] = None
+    appendix: Any = None
+
+    @property
+    def n_hla(self) -> int:
+        return len(self.hla_allele)
+
+    @property
+    def n_cell(self) -> int:
+        """Length of the allele-pair posterior vector, nHLA(nHLA+1)/2 (src/LibHLA.cpp:1481)."""
+        return self.n_hla * (self.n_hla + 1) // 2
+
+    def pair_evals_per_sample(self) -> int:
+        """Sum over classifiers of H(H+1)/2 haplotype-pair evaluations."""
+        return int(sum(len(c.freq) * (len(c.freq) + 1) // 2 for c in self.classifiers))
+
+
+@dataclass
+class HlaSNPGeno:
+    """``hlaSNPGenoClass``: ``genotype`` is [n_snp, n_samp] like the R matrix
+    (values 0/1/2 = number of A alleles, NA = INT_MIN)."""
+    genotype: np.ndarray
+    sample_id: List[str]
+    snp_id: List[str]
+    snp_position: Optional[np.ndarray] = None
+    snp_allele: List[str] = field(default_factory=list)
+    assembly: str = "unknown"
+
+    def sample_major(self, snp_sel: Optional[Sequence[int]] = None) -> np.ndarray:
+        """int32 [n_samp, n_snp] -- the memory order ``.Call(HIBAG_Predict_*, as.integer(snp), ...)``
+        hands the C side (R matrices are column-major, ``R/HIBAG.R:715-725``)."""
+        g = self.genotype if snp_sel is None else self.genotype[np.asarray(snp_sel)]
+        return np.ascontiguousarray(g.T, np.int32)
+
+
+def _strs(x) -> List[str]:
+    if x is None:
+        return []
+    if isinstance(x, (list, tuple)):
+        return [s for s in x]
+    return rdata.factor_to_strings(x)
+
+
+def model_from_robj(obj) -> HlaAttrBagObj:
+    """Decoded R list of class ``hlaAttrBagObj`` -> :class:`HlaAttrBagObj`.
+
+    Error behaviour follows ``hlaModelFromObj`` (``R/HIBAG.R:1135-1163``)."""
+    cls_attr = obj.attrs.get("class") or []
+    if "hlaAttrBagObj" not in cls_attr:
+        raise TypeError("inherits(obj, \"hlaAttrBagObj\") is not TRUE")
+    alleles = _strs(obj["hla.allele"])
+    lut = {a: i for i, a in enumerate(alleles)}
+    n_samp = int(np.asarray(obj["n.samp"])[0])
+    out = []
+    for tree in obj["classifiers"]:
+        hp = tree["haplos"]
+        if "haplo" not in hp:
+            raise ValueError("No 'haplo' component. The model may be used by the higher version of HIBAG.")
+        names = _strs(hp["hla"])
+        if any(a not in lut for a in names):
+            raise ValueError("Invalid HLA alleles in the individual classifier.")
+        sn = tree.get("samp.num")
+        out.append(Classifier(
+            snpidx=np.asarray(tree["snpidx"], np.int64) - 1,
+            freq=np.asarray(hp["freq"], np.float64),
+            hla=np.array([lut[a] for a in names], np.int32),
+            haplo=_strs(hp["haplo"]),
+            samp_num=(np.ones(n_samp, np.int32) if sn is None else np.asarray(sn, np.int32)),
+            outofbag_acc=float(np.asarray(tree["outofbag.acc"])[0]) if "outofbag.acc" in tree else 0.0))
+    asm = _strs(obj.get("assembly"))
+    m = obj.get("matching")
+    return HlaAttrBagObj(
+        n_samp=n_samp, n_snp=int(np.asarray(obj["n.snp"])[0]), hla_allele=alleles, classifiers=out,
+        hla_locus=(_strs(obj.get("hla.locus")) or [""])[0],
+        sample_id=_strs(obj.get("sample.id")), snp_id=_strs(obj.get("snp.id")),
+        snp_position=None if obj.get("snp.position") is None else np.asarray(obj["snp.position"], np.float64),
+        snp_allele=_strs(obj.get("snp.allele")),
+        snp_allele_freq=None if obj.get("snp.allele.freq") is None else np.asarray(obj["snp.allele.freq"], np.float64),
+        hla_freq=None if obj.get("hla.freq") is None else np.asarray(obj["hla.freq"], np.float64),
+        assembly=(asm[0] if asm and asm[0] is not None else "unknown"),
+        matching=None if m is None else np.asarray(m, np.float64),
+        appendix=obj.get("appendix"))
+
+
+def geno_from_robj(obj) -> HlaSNPGeno:
+    if "hlaSNPGenoClass" not in (obj.attrs.get("class") or []):
+        raise TypeError("inherits(obj, \"hlaSNPGenoClass\") is not TRUE")
+    g = obj["genotype"]
+    dim = [int(v) for v in np.asarray(g.attrs["dim"])]
+    mat = np.asarray(g, np.int32).reshape(dim[1], dim[0]).T  # R is column-major: [n_snp, n_samp]
+    asm = _strs(obj.get("assembly"))
+    return HlaSNPGeno(genotype=np.ascontiguousarray(mat), sample_id=_strs(obj["sample.id"]),
+                      snp_id=_strs(obj["snp.id"]),
+                      snp_position=np.asarray(obj["snp.position"], np.float64),
+                      snp_allele=_strs(obj["snp.allele"]),
+                      assembly=(asm[0] if asm and asm[0] is not None else "unknown"))
+
+
+def load_model(path: str, name: Optional[str] = None, gene: Optional[str] = None) -> HlaAttrBagObj:
+    """Load an ``hlaAttrBagObj`` from an R workspace.  ``name`` picks the object,
+    ``gene`` an element of a model list such as ``modellist$A``."""
+    ws = rdata.load_rdata(path)
+    obj = ws[name] if name else next(iter(ws.values()))
+    if gene is not None:
+        obj = obj[gene]
+    return model_from_robj(obj)
+
+
+def load_geno(path: str, name: Optional[str] = None) -> HlaSNPGeno:
+    ws = rdata.load_rdata(path)
+    obj = ws[name] if name else next(iter(ws.values()))
+    return geno_from_robj(obj)

@@ -1,0 +1,308 @@
+"""R-free reader for R workspace files (``.rdata`` / ``.RData`` / ``.rda``).
+
+HIBAG ships and publishes its pre-fit models as R workspaces holding an
+``hlaAttrBagObj`` list (reference: ``R/HIBAG.R:1041-1062`` writes the object,
+``R/HIBAG.R:1135-1178`` loads it; field list in ``man/hlaAttrBagObj.Rd:9-38``)
+and its genotypes as ``hlaSNPGenoClass`` lists (``R/DataUtilities.R:236-244``).
+R is not available on the GPU box, so this module decodes the serialisation
+itself: gzip / bzip2 / xz container, ``RDX2``/``RDX3`` magic, XDR (big-endian)
+body, as described in "R Internals" section 1.8 (Serialization Formats).
+
+Only the SEXP kinds that occur in data objects are supported (no closures,
+environments other than the global/base/empty markers, byte code, S4).  R
+attributes are kept: a decoded vector is an :class:`RVector` (an ``ndarray``
+or ``list`` subclass carrying ``.attrs``); pairlists become ``dict``.
+
+``NA_integer_`` stays ``INT_MIN`` (-2147483648) exactly as the C side of the
+reference sees it (``src/LibHLA.cpp:2427`` treats anything outside 0..2 as
+missing); ``NA_character_`` becomes ``None``.
+"""
+
+from __future__ import annotations
+
+import bz2
+import gzip
+import lzma
+import struct
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+NA_INTEGER = -2147483648
+
+# SEXPTYPE codes (R Internals 1.1.1) and serialisation pseudo-types (serialize.c)
+_NILSXP, _SYMSXP, _LISTSXP, _CLOSXP, _ENVSXP, _PROMSXP, _LANGSXP = 0, 1, 2, 3, 4, 5, 6
+_CHARSXP, _LGLSXP, _INTSXP, _REALSXP, _CPLXSXP, _STRSXP = 9, 10, 13, 14, 15, 16
+_DOTSXP, _VECSXP, _EXPRSXP, _RAWSXP = 17, 19, 20, 24
+_ALTREP, _ATTRLISTSXP, _ATTRLANGSXP = 238, 239, 240
+_BASEENV, _EMPTYENV, _GLOBALENV, _UNBOUND, _MISSINGARG, _BASENAMESPACE = 241, 242, 253, 252, 251, 247
+_NAMESPACESXP, _PACKAGESXP, _PERSISTSXP, _REFSXP, _NILVALUE = 249, 250, 248, 255, 254
+
+
+class RArray(np.ndarray):
+    """numpy array with R attributes (``.attrs`` dict: names, dim, levels, class...)."""
+
+    attrs: Dict[str, Any]
+
+    def __new__(cls, arr, attrs=None):
+        obj = np.asarray(arr).view(cls)
+        obj.attrs = attrs or {}
+        return obj
+
+    def __array_finalize__(self, obj):
+        self.attrs = getattr(obj, "attrs", {}) if obj is not None else {}
+
+
+class RList(list):
+    """R generic vector (VECSXP); ``x["name"]`` looks up by the ``names`` attribute."""
+
+    def __init__(self, items=(), attrs=None):
+        super().__init__(items)
+        self.attrs: Dict[str, Any] = attrs or {}
+
+    @property
+    def names(self) -> List[Optional[str]]:
+        n = self.attrs.get("names")
+        return list(n) if n is not None else []
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            names = self.names
+            if key not in names:
+                raise KeyError(key)
+            return super().__getitem__(names.index(key))
+        return super().__getitem__(key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def __contains__(self, key):
+        if isinstance(key, str):
+            return key in self.names
+        return super().__contains__(key)
+
+
+class RStrings(list):
+    """R character vector (STRSXP) with attributes."""
+
+    def __init__(self, items=(), attrs=None):
+        super().__init__(items)
+        self.attrs: Dict[str, Any] = attrs or {}
+
+
+class _Reader:
+    def __init__(self, buf: bytes):
+        self.b = buf
+        self.p = 0
+        self.refs: List[Any] = []
+
+    def i32(self) -> int:
+        v = struct.unpack_from(">i", self.b, self.p)[0]
+        self.p += 4
+        return v
+
+    def length(self) -> int:
+        n = self.i32()
+        if n == -1:  # long vector: two 32-bit halves
+            hi, lo = struct.unpack_from(">II", self.b, self.p)
+            self.p += 8
+            n = (hi << 32) | lo
+        return n
+
+    def raw(self, n: int) -> bytes:
+        v = self.b[self.p:self.p + n]
+        if len(v) != n:
+            raise ValueError("truncated R serialisation stream")
+        self.p += n
+        return v
+
+    def item(self) -> Any:
+        flags = self.i32()
+        ty = flags & 0xFF
+        has_attr = bool(flags & 0x200)
+        has_tag = bool(flags & 0x400)
+
+        if ty == _NILVALUE or ty == _NILSXP:
+            return None
+        if ty in (_GLOBALENV, _BASEENV, _EMPTYENV, _BASENAMESPACE, _UNBOUND, _MISSINGARG):
+            return None
+        if ty == _REFSXP:
+            idx = flags >> 8
+            if idx == 0:
+                idx = self.i32()
+            return self.refs[idx - 1]
+        if ty == _SYMSXP:
+            name = self.item()  # a CHARSXP
+            self.refs.append(name)
+            return name
+        if ty in (_NAMESPACESXP, _PACKAGESXP, _PERSISTSXP):
+            self.i32()  # always 0
+            n = self.i32()
+            v = [self.item() for _ in range(n)]
+            self.refs.append(v)
+            return v
+        if ty in (_LISTSXP, _LANGSXP, _ATTRLISTSXP, _ATTRLANGSXP, _DOTSXP, _PROMSXP, _CLOSXP):
+            # pairlist: iterate over the spine instead of recursing on the CDR
+            out: Dict[Any, Any] = {}
+            k = 0
+            while True:
+                attrs = self.item() if has_attr else None  # noqa: F841 (pairlist attrs unused)
+                tag = self.item() if has_tag else None
+                car = self.item()
+                out[tag if tag is not None else k] = car
+                k += 1
+                flags = self.i32()
+                ty = flags & 0xFF
+                has_attr = bool(flags & 0x200)
+                has_tag = bool(flags & 0x400)
+                if ty in (_NILVALUE, _NILSXP):
+                    break
+                if ty not in (_LISTSXP, _LANGSXP, _ATTRLISTSXP, _ATTRLANGSXP):
+                    raise ValueError(f"unsupported pairlist tail type {ty}")
+            return out
+        if ty == _CHARSXP:
+            n = self.i32()
+            if n == -1:
+                return None  # NA_character_
+            raw = self.raw(n)
+            if flags & (1 << 14):      # LATIN1_MASK in the gp field (bit 2 of levels<<12)
+                return raw.decode("latin-1")
+            return raw.decode("utf-8", errors="replace")
+        if ty == _ALTREP:
+            info = self.item()
+            state = self.item()
+            self.item()  # attributes
+            return self._altrep(info, state)
+
+        if ty in (_LGLSXP, _INTSXP):
+            n = self.length()
+            v = np.frombuffer(self.raw(4 * n), dtype=">i4").astype(np.int32)
+            obj: Any = RArray(v)
+        elif ty == _REALSXP:
+            n = self.length()
+            v = np.frombuffer(self.raw(8 * n), dtype=">f8").astype(np.float64)
+            obj = RArray(v)
+        elif ty == _CPLXSXP:
+            n = self.length()
+            v = np.frombuffer(self.raw(16 * n), dtype=">c16").astype(np.complex128)
+            obj = RArray(v)
+        elif ty == _RAWSXP:
+            n = self.length()
+            obj = RArray(np.frombuffer(self.raw(n), dtype=np.uint8).copy())
+        elif ty == _STRSXP:
+            n = self.length()
+            obj = RStrings([self.item() for _ in range(n)])
+        elif ty in (_VECSXP, _EXPRSXP):
+            n = self.length()
+            obj = RList([self.item() for _ in range(n)])
+        elif ty == _ENVSXP:
+            # locked flag, enclos, frame, hashtab, attrib — decode the frame as a dict
+            self.i32()
+            placeholder: Dict[Any, Any] = {}
+            self.refs.append(placeholder)
+            self.item()
+            frame = self.item()
+            hashtab = self.item()
+            self.item()
+            if isinstance(frame, dict):
+                placeholder.update(frame)
+            if isinstance(hashtab, list):
+                for chain in hashtab:
+                    if isinstance(chain, dict):
+                        placeholder.update(chain)
+            return placeholder
+        else:
+            raise ValueError(f"unsupported SEXP type {ty} at byte {self.p}")
+
+        if has_attr:
+            attrs = self.item()
+            if isinstance(attrs, dict):
+                obj.attrs = {k: _plain_attr(v) for k, v in attrs.items()}
+        return obj
+
+    def _altrep(self, info, state):
+        # info is a pairlist {0: class symbol, 1: package symbol, 2: type}
+        cls = info.get(0) if isinstance(info, dict) else None
+        if cls == "compact_intseq":
+            n, start, step = (int(x) for x in np.asarray(state)[:3])
+            return RArray(np.arange(start, start + n * step, step, dtype=np.int32))
+        if cls == "compact_realseq":
+            n, start, step = (float(x) for x in np.asarray(state)[:3])
+            return RArray(start + step * np.arange(int(n), dtype=np.float64))
+        if cls in ("wrap_integer", "wrap_real", "wrap_string", "wrap_logical", "wrap_list", "wrap_raw"):
+            return state[0] if isinstance(state, (list, dict)) and not hasattr(state, "dtype") else state
+        if cls == "deferred_string":
+            src = state.get(0) if isinstance(state, dict) else state
+            return RStrings([_num_to_rstring(x) for x in np.asarray(src)])
+        raise ValueError(f"unsupported ALTREP class {cls!r}")
+
+
+def _num_to_rstring(x) -> Optional[str]:
+    if isinstance(x, (np.integer, int)):
+        return None if int(x) == NA_INTEGER else str(int(x))
+    return repr(float(x)) if float(x) != int(x) else str(int(x))
+
+
+def _plain_attr(v):
+    if isinstance(v, RStrings):
+        return list(v)
+    return v
+
+
+def _decompress(blob: bytes) -> bytes:
+    if blob[:2] == b"\x1f\x8b":
+        return gzip.decompress(blob)
+    if blob[:3] == b"BZh":
+        return bz2.decompress(blob)
+    if blob[:6] == b"\xfd7zXZ\x00":
+        return lzma.decompress(blob)
+    return blob
+
+
+def _read_stream(buf: bytes, start: int) -> _Reader:
+    if buf[start:start + 2] != b"X\n":
+        raise ValueError("only the XDR binary serialisation format is supported")
+    r = _Reader(buf)
+    r.p = start + 2
+    version = r.i32()
+    r.i32()  # writer R version
+    r.i32()  # minimal reader R version
+    if version == 3:
+        n = r.i32()
+        r.raw(n)  # native encoding name
+    elif version != 2:
+        raise ValueError(f"unsupported serialisation version {version}")
+    return r
+
+
+def load_rdata(path: str) -> Dict[str, Any]:
+    """Load an R workspace (``save()`` output) → ``{object name: value}``."""
+    with open(path, "rb") as f:
+        buf = _decompress(f.read())
+    if buf[:5] not in (b"RDX2\n", b"RDX3\n"):
+        raise ValueError(f"{path}: not an R workspace (magic {buf[:5]!r})")
+    r = _read_stream(buf, 5)
+    top = r.item()
+    if not isinstance(top, dict):
+        raise ValueError(f"{path}: unexpected top-level object")
+    return top
+
+
+def load_rds(path: str) -> Any:
+    """Load a single serialised R object (``saveRDS()`` output)."""
+    with open(path, "rb") as f:
+        buf = _decompress(f.read())
+    return _read_stream(buf, 0).item()
+
+
+def factor_to_strings(x) -> List[Optional[str]]:
+    """R factor (int codes + ``levels``) or character vector → list of str."""
+    if isinstance(x, RStrings) or (isinstance(x, list) and not isinstance(x, RList)):
+        return list(x)
+    levels = x.attrs.get("levels")
+    if levels is None:
+        raise ValueError("not a factor")
+    return [None if int(k) == NA_INTEGER else levels[int(k) - 1] for k in np.asarray(x)]
