@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the hlaPredict() hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): hlaPredict() samples/sec (+ achieved HBM GB/s) on the
+10k-sample x 100-classifier HLA-B configuration.  A *step* is one pass of the
+hot path (CAttrBag_Model::PredictHLA, src/LibHLA.cpp:2317-2412, with the
+default outputs of type="response+dosage": calls, probability, matching,
+dosage) over one batch of 10,000 synthetic samples that already sit in HBM.
+With N > 1 every rank owns its own 10,000 samples (samples are independent, no
+data-path collective; weak scaling) -- one process per GPU, launched by
+torch.distributed.run, rendezvous over RCCL.
+
+Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
+  roofline     : the dominant kernel against the HBM roof the metric names,
+                 from HIP events recorded on the launch stream inside the timed
+                 region (and, under "valu", against the vector-ALU issue ceiling
+                 that actually binds this popcount/FP64 path -- DESIGN.md);
+  cpu_baseline : the AVX2 + threads CPU port of the reference's kernel
+                 (oracle/, kind "port") timed on this box's host cores on a
+                 bounded sample of the same workload (rank 0, N = 1 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SAMPLES_PER_GPU = 10_000
+SHAPE = "hla-b"
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+# vector-ALU issue ceiling used for the "valu" block (DESIGN.md "Rooflines"):
+# 256 CUs x 4 SIMDs x 2.4 GHz wave-instruction issue slots (a wave64 int32 op
+# holds a SIMD for 2 cycles, an FP64 op for 4).
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--samples", type=int, default=SAMPLES_PER_GPU, help="samples per GPU per step")
+    ap.add_argument("--shape", default=SHAPE)
+    ap.add_argument("--prob", action="store_true", help="also return the full posterior matrix (type='response+prob')")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: hibag_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    import hibag_amd
+    from hibag_amd import synth
+
+    hibag_amd._lib.check(hibag_amd._lib.lib().hibag_hip_set_device(local_rank))
+    target = hibag_amd.hlaSetKernelTarget("hip")[0]
+    model_obj, founders, afreq = synth.make_model(args.shape)
+    n = args.samples
+    geno, truth = synth.make_samples(founders, afreq, n, seed=synth.DEFAULT_SEED + 1 + rank)
+    model = hibag_amd.hlaModelFromObj(model_obj, device=local_rank)
+
+    n_hla, P, S = model_obj.n_hla, model_obj.n_cell, model_obj.n_snp
+    d_geno = torch.from_numpy(geno).to(dev)
+    d_h1 = torch.empty(n, dtype=torch.int32, device=dev)
+    d_h2 = torch.empty(n, dtype=torch.int32, device=dev)
+    d_prob = torch.empty(n, dtype=torch.float64, device=dev)
+    d_match = torch.empty(n, dtype=torch.float64, device=dev)
+    d_dos = torch.empty((n, n_hla), dtype=torch.float64, device=dev)
+    d_pp = torch.empty((n, P), dtype=torch.float64, device=dev) if args.prob else None
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        model.predict_device(d_geno.data_ptr(), n, 1, d_h1.data_ptr(), d_h2.data_ptr(), d_prob.data_ptr(),
+                             d_match.data_ptr(), d_dos.data_ptr(), None if d_pp is None else d_pp.data_ptr(),
+                             stream=stream.cuda_stream)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    model.set_timing(True)
+    model.reset_timing()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    timing = model.get_timing()
+    model.set_timing(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity on the timed outputs: calls of samples drawn from the model
+    h1 = d_h1.cpu().numpy(); h2 = d_h2.cpu().numpy()
+    call_acc = float(np.mean((h1 == truth[:, 0]) & (h2 == truth[:, 1])))
+
+    total_samples = n * world * args.steps
+    value = total_samples / dt
+    pair_evals = model_obj.pair_evals_per_sample()
+
+    # ---- roofline of the dominant kernel (HIP events on the launch stream) ----
+    dom = max(("total", "accum"), key=lambda k: timing[k][0])
+    dom_ms, dom_launches = timing[dom]
+    avg_ms = dom_ms / max(dom_launches, 1)
+    bytes_per_sample = 4 * S + 24 + 8 * n_hla + (8 * P if args.prob else 0)
+    alg_bytes = bytes_per_sample * n                                           # one launch covers the batch
+    achieved_gbs = alg_bytes / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(f"k_{dom}", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    pairs_per_s_kernel = pair_evals * n / (avg_ms * 1e-3)
+    cyc_per_pair_wave = SIMD_CYCLES_PER_S / (pairs_per_s_kernel / 64.0)
+    roofline = {
+        "kernel": f"k_{dom}", "bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+        "avg_launch_ms": round(avg_ms, 4), "launches": int(dom_launches),
+        "algorithmic_bytes_per_launch": int(alg_bytes),
+        "valu": {"pair_evals_per_s": pairs_per_s_kernel,
+                 "simd_cycles_per_wave_pair": round(cyc_per_pair_wave, 2),
+                 "note": "binding ceiling is VALU issue, not HBM (DESIGN.md); lower cycles/pair is better"},
+        "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in timing.items()},
+    }
+
+    out = {
+        "metric": "hlaPredict() samples/sec, 10k samples x 100-classifier HLA-B",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"synthetic {args.shape} model ({n_hla} alleles, {len(model_obj.classifiers)} classifiers, "
+                               f"{S} SNPs, {pair_evals} haplotype-pair evaluations/sample), {n} samples per GPU per step, "
+                               f"type={'response+prob' if args.prob else 'response+dosage'}, vote=prob",
+                   "samples_per_gpu": n, "parallelism": f"sample-sharded x{world} (no collective)",
+                   "kernel_target": target},
+        "pair_evals_per_s": value * pair_evals,
+        "call_accuracy_vs_truth": call_acc,
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model_obj, geno, h1, h2)
+        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(model_obj, geno, gpu_h1, gpu_h2):
+    """AVX2 + threads port of the reference's CPU kernel (oracle/hibag_oracle_avx2.c) on all host
+    cores, on a bounded prefix of the same batch; also cross-checks the GPU's calls on it."""
+    import numpy as np
+    from oracle import oracle as O
+    O.build()
+    fm = O.flatten(model_obj)
+    cores = os.cpu_count() or 1
+    probe = min(len(geno), 8 * cores)
+    t = time.perf_counter()
+    O.predict(fm, geno[:probe], avx2=True, n_threads=cores, want_dosage=True, want_prob=False)
+    rate = probe / max(time.perf_counter() - t, 1e-6)
+    m = int(min(len(geno), max(probe, rate * 12.0)))          # ~12 s of CPU work
+    t = time.perf_counter()
+    ref = O.predict(fm, geno[:m], avx2=True, n_threads=cores, want_dosage=True, want_prob=False)
+    dt = time.perf_counter() - t
+    same = bool(np.array_equal(ref["h1"], gpu_h1[:m]) and np.array_equal(ref["h2"], gpu_h2[:m]))
+    return {"value": m / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"first {m} of the {len(geno)} samples of the timed batch, same model, same outputs; "
+                      f"AVX2 4-wide inner loop + {cores} threads over samples",
+            "calls_identical_to_gpu": same}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,17 @@
+"""hibag_amd -- MI355X-native implementation of HIBAG's attribute-bagging
+prediction hot path (haplotype-pair posterior loop) behind the reference's own
+interface: ``hlaSetKernelTarget("hip")``, ``hlaModelFromObj``, ``hlaPredict``.
+
+The compute lives in ``csrc/libhibag_hip.so`` (hand-written HIP for gfx950,
+C ABI in ``include/hibag_hip.h``); there is no CPU fallback in this package.
+"""
+
+from .model import (NA_INTEGER, Classifier, HlaAttrBagObj, HlaSNPGeno, load_geno, load_model)  # noqa: F401
+from .hibag import (HlaAlleleClass, HlaAttrBagClass, hlaClose, hlaModelFromObj, hlaModelToObj,   # noqa: F401
+                    hlaPredict, hlaSetKernelTarget)
+from .snpmatch import hlaGenoSwitchStrand, hlaSNPID  # noqa: F401
+from ._lib import HibagHipError  # noqa: F401
+
+__all__ = ["NA_INTEGER", "Classifier", "HlaAttrBagObj", "HlaSNPGeno", "load_geno", "load_model",
+           "HlaAlleleClass", "HlaAttrBagClass", "hlaClose", "hlaModelFromObj", "hlaModelToObj",
+           "hlaPredict", "hlaSetKernelTarget", "hlaGenoSwitchStrand", "hlaSNPID", "HibagHipError"]

@@ -1,0 +1,93 @@
+"""ctypes binding of ``libhibag_hip.so`` (C ABI: ``include/hibag_hip.h``).
+
+The library is the product; this module only declares its prototypes and turns
+its error codes into exceptions.  There is no fallback: if the shared object is
+missing, or there is no MI355X, compute entry points raise.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libhibag_hip.so")
+
+K_PACK, K_TOTAL, K_ACCUM, K_FINISH, K_COUNT = 0, 1, 2, 3, 4
+KERNEL_NAMES = {K_PACK: "pack", K_TOTAL: "total", K_ACCUM: "accum", K_FINISH: "finish"}
+
+EXPORTS = [
+    "hibag_hip_abi_version", "hibag_hip_last_error", "hibag_hip_device_count", "hibag_hip_set_device",
+    "hibag_hip_set_kernel_target", "hibag_hip_model_new", "hibag_hip_model_add_classifier",
+    "hibag_hip_model_add_classifier_packed", "hibag_hip_model_finalize", "hibag_hip_model_free",
+    "hibag_hip_model_n_hla", "hibag_hip_model_n_snp", "hibag_hip_model_n_classifier",
+    "hibag_hip_model_pair_evals", "hibag_hip_model_mutation_table", "hibag_hip_predict",
+    "hibag_hip_predict_device", "hibag_hip_model_set_snp_weights", "hibag_hip_predict_partial_device",
+    "hibag_hip_finish_device", "hibag_hip_set_timing", "hibag_hip_get_timing", "hibag_hip_reset_timing",
+    "hibag_hip_gpu_ext_proc",
+]
+
+
+class HibagHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(message or f"libhibag_hip error {code}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 (``make -C hibag_amd/csrc``)."""
+    cmd = ["make", "-C", CSRC, "-s", "-j2"] + (["-B"] if force else [])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C hibag_amd/csrc`.  hibag_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    L.hibag_hip_abi_version.restype = i32
+    L.hibag_hip_last_error.restype = C.c_char_p
+    L.hibag_hip_device_count.restype = i32
+    L.hibag_hip_set_device.argtypes = [i32]
+    L.hibag_hip_set_kernel_target.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.hibag_hip_model_new.argtypes = [i32, i32]
+    L.hibag_hip_model_new.restype = vp
+    L.hibag_hip_model_add_classifier.argtypes = [vp, i32, vp, i32, vp, vp, C.POINTER(C.c_char_p)]
+    L.hibag_hip_model_add_classifier_packed.argtypes = [vp, i32, vp, i32, vp, vp, vp]
+    L.hibag_hip_model_set_snp_weights.argtypes = [vp, vp]
+    L.hibag_hip_model_finalize.argtypes = [vp]
+    L.hibag_hip_model_free.argtypes = [vp]
+    L.hibag_hip_model_free.restype = None
+    for f in (L.hibag_hip_model_n_hla, L.hibag_hip_model_n_snp, L.hibag_hip_model_n_classifier):
+        f.argtypes = [vp]
+        f.restype = i32
+    L.hibag_hip_model_pair_evals.argtypes = [vp]
+    L.hibag_hip_model_pair_evals.restype = i64
+    L.hibag_hip_model_mutation_table.argtypes = [vp, vp]
+    L.hibag_hip_predict.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.hibag_hip_predict_device.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.hibag_hip_predict_partial_device.argtypes = [vp, vp, i32, vp, vp]
+    L.hibag_hip_finish_device.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.hibag_hip_set_timing.argtypes = [vp, i32]
+    L.hibag_hip_get_timing.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(i64)]
+    L.hibag_hip_reset_timing.argtypes = [vp]
+    L.hibag_hip_gpu_ext_proc.restype = vp
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise HibagHipError(rc, lib().hibag_hip_last_error().decode("utf-8", "replace"))

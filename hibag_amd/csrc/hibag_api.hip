@@ -1,0 +1,811 @@
+// hibag_api.hip -- host side of libhibag_hip.so: the model container, the
+// batch driver that replaces CAttrBag_Model::PredictHLA, the C ABI declared in
+// include/hibag_hip.h and the TypeGPUExtProc-compatible plugin table.
+//
+// There is no CPU fallback here: every compute entry runs the HIP kernels or
+// fails with an error code.
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hibag_hip.h"
+#include "hibag_device.h"
+#include "hibag_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+thread_local int g_device = 0;
+
+int fail(int code, const char *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	g_last_error = buf;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+	do {                                                                                \
+		hipError_t e_ = (expr);                                                         \
+		if (e_ != hipSuccess)                                                           \
+			return fail(e_ == hipErrorOutOfMemory ? HIBAG_HIP_ENOMEM : HIBAG_HIP_ENODEV, \
+				"%s failed: %s", #expr, hipGetErrorString(e_));                         \
+	} while (0)
+
+// Grow-only device buffer.
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	int reserve(size_t bytes)
+	{
+		if (bytes <= cap) return 0;
+		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+		HIP_TRY(hipMalloc(&p, bytes));
+		cap = bytes;
+		return 0;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	template <class T> T *as() const { return (T *)p; }
+};
+
+struct HostClassifier {
+	std::vector<int> snpidx;         // may be empty for plugin-built models
+	int n_snp = 0;
+	std::vector<uint64_t> bits;      // [H][2], bits >= n_snp cleared
+	std::vector<double> freq;
+	std::vector<int> hla;
+};
+
+struct KernelTimer {
+	struct Pending { int k; hipEvent_t a, b; };
+	bool enabled = false;
+	std::vector<Pending> pending;
+	std::vector<hipEvent_t> pool;
+	double ms[HIBAG_HIP_K_COUNT] = {0, 0, 0, 0};
+	int64_t n[HIBAG_HIP_K_COUNT] = {0, 0, 0, 0};
+
+	hipEvent_t get()
+	{
+		if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+		hipEvent_t e;
+		(void)hipEventCreate(&e);
+		return e;
+	}
+	void begin(int k, hipStream_t st)
+	{
+		if (!enabled) return;
+		Pending p{k, get(), get()};
+		(void)hipEventRecord(p.a, st);
+		pending.push_back(p);
+	}
+	void end(hipStream_t st)
+	{
+		if (!enabled) return;
+		(void)hipEventRecord(pending.back().b, st);
+	}
+	void resolve()
+	{
+		for (auto &p : pending) {
+			(void)hipEventSynchronize(p.b);
+			float t = 0;
+			if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { ms[p.k] += t; n[p.k]++; }
+			pool.push_back(p.a);
+			pool.push_back(p.b);
+		}
+		pending.clear();
+	}
+	void reset()
+	{
+		resolve();
+		for (int k = 0; k < HIBAG_HIP_K_COUNT; k++) { ms[k] = 0; n[k] = 0; }
+	}
+	void destroy()
+	{
+		resolve();
+		for (auto e : pool) (void)hipEventDestroy(e);
+		pool.clear();
+	}
+};
+
+} // namespace
+
+struct hibag_hip_model {
+	int device = 0;
+	int n_hla = 0, n_snp = 0;
+	bool finalized = false;
+	bool have_snpidx = true;
+	std::vector<HostClassifier> cls;
+	std::vector<int> snp_weight_override;   // classifier-sharded runs
+	int64_t pair_evals = 0;
+	double tab[HIBAG_TAB_N];
+
+	// device model
+	DevBuf d_int, d_bits, d_freq, d_tab;
+	HibagModelView view{};
+	int geno_rows = 0;
+
+	// per-batch workspace (grow-only)
+	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out;
+	// plugin staging
+	DevBuf ws_tgeno, ws_weight;
+
+	KernelTimer timer;
+	std::mutex lock;
+
+	~hibag_hip_model()
+	{
+		(void)hipSetDevice(device);
+		timer.destroy();
+		for (DevBuf *b : {&d_int, &d_bits, &d_freq, &d_tab, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
+		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_tgeno, &ws_weight})
+			b->release();
+	}
+};
+
+namespace {
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// The mutation/error weights exp(d*log(1e-5)), TAB[0]=1, non-finite -> 0:
+// the same expression, evaluated by the host libm like the reference does in
+// its static initialiser (src/LibHLA.cpp:166-183).
+void build_table(double *tab)
+{
+	const double min_rare_freq = 1e-5;   // inst/include/LibHLA_ext.h:230
+	for (int i = 0; i < HIBAG_TAB_N; i++) tab[i] = std::exp(i * std::log(min_rare_freq));
+	tab[0] = 1;
+	for (int i = 0; i < HIBAG_TAB_N; i++)
+		if (!std::isfinite(tab[i])) tab[i] = 0;
+}
+
+int check_classifier_args(hibag_hip_model *m, int n_snp_c, const int32_t *snpidx, int n_haplo,
+	const double *freq, const int32_t *hla)
+{
+	if (!m) return fail(HIBAG_HIP_EINVAL, "model is NULL");
+	if (m->finalized) return fail(HIBAG_HIP_ESTATE, "model already finalized");
+	if (n_snp_c < 0 || n_snp_c > HIBAG_HIP_MAX_SNP_IN_CLASSIFIER)
+		return fail(HIBAG_HIP_EINVAL, "there are too many SNP markers in a classifier (%d > %d).",
+			n_snp_c, HIBAG_HIP_MAX_SNP_IN_CLASSIFIER);
+	if (n_haplo < 0 || (n_haplo > 0 && (!freq || !hla)))
+		return fail(HIBAG_HIP_EINVAL, "invalid haplotype list");
+	if (snpidx)
+		for (int i = 0; i < n_snp_c; i++)
+			if (snpidx[i] < 0 || snpidx[i] >= m->n_snp)
+				return fail(HIBAG_HIP_EINVAL, "SNP index %d out of range [0,%d)", snpidx[i], m->n_snp);
+	for (int i = 0; i < n_haplo; i++) {
+		if (hla[i] < 0 || hla[i] >= m->n_hla)
+			return fail(HIBAG_HIP_EINVAL, "HLA allele index %d out of range [0,%d)", hla[i], m->n_hla);
+		if (i > 0 && hla[i] < hla[i - 1])
+			return fail(HIBAG_HIP_EINVAL, "haplotypes must be grouped by ascending HLA allele index");
+	}
+	return 0;
+}
+
+void push_classifier(hibag_hip_model *m, int n_snp_c, const int32_t *snpidx, int n_haplo,
+	const double *freq, const int32_t *hla, std::vector<uint64_t> &&bits)
+{
+	HostClassifier c;
+	c.n_snp = n_snp_c;
+	if (snpidx) c.snpidx.assign(snpidx, snpidx + n_snp_c);
+	else m->have_snpidx = false;
+	c.freq.assign(freq, freq + n_haplo);
+	c.hla.assign(hla, hla + n_haplo);
+	c.bits = std::move(bits);
+	m->cls.push_back(std::move(c));
+}
+
+// Cell tiles for pass 2: every allele-pair cell goes to exactly one tile of at
+// most T cells; tiles are filled longest-processing-time-first so that their
+// pair counts (summed over classifiers) are balanced.
+void build_tiles(const hibag_hip_model *m, const std::vector<int> &hla_start, int T,
+	std::vector<int> &tile_cell, int &n_tile, std::vector<int> &h1v, std::vector<int> &h2v)
+{
+	const int nh = m->n_hla, C = (int)m->cls.size();
+	const int P = nh * (nh + 1) / 2;
+	h1v.resize(P); h2v.resize(P);
+	std::vector<int64_t> work(P, 0);
+	int p = 0;
+	for (int h1 = 0; h1 < nh; h1++)
+		for (int h2 = h1; h2 < nh; h2++, p++) {
+			h1v[p] = h1; h2v[p] = h2;
+			int64_t w = 0;
+			for (int c = 0; c < C; c++) {
+				const int *st = &hla_start[(size_t)c * (nh + 1)];
+				const int64_t n1 = st[h1 + 1] - st[h1], n2 = st[h2 + 1] - st[h2];
+				w += (h1 == h2) ? n1 * (n1 + 1) / 2 : n1 * n2;
+				w += (n1 && n2) ? 2 : 0;   // fixed per-cell cost
+			}
+			work[p] = w;
+		}
+	n_tile = (P + T - 1) / T;
+	std::vector<int> order(P);
+	for (int i = 0; i < P; i++) order[i] = i;
+	std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return work[a] > work[b]; });
+	std::vector<int64_t> load(n_tile, 0);
+	std::vector<int> fill(n_tile, 0);
+	tile_cell.assign((size_t)n_tile * T, -1);
+	for (int i = 0; i < P; i++) {
+		int best = -1;
+		for (int t = 0; t < n_tile; t++)
+			if (fill[t] < T && (best < 0 || load[t] < load[best])) best = t;
+		tile_cell[(size_t)best * T + fill[best]++] = order[i];
+		load[best] += work[order[i]];
+	}
+	// heaviest tiles first in launch order
+	std::vector<int> torder(n_tile);
+	for (int t = 0; t < n_tile; t++) torder[t] = t;
+	std::stable_sort(torder.begin(), torder.end(), [&](int a, int b) { return load[a] > load[b]; });
+	std::vector<int> sorted((size_t)n_tile * T);
+	for (int t = 0; t < n_tile; t++)
+		std::copy(tile_cell.begin() + (size_t)torder[t] * T, tile_cell.begin() + (size_t)(torder[t] + 1) * T,
+			sorted.begin() + (size_t)t * T);
+	tile_cell.swap(sorted);
+}
+
+int finalize_model(hibag_hip_model *m)
+{
+	if (m->finalized) return fail(HIBAG_HIP_ESTATE, "model already finalized");
+	HIP_TRY(hipSetDevice(m->device));
+	const int C = (int)m->cls.size(), nh = m->n_hla, S = m->n_snp;
+	const int P = nh * (nh + 1) / 2;
+
+	std::vector<int> n_snp_c(C), n_word(C), snp_off(C), n_hap(C), hap_off(C), bits_off(C), geno_row(C),
+		c_order(C), snp_index, snp_weight(std::max(S, 1), 0), hla_start((size_t)C * (nh + 1), 0);
+	std::vector<uint32_t> hbits;
+	std::vector<double> hfreq;
+	std::vector<int64_t> pairs(C);
+	int rows = 0;
+	m->pair_evals = 0;
+	for (int c = 0; c < C; c++) {
+		const HostClassifier &k = m->cls[c];
+		const int H = (int)k.freq.size();
+		n_snp_c[c] = k.n_snp;
+		n_word[c] = std::max(1, (k.n_snp + 31) / 32);
+		snp_off[c] = (int)snp_index.size();
+		for (int v : k.snpidx) { snp_index.push_back(v); snp_weight[v]++; }
+		if (k.snpidx.empty()) snp_index.insert(snp_index.end(), (size_t)k.n_snp, 0);
+		n_hap[c] = H;
+		hap_off[c] = (int)hfreq.size();
+		bits_off[c] = (int)hbits.size();
+		geno_row[c] = rows;
+		rows += 2 * n_word[c];
+		hfreq.insert(hfreq.end(), k.freq.begin(), k.freq.end());
+		for (int w = 0; w < n_word[c]; w++)
+			for (int i = 0; i < H; i++)
+				hbits.push_back((uint32_t)(k.bits[2 * (size_t)i + (w >> 1)] >> (32 * (w & 1))));
+		int *st = &hla_start[(size_t)c * (nh + 1)];
+		for (int i = 0; i < H; i++) st[k.hla[i] + 1]++;
+		for (int h = 0; h < nh; h++) st[h + 1] += st[h];
+		pairs[c] = (int64_t)H * (H + 1) / 2;
+		m->pair_evals += pairs[c];
+		c_order[c] = c;
+	}
+	if (!m->snp_weight_override.empty()) snp_weight = m->snp_weight_override;
+	std::stable_sort(c_order.begin(), c_order.end(), [&](int a, int b) { return pairs[a] > pairs[b]; });
+	if (hbits.empty()) hbits.push_back(0);
+	if (hfreq.empty()) hfreq.push_back(0);
+	if (snp_index.empty()) snp_index.push_back(0);
+
+	const int T = 16;
+	std::vector<int> tile_cell, h1v, h2v;
+	int n_tile = 0;
+	build_tiles(m, hla_start, T, tile_cell, n_tile, h1v, h2v);
+
+	// one int arena
+	std::vector<int> arena;
+	auto put = [&](const std::vector<int> &v) {
+		size_t off = arena.size();
+		arena.insert(arena.end(), v.begin(), v.end());
+		if (v.empty()) arena.push_back(0);
+		return off;
+	};
+	const size_t o_nsnp = put(n_snp_c), o_nword = put(n_word), o_snpoff = put(snp_off), o_snpidx = put(snp_index),
+		o_snpw = put(snp_weight), o_nhap = put(n_hap), o_hapoff = put(hap_off), o_bitsoff = put(bits_off),
+		o_grow = put(geno_row), o_start = put(hla_start), o_order = put(c_order), o_tile = put(tile_cell),
+		o_h1 = put(h1v), o_h2 = put(h2v);
+
+	if (int rc = m->d_int.reserve(arena.size() * sizeof(int))) return rc;
+	if (int rc = m->d_bits.reserve(hbits.size() * sizeof(uint32_t))) return rc;
+	if (int rc = m->d_freq.reserve(hfreq.size() * sizeof(double))) return rc;
+	if (int rc = m->d_tab.reserve(sizeof(m->tab))) return rc;
+	HIP_TRY(hipMemcpy(m->d_int.p, arena.data(), arena.size() * sizeof(int), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(m->d_bits.p, hbits.data(), hbits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(m->d_freq.p, hfreq.data(), hfreq.size() * sizeof(double), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(m->d_tab.p, m->tab, sizeof(m->tab), hipMemcpyHostToDevice));
+
+	HibagModelView &V = m->view;
+	const int *base = m->d_int.as<int>();
+	V.n_hla = nh; V.n_classifier = C; V.n_snp = S; V.n_cell = P; V.geno_rows = rows;
+	V.n_tile = n_tile; V.tile_cells = T;
+	V.n_snp_c = base + o_nsnp; V.n_word = base + o_nword; V.snp_off = base + o_snpoff;
+	V.snp_index = base + o_snpidx; V.snp_weight = base + o_snpw; V.n_hap = base + o_nhap;
+	V.hap_off = base + o_hapoff; V.bits_off = base + o_bitsoff; V.geno_row = base + o_grow;
+	V.hla_start = base + o_start; V.c_order = base + o_order;
+	V.tile_cell = base + o_tile; V.cell_h1 = base + o_h1; V.cell_h2 = base + o_h2;
+	V.hbits = m->d_bits.as<uint32_t>(); V.hfreq = m->d_freq.as<double>(); V.tab = m->d_tab.as<double>();
+	m->geno_rows = rows;
+	m->finalized = true;
+	return 0;
+}
+
+// Samples per batch: bounds the workspace (the [P+3][n_pad] partial sums
+// dominate) to roughly 1.5 GB while keeping batches large enough to fill the
+// 256 CUs many times over.
+int batch_limit(const hibag_hip_model *m)
+{
+	const double per_sample = 8.0 * (m->view.n_cell + 3) + 24.0 * m->view.n_classifier +
+		4.0 * m->geno_rows + 4.0 * m->view.n_classifier;
+	int lim = (int)(1.5e9 / std::max(per_sample, 1.0));
+	lim = std::max(64, std::min(lim, 1 << 17));
+	return lim / 64 * 64;
+}
+
+int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B)
+{
+	const int n_pad = round_up(std::max(n_samp, 1), HIBAG_WAVE);
+	const size_t C = (size_t)std::max(m->view.n_classifier, 1);
+	if (int rc = m->ws_planes.reserve((size_t)std::max(m->geno_rows, 1) * n_pad * sizeof(uint32_t))) return rc;
+	if (int rc = m->ws_cw.reserve(C * n_pad * sizeof(double))) return rc;
+	if (int rc = m->ws_tot.reserve(C * n_pad * sizeof(double))) return rc;
+	if (int rc = m->ws_inv.reserve(C * n_pad * sizeof(double))) return rc;
+	if (int rc = m->ws_part.reserve((size_t)(m->view.n_cell + 3) * n_pad * sizeof(double))) return rc;
+	if (need_best)
+		if (int rc = m->ws_best.reserve(C * n_pad * sizeof(int))) return rc;
+	B.n_samp = n_samp; B.n_pad = n_pad;
+	B.planes = m->ws_planes.as<uint32_t>();
+	B.cw = m->ws_cw.as<double>(); B.tot = m->ws_tot.as<double>(); B.inv = m->ws_inv.as<double>();
+	B.part = m->ws_part.as<double>();
+	return 0;
+}
+
+// Passes 1 and 2 (+ majority-vote variant) and the ensemble scalars for a
+// batch whose planes / weights are already on the device.
+void run_core(hibag_hip_model *m, HibagBatchView &B, int vote_method, double *d_part, hipStream_t st)
+{
+	KernelTimer &T = m->timer;
+	B.part = d_part;
+	T.begin(HIBAG_HIP_K_TOTAL, st);
+	hibag_launch_total(m->view, B, st);
+	T.end(st);
+	T.begin(HIBAG_HIP_K_ACCUM, st);
+	if (vote_method == 1) {
+		hibag_launch_accum(m->view, B, st);
+		hibag_launch_scalars(m->view, B, nullptr, st);
+	} else {
+		hibag_launch_vote(m->view, B, m->ws_best.as<int>(), st);
+		hibag_launch_scalars(m->view, B, m->ws_best.as<int>(), st);
+	}
+	T.end(st);
+}
+
+int check_predict_args(hibag_hip_model *m, const void *geno, int n_samp, int vote_method,
+	const void *H1, const void *H2)
+{
+	if (!m) return fail(HIBAG_HIP_EINVAL, "model is NULL");
+	if (!m->finalized) return fail(HIBAG_HIP_ESTATE, "model not finalized");
+	if (vote_method < 1 || vote_method > 2)
+		return fail(HIBAG_HIP_EINVAL, "Invalid 'vote_method'.");   // src/LibHLA.cpp:2321-2322
+	if (n_samp < 0) return fail(HIBAG_HIP_EINVAL, "n_samp < 0");
+	if (n_samp > 0 && !geno) return fail(HIBAG_HIP_EINVAL, "geno is NULL");
+	if ((H1 == nullptr) != (H2 == nullptr)) return fail(HIBAG_HIP_EINVAL, "H1 and H2 must be given together");
+	if (!m->have_snpidx)
+		return fail(HIBAG_HIP_ESTATE, "model was built without SNP indices (plugin path): raw genotypes cannot be packed");
+	return 0;
+}
+
+int predict_device_locked(hibag_hip_model *m, const int32_t *d_geno, int n_samp, int vote_method,
+	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching, double *d_dosage,
+	double *d_postprob, hipStream_t st)
+{
+	HIP_TRY(hipSetDevice(m->device));
+	const int lim = batch_limit(m);
+	const size_t P = (size_t)m->view.n_cell;
+	for (int s0 = 0; s0 < n_samp; s0 += lim) {
+		const int n = std::min(lim, n_samp - s0);
+		HibagBatchView B;
+		if (int rc = make_batch(m, n, vote_method == 2, B)) return rc;
+		m->timer.begin(HIBAG_HIP_K_PACK, st);
+		hibag_launch_pack(m->view, B, d_geno + (size_t)s0 * m->n_snp, st);
+		m->timer.end(st);
+		run_core(m, B, vote_method, m->ws_part.as<double>(), st);
+		m->timer.begin(HIBAG_HIP_K_FINISH, st);
+		hibag_launch_finish(m->view, B, B.part,
+			d_H1 ? d_H1 + s0 : nullptr, d_H2 ? d_H2 + s0 : nullptr,
+			d_max_prob ? d_max_prob + s0 : nullptr, d_matching ? d_matching + s0 : nullptr,
+			d_dosage ? d_dosage + (size_t)s0 * m->n_hla : nullptr,
+			d_postprob ? d_postprob + (size_t)s0 * P : nullptr, st);
+		m->timer.end(st);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+} // namespace
+
+// ===========================================================================
+// C ABI
+
+extern "C" {
+
+int hibag_hip_abi_version(void) { return HIBAG_HIP_ABI_VERSION; }
+
+const char *hibag_hip_last_error(void) { return g_last_error.c_str(); }
+
+int hibag_hip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return n;
+}
+
+int hibag_hip_set_device(int device)
+{
+	const int n = hibag_hip_device_count();
+	if (device < 0 || device >= n)
+		return fail(HIBAG_HIP_ENODEV, "HIP device %d not available (%d visible)", device, n);
+	g_device = device;
+	return 0;
+}
+
+int hibag_hip_set_kernel_target(const char *target, char *info, size_t info_len)
+{
+	if (!target || strcmp(target, "hip") != 0)
+		return fail(HIBAG_HIP_EINVAL, "this library implements the kernel target \"hip\" only (got \"%s\")",
+			target ? target : "(null)");
+	const int n = hibag_hip_device_count();
+	if (n <= 0 || g_device >= n) return fail(HIBAG_HIP_ENODEV, "no HIP device available");
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return fail(HIBAG_HIP_ENODEV, "device %d is %s; the kernels are built for gfx950 only", g_device, prop.gcnArchName);
+	if (info && info_len)
+		snprintf(info, info_len, "HIP, %s, %s, %d CUs", prop.gcnArchName, prop.name, prop.multiProcessorCount);
+	return 0;
+}
+
+hibag_hip_model *hibag_hip_model_new(int n_hla, int n_snp)
+{
+	if (n_hla <= 0 || n_hla > 46340 || n_snp < 0) {
+		fail(HIBAG_HIP_EINVAL, "invalid model dimensions (n_hla=%d, n_snp=%d)", n_hla, n_snp);
+		return nullptr;
+	}
+	hibag_hip_model *m = new (std::nothrow) hibag_hip_model;
+	if (!m) { fail(HIBAG_HIP_ENOMEM, "out of host memory"); return nullptr; }
+	m->device = g_device;
+	m->n_hla = n_hla;
+	m->n_snp = n_snp;
+	build_table(m->tab);
+	return m;
+}
+
+int hibag_hip_model_add_classifier(hibag_hip_model *m, int n_snp_c, const int32_t *snpidx,
+	int n_haplo, const double *freq, const int32_t *hla, const char *const *haplo)
+{
+	if (int rc = check_classifier_args(m, n_snp_c, snpidx, n_haplo, freq, hla)) return rc;
+	if (n_snp_c > 0 && !snpidx) return fail(HIBAG_HIP_EINVAL, "snpidx is NULL");
+	if (n_haplo > 0 && !haplo) return fail(HIBAG_HIP_EINVAL, "haplo is NULL");
+	std::vector<uint64_t> bits((size_t)n_haplo * 2, 0);
+	for (int i = 0; i < n_haplo; i++) {
+		const char *s = haplo[i];
+		const size_t len = s ? strlen(s) : 0;
+		if (len > HIBAG_HIP_MAX_SNP_IN_CLASSIFIER)   // src/LibHLA.cpp:328-329
+			return fail(HIBAG_HIP_EINVAL, "THaplotype::StrToHaplo, the input string is too long.");
+		if ((int)len != n_snp_c)
+			return fail(HIBAG_HIP_EINVAL, "haplotype %d has %zu alleles, expected %d", i, len, n_snp_c);
+		for (size_t j = 0; j < len; j++) {
+			if (s[j] == '1') bits[2 * (size_t)i + (j >> 6)] |= (uint64_t)1 << (j & 63);
+			else if (s[j] != '0')                    // src/LibHLA.cpp:333-334
+				return fail(HIBAG_HIP_EINVAL, "THaplotype::StrToHaplo, the input string should be '0' or '1'");
+		}
+	}
+	push_classifier(m, n_snp_c, snpidx, n_haplo, freq, hla, std::move(bits));
+	return 0;
+}
+
+int hibag_hip_model_add_classifier_packed(hibag_hip_model *m, int n_snp_c, const int32_t *snpidx,
+	int n_haplo, const double *freq, const int32_t *hla, const uint64_t *bits_in)
+{
+	if (int rc = check_classifier_args(m, n_snp_c, snpidx, n_haplo, freq, hla)) return rc;
+	if (n_haplo > 0 && !bits_in) return fail(HIBAG_HIP_EINVAL, "bits is NULL");
+	// clear bits >= n_snp_c: the reference leaves them uninitialised (src/LibHLA.cpp:287-292)
+	uint64_t mask[2];
+	for (int w = 0; w < 2; w++) {
+		const int lo = 64 * w;
+		mask[w] = n_snp_c >= lo + 64 ? ~(uint64_t)0 : (n_snp_c <= lo ? 0 : (((uint64_t)1 << (n_snp_c - lo)) - 1));
+	}
+	std::vector<uint64_t> bits((size_t)n_haplo * 2);
+	for (int i = 0; i < n_haplo; i++)
+		for (int w = 0; w < 2; w++) bits[2 * (size_t)i + w] = bits_in[2 * (size_t)i + w] & mask[w];
+	push_classifier(m, n_snp_c, snpidx, n_haplo, freq, hla, std::move(bits));
+	return 0;
+}
+
+int hibag_hip_model_set_snp_weights(hibag_hip_model *m, const int32_t *snp_weight)
+{
+	if (!m || !snp_weight) return fail(HIBAG_HIP_EINVAL, "NULL argument");
+	if (m->finalized) return fail(HIBAG_HIP_ESTATE, "model already finalized");
+	m->snp_weight_override.assign(snp_weight, snp_weight + std::max(m->n_snp, 1));
+	return 0;
+}
+
+int hibag_hip_model_finalize(hibag_hip_model *m)
+{
+	if (!m) return fail(HIBAG_HIP_EINVAL, "model is NULL");
+	std::lock_guard<std::mutex> g(m->lock);
+	return finalize_model(m);
+}
+
+void hibag_hip_model_free(hibag_hip_model *m) { delete m; }
+
+int hibag_hip_model_n_hla(const hibag_hip_model *m) { return m ? m->n_hla : 0; }
+int hibag_hip_model_n_snp(const hibag_hip_model *m) { return m ? m->n_snp : 0; }
+int hibag_hip_model_n_classifier(const hibag_hip_model *m) { return m ? (int)m->cls.size() : 0; }
+
+int64_t hibag_hip_model_pair_evals(const hibag_hip_model *m)
+{
+	if (!m) return 0;
+	int64_t n = 0;
+	for (const auto &c : m->cls) n += (int64_t)c.freq.size() * ((int64_t)c.freq.size() + 1) / 2;
+	return n;
+}
+
+int hibag_hip_model_mutation_table(const hibag_hip_model *m, double *out)
+{
+	if (!m || !out) return fail(HIBAG_HIP_EINVAL, "NULL argument");
+	memcpy(out, m->tab, sizeof(m->tab));
+	return 0;
+}
+
+int hibag_hip_predict_device(hibag_hip_model *m, const int32_t *d_geno, int n_samp, int vote_method,
+	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching, double *d_dosage,
+	double *d_postprob, void *stream)
+{
+	if (int rc = check_predict_args(m, d_geno, n_samp, vote_method, d_H1, d_H2)) return rc;
+	std::lock_guard<std::mutex> g(m->lock);
+	return predict_device_locked(m, d_geno, n_samp, vote_method, d_H1, d_H2, d_max_prob, d_matching,
+		d_dosage, d_postprob, (hipStream_t)stream);
+}
+
+int hibag_hip_predict(hibag_hip_model *m, const int32_t *geno, int n_samp, int vote_method,
+	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob)
+{
+	if (int rc = check_predict_args(m, geno, n_samp, vote_method, H1, H2)) return rc;
+	if (n_samp == 0) return 0;
+	std::lock_guard<std::mutex> g(m->lock);
+	HIP_TRY(hipSetDevice(m->device));
+	const size_t P = (size_t)m->view.n_cell, nh = (size_t)m->n_hla, S = (size_t)m->n_snp;
+	// stage in slices so that the posterior matrix never needs more than a slice on the device
+	const int slice = batch_limit(m);
+	const size_t geno_bytes = (size_t)slice * std::max<size_t>(S, 1) * sizeof(int32_t);
+	const size_t o_h1 = 0, o_h2 = o_h1 + (size_t)slice * 4, o_mp = (o_h2 + (size_t)slice * 4 + 7) / 8 * 8,
+		o_mt = o_mp + (size_t)slice * 8, o_ds = o_mt + (size_t)slice * 8, o_pp = o_ds + (size_t)slice * nh * 8,
+		out_bytes = o_pp + (postprob ? (size_t)slice * P * 8 : 0);
+	if (int rc = m->ws_geno.reserve(geno_bytes)) return rc;
+	if (int rc = m->ws_out.reserve(out_bytes)) return rc;
+	char *o = m->ws_out.as<char>();
+	for (int s0 = 0; s0 < n_samp; s0 += slice) {
+		const int n = std::min(slice, n_samp - s0);
+		HIP_TRY(hipMemcpyAsync(m->ws_geno.p, geno + (size_t)s0 * S, (size_t)n * S * sizeof(int32_t),
+			hipMemcpyHostToDevice, 0));
+		if (int rc = predict_device_locked(m, m->ws_geno.as<int32_t>(), n, vote_method,
+				H1 ? (int32_t *)(o + o_h1) : nullptr, H2 ? (int32_t *)(o + o_h2) : nullptr,
+				max_prob ? (double *)(o + o_mp) : nullptr, matching ? (double *)(o + o_mt) : nullptr,
+				dosage ? (double *)(o + o_ds) : nullptr, postprob ? (double *)(o + o_pp) : nullptr, 0))
+			return rc;
+		if (H1) {
+			HIP_TRY(hipMemcpyAsync(H1 + s0, o + o_h1, (size_t)n * 4, hipMemcpyDeviceToHost, 0));
+			HIP_TRY(hipMemcpyAsync(H2 + s0, o + o_h2, (size_t)n * 4, hipMemcpyDeviceToHost, 0));
+		}
+		if (max_prob) HIP_TRY(hipMemcpyAsync(max_prob + s0, o + o_mp, (size_t)n * 8, hipMemcpyDeviceToHost, 0));
+		if (matching) HIP_TRY(hipMemcpyAsync(matching + s0, o + o_mt, (size_t)n * 8, hipMemcpyDeviceToHost, 0));
+		if (dosage) HIP_TRY(hipMemcpyAsync(dosage + (size_t)s0 * nh, o + o_ds, (size_t)n * nh * 8, hipMemcpyDeviceToHost, 0));
+		if (postprob) HIP_TRY(hipMemcpyAsync(postprob + (size_t)s0 * P, o + o_pp, (size_t)n * P * 8, hipMemcpyDeviceToHost, 0));
+		HIP_TRY(hipStreamSynchronize(0));
+	}
+	return 0;
+}
+
+int hibag_hip_predict_partial_device(hibag_hip_model *m, const int32_t *d_geno, int n_samp,
+	double *d_partial, void *stream)
+{
+	if (int rc = check_predict_args(m, d_geno, n_samp, 1, nullptr, nullptr)) return rc;
+	if (!d_partial) return fail(HIBAG_HIP_EINVAL, "d_partial is NULL");
+	if (n_samp > batch_limit(m))
+		return fail(HIBAG_HIP_EINVAL, "n_samp %d exceeds the batch limit %d of the partial entry", n_samp, batch_limit(m));
+	if (n_samp == 0) return 0;
+	std::lock_guard<std::mutex> g(m->lock);
+	HIP_TRY(hipSetDevice(m->device));
+	hipStream_t st = (hipStream_t)stream;
+	HibagBatchView B;
+	if (int rc = make_batch(m, n_samp, false, B)) return rc;
+	m->timer.begin(HIBAG_HIP_K_PACK, st);
+	hibag_launch_pack(m->view, B, d_geno, st);
+	m->timer.end(st);
+	run_core(m, B, 1, d_partial, st);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int hibag_hip_finish_device(hibag_hip_model *m, const double *d_partial, int n_samp,
+	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching, double *d_dosage,
+	double *d_postprob, void *stream)
+{
+	if (!m || !m->finalized) return fail(HIBAG_HIP_ESTATE, "model not finalized");
+	if (!d_partial) return fail(HIBAG_HIP_EINVAL, "d_partial is NULL");
+	if ((d_H1 == nullptr) != (d_H2 == nullptr)) return fail(HIBAG_HIP_EINVAL, "H1 and H2 must be given together");
+	if (n_samp <= 0) return n_samp == 0 ? 0 : fail(HIBAG_HIP_EINVAL, "n_samp < 0");
+	std::lock_guard<std::mutex> g(m->lock);
+	HIP_TRY(hipSetDevice(m->device));
+	hipStream_t st = (hipStream_t)stream;
+	HibagBatchView B{};
+	B.n_samp = n_samp; B.n_pad = round_up(n_samp, HIBAG_WAVE);
+	m->timer.begin(HIBAG_HIP_K_FINISH, st);
+	hibag_launch_finish(m->view, B, (double *)d_partial, d_H1, d_H2, d_max_prob, d_matching, d_dosage, d_postprob, st);
+	m->timer.end(st);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+int hibag_hip_set_timing(hibag_hip_model *m, int enabled)
+{
+	if (!m) return fail(HIBAG_HIP_EINVAL, "model is NULL");
+	std::lock_guard<std::mutex> g(m->lock);
+	(void)hipSetDevice(m->device);
+	m->timer.resolve();
+	m->timer.enabled = enabled != 0;
+	return 0;
+}
+
+int hibag_hip_get_timing(hibag_hip_model *m, int k, double *ms_total, int64_t *launches)
+{
+	if (!m || k < 0 || k >= HIBAG_HIP_K_COUNT) return fail(HIBAG_HIP_EINVAL, "bad timing query");
+	std::lock_guard<std::mutex> g(m->lock);
+	(void)hipSetDevice(m->device);
+	m->timer.resolve();
+	if (ms_total) *ms_total = m->timer.ms[k];
+	if (launches) *launches = m->timer.n[k];
+	return 0;
+}
+
+int hibag_hip_reset_timing(hibag_hip_model *m)
+{
+	if (!m) return fail(HIBAG_HIP_EINVAL, "model is NULL");
+	std::lock_guard<std::mutex> g(m->lock);
+	(void)hipSetDevice(m->device);
+	m->timer.reset();
+	return 0;
+}
+
+} // extern "C"
+
+// ===========================================================================
+// HIBAG plugin table: layout-compatible with HLA_LIB::TypeGPUExtProc
+// (inst/include/LibHLA_ext.h:358-388).  The host calls predict_init once per
+// PredictHLA (src/LibHLA.cpp:2498-2523), predict_avg_prob once per sample with
+// nthread = 1 (:2433-2441) and predict_done from a destructor (:2525-2531).
+// A failure cannot be returned through these void signatures; like a C++
+// plugin would, it throws `const char *`, which the host's CORE_CATCH turns
+// into an R error (src/HIBAG.cpp:41-60).
+
+namespace {
+
+// Mirrors of the two packed POD types the host hands over (sizes 32 and 48).
+struct PluginHaplotype {            // THaplotype, LibHLA_ext.h:261-299
+	int64_t packed[2];
+	double freq;
+	struct { float freq_f32; int hla_allele; } aux;
+};
+struct PluginGenotype {             // TGenotype, LibHLA_ext.h:311-352
+	int64_t snp1[2], snp2[2];
+	int bootstrap_count, hla1, hla2, pad;
+};
+static_assert(sizeof(PluginHaplotype) == 32, "THaplotype must be 32 bytes");
+static_assert(sizeof(PluginGenotype) == 48, "TGenotype must be 48 bytes");
+
+hibag_hip_model *g_plugin_model = nullptr;
+thread_local char g_plugin_msg[600];
+
+[[noreturn]] void plugin_throw(const char *what)
+{
+	snprintf(g_plugin_msg, sizeof(g_plugin_msg), "HIBAG HIP plugin: %s: %s", what, hibag_hip_last_error());
+	throw (const char *)g_plugin_msg;
+}
+
+void plugin_predict_done()
+{
+	hibag_hip_model_free(g_plugin_model);
+	g_plugin_model = nullptr;
+}
+
+void plugin_predict_init(int n_hla, int n_classifier, const PluginHaplotype *const p_haplo[],
+	const int n_haplo[], const int n_snp[])
+{
+	plugin_predict_done();
+	hibag_hip_model *m = hibag_hip_model_new(n_hla, 0);
+	if (!m) plugin_throw("predict_init");
+	for (int c = 0; c < n_classifier; c++) {
+		const int H = n_haplo[c];
+		std::vector<double> freq(H);
+		std::vector<int32_t> hla(H);
+		std::vector<uint64_t> bits((size_t)H * 2);
+		for (int i = 0; i < H; i++) {
+			freq[i] = p_haplo[c][i].freq;
+			hla[i] = p_haplo[c][i].aux.hla_allele;       // filled by SetHaploAux_GPU, src/LibHLA.cpp:565-578
+			bits[2 * (size_t)i] = (uint64_t)p_haplo[c][i].packed[0];
+			bits[2 * (size_t)i + 1] = (uint64_t)p_haplo[c][i].packed[1];
+		}
+		if (hibag_hip_model_add_classifier_packed(m, n_snp[c], nullptr, H, freq.data(), hla.data(), bits.data())) {
+			hibag_hip_model_free(m);
+			plugin_throw("predict_init");
+		}
+	}
+	if (hibag_hip_model_finalize(m)) { hibag_hip_model_free(m); plugin_throw("predict_init"); }
+	g_plugin_model = m;
+}
+
+int plugin_avg_prob(hibag_hip_model *m, const PluginGenotype geno[], const double weight[],
+	double out_prob[], double out_match[])
+{
+	std::lock_guard<std::mutex> g(m->lock);
+	HIP_TRY(hipSetDevice(m->device));
+	const int C = m->view.n_classifier;
+	const size_t P = (size_t)m->view.n_cell;
+	HibagBatchView B;
+	if (int rc = make_batch(m, 1, false, B)) return rc;
+	if (int rc = m->ws_tgeno.reserve((size_t)std::max(C, 1) * sizeof(PluginGenotype))) return rc;
+	if (int rc = m->ws_weight.reserve((size_t)std::max(C, 1) * sizeof(double))) return rc;
+	if (int rc = m->ws_out.reserve((P + 1) * sizeof(double))) return rc;
+	hipStream_t st = 0;
+	HIP_TRY(hipMemcpyAsync(m->ws_tgeno.p, geno, (size_t)C * sizeof(PluginGenotype), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(m->ws_weight.p, weight, (size_t)C * sizeof(double), hipMemcpyHostToDevice, st));
+	hibag_launch_unpack_tgeno(m->view, B, m->ws_tgeno.as<uint64_t>(), m->ws_weight.as<double>(), st);
+	run_core(m, B, 1, m->ws_part.as<double>(), st);
+	double *d_out = m->ws_out.as<double>();
+	hibag_launch_finish(m->view, B, B.part, nullptr, nullptr, nullptr, d_out + P, nullptr, d_out, st);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(out_prob, d_out, P * sizeof(double), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(out_match, d_out + P, sizeof(double), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	return 0;
+}
+
+void plugin_predict_avg_prob(const PluginGenotype geno[], const double weight[],
+	double out_prob[], double out_match[])
+{
+	if (!g_plugin_model) { fail(HIBAG_HIP_ESTATE, "predict_init was not called"); plugin_throw("predict_avg_prob"); }
+	if (plugin_avg_prob(g_plugin_model, geno, weight, out_prob, out_match)) plugin_throw("predict_avg_prob");
+}
+
+struct PluginTable {                // TypeGPUExtProc, LibHLA_ext.h:358-388
+	void (*build_init)(int, int);
+	void (*build_done)();
+	void (*build_set_bootstrap)(const int[]);
+	uint32_t *(*build_haplomatch)(const PluginHaplotype[], const size_t[], int, const PluginGenotype[], size_t &);
+	void (*build_set_haplo_geno)(const PluginHaplotype[], int, const PluginGenotype[], int);
+	int (*build_acc_oob)();
+	double (*build_acc_ib)();
+	void (*predict_init)(int, int, const PluginHaplotype *const[], const int[], const int[]);
+	void (*predict_done)();
+	void (*predict_avg_prob)(const PluginGenotype[], const double[], double[], double[]);
+};
+
+const PluginTable g_plugin_table = {
+	nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+	plugin_predict_init, plugin_predict_done, plugin_predict_avg_prob,
+};
+
+} // namespace
+
+extern "C" const void *hibag_hip_gpu_ext_proc(void) { return &g_plugin_table; }

@@ -1,0 +1,21 @@
+// hibag_kernels.h -- launchers of the gfx950 kernels (hibag_kernels.hip).
+// All launchers enqueue on `st` and return; they never allocate or synchronise.
+#ifndef HIBAG_KERNELS_H_
+#define HIBAG_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hibag_device.h"
+
+void hibag_launch_pack(const HibagModelView &M, const HibagBatchView &B, const int32_t *d_geno, hipStream_t st);
+void hibag_launch_unpack_tgeno(const HibagModelView &M, const HibagBatchView &B, const uint64_t *d_tgeno,
+	const double *d_weight, hipStream_t st);
+void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st);
+void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStream_t st);
+void hibag_launch_vote(const HibagModelView &M, const HibagBatchView &B, int *d_best_cell, hipStream_t st);
+void hibag_launch_scalars(const HibagModelView &M, const HibagBatchView &B, const int *d_best_cell, hipStream_t st);
+void hibag_launch_finish(const HibagModelView &M, const HibagBatchView &B, double *d_part,
+	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching,
+	double *d_dosage, double *d_postprob, hipStream_t st);
+
+#endif

@@ -1,0 +1,321 @@
+"""Host-side mirror of the reference's R interface for the prediction path.
+
+Same names, argument meaning and error behaviour as the reference's
+``hlaSetKernelTarget`` (``R/HIBAG.R:1668-1674``), ``hlaModelFromObj`` /
+``hlaModelToObj`` (``R/HIBAG.R:1135-1178`` / ``:1041-1062``) and ``hlaPredict``
+(``R/HIBAG.R:481-818``); the compute goes through the C ABI of
+``libhibag_hip.so`` (``include/hibag_hip.h``) and nowhere else.
+
+R is not available on the GPU box, so the thin R layer is restated in Python
+(the reference itself has no Python).  PyTorch appears only where a caller
+hands over device tensors.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import sys
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import HibagHipError
+from .model import (NA_INTEGER, Classifier, HlaAttrBagObj, HlaSNPGeno)
+
+_TARGETS_CPU = ("max", "auto.avx2", "base", "sse2", "sse4", "avx", "avx2", "avx512f", "avx512bw",
+                "avx512vpopcnt")   # src/LibHLA.cpp:1279-1456, man/hlaSetKernelTarget.Rd
+_kernel_target: Optional[str] = None
+_kernel_info: str = ""
+
+
+def hlaSetKernelTarget(cpu: str = "hip") -> List[str]:
+    """Select the kernel target.  The reference accepts CPU instruction sets
+    (``src/LibHLA.cpp:1266-1475``); this build adds the value ``"hip"`` and
+    implements only that: the CPU names raise, as the reference does for a
+    target the build does not support (``Rf_error("Not support AVX2.")``)."""
+    global _kernel_target, _kernel_info
+    cpu = str(cpu)
+    if cpu != "hip":
+        if cpu in _TARGETS_CPU:
+            raise HibagHipError(_lib.lib().hibag_hip_set_kernel_target(cpu.encode(), None, 0),
+                                f"Not support {cpu.upper()}: hibag_amd implements the \"hip\" kernel target only.")
+        raise ValueError(f"'arg' should be one of \"hip\", {', '.join(repr(t) for t in _TARGETS_CPU)}")
+    buf = C.create_string_buffer(256)
+    _lib.check(_lib.lib().hibag_hip_set_kernel_target(b"hip", buf, len(buf)))
+    _kernel_target, _kernel_info = "hip", buf.value.decode()
+    return [_kernel_info]
+
+
+def _as_ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class HlaAttrBagClass:
+    """``hlaAttrBagClass``: an ``hlaAttrBagObj`` plus the native model handle
+    (the reference keeps an index into a handle table and frees it from a
+    finalizer, ``src/HIBAG.cpp:409-475``)."""
+
+    def __init__(self, obj: HlaAttrBagObj, device: Optional[int] = None,
+                 snp_weight: Optional[np.ndarray] = None):
+        L = _lib.lib()
+        self.obj = obj
+        self._h = None
+        if device is not None:
+            _lib.check(L.hibag_hip_set_device(int(device)))
+        h = L.hibag_hip_model_new(int(obj.n_hla), int(obj.n_snp))
+        if not h:
+            raise HibagHipError(-1, L.hibag_hip_last_error().decode())
+        self._h = C.c_void_p(h)
+        try:
+            for c in obj.classifiers:
+                strs = (C.c_char_p * len(c.haplo))(*[s.encode() for s in c.haplo])
+                _lib.check(L.hibag_hip_model_add_classifier(
+                    self._h, len(c.snpidx), _as_ptr(c.snpidx), len(c.freq), _as_ptr(c.freq), _as_ptr(c.hla), strs))
+            if snp_weight is not None:
+                sw = np.ascontiguousarray(snp_weight, np.int32)
+                if sw.shape != (obj.n_snp,):
+                    raise ValueError("snp_weight must have one entry per model SNP")
+                _lib.check(L.hibag_hip_model_set_snp_weights(self._h, _as_ptr(sw)))
+            _lib.check(L.hibag_hip_model_finalize(self._h))
+        except Exception:
+            self.close()
+            raise
+
+    # attribute access like the R list: model$hla.allele -> model.hla_allele
+    def __getattr__(self, name):
+        if name in ("obj", "_h"):
+            raise AttributeError(name)
+        return getattr(self.obj, name)
+
+    @property
+    def handle(self) -> C.c_void_p:
+        if self._h is None:
+            raise HibagHipError(-4, "the model has been closed")
+        return self._h
+
+    def close(self):
+        """``hlaClose`` (``R/HIBAG.R:1023-1035``)."""
+        if getattr(self, "_h", None) is not None:
+            _lib.lib().hibag_hip_model_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def pair_evals(self) -> int:
+        return int(_lib.lib().hibag_hip_model_pair_evals(self.handle))
+
+    def mutation_table(self) -> np.ndarray:
+        t = np.empty(257, np.float64)
+        _lib.check(_lib.lib().hibag_hip_model_mutation_table(self.handle, _as_ptr(t)))
+        return t
+
+    # --- timing of the kernels (HIP events on the launch stream) ---
+    def set_timing(self, enabled: bool = True):
+        _lib.check(_lib.lib().hibag_hip_set_timing(self.handle, int(bool(enabled))))
+
+    def reset_timing(self):
+        _lib.check(_lib.lib().hibag_hip_reset_timing(self.handle))
+
+    def get_timing(self) -> dict:
+        out = {}
+        for k, name in _lib.KERNEL_NAMES.items():
+            ms, n = C.c_double(0), C.c_int64(0)
+            _lib.check(_lib.lib().hibag_hip_get_timing(self.handle, k, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    # --- raw entry points -------------------------------------------------
+    def predict_raw(self, genomat: np.ndarray, vote_method: int = 1, want_dosage: bool = True,
+                    want_prob: bool = False) -> dict:
+        """``CAttrBag_Model::PredictHLA`` on host arrays: ``genomat`` int32 [n_samp, n_snp]."""
+        g = np.ascontiguousarray(genomat, np.int32)
+        if g.ndim != 2 or g.shape[1] != self.obj.n_snp:
+            raise ValueError("genomat must be [n_samp, n.snp] int32")
+        n = g.shape[0]
+        out = dict(h1=np.zeros(n, np.int32), h2=np.zeros(n, np.int32),
+                   prob=np.zeros(n, np.float64), matching=np.zeros(n, np.float64))
+        if want_dosage:
+            out["dosage"] = np.zeros((n, self.obj.n_hla), np.float64)
+        if want_prob:
+            out["postprob"] = np.zeros((n, self.obj.n_cell), np.float64)
+        _lib.check(_lib.lib().hibag_hip_predict(
+            self.handle, _as_ptr(g), n, int(vote_method), _as_ptr(out["h1"]), _as_ptr(out["h2"]),
+            _as_ptr(out["prob"]), _as_ptr(out["matching"]), _as_ptr(out.get("dosage")), _as_ptr(out.get("postprob"))))
+        return out
+
+    def predict_device(self, d_geno, n_samp: int, vote_method: int = 1, d_h1=None, d_h2=None, d_prob=None,
+                       d_matching=None, d_dosage=None, d_postprob=None, stream=None):
+        """Device-pointer form; arguments are ints (``tensor.data_ptr()``) or None."""
+        def p(x):
+            return None if x is None else C.c_void_p(int(x))
+        _lib.check(_lib.lib().hibag_hip_predict_device(
+            self.handle, p(d_geno), int(n_samp), int(vote_method), p(d_h1), p(d_h2), p(d_prob), p(d_matching),
+            p(d_dosage), p(d_postprob), p(stream)))
+
+    def predict_partial_device(self, d_geno, n_samp: int, d_partial, stream=None):
+        def p(x):
+            return None if x is None else C.c_void_p(int(x))
+        _lib.check(_lib.lib().hibag_hip_predict_partial_device(self.handle, p(d_geno), int(n_samp), p(d_partial), p(stream)))
+
+    def finish_device(self, d_partial, n_samp: int, d_h1=None, d_h2=None, d_prob=None, d_matching=None,
+                      d_dosage=None, d_postprob=None, stream=None):
+        def p(x):
+            return None if x is None else C.c_void_p(int(x))
+        _lib.check(_lib.lib().hibag_hip_finish_device(
+            self.handle, p(d_partial), int(n_samp), p(d_h1), p(d_h2), p(d_prob), p(d_matching), p(d_dosage),
+            p(d_postprob), p(stream)))
+
+
+def hlaModelFromObj(obj: HlaAttrBagObj, device: Optional[int] = None) -> HlaAttrBagClass:
+    """``hlaModelFromObj`` (``R/HIBAG.R:1135-1178``)."""
+    if not isinstance(obj, HlaAttrBagObj):
+        raise TypeError("inherits(obj, \"hlaAttrBagObj\") is not TRUE")
+    return HlaAttrBagClass(obj, device)
+
+
+def hlaModelToObj(model: HlaAttrBagClass) -> HlaAttrBagObj:
+    """``hlaModelToObj`` (``R/HIBAG.R:1041-1062``)."""
+    if not isinstance(model, HlaAttrBagClass):
+        raise TypeError("inherits(model, \"hlaAttrBagClass\") is not TRUE")
+    return model.obj
+
+
+def hlaClose(model: HlaAttrBagClass) -> None:
+    model.close()
+
+
+@dataclass
+class HlaAlleleClass:
+    """``hlaAlleleClass`` as returned by ``hlaPredict`` (``R/HIBAG.R:729-748``)."""
+    locus: str
+    sample_id: List
+    allele1: List[Optional[str]]
+    allele2: List[Optional[str]]
+    prob: np.ndarray
+    matching: np.ndarray
+    assembly: str = "unknown"
+    dosage: Optional[np.ndarray] = None        # [n_hla, n_samp], rows = hla.allele
+    postprob: Optional[np.ndarray] = None      # [n_cell, n_samp], rows = pair_names
+    pair_names: List[str] = field(default_factory=list)
+    h1: Optional[np.ndarray] = None            # 0-based allele indices (NA = INT_MIN)
+    h2: Optional[np.ndarray] = None
+
+
+def _pair_names(alleles: Sequence[str]) -> List[str]:
+    # outer(a, a, paste, sep="/")[lower.tri(, diag=TRUE)] (R/HIBAG.R:746-747): column-major
+    # lower triangle = for h1, for h2 >= h1: a[h2]/a[h1] -- the posterior vector's order
+    return [f"{alleles[j]}/{alleles[i]}" for i in range(len(alleles)) for j in range(i, len(alleles))]
+
+
+def _snp_ids(obj, match_type: str) -> List:
+    """``hlaSNPID`` (``R/DataUtilities.R:512-524``)."""
+    pos = [None if p is None else (int(p) if float(p).is_integer() else float(p)) for p in (obj.snp_position if obj.snp_position is not None else [])]
+    if match_type == "Position":
+        return pos
+    if match_type == "Pos+Allele":
+        return [f"{p}-{a}" for p, a in zip(pos, obj.snp_allele)]
+    if match_type == "RefSNP+Position":
+        return [f"{i}-{p}" for i, p in zip(obj.snp_id, pos)]
+    if match_type == "RefSNP":
+        return list(obj.snp_id)
+    raise ValueError("'arg' should be one of \"Position\", \"Pos+Allele\", \"RefSNP+Position\", \"RefSNP\"")
+
+
+_TYPES = ("response+dosage", "response", "prob", "response+prob")
+_VOTES = ("prob", "majority")
+
+
+def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, np.ndarray], cl=False,
+               type: str = "response+dosage", vote: str = "prob", allele_check: bool = True,
+               match_type: str = "Position", same_strand: bool = False, verbose: bool = True,
+               verbose_match: bool = True):
+    """``hlaPredict`` (``R/HIBAG.R:481-818``).
+
+    ``snp`` is an :class:`HlaSNPGeno` or a numeric matrix [n.snp, n.samp] (or a
+    vector of length n.snp) laid out like the R argument.  ``cl`` is accepted
+    for signature compatibility; the device processes the whole batch at once,
+    so there is nothing to spread over threads or cluster nodes.
+    Returns :class:`HlaAlleleClass`, or for ``type="prob"`` the posterior matrix
+    [n_cell, n_samp] like the reference.
+    """
+    if not isinstance(object, HlaAttrBagClass):
+        raise TypeError("inherits(object, \"hlaAttrBagClass\") is not TRUE")
+    if type not in _TYPES:
+        raise ValueError("'arg' should be one of " + ", ".join(f'"{t}"' for t in _TYPES))
+    if vote not in _VOTES:
+        raise ValueError("'arg' should be one of \"prob\", \"majority\"")
+    vote_method = _VOTES.index(vote) + 1
+    obj = object.obj
+    out = sys.stdout
+
+    if verbose:
+        s = list(obj.hla_allele)
+        if len(s) > 3:
+            s = s[:3] + ["..."]
+        n_c = len(obj.classifiers)
+        print(f"HIBAG model for HLA-{obj.hla_locus}:\n    {n_c} individual classifier{'s' if n_c > 1 else ''}\n"
+              f"    {len(obj.snp_id)} SNPs\n    {obj.n_hla} unique HLA alleles: {', '.join(s)}", file=out)
+        print("Prediction:\n    " + ("based on the averaged posterior probabilities" if vote_method == 1
+                                      else "by voting from all individual classifiers"), file=out)
+
+    if not isinstance(snp, HlaSNPGeno):
+        g = np.asarray(snp)
+        if g.ndim == 1:
+            if g.shape[0] != obj.n_snp:
+                raise ValueError("length(snp) == object$n.snp is not TRUE")
+            g = g.reshape(-1, 1)
+        elif g.ndim != 2 or g.shape[0] != obj.n_snp:
+            raise ValueError("nrow(snp) == object$n.snp is not TRUE")
+        geno_sampid: List = list(range(1, g.shape[1] + 1))
+        assembly = "auto-silent"
+        mat = g
+    else:
+        from .snpmatch import match_snps_for_predict
+        mat, assembly = match_snps_for_predict(obj, snp, match_type, allele_check, same_strand,
+                                               verbose, verbose_match)
+        geno_sampid = list(snp.sample_id)
+
+    if mat.shape[0] != obj.n_snp:
+        raise ValueError("The number of SNPs is not valid, and it maybe due to duplicated 'snp.id' "
+                         "or incorrect dimension of genotype matrix.")
+    n_samp = mat.shape[1]
+    if verbose:
+        print(f"# of samples: {n_samp}", file=out)
+        print(f"Kernel target: {_kernel_info or 'hip'}", file=out)
+
+    # as.integer(snp): R's NA -> NA_integer_ ; the C side treats anything outside 0..2 as missing
+    if mat.dtype.kind == "f":
+        gi = np.where(np.isfinite(mat), mat, NA_INTEGER).astype(np.int64)
+    else:
+        gi = mat.astype(np.int64)
+    genomat = np.ascontiguousarray(gi.T.astype(np.int32))     # [n_samp, n_snp]
+
+    want_prob = type in ("prob", "response+prob")
+    want_dosage = type != "response"
+    rv = object.predict_raw(genomat, vote_method, want_dosage=want_dosage, want_prob=want_prob)
+
+    names = _pair_names(obj.hla_allele)
+    if type == "prob":
+        res = np.ascontiguousarray(rv["postprob"].T)
+        na_cnt = int(np.nansum(res.sum(axis=0) <= 0))
+    else:
+        def nm(ix):
+            return [None if int(k) == NA_INTEGER else obj.hla_allele[int(k)] for k in ix]
+        res = HlaAlleleClass(locus=obj.hla_locus, sample_id=geno_sampid, allele1=nm(rv["h1"]), allele2=nm(rv["h2"]),
+                             prob=rv["prob"], matching=rv["matching"], assembly=assembly,
+                             dosage=(np.ascontiguousarray(rv["dosage"].T) if type != "response" else None),
+                             postprob=(np.ascontiguousarray(rv["postprob"].T) if want_prob else None),
+                             pair_names=names if want_prob else [], h1=rv["h1"], h2=rv["h2"])
+        na_cnt = sum(1 for a, b in zip(res.allele1, res.allele2) if a is None or b is None)
+
+    if na_cnt > 0:   # R/HIBAG.R:811-815
+        import warnings
+        warnings.warn(f"No prediction output{'s' if na_cnt > 1 else ''} for {na_cnt} individual"
+                      f"{'s' if na_cnt > 1 else ''} (possibly due to missing SNPs).")
+    return res

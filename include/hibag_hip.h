@@ -1,0 +1,175 @@
+/*
+ * hibag_hip.h -- C ABI of libhibag_hip.so, the MI355X (gfx950) implementation
+ * of HIBAG's attribute-bagging prediction hot path.
+ *
+ * Plain C: pointers, sizes, int/double only.  No exception crosses this
+ * boundary: every entry returns 0 on success or a negative HIBAG_HIP_E* code,
+ * and hibag_hip_last_error() returns the message of the calling thread's last
+ * failure (the reference throws ErrHLA and turns it into Rf_error,
+ * src/HIBAG.cpp:41-60; a binding re-raises from the code + message).
+ *
+ * Each entry names the reference interface it replaces.  Paths are relative to
+ * the HIBAG source tree (zhengxwen/HIBAG, package 1.47.3, kernel 1.5).
+ */
+#ifndef HIBAG_HIP_H_
+#define HIBAG_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIBAG_HIP_ABI_VERSION 1
+
+/* error codes */
+#define HIBAG_HIP_OK          0
+#define HIBAG_HIP_EINVAL     (-1)  /* bad argument (message says which)            */
+#define HIBAG_HIP_ENODEV     (-2)  /* no usable HIP device / HIP runtime error     */
+#define HIBAG_HIP_ENOMEM     (-3)  /* host or device allocation failed             */
+#define HIBAG_HIP_ESTATE     (-4)  /* call order violated (e.g. predict before finalize) */
+
+/* R's NA_integer_: what H1/H2 hold when no allele pair has positive
+ * probability (src/LibHLA.cpp:1552), and the usual missing-genotype code. */
+#define HIBAG_HIP_NA_INTEGER (-2147483647 - 1)
+
+/* limits fixed by the reference's packed types */
+#define HIBAG_HIP_MAX_SNP_IN_CLASSIFIER 128   /* inst/include/LibHLA_ext.h:223 */
+
+typedef struct hibag_hip_model hibag_hip_model;  /* opaque handle */
+
+/* ---- library / device ---------------------------------------------------- */
+
+int hibag_hip_abi_version(void);
+
+/* Message of this thread's most recent failing call ("" if none). */
+const char *hibag_hip_last_error(void);
+
+/* Number of HIP devices visible to the process (0 if none / no driver). */
+int hibag_hip_device_count(void);
+
+/* Device used by models created afterwards on this thread (default 0). */
+int hibag_hip_set_device(int device);
+
+/* Kernel-target selection -- the extension of hlaSetKernelTarget()
+ * (R/HIBAG.R:1668-1674 -> HIBAG_Kernel_SetTarget, src/HIBAG.cpp:1430-1435 ->
+ * CAlg_Prediction::Init_Target_IFunc, src/LibHLA.cpp:1266-1475).  The
+ * reference accepts CPU names only; this library accepts exactly "hip" and
+ * fails (EINVAL) for anything else, and fails (ENODEV) when no gfx950 device is
+ * present -- there is no CPU fallback in this library.  On success writes a
+ * description such as "HIP, gfx950, AMD Instinct MI355X, 256 CUs" to `info`. */
+int hibag_hip_set_kernel_target(const char *target, char *info, size_t info_len);
+
+/* ---- model construction: replaces HIBAG_New + HIBAG_NewClassifierHaplo --- */
+
+/* HIBAG_New(n.samp, n.snp, n.hla) (src/HIBAG.cpp:486-503).  n_samp is only
+ * book-keeping in the reference (bootstrap counts) and is not needed here. */
+hibag_hip_model *hibag_hip_model_new(int n_hla, int n_snp);
+
+/* HIBAG_NewClassifierHaplo(model, snpidx-1, samp.num, freq, hla-1, haplo, acc)
+ * (src/HIBAG.cpp:817-841 -> CAttrBag_Classifier::Assign, src/LibHLA.cpp:2142-2165).
+ *   snpidx[n_snp_c]  0-based indices into the model's SNP list
+ *   freq[n_haplo], hla[n_haplo] (0-based, ascending -- haplotypes are grouped
+ *   by allele, src/HIBAG.cpp:915-924), haplo[n_haplo] strings of '0'/'1' of
+ *   length n_snp_c (char s <-> SNP snpidx[s]).
+ * Errors like the reference: more than 128 SNPs, characters other than 0/1. */
+int hibag_hip_model_add_classifier(hibag_hip_model *m, int n_snp_c,
+	const int32_t *snpidx, int n_haplo, const double *freq,
+	const int32_t *hla, const char *const *haplo);
+
+/* Same, from packed haplotypes: bits[2*i], bits[2*i+1] are the two 64-bit words
+ * of THaplotype::PackedHaplo (inst/include/LibHLA_ext.h:261-299); bits at
+ * positions >= n_snp_c are ignored. */
+int hibag_hip_model_add_classifier_packed(hibag_hip_model *m, int n_snp_c,
+	const int32_t *snpidx, int n_haplo, const double *freq,
+	const int32_t *hla, const uint64_t *bits);
+
+/* Build the device tables (haplotype SoA, cell schedule, mutation table) and
+ * upload them.  Must be called once after the last add_classifier. */
+int hibag_hip_model_finalize(hibag_hip_model *m);
+
+void hibag_hip_model_free(hibag_hip_model *m);
+
+/* queries */
+int hibag_hip_model_n_hla(const hibag_hip_model *m);
+int hibag_hip_model_n_snp(const hibag_hip_model *m);
+int hibag_hip_model_n_classifier(const hibag_hip_model *m);
+/* sum over classifiers of H_c(H_c+1)/2: haplotype-pair evaluations per sample */
+int64_t hibag_hip_model_pair_evals(const hibag_hip_model *m);
+/* the 257-entry mutation/error table the device uses, exp(d*log(1e-5))
+ * (src/LibHLA.cpp:166-183); out[257] */
+int hibag_hip_model_mutation_table(const hibag_hip_model *m, double *out);
+
+/* ---- prediction: replaces CAttrBag_Model::PredictHLA -------------------- */
+
+/* CAttrBag_Model::PredictHLA (src/LibHLA.cpp:2317-2412) as reached from
+ * HIBAG_Predict_Resp / _Dosage / _Resp_Prob (src/HIBAG.cpp:649-803).
+ *   geno        int32 [n_samp][n_snp], sample-major (the memory of the R SNP x
+ *               sample matrix); values outside 0..2 (incl. NA_integer_) = missing
+ *   vote_method 1 = average posteriors, 2 = majority vote; else EINVAL with the
+ *               reference's message "Invalid 'vote_method'."
+ * Outputs (any may be NULL; H1 and H2 only together):
+ *   H1,H2[n_samp]        0-based allele indices or NA_integer_
+ *   max_prob[n_samp]     posterior of the called pair (0 if NA)
+ *   matching[n_samp]     weighted mean of the pre-normalisation totals
+ *   dosage[n_samp][n_hla]
+ *   postprob[n_samp][n_hla(n_hla+1)/2]   pair order h1<=h2, h2 fastest
+ * Host-pointer form: copies geno to the device, runs, copies results back. */
+int hibag_hip_predict(hibag_hip_model *m, const int32_t *geno, int n_samp,
+	int vote_method, int32_t *H1, int32_t *H2, double *max_prob,
+	double *matching, double *dosage, double *postprob);
+
+/* Device-pointer form of the same call: every pointer is device memory on the
+ * model's device, work is enqueued on `stream` (a hipStream_t, NULL = default
+ * stream) and the call returns without synchronising. */
+int hibag_hip_predict_device(hibag_hip_model *m, const int32_t *d_geno, int n_samp,
+	int vote_method, int32_t *d_H1, int32_t *d_H2, double *d_max_prob,
+	double *d_matching, double *d_dosage, double *d_postprob, void *stream);
+
+/* Classifier-sharded partial pass for multi-GPU runs: each rank owns a model
+ * holding a subset of the classifiers but built with the FULL model's per-SNP
+ * classifier counts (snp_weight[n_snp], _GetSNPWeights src/LibHLA.cpp:2484-2496,
+ * which the classifier weights depend on).  Writes the un-normalised partial
+ * ensemble sums so that one sum all-reduce merges ranks:
+ *   d_partial [n_hla(n_hla+1)/2 + 3][n_pad]  (n_pad = n_samp rounded up to 64):
+ *   rows 0..P-1 sum_c w_c*prob_c, row P sum_c w_c, row P+1 sum_c w_c*total_c,
+ *   row P+2 unused.  hibag_hip_finish_device() turns merged partials into the
+ *   PredictHLA outputs. */
+int hibag_hip_model_set_snp_weights(hibag_hip_model *m, const int32_t *snp_weight);
+int hibag_hip_predict_partial_device(hibag_hip_model *m, const int32_t *d_geno,
+	int n_samp, double *d_partial, void *stream);
+int hibag_hip_finish_device(hibag_hip_model *m, const double *d_partial, int n_samp,
+	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching,
+	double *d_dosage, double *d_postprob, void *stream);
+
+/* ---- kernel timing (HIP events on the launch stream) --------------------- */
+
+#define HIBAG_HIP_K_PACK     0   /* genotype packing + classifier weights        */
+#define HIBAG_HIP_K_TOTAL    1   /* pass 1: per-classifier in-order totals       */
+#define HIBAG_HIP_K_ACCUM    2   /* pass 2: normalised weighted accumulation     */
+#define HIBAG_HIP_K_FINISH   3   /* arg-max, dosage, transposed posterior output */
+#define HIBAG_HIP_K_COUNT    4
+
+/* When enabled every kernel launch is bracketed by hipEvents on its stream. */
+int hibag_hip_set_timing(hibag_hip_model *m, int enabled);
+/* Resolves pending events (synchronises on them) and returns, for kernel `k`,
+ * the summed duration in ms and the number of launches since the last reset. */
+int hibag_hip_get_timing(hibag_hip_model *m, int k, double *ms_total, int64_t *launches);
+int hibag_hip_reset_timing(hibag_hip_model *m);
+
+/* ---- HIBAG plugin table (per-sample, drop-in for an unmodified HIBAG) ---- */
+
+/* Returns a pointer to a static struct laid out exactly like
+ * HLA_LIB::TypeGPUExtProc (inst/include/LibHLA_ext.h:358-388): ten function
+ * pointers.  predict_init / predict_done / predict_avg_prob are implemented
+ * (src/LibHLA.cpp:2498-2531, :2433-2441); the seven build_* entries are NULL
+ * (the host NULL-checks each one, e.g. src/LibHLA.cpp:2258, :2290, :1916).
+ * An R package hands it to hlaPredict() as attr(cl, "proc_ptr")
+ * (R/HIBAG.R:707); see INTEGRATION.md. */
+const void *hibag_hip_gpu_ext_proc(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIBAG_HIP_H_ */

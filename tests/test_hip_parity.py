@@ -1,0 +1,258 @@
+"""GPU parity: the HIP path (through the C ABI of libhibag_hip.so) against the
+CPU oracle on the same inputs, against values stored by the reference in its
+own fixtures, and -- at BASELINE.json's full size -- through size-independent
+properties.  Integer outputs (allele calls) and every double are required to be
+BIT-IDENTICAL; the north star only asks for 1e-10 relative on posteriors, the
+kernels are exact by construction so the tests hold them to that.
+"""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import align_geno
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("h1", "h2", "prob", "matching", "dosage", "postprob")
+
+
+@pytest.fixture(scope="module")
+def hib():
+    import hibag_amd
+    info = hibag_amd.hlaSetKernelTarget("hip")
+    assert "gfx950" in info[0]
+    return hibag_amd
+
+
+def assert_same(got, want, keys=KEYS):
+    for k in keys:
+        a, b = got[k], want[k]
+        assert a.shape == b.shape, k
+        if not np.array_equal(a, b, equal_nan=True):
+            bad = np.argwhere(~((a == b) | (np.isnan(a) & np.isnan(b)))) if a.dtype.kind == "f" else np.argwhere(a != b)
+            i = tuple(bad[0])
+            raise AssertionError(f"{k}: {len(bad)} entries differ, first at {i}: hip={a[i]!r} oracle={b[i]!r}")
+
+
+def test_kernel_target_selection(hib):
+    # the reference errors for a target the build lacks (src/LibHLA.cpp:1374-1375 etc.)
+    with pytest.raises(hib.HibagHipError):
+        hib.hlaSetKernelTarget("avx2")
+    with pytest.raises(ValueError):
+        hib.hlaSetKernelTarget("cuda")
+
+
+@pytest.mark.parametrize("vote", [1, 2])
+@pytest.mark.parametrize("which", ["a", "oob"])
+def test_bundled_hla_a_model_hapmap(hib, oracle, hapmap_geno, model_a, model_oob, which, vote):
+    """BASELINE config 1: bundled HLA-A model x the 60 HapMap CEU samples."""
+    model = model_a if which == "a" else model_oob
+    G = align_geno(model, hapmap_geno, hapmap_geno.sample_id)
+    want = oracle.predict(oracle.flatten(model), G, vote_method=vote)
+    got = hib.hlaModelFromObj(model).predict_raw(G, vote, want_dosage=True, want_prob=True)
+    assert_same(got, want)
+
+
+def test_matching_stored_by_the_reference(hib, hapmap_geno, model_oob):
+    """`matching` written by the reference's own hlaPredict() into OutOfBag.RData."""
+    G = align_geno(model_oob, hapmap_geno)
+    got = hib.hlaModelFromObj(model_oob).predict_raw(G, 1, want_dosage=False)
+    complete = np.array([np.all((g >= 0) & (g <= 2)) for g in G])
+    assert complete.sum() == 27
+    assert np.array_equal(got["matching"][complete], model_oob.matching[complete])
+
+
+def test_knocked_out_snps_change_classifier_weights(hib, oracle, hapmap_geno, model_a):
+    G = align_geno(model_a, hapmap_geno, hapmap_geno.sample_id).copy()
+    rng = np.random.default_rng(7)
+    G[:, rng.choice(G.shape[1], 120, replace=False)] = hib.NA_INTEGER     # whole SNPs gone
+    G[rng.random(G.shape) < 0.05] = -1                                      # scattered, other missing code
+    G[3, :] = 3                                                             # out-of-range value = missing
+    want = oracle.predict(oracle.flatten(model_a), G)
+    got = hib.hlaModelFromObj(model_a).predict_raw(G, 1, want_dosage=True, want_prob=True)
+    assert_same(got, want)
+    assert got["h1"][3] == hib.NA_INTEGER and got["prob"][3] == 0 and np.isnan(got["matching"][3])
+
+
+@pytest.mark.parametrize("shape,n", [("hla-a-small", 200), ("hla-b", 192), ("hla-drb1", 64)])
+@pytest.mark.parametrize("vote", [1, 2])
+def test_synthetic_models(hib, oracle, shape, n, vote):
+    from hibag_amd import synth
+    model, founders, af = synth.make_model(shape)
+    G, _ = synth.make_samples(founders, af, n)
+    G[1, :] = hib.NA_INTEGER
+    want = oracle.predict(oracle.flatten(model), G, vote_method=vote, avx2=True, n_threads=8)
+    got = hib.hlaModelFromObj(model).predict_raw(G, vote, want_dosage=True, want_prob=True)
+    assert_same(got, want)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 130])
+def test_ragged_batch_sizes(hib, oracle, n):
+    from hibag_amd import synth
+    model, founders, af = synth.make_model("hla-a-small", n_classifier=6)
+    G, _ = synth.make_samples(founders, af, max(n, 1))
+    G = G[:n]
+    got = hib.hlaModelFromObj(model).predict_raw(G, 1, want_dosage=True, want_prob=True)
+    want = oracle.predict(oracle.flatten(model), G)
+    assert_same(got, want)
+
+
+def test_underflow_gives_nan_like_the_reference(hib, oracle):
+    """A classifier whose every pair is >= 65 mismatches away has total 0, so
+    1/total = inf and 0*inf = NaN poisons the whole sample (src/LibHLA.cpp:1826-1828)."""
+    from hibag_amd.model import Classifier, HlaAttrBagObj
+    k = 100
+    far = Classifier(np.arange(k), [0.5, 0.5], [0, 1], ["1" * k, "1" * k])
+    near = Classifier(np.arange(4), [0.3, 0.3, 0.4], [0, 1, 2], ["0000", "0101", "1111"])
+    model = HlaAttrBagObj(0, k, ["a", "b", "c"], [near, far])
+    G = np.zeros((3, k), np.int32)        # all homozygous B: 2 mismatches per SNP against "111..."
+    G[1, 40:] = hib.NA_INTEGER            # 40 typed SNPs -> 80 mismatches: exact zero; sample 2 sees neither
+    G[2, :] = hib.NA_INTEGER
+    want = oracle.predict(oracle.flatten(model), G)
+    assert np.isnan(want["postprob"][0]).all() and want["h1"][0] == hib.NA_INTEGER
+    got = hib.hlaModelFromObj(model).predict_raw(G, 1, want_dosage=True, want_prob=True)
+    assert_same(got, want)
+    got2 = hib.hlaModelFromObj(model).predict_raw(G, 2, want_dosage=True, want_prob=True)
+    assert_same(got2, oracle.predict(oracle.flatten(model), G, vote_method=2))
+
+
+def test_empty_alleles_and_single_haplotype(hib, oracle):
+    from hibag_amd.model import Classifier, HlaAttrBagObj
+    c1 = Classifier([2, 0], [1.0], [3], ["10"])                        # one haplotype, alleles 0-2,4 empty
+    c2 = Classifier([1], [0.25, 0.75], [0, 4], ["0", "1"])
+    model = HlaAttrBagObj(0, 3, list("abcde"), [c1, c2])
+    G = np.array([[0, 1, 2], [2, 2, 0], [1, 1, 1], [-1, 0, -1]], np.int32)
+    assert_same(hib.hlaModelFromObj(model).predict_raw(G, 1, True, True), oracle.predict(oracle.flatten(model), G))
+
+
+def test_invalid_vote_method_message(hib, model_a):
+    dev = hib.hlaModelFromObj(model_a)
+    with pytest.raises(hib.HibagHipError, match="Invalid 'vote_method'."):
+        dev.predict_raw(np.zeros((1, model_a.n_snp), np.int32), vote_method=3)
+
+
+def test_hlaPredict_interface(hib, oracle, hapmap_geno, model_a):
+    """The R-level call: SNPs matched by position, strands checked, R-shaped result."""
+    dev = hib.hlaModelFromObj(model_a)
+    res = hib.hlaPredict(dev, hapmap_geno, type="response+prob", match_type="RefSNP+Position", verbose=False)
+    G = align_geno(model_a, hapmap_geno, hapmap_geno.sample_id)
+    want = oracle.predict(oracle.flatten(model_a), G)
+    assert res.sample_id == hapmap_geno.sample_id
+    assert res.allele1 == [model_a.hla_allele[i] for i in want["h1"]]
+    assert res.allele2 == [model_a.hla_allele[i] for i in want["h2"]]
+    assert np.array_equal(res.prob, want["prob"]) and np.array_equal(res.matching, want["matching"])
+    assert np.array_equal(res.dosage, want["dosage"].T) and np.array_equal(res.postprob, want["postprob"].T)
+    assert res.pair_names[:3] == ["01:01/01:01", "02:01/01:01", "02:06/01:01"]
+    # a plain matrix (n.snp x n.samp) takes the other branch of hlaPredict
+    res2 = hib.hlaPredict(dev, G.T, type="response", verbose=False)
+    assert res2.allele1 == res.allele1 and res2.dosage is None
+    p = hib.hlaPredict(dev, G.T, type="prob", verbose=False)
+    assert np.array_equal(p, want["postprob"].T)
+
+
+# --- the HIBAG plugin table (TypeGPUExtProc), driven the way the host does --------------
+
+class _THaplotype(C.Structure):          # inst/include/LibHLA_ext.h:261-299
+    _fields_ = [("packed", C.c_int64 * 2), ("freq", C.c_double), ("freq_f32", C.c_float), ("hla", C.c_int)]
+
+
+class _TGenotype(C.Structure):           # inst/include/LibHLA_ext.h:311-352
+    _fields_ = [("s1", C.c_int64 * 2), ("s2", C.c_int64 * 2), ("boot", C.c_int), ("a1", C.c_int),
+                ("a2", C.c_int), ("pad", C.c_int)]
+
+
+class _Table(C.Structure):               # inst/include/LibHLA_ext.h:358-388
+    _fields_ = [(n, C.c_void_p) for n in ("build_init", "build_done", "build_set_bootstrap", "build_haplomatch",
+                                           "build_set_haplo_geno", "build_acc_oob", "build_acc_ib")] + [
+        ("predict_init", C.CFUNCTYPE(None, C.c_int, C.c_int, C.POINTER(C.POINTER(_THaplotype)),
+                                     C.POINTER(C.c_int), C.POINTER(C.c_int))),
+        ("predict_done", C.CFUNCTYPE(None)),
+        ("predict_avg_prob", C.CFUNCTYPE(None, C.POINTER(_TGenotype), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double)))]
+
+
+def test_plugin_table_per_sample_path(hib, oracle, hapmap_geno, model_a):
+    from hibag_amd import _lib
+    assert C.sizeof(_THaplotype) == 32 and C.sizeof(_TGenotype) == 48
+    tab = _Table.from_address(_lib.lib().hibag_hip_gpu_ext_proc())
+    assert all(getattr(tab, n) is None for n, _ in _Table._fields_[:7])       # build_* are NULL
+    fm = oracle.flatten(model_a)
+    G = align_geno(model_a, hapmap_geno, hapmap_geno.sample_id)[:8].copy()
+    G[2, ::3] = hib.NA_INTEGER
+    nC = fm.n_classifier
+    lists = []
+    for c in range(nC):                                  # what _Init_GPU_PredHLA hands over (src/LibHLA.cpp:2498-2523)
+        _, lens, bits, freq, _ = fm.classifier(c)
+        arr = (_THaplotype * len(freq))()
+        hla = np.repeat(np.arange(fm.n_hla), lens)
+        for i in range(len(freq)):
+            arr[i].packed[0] = int(bits[i, 0]) - (1 << 64 if bits[i, 0] >> 63 else 0)
+            arr[i].packed[1] = -1                        # garbage above n_snp, as the reference leaves it
+            arr[i].freq = freq[i]; arr[i].freq_f32 = freq[i]; arr[i].hla = int(hla[i])
+        lists.append(arr)
+    ptrs = (C.POINTER(_THaplotype) * nC)(*[C.cast(a, C.POINTER(_THaplotype)) for a in lists])
+    n_hap = (C.c_int * nC)(*[len(a) for a in lists])
+    n_snp = (C.c_int * nC)(*[int(v) for v in fm.n_snp_c])
+    tab.predict_init(fm.n_hla, nC, ptrs, n_hap, n_snp)
+    want = oracle.predict(fm, G)
+    sw = np.zeros(fm.n_snp_total, np.int32)
+    for c in model_a.classifiers:
+        sw[c.snpidx] += 1
+    P = fm.n_hla * (fm.n_hla + 1) // 2
+    for i in range(len(G)):                              # _PredictHLA's GPU branch (src/LibHLA.cpp:2418-2441)
+        geno = (_TGenotype * nC)()
+        wt = (C.c_double * nC)()
+        for c, cl in enumerate(model_a.classifiers):
+            s1, s2 = oracle.int_to_snp(G[i], cl.snpidx)
+            for w in range(2):
+                geno[c].s1[w] = int(s1[w]) - (1 << 64 if s1[w] >> 63 else 0)
+                geno[c].s2[w] = int(s2[w]) - (1 << 64 if s2[w] >> 63 else 0)
+            g = G[i][cl.snpidx]
+            ok = (g >= 0) & (g <= 2)
+            tot = int(sw[cl.snpidx].sum())
+            wt[c] = float(int(sw[cl.snpidx][ok].sum())) / tot if tot > 0 else 0.0
+        prob = (C.c_double * P)()
+        match = (C.c_double * 1)()
+        tab.predict_avg_prob(geno, wt, prob, match)
+        assert np.array_equal(np.frombuffer(prob, np.float64), want["postprob"][i], equal_nan=True), i
+        assert match[0] == want["matching"][i]
+    tab.predict_done()
+
+
+# --- BASELINE config 2 at full size: properties that do not need the oracle ------------
+
+def test_full_size_hla_b_properties(hib, oracle):
+    from hibag_amd import synth
+    model, founders, af = synth.make_model("hla-b")
+    N = 10_000
+    G, truth = synth.make_samples(founders, af, N)
+    dev = hib.hlaModelFromObj(model)
+    out = dev.predict_raw(G, 1, want_dosage=True, want_prob=True)
+    # (a classifier whose total underflows turns cells into inf/NaN like the reference; keep finite rows)
+    ok = (out["h1"] != hib.NA_INTEGER) & np.isfinite(out["postprob"]).all(axis=1)
+    assert ok.mean() > 0.99
+    # a posterior is a distribution; dosages of a diploid sum to 2
+    np.testing.assert_allclose(out["postprob"][ok].sum(axis=1), 1.0, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out["dosage"][ok].sum(axis=1), 2.0, rtol=0, atol=1e-12)
+    # the call is the first maximum of the posterior and `prob` is its value
+    p = out["postprob"][ok]
+    assert np.array_equal(p.max(axis=1), out["prob"][ok])
+    h1 = np.repeat(np.arange(model.n_hla), np.arange(model.n_hla, 0, -1))
+    h2 = np.concatenate([np.arange(i, model.n_hla) for i in range(model.n_hla)])
+    am = p.argmax(axis=1)
+    assert np.array_equal(h1[am], out["h1"][ok]) and np.array_equal(h2[am], out["h2"][ok])
+    # samples are independent: any permutation / any batch split gives the same bits per sample
+    perm = np.random.default_rng(3).permutation(N)
+    out_p = dev.predict_raw(G[perm], 1, want_dosage=True, want_prob=False)
+    for k in ("h1", "h2", "prob", "matching", "dosage"):
+        assert np.array_equal(out_p[k], out[k][perm], equal_nan=True), k
+    part = dev.predict_raw(G[1234:1301], 1, want_dosage=False, want_prob=True)
+    assert np.array_equal(part["postprob"], out["postprob"][1234:1301], equal_nan=True)
+    # samples drawn from the model are called correctly almost always
+    assert np.mean((out["h1"] == truth[:, 0]) & (out["h2"] == truth[:, 1])) > 0.97
+    # and a random subset agrees with the oracle to the last bit
+    sub = np.sort(np.random.default_rng(5).choice(N, 160, replace=False))
+    want = oracle.predict(oracle.flatten(model), G[sub], avx2=True, n_threads=8)
+    assert_same({k: v[sub] for k, v in out.items()}, want)

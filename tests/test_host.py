@@ -1,0 +1,130 @@
+"""CPU-only checks of the host logic: the C-ABI library loads and exports what
+include/hibag_hip.h declares, model-building errors follow the reference, the R
+workspace reader and the SNP matching / strand logic behave like the R code."""
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REFDATA, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from hibag_amd import _lib
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "hibag_hip.h")).read()
+    declared = set(re.findall(r"\b(hibag_hip_[a-z_0-9]+)\s*\(", hdr))
+    declared.discard("hibag_hip_model")      # the opaque struct tag
+    assert declared == set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.hibag_hip_abi_version() == 1
+
+
+def test_no_cpu_fallback_in_product():
+    """The product must not reach into oracle/ (checker only)."""
+    for d, _, files in os.walk(os.path.join(ROOT, "hibag_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                src = open(os.path.join(d, f), errors="replace").read()
+                assert "oracle" not in src.replace("the CPU oracle", ""), os.path.join(d, f)
+
+
+def test_model_building_errors_follow_the_reference():
+    from hibag_amd import _lib
+    L = _lib.lib()
+    err = lambda: L.hibag_hip_last_error().decode()
+    assert not L.hibag_hip_model_new(0, 10)
+    m = C.c_void_p(L.hibag_hip_model_new(3, 10))
+    i32 = lambda v: np.ascontiguousarray(v, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    f = np.array([0.5, 0.5])
+    strs = lambda *s: (C.c_char_p * len(s))(*[x.encode() for x in s])
+    # characters other than 0/1 (src/LibHLA.cpp:333-334)
+    assert L.hibag_hip_model_add_classifier(m, 2, p(i32([0, 1])), 2, p(f), p(i32([0, 1])), strs("01", "0x")) == -1
+    assert "should be '0' or '1'" in err()
+    # more than 128 SNPs (src/LibHLA.cpp:328-329, inst/include/LibHLA_ext.h:223)
+    assert L.hibag_hip_model_add_classifier(m, 129, p(i32(np.zeros(129))), 0, None, None, None) == -1
+    # alleles out of range / not grouped ascending (src/HIBAG.cpp:915-924 emits them grouped)
+    assert L.hibag_hip_model_add_classifier(m, 2, p(i32([0, 1])), 2, p(f), p(i32([0, 3])), strs("01", "00")) == -1
+    assert L.hibag_hip_model_add_classifier(m, 2, p(i32([0, 1])), 2, p(f), p(i32([1, 0])), strs("01", "00")) == -1
+    assert L.hibag_hip_model_add_classifier(m, 2, p(i32([0, 10])), 2, p(f), p(i32([0, 1])), strs("01", "00")) == -1
+    assert L.hibag_hip_model_add_classifier(m, 2, p(i32([0, 1])), 2, p(f), p(i32([0, 1])), strs("01", "00")) == 0
+    assert L.hibag_hip_model_n_classifier(m) == 1 and L.hibag_hip_model_pair_evals(m) == 3
+    # predicting before finalize is a state error, a bad vote_method carries the reference's text
+    g = i32(np.zeros((1, 10)))
+    assert L.hibag_hip_predict(m, p(g), 1, 1, None, None, None, None, None, None) == -4
+    tab = np.zeros(257)
+    assert L.hibag_hip_model_mutation_table(m, p(tab)) == 0 and tab[0] == 1 and tab[65] == 0
+    L.hibag_hip_model_free(m)
+    buf = C.create_string_buffer(64)
+    assert L.hibag_hip_set_kernel_target(b"avx2", buf, 64) == -1
+
+
+def test_mutation_table_matches_oracle(oracle):
+    from hibag_amd import _lib
+    L = _lib.lib()
+    m = C.c_void_p(L.hibag_hip_model_new(2, 1))
+    tab = np.zeros(257)
+    L.hibag_hip_model_mutation_table(m, tab.ctypes.data_as(C.c_void_p))
+    L.hibag_hip_model_free(m)
+    assert np.array_equal(tab, oracle.mutation_table())
+
+
+def test_rdata_reader_on_reference_fixtures(hapmap_geno, hla_type_table, model_a, model_oob):
+    assert hapmap_geno.genotype.shape == (1564, 60) and hapmap_geno.assembly == "hg19"
+    assert set(np.unique(hapmap_geno.genotype)) == {-2147483648, 0, 1, 2}
+    assert len(hla_type_table["sample.id"]) == 60 and hla_type_table["B.2"][2] is None      # NA_character_
+    for m, n in ((model_a, 60), (model_oob, 34)):
+        assert (m.n_samp, m.n_snp, m.n_hla, len(m.classifiers)) == (n, 266, 14, 100)
+        for c in m.classifiers:
+            assert len(c.haplo[0]) == len(c.snpidx) and c.snpidx.min() >= 0 and c.snpidx.max() < 266
+            assert np.all(np.diff(c.hla) >= 0) and abs(c.freq.sum() - 1) < 1e-9
+    assert model_a.pair_evals_per_sample() == 91645
+    assert model_oob.matching.shape == (34,) and model_a.matching is None
+
+
+def test_strand_logic():
+    from hibag_amd.snpmatch import allele_strand_flags
+    tpl = ["A/G", "A/G", "A/G", "A/G", "C/G", "C/G", "A/G", "A/T", "I/D", "I/D"]
+    tgt = ["A/G", "G/A", "T/C", "C/T", "C/G", "G/C", "A/C", "T/A", "I/D", "D/I"]
+    f1 = [0.2] * 10
+    f2 = [0.2, 0.8, 0.2, 0.8, 0.8, 0.2, 0.7, 0.3, 0.2, 0.8]
+    flip, amb, mis, swap = allele_strand_flags(tpl, f1, tgt, f2, same_strand=False)
+    #        same  swap  strand strand+swap  C/G amb(by freq)  mismatch(by freq)  A/T amb  indel same / swapped
+    assert flip.tolist() == [False, True, False, True, True, False, True, False, False, True]
+    assert (amb, mis, swap) == (3, 1, 2)
+    flip2, amb2, mis2, swap2 = allele_strand_flags(tpl[:4], f1[:4], tgt[:4], f2[:4], same_strand=True)
+    assert flip2.tolist() == [False, True, False, True] and (amb2, mis2, swap2) == (0, 2, 0)
+
+
+def test_snp_matching_subset_and_flip(model_a, hapmap_geno):
+    from hibag_amd.snpmatch import match_snps_for_predict
+    from hibag_amd.model import HlaSNPGeno
+    mat, asm = match_snps_for_predict(model_a, hapmap_geno, "Position", True, False, False, False)
+    assert asm == "hg19" and mat.shape == (266, 60)
+    gi = {s: i for i, s in enumerate(hapmap_geno.snp_id)}
+    assert np.array_equal(mat, hapmap_geno.genotype[[gi[s] for s in model_a.snp_id]])
+    # drop 100 model SNPs from the data and swap the alleles of 20 others
+    keep = np.ones(1564, bool)
+    keep[[gi[s] for s in model_a.snp_id[:100]]] = False
+    sub = HlaSNPGeno(hapmap_geno.genotype[keep].copy(), hapmap_geno.sample_id,
+                     [s for s, k in zip(hapmap_geno.snp_id, keep) if k], hapmap_geno.snp_position[keep],
+                     [a for a, k in zip(hapmap_geno.snp_allele, keep) if k], "hg19")
+    pos = {s: i for i, s in enumerate(sub.snp_id)}
+    for s in model_a.snp_id[100:120]:
+        j = pos[s]
+        a, b = sub.snp_allele[j].split("/")
+        sub.snp_allele[j] = f"{b}/{a}"
+        row = sub.genotype[j]
+        sub.genotype[j] = np.where(row == -2147483648, row, 2 - row)
+    mat2, _ = match_snps_for_predict(model_a, sub, "RefSNP", True, False, False, False)
+    assert np.all(mat2[:100] == -2147483648)
+    unamb = [i for i in range(100, 266) if set(model_a.snp_allele[i].split("/")) not in ({"A", "T"}, {"C", "G"})]
+    assert np.array_equal(mat2[unamb], mat[unamb])
+    with pytest.raises(ValueError, match="no overlapping"):
+        none = HlaSNPGeno(sub.genotype[:3], sub.sample_id, ["x1", "x2", "x3"], np.array([1., 2., 3.]), ["A/G"] * 3, "hg19")
+        match_snps_for_predict(model_a, none, "RefSNP", True, False, False, False)
