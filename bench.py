@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--shape", default=SHAPE)
     ap.add_argument("--prob", action="store_true", help="also return the full posterior matrix (type='response+prob')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-wide", action="store_true", help="diagnostic: drop the one 100-SNP classifier of the synthetic model")
     args = ap.parse_args()
 
     import numpy as np
@@ -76,7 +77,7 @@ def main():
 
     hibag_amd._lib.check(hibag_amd._lib.lib().hibag_hip_set_device(local_rank))
     target = hibag_amd.hlaSetKernelTarget("hip")[0]
-    model_obj, founders, afreq = synth.make_model(args.shape)
+    model_obj, founders, afreq = synth.make_model(args.shape, wide_classifier=not args.no_wide)
     n = args.samples
     geno, truth = synth.make_samples(founders, afreq, n, seed=synth.DEFAULT_SEED + 1 + rank)
     model = hibag_amd.hlaModelFromObj(model_obj, device=local_rank)

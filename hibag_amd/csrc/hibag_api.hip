@@ -132,9 +132,10 @@ struct hibag_hip_model {
 	double tab[HIBAG_TAB_N];
 
 	// device model
-	DevBuf d_int, d_bits, d_freq, d_tab;
+	DevBuf d_int, d_stream, d_tile, d_tab;
 	HibagModelView view{};
-	int geno_rows = 0;
+	int mask_rows = 0;
+	size_t stream_bytes = 0;
 
 	// per-batch workspace (grow-only)
 	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out;
@@ -148,7 +149,7 @@ struct hibag_hip_model {
 	{
 		(void)hipSetDevice(device);
 		timer.destroy();
-		for (DevBuf *b : {&d_int, &d_bits, &d_freq, &d_tab, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
+		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
 		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_tgeno, &ws_weight})
 			b->release();
 	}
@@ -206,52 +207,108 @@ void push_classifier(hibag_hip_model *m, int n_snp_c, const int32_t *snpidx, int
 	m->cls.push_back(std::move(c));
 }
 
-// Cell tiles for pass 2: every allele-pair cell goes to exactly one tile of at
-// most T cells; tiles are filled longest-processing-time-first so that their
-// pair counts (summed over classifiers) are balanced.
-void build_tiles(const hibag_hip_model *m, const std::vector<int> &hla_start, int T,
-	std::vector<int> &tile_cell, int &n_tile, std::vector<int> &h1v, std::vector<int> &h2v)
+// Words per pair record: ceil(3k/32) rounded up to a width the kernels are
+// specialised for (HIBAG_DISPATCH_NWP in hibag_kernels.hip).
+int round_nwp(int n)
 {
-	const int nh = m->n_hla, C = (int)m->cls.size();
-	const int P = nh * (nh + 1) / 2;
-	h1v.resize(P); h2v.resize(P);
-	std::vector<int64_t> work(P, 0);
-	int p = 0;
-	for (int h1 = 0; h1 < nh; h1++)
-		for (int h2 = h1; h2 < nh; h2++, p++) {
-			h1v[p] = h1; h2v[p] = h2;
-			int64_t w = 0;
-			for (int c = 0; c < C; c++) {
-				const int *st = &hla_start[(size_t)c * (nh + 1)];
-				const int64_t n1 = st[h1 + 1] - st[h1], n2 = st[h2 + 1] - st[h2];
-				w += (h1 == h2) ? n1 * (n1 + 1) / 2 : n1 * n2;
-				w += (n1 && n2) ? 2 : 0;   // fixed per-cell cost
+	for (int v : {1, 2, 3, 4, 6, 8, 12})
+		if (n <= v) return v;
+	return HIBAG_MAX_NWP;
+}
+
+// OR the low `nbits` bits of the 128-bit value src into the multiword string dst at bit `pos`.
+void or_bits(uint32_t *dst, const uint64_t src[2], int nbits, int pos)
+{
+	for (int i = 0; i < nbits; i++)
+		if ((src[i >> 6] >> (i & 63)) & 1) dst[(pos + i) >> 5] |= 1u << ((pos + i) & 31);
+}
+
+// Flatten one classifier's _PostProb2 loop nest (src/LibHLA.cpp:1776-1821) into
+// pair records in the reference's visiting order.  For every allele-pair cell
+// (posterior order) appends whole chunks to `stream` and returns the chunk count
+// per cell in `cell_chunks[P]`.  The frequency factor is rounded exactly as the
+// reference does: f1*f1 for the leading diagonal term (:1786), (2*f1)*f2 else
+// (:1789-1793, :1808-1812); this file is compiled with -ffp-contract=off.
+void build_pair_stream(const HostClassifier &k, int n_hla, int nwp, const int *st,
+	std::vector<uint32_t> &stream, std::vector<uint32_t> &cell_chunks)
+{
+	const int ks = k.n_snp;
+	const uint64_t lowmask[2] = {
+		ks >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << ks) - 1),
+		ks >= 128 ? ~(uint64_t)0 : (ks <= 64 ? 0 : (((uint64_t)1 << (ks - 64)) - 1)) };
+	std::vector<uint32_t> recw;       // records of the current cell: nwp words each
+	std::vector<double> recp;
+	auto emit = [&](int a, int b, double prod) {
+		const uint64_t *A = &k.bits[2 * (size_t)a], *Bb = &k.bits[2 * (size_t)b];
+		const uint64_t same[2] = { ~(A[0] ^ Bb[0]) & lowmask[0], ~(A[1] ^ Bb[1]) & lowmask[1] };
+		const size_t at = recw.size();
+		recw.resize(at + nwp, 0);
+		or_bits(&recw[at], A, ks, 0);
+		or_bits(&recw[at], Bb, ks, ks);
+		or_bits(&recw[at], same, ks, 2 * ks);
+		recp.push_back(prod);
+	};
+	auto flush = [&]() -> uint32_t {
+		const size_t n = recp.size();
+		const size_t nchunk = (n + HIBAG_CHUNK - 1) / HIBAG_CHUNK;
+		for (size_t ch = 0; ch < nchunk; ch++) {
+			const size_t base = stream.size();
+			stream.resize(base + HIBAG_CHUNK_DWORDS(nwp), 0);
+			for (int r = 0; r < HIBAG_CHUNK; r++) {
+				const size_t i = ch * HIBAG_CHUNK + r;
+				double prod = 0.0;                    // padding record: + (+0.0 * TAB[d]) is exact
+				if (i < n) {
+					for (int w = 0; w < nwp; w++) stream[base + (size_t)w * HIBAG_CHUNK + r] = recw[i * nwp + w];
+					prod = recp[i];
+				}
+				memcpy(&stream[base + (size_t)nwp * HIBAG_CHUNK + 2 * (size_t)r], &prod, sizeof(double));
 			}
-			work[p] = w;
 		}
-	n_tile = (P + T - 1) / T;
-	std::vector<int> order(P);
-	for (int i = 0; i < P; i++) order[i] = i;
-	std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return work[a] > work[b]; });
-	std::vector<int64_t> load(n_tile, 0);
-	std::vector<int> fill(n_tile, 0);
-	tile_cell.assign((size_t)n_tile * T, -1);
-	for (int i = 0; i < P; i++) {
-		int best = -1;
-		for (int t = 0; t < n_tile; t++)
-			if (fill[t] < T && (best < 0 || load[t] < load[best])) best = t;
-		tile_cell[(size_t)best * T + fill[best]++] = order[i];
-		load[best] += work[order[i]];
+		recw.clear(); recp.clear();
+		return (uint32_t)nchunk;
+	};
+	size_t p = 0;
+	for (int h1 = 0; h1 < n_hla; h1++) {
+		const int a0 = st[h1], a1 = st[h1 + 1];
+		for (int a = a0; a < a1; a++) {
+			emit(a, a, k.freq[a] * k.freq[a]);
+			const double ff = 2 * k.freq[a];
+			for (int b = a + 1; b < a1; b++) emit(a, b, ff * k.freq[b]);
+		}
+		cell_chunks[p++] = flush();
+		for (int h2 = h1 + 1; h2 < n_hla; h2++) {
+			const int b0 = st[h2], b1 = st[h2 + 1];
+			for (int a = a0; a < a1; a++) {
+				const double ff = 2 * k.freq[a];
+				for (int b = b0; b < b1; b++) emit(a, b, ff * k.freq[b]);
+			}
+			cell_chunks[p++] = flush();
+		}
 	}
-	// heaviest tiles first in launch order
-	std::vector<int> torder(n_tile);
-	for (int t = 0; t < n_tile; t++) torder[t] = t;
-	std::stable_sort(torder.begin(), torder.end(), [&](int a, int b) { return load[a] > load[b]; });
-	std::vector<int> sorted((size_t)n_tile * T);
-	for (int t = 0; t < n_tile; t++)
-		std::copy(tile_cell.begin() + (size_t)torder[t] * T, tile_cell.begin() + (size_t)(torder[t] + 1) * T,
-			sorted.begin() + (size_t)t * T);
-	tile_cell.swap(sorted);
+}
+
+// Tiles for pass 2: consecutive posterior cells, at most HIBAG_TILE each, cut so
+// that the chunk counts (summed over classifiers, plus a per-cell constant) are
+// balanced.  Consecutive cells keep one pair stream valid for both passes.
+void build_tiles(int P, const std::vector<uint64_t> &cell_work, std::vector<int> &tile_p0, std::vector<int> &tile_n)
+{
+	uint64_t total = 0;
+	for (int p = 0; p < P; p++) total += cell_work[p] + 1;
+	const int min_tiles = (P + HIBAG_TILE - 1) / HIBAG_TILE;
+	const uint64_t target = std::max<uint64_t>(1, total / (uint64_t)std::max(min_tiles, 1));
+	tile_p0.clear(); tile_n.clear();
+	int p = 0;
+	while (p < P) {
+		int n = 0;
+		uint64_t w = 0;
+		while (p + n < P && n < HIBAG_TILE) {
+			const uint64_t cw = cell_work[p + n] + 1;
+			if (n > 0 && w + cw > target + target / 4) break;
+			w += cw; n++;
+		}
+		tile_p0.push_back(p); tile_n.push_back(n);
+		p += n;
+	}
 }
 
 int finalize_model(hibag_hip_model *m)
@@ -261,10 +318,11 @@ int finalize_model(hibag_hip_model *m)
 	const int C = (int)m->cls.size(), nh = m->n_hla, S = m->n_snp;
 	const int P = nh * (nh + 1) / 2;
 
-	std::vector<int> n_snp_c(C), n_word(C), snp_off(C), n_hap(C), hap_off(C), bits_off(C), geno_row(C),
-		c_order(C), snp_index, snp_weight(std::max(S, 1), 0), hla_start((size_t)C * (nh + 1), 0);
-	std::vector<uint32_t> hbits;
-	std::vector<double> hfreq;
+	std::vector<int> n_snp_c(C), nwp(C), snp_off(C), mask_row(C), c_order(C), snp_index,
+		snp_weight(std::max(S, 1), 0);
+	std::vector<uint64_t> stream_off(std::max(C, 1), 0), cell_work(P, 0);
+	std::vector<uint32_t> stream;
+	std::vector<std::vector<uint32_t>> cell_chunks(C);
 	std::vector<int64_t> pairs(C);
 	int rows = 0;
 	m->pair_evals = 0;
@@ -272,36 +330,47 @@ int finalize_model(hibag_hip_model *m)
 		const HostClassifier &k = m->cls[c];
 		const int H = (int)k.freq.size();
 		n_snp_c[c] = k.n_snp;
-		n_word[c] = std::max(1, (k.n_snp + 31) / 32);
+		nwp[c] = round_nwp((3 * k.n_snp + 31) / 32);
 		snp_off[c] = (int)snp_index.size();
 		for (int v : k.snpidx) { snp_index.push_back(v); snp_weight[v]++; }
 		if (k.snpidx.empty()) snp_index.insert(snp_index.end(), (size_t)k.n_snp, 0);
-		n_hap[c] = H;
-		hap_off[c] = (int)hfreq.size();
-		bits_off[c] = (int)hbits.size();
-		geno_row[c] = rows;
-		rows += 2 * n_word[c];
-		hfreq.insert(hfreq.end(), k.freq.begin(), k.freq.end());
-		for (int w = 0; w < n_word[c]; w++)
-			for (int i = 0; i < H; i++)
-				hbits.push_back((uint32_t)(k.bits[2 * (size_t)i + (w >> 1)] >> (32 * (w & 1))));
-		int *st = &hla_start[(size_t)c * (nh + 1)];
+		mask_row[c] = rows;
+		rows += 2 * nwp[c];
+		std::vector<int> st(nh + 1, 0);
 		for (int i = 0; i < H; i++) st[k.hla[i] + 1]++;
 		for (int h = 0; h < nh; h++) st[h + 1] += st[h];
+		if (stream.size() & 1) stream.push_back(0);          // 8-byte alignment of the doubles inside
+		stream_off[c] = stream.size();
+		cell_chunks[c].assign(P, 0);
+		build_pair_stream(k, nh, nwp[c], st.data(), stream, cell_chunks[c]);
+		for (int p = 0; p < P; p++) cell_work[p] += (uint64_t)cell_chunks[c][p] * (nwp[c] + 2);
 		pairs[c] = (int64_t)H * (H + 1) / 2;
 		m->pair_evals += pairs[c];
 		c_order[c] = c;
 	}
 	if (!m->snp_weight_override.empty()) snp_weight = m->snp_weight_override;
-	std::stable_sort(c_order.begin(), c_order.end(), [&](int a, int b) { return pairs[a] > pairs[b]; });
-	if (hbits.empty()) hbits.push_back(0);
-	if (hfreq.empty()) hfreq.push_back(0);
+	std::stable_sort(c_order.begin(), c_order.end(), [&](int a, int b) { return pairs[a] * nwp[a] > pairs[b] * nwp[b]; });
+	// the walker fetches one chunk ahead: keep a widest-record chunk of slack behind the last record
+	stream.insert(stream.end(), HIBAG_CHUNK_DWORDS(HIBAG_MAX_NWP), 0);
 	if (snp_index.empty()) snp_index.push_back(0);
 
-	const int T = 16;
-	std::vector<int> tile_cell, h1v, h2v;
-	int n_tile = 0;
-	build_tiles(m, hla_start, T, tile_cell, n_tile, h1v, h2v);
+	std::vector<int> tile_p0, tile_n;
+	build_tiles(P, cell_work, tile_p0, tile_n);
+	const int n_tile = (int)tile_p0.size();
+	// +1: the walker reads the count after the last cell; see walk_cells()
+	std::vector<uint32_t> tile_cnt((size_t)std::max(C, 1) * n_tile * HIBAG_TILE + 1, 0), tile_off((size_t)std::max(C, 1) * n_tile, 0);
+	for (int c = 0; c < C; c++) {
+		uint64_t off = 0;
+		for (int t = 0; t < n_tile; t++) {
+			if (off > 0xFFFFFFFFull) return fail(HIBAG_HIP_EINVAL, "classifier %d has too many haplotype pairs", c);
+			tile_off[(size_t)c * n_tile + t] = (uint32_t)off;
+			for (int j = 0; j < tile_n[t]; j++) {
+				const uint32_t n = cell_chunks[c][tile_p0[t] + j];
+				tile_cnt[((size_t)c * n_tile + t) * HIBAG_TILE + j] = n;
+				off += n;
+			}
+		}
+	}
 
 	// one int arena
 	std::vector<int> arena;
@@ -311,31 +380,35 @@ int finalize_model(hibag_hip_model *m)
 		if (v.empty()) arena.push_back(0);
 		return off;
 	};
-	const size_t o_nsnp = put(n_snp_c), o_nword = put(n_word), o_snpoff = put(snp_off), o_snpidx = put(snp_index),
-		o_snpw = put(snp_weight), o_nhap = put(n_hap), o_hapoff = put(hap_off), o_bitsoff = put(bits_off),
-		o_grow = put(geno_row), o_start = put(hla_start), o_order = put(c_order), o_tile = put(tile_cell),
-		o_h1 = put(h1v), o_h2 = put(h2v);
+	const size_t o_nsnp = put(n_snp_c), o_nwp = put(nwp), o_snpoff = put(snp_off), o_snpidx = put(snp_index),
+		o_snpw = put(snp_weight), o_mrow = put(mask_row), o_order = put(c_order), o_tp0 = put(tile_p0), o_tn = put(tile_n);
 
 	if (int rc = m->d_int.reserve(arena.size() * sizeof(int))) return rc;
-	if (int rc = m->d_bits.reserve(hbits.size() * sizeof(uint32_t))) return rc;
-	if (int rc = m->d_freq.reserve(hfreq.size() * sizeof(double))) return rc;
+	if (int rc = m->d_stream.reserve(stream.size() * sizeof(uint32_t))) return rc;
+	if (int rc = m->d_tile.reserve((tile_cnt.size() + tile_off.size()) * sizeof(uint32_t) + stream_off.size() * sizeof(uint64_t))) return rc;
 	if (int rc = m->d_tab.reserve(sizeof(m->tab))) return rc;
 	HIP_TRY(hipMemcpy(m->d_int.p, arena.data(), arena.size() * sizeof(int), hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(m->d_bits.p, hbits.data(), hbits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(m->d_freq.p, hfreq.data(), hfreq.size() * sizeof(double), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(m->d_stream.p, stream.data(), stream.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	char *tbase = m->d_tile.as<char>();
+	const size_t tb_off = 0, tb_cnt = stream_off.size() * sizeof(uint64_t), tb_toff = tb_cnt + tile_cnt.size() * sizeof(uint32_t);
+	HIP_TRY(hipMemcpy(tbase + tb_off, stream_off.data(), stream_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(tbase + tb_cnt, tile_cnt.data(), tile_cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(tbase + tb_toff, tile_off.data(), tile_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(m->d_tab.p, m->tab, sizeof(m->tab), hipMemcpyHostToDevice));
 
 	HibagModelView &V = m->view;
 	const int *base = m->d_int.as<int>();
-	V.n_hla = nh; V.n_classifier = C; V.n_snp = S; V.n_cell = P; V.geno_rows = rows;
-	V.n_tile = n_tile; V.tile_cells = T;
-	V.n_snp_c = base + o_nsnp; V.n_word = base + o_nword; V.snp_off = base + o_snpoff;
-	V.snp_index = base + o_snpidx; V.snp_weight = base + o_snpw; V.n_hap = base + o_nhap;
-	V.hap_off = base + o_hapoff; V.bits_off = base + o_bitsoff; V.geno_row = base + o_grow;
-	V.hla_start = base + o_start; V.c_order = base + o_order;
-	V.tile_cell = base + o_tile; V.cell_h1 = base + o_h1; V.cell_h2 = base + o_h2;
-	V.hbits = m->d_bits.as<uint32_t>(); V.hfreq = m->d_freq.as<double>(); V.tab = m->d_tab.as<double>();
-	m->geno_rows = rows;
+	V.n_hla = nh; V.n_classifier = C; V.n_snp = S; V.n_cell = P; V.mask_rows = rows; V.n_tile = n_tile;
+	V.n_snp_c = base + o_nsnp; V.nwp = base + o_nwp; V.snp_off = base + o_snpoff;
+	V.snp_index = base + o_snpidx; V.snp_weight = base + o_snpw; V.mask_row = base + o_mrow;
+	V.c_order = base + o_order; V.tile_p0 = base + o_tp0; V.tile_n = base + o_tn;
+	V.stream_off = (const uint64_t *)(tbase + tb_off);
+	V.tile_cnt = (const uint32_t *)(tbase + tb_cnt);
+	V.tile_off = (const uint32_t *)(tbase + tb_toff);
+	V.stream = m->d_stream.as<uint32_t>();
+	V.tab = m->d_tab.as<double>();
+	m->mask_rows = rows;
+	m->stream_bytes = stream.size() * sizeof(uint32_t);
 	m->finalized = true;
 	return 0;
 }
@@ -346,7 +419,7 @@ int finalize_model(hibag_hip_model *m)
 int batch_limit(const hibag_hip_model *m)
 {
 	const double per_sample = 8.0 * (m->view.n_cell + 3) + 24.0 * m->view.n_classifier +
-		4.0 * m->geno_rows + 4.0 * m->view.n_classifier;
+		4.0 * m->mask_rows + 4.0 * m->view.n_classifier;
 	int lim = (int)(1.5e9 / std::max(per_sample, 1.0));
 	lim = std::max(64, std::min(lim, 1 << 17));
 	return lim / 64 * 64;
@@ -356,7 +429,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 {
 	const int n_pad = round_up(std::max(n_samp, 1), HIBAG_WAVE);
 	const size_t C = (size_t)std::max(m->view.n_classifier, 1);
-	if (int rc = m->ws_planes.reserve((size_t)std::max(m->geno_rows, 1) * n_pad * sizeof(uint32_t))) return rc;
+	if (int rc = m->ws_planes.reserve((size_t)std::max(m->mask_rows, 1) * n_pad * sizeof(uint32_t))) return rc;
 	if (int rc = m->ws_cw.reserve(C * n_pad * sizeof(double))) return rc;
 	if (int rc = m->ws_tot.reserve(C * n_pad * sizeof(double))) return rc;
 	if (int rc = m->ws_inv.reserve(C * n_pad * sizeof(double))) return rc;
@@ -364,7 +437,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	if (need_best)
 		if (int rc = m->ws_best.reserve(C * n_pad * sizeof(int))) return rc;
 	B.n_samp = n_samp; B.n_pad = n_pad;
-	B.planes = m->ws_planes.as<uint32_t>();
+	B.masks = m->ws_planes.as<uint32_t>();
 	B.cw = m->ws_cw.as<double>(); B.tot = m->ws_tot.as<double>(); B.inv = m->ws_inv.as<double>();
 	B.part = m->ws_part.as<double>();
 	return 0;

@@ -1,24 +1,31 @@
 // hibag_device.h -- device-side views shared by the kernels and the host code
 // of libhibag_hip.so.  gfx950 only.
 //
-// Data layout in HBM (see DESIGN.md "Data layout"):
+// Data layout in HBM (DESIGN.md "Data layout"):
 //
-//  Model (read-only, a few hundred KB, uniform across a wavefront -> fetched
-//  with scalar loads):
-//    hbits  : per classifier c, NW_c rows of H_c uint32: row w holds bits
-//             32w..32w+31 of every haplotype (SoA; the reference's AVX path
-//             keeps the same idea with 64-bit words, src/LibHLA.cpp:543-563)
-//    hfreq  : per classifier H_c doubles
-//    hla_start[c][0..n_hla] : prefix sums of LenPerHLA (src/LibHLA.h:85-140)
+//  MODEL (read-only, wave-uniform -> fetched with scalar loads).
+//    The loop nest of _PostProb2 (src/LibHLA.cpp:1776-1821) depends only on the
+//    model, so the host flattens it once per classifier into a PAIR STREAM in
+//    exactly the reference's visiting order (allele pair h1<=h2, then haplotype
+//    i1, then i2).  One record per haplotype pair:
+//        W[nwp]  the 3k-bit string  H1 | H2 << k | ~(H1^H2) << 2k   (k = #SNPs)
+//        prod    the frequency factor, rounded as the reference rounds it:
+//                f1*f1 for the leading diagonal term, (2*f1)*f2 otherwise
+//    Records are grouped in CHUNKS of HIBAG_CHUNK, SoA inside a chunk
+//    (W[nwp][CHUNK] then prod[CHUNK]); every allele-pair cell owns whole chunks,
+//    padded with {W=0, prod=+0.0} records (adding +0.0*TAB[d] is exact).
+//    Cells are grouped in TILES of up to HIBAG_TILE consecutive cells with about
+//    equal work; tile_cnt[c][t][j] = chunks of cell j of tile t in classifier c,
+//    tile_off[c][t] = first chunk of the tile in the classifier's stream.
 //
-//  Per batch of samples ("lane = sample": consecutive samples are consecutive
-//  addresses, so every wave access below is one coalesced row segment):
-//    planes : uint32 [geno_rows][n_pad]; classifier c owns rows
-//             geno_row[c] + 2*w + {0: S1, 1: S2}  (TGenotype bit planes,
-//             inst/include/LibHLA_ext.h:245-255)
+//  BATCH ("lane = sample": consecutive samples are consecutive addresses, so
+//  every per-lane access is one coalesced row segment of a wavefront):
+//    masks : uint32 [mask_rows][n_pad]; classifier c owns rows mask_row[c] +
+//            {0..nwp-1: XOR mask T', nwp..2nwp-1: AND mask M'} so that the
+//            distance of src/LibHLA.cpp:747-819 is  sum_w popc((W[w]^T'[w])&M'[w])
 //    cw, tot, inv : double [C][n_pad]  classifier weight, in-order posterior
-//             total, 1/total
-//    part   : double [P+3][n_pad]  ensemble sums per allele pair + 3 scalars
+//            total, 1/total
+//    part  : double [P+3][n_pad]  ensemble sums per allele pair + 3 scalars
 #ifndef HIBAG_DEVICE_H_
 #define HIBAG_DEVICE_H_
 
@@ -26,41 +33,41 @@
 
 #define HIBAG_WAVE 64
 #define HIBAG_TAB_N 257          // 2*128 + 1 distances (src/LibHLA.cpp:167)
-#define HIBAG_MAX_WORDS 4        // 128 SNPs / 32
+#define HIBAG_TILE 16            // allele-pair cells per tile (accumulators live in VGPRs)
+#define HIBAG_CHUNK 2            // pair records per chunk
+#define HIBAG_MAX_NWP 12         // ceil(3*128/32) words of the packed pair string
+
+// dwords of one chunk for a classifier with nwp words per record
+#define HIBAG_CHUNK_DWORDS(nwp) (HIBAG_CHUNK * ((nwp) + 2))
 
 struct HibagModelView {
 	int n_hla;
 	int n_classifier;
 	int n_snp;          // SNPs in the model (row length of the raw genotype matrix)
 	int n_cell;         // n_hla*(n_hla+1)/2
-	int geno_rows;      // sum_c 2*NW_c
-	int n_tile;         // cell tiles for the accumulate pass
-	int tile_cells;     // cells per tile (compile-time T of the kernel)
+	int mask_rows;      // sum_c 2*nwp_c
+	int n_tile;
 
-	const int *n_snp_c;       // [C]
-	const int *n_word;        // [C] 32-bit words per bit plane = ceil(n_snp_c/32)
-	const int *snp_off;       // [C]
-	const int *snp_index;     // concatenated 0-based SNP indices
-	const int *snp_weight;    // [n_snp] #classifiers using the SNP (src/LibHLA.cpp:2484-2496)
-	const int *n_hap;         // [C]
-	const int *hap_off;       // [C] into hfreq
-	const int *bits_off;      // [C] into hbits (uint32 units)
-	const int *geno_row;      // [C] first plane row of the classifier
-	const int *hla_start;     // [C][n_hla+1]
-	const int *c_order;       // [C] classifiers sorted by pair count, heaviest first
-	const uint32_t *hbits;
-	const double *hfreq;
-	const double *tab;        // [257] exp(d*log(1e-5))
-
-	const int *tile_cell;     // [n_tile][tile_cells] posterior index p, -1 = padding
-	const int *cell_h1;       // [n_cell]
-	const int *cell_h2;       // [n_cell]
+	const int *n_snp_c;          // [C]
+	const int *nwp;              // [C] 32-bit words of the packed pair string = ceil(3*n_snp_c/32)
+	const int *snp_off;          // [C]
+	const int *snp_index;        // concatenated 0-based SNP indices
+	const int *snp_weight;       // [n_snp] #classifiers using the SNP (src/LibHLA.cpp:2484-2496)
+	const int *mask_row;         // [C] first mask row of the classifier
+	const int *c_order;          // [C] classifiers sorted by pair count, heaviest first
+	const int *tile_p0;          // [n_tile] first cell (posterior index) of the tile
+	const int *tile_n;           // [n_tile] cells in the tile (1..HIBAG_TILE)
+	const uint32_t *tile_cnt;    // [C][n_tile][HIBAG_TILE] chunks per cell
+	const uint32_t *tile_off;    // [C][n_tile] first chunk of the tile
+	const uint64_t *stream_off;  // [C] dword offset of the classifier's stream
+	const uint32_t *stream;      // the pair streams
+	const double *tab;           // [257] exp(d*log(1e-5))
 };
 
 struct HibagBatchView {
 	int n_samp;         // samples in this batch
 	int n_pad;          // rounded up to a multiple of 64
-	uint32_t *planes;   // [geno_rows][n_pad]
+	uint32_t *masks;    // [mask_rows][n_pad]
 	double *cw;         // [C][n_pad]
 	double *tot;        // [C][n_pad]
 	double *inv;        // [C][n_pad]

@@ -5,18 +5,25 @@
 //
 // Mapping: LANE = SAMPLE.  A wavefront holds 64 samples and walks the model's
 // loop nest (classifier -> allele pair -> haplotype pair) in the reference's
-// order.  The nest depends only on the model, so control flow is wave-uniform,
-// every haplotype word / frequency is a scalar (SMEM) load, and each lane
-// reproduces the reference's rounding sequence for its own sample: results are
-// bit-identical to the CPU kernels by construction, with no cross-lane
-// reduction anywhere on the numeric path.
+// order.  The nest depends only on the model, so the host flattens it into a
+// pair stream (hibag_device.h); control flow is wave-uniform, every model word
+// arrives through the scalar cache (s_load), and each lane reproduces the
+// reference's rounding sequence for its own sample: results are bit-identical
+// to the CPU kernels by construction, with no cross-lane reduction anywhere on
+// the numeric path.
+//
+// Per haplotype pair and wavefront the inner loop is
+//     d    = sum_w popc((W[w] ^ T'[w]) & M'[w])      v_bitop3_b32 + v_bcnt_u32_b32 per word
+//     cell += prod * TAB[d]                          ds_read_b64, v_mul_f64, v_add_f64
+// (W, prod uniform in SGPRs, fetched one chunk ahead; T', M' the lane's
+// genotype masks; TAB in LDS).
 //
 // The normalisation 1/sum of a classifier's posterior needs all of its cells,
-// and holding 64 samples x P cells does not fit on chip, so the pair loop runs
-// twice: pass 1 (k_total) produces the in-order total per (sample, classifier),
-// pass 2 (k_accum) recomputes each cell, scales it and adds it to the ensemble
-// sum kept in LDS.  Recomputing is cheaper than spilling 8*P bytes per
-// (sample, classifier) to HBM (DESIGN.md "Why two passes").
+// and 64 samples x P cells do not fit on chip, so the pair loop runs twice:
+// pass 1 (k_total) produces the in-order total per (sample, classifier), pass 2
+// (k_accum) recomputes each cell, scales it and adds it to the ensemble sum held
+// in VGPRs.  Recomputing is cheaper than moving 8*P bytes per (sample,
+// classifier) through HBM (DESIGN.md "Why two passes").
 //
 // No MFMA: the pair weight 1e-5^d(i,j) does not factor over (i,j) at
 // heterozygous SNPs, so there is no contraction to feed a matrix core.
@@ -26,80 +33,122 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "hibag_device.h"
 #include "hibag_kernels.h"
 
 #define NA_INTEGER (-2147483647 - 1)
+#define CH HIBAG_CHUNK
+#ifndef BLOCK_WAVES
+#define BLOCK_WAVES 4                       // wavefronts per workgroup (each on its own work item)
+#endif
+#define BLOCK_THREADS (BLOCK_WAVES * HIBAG_WAVE)
 
-// ---------------------------------------------------------------------------
-// Per-lane genotype of one classifier, re-encoded from the (S1,S2) bit planes
-// into three disjoint masks so that the distance of src/LibHLA.cpp:747-819
-//     d = popc((H1^S1)&MASK) + popc((H2^S2)&MASK),
-//     MASK = ((H1^S2)|(H2^S1)) & ~(S2&~S1)
-// becomes, SNP by SNP (g=0: h1+h2, g=2: 2-h1-h2, g=1: [h1==h2], missing: 0),
-//     d = popc((H1^T)&ZT) + popc((H2^T)&ZT) + popc(~(H1^H2)&E)
-// with ZT = homozygous, T = g==2, E = heterozygous.  Same integer, fewer VALU
-// ops, and ~(H1^H2) is wave-uniform so it runs on the scalar unit.
-template <int NW>
-struct LaneGeno {
-	uint32_t zt[NW], t[NW], e[NW];
-	int n_het;
+// The lane's genotype for one classifier: XOR mask x (= T') and AND mask m (= M').
+template <int NWP>
+struct LaneMask {
+	uint32_t x[NWP], m[NWP];
 };
 
-template <int NW>
-__device__ __forceinline__ void load_geno(const HibagBatchView &B, int row0, int s, LaneGeno<NW> &G)
+template <int NWP>
+__device__ __forceinline__ void load_masks(const HibagBatchView &B, int row0, int s, LaneMask<NWP> &L)
 {
-	G.n_het = 0;
 #pragma unroll
-	for (int w = 0; w < NW; w++) {
-		const uint32_t s1 = B.planes[(size_t)(row0 + 2 * w) * B.n_pad + s];
-		const uint32_t s2 = B.planes[(size_t)(row0 + 2 * w + 1) * B.n_pad + s];
-		G.zt[w] = ~(s1 ^ s2);
-		G.t[w] = s1 & s2;
-		G.e[w] = s1 & ~s2;
-		G.n_het += __popc(G.e[w]);
+	for (int w = 0; w < NWP; w++) {
+		L.x[w] = B.masks[(size_t)(row0 + w) * B.n_pad + s];
+		L.m[w] = B.masks[(size_t)(row0 + NWP + w) * B.n_pad + s];
 	}
 }
 
-// Sum of one allele-pair cell in the reference's order
-// (src/LibHLA.cpp:1781-1797 diagonal, :1804-1816 off-diagonal):
-//   diagonal:  for a: cell += (f_a*f_a)*TAB[d(a,a)]; for b>a: cell += ((2 f_a)*f_b)*TAB[d(a,b)]
-//   otherwise: for a in h1, b in h2: cell += ((2 f_a)*f_b)*TAB[d(a,b)]
-// hb: this classifier's haplotype words [NW][H]; hf: frequencies; all uniform.
-template <int NW>
-__device__ __forceinline__ double cell_value(const uint32_t *__restrict__ hb,
-	const double *__restrict__ hf, int H, int a0, int a1, int b0, int b1, bool diagonal,
-	const LaneGeno<NW> &G, const double *tab_s)
+// popc(x) + acc in one VALU op.  Written as asm so that the compiler keeps the
+// distance a single chained sum (it otherwise scales every partial count by 8
+// for the table address, one shift per word).
+__device__ __forceinline__ int bcnt_acc(uint32_t x, int acc)
 {
-	double cell = 0;
-	for (int a = a0; a < a1; a++) {
-		uint32_t A[NW];
-		int ca = 0;
+	int r;
+	asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+	return r;
+}
+
+// One chunk of the pair stream, wave-uniform (lives in SGPRs).
+template <int NWP>
+struct Chunk {
+	uint32_t w[NWP * CH];
+	double p[CH];
+};
+
+template <int NWP>
+__device__ __forceinline__ void load_chunk(Chunk<NWP> &c, const uint32_t *__restrict__ cp)
+{
 #pragma unroll
-		for (int w = 0; w < NW; w++) {
-			A[w] = hb[w * H + a];
-			ca += __popc((A[w] ^ G.t[w]) & G.zt[w]);
-		}
-		const double fa = hf[a];
-		int b = b0;
-		if (diagonal) {
-			cell += (fa * fa) * tab_s[2 * ca + G.n_het];
-			b = a + 1;
-		}
-		const double ff = 2 * fa;
-		for (; b < b1; b++) {
-			int d = ca;
+	for (int i = 0; i < NWP * CH; i++) c.w[i] = cp[i];
+	const double *__restrict__ pr = reinterpret_cast<const double *>(cp + NWP * CH);
 #pragma unroll
-			for (int w = 0; w < NW; w++) {
-				const uint32_t Bw = hb[w * H + b];
-				const uint32_t same = ~(A[w] ^ Bw);   // uniform -> SALU
-				d += __popc((Bw ^ G.t[w]) & G.zt[w]) + __popc(same & G.e[w]);
-			}
-			cell += (ff * hf[b]) * tab_s[d];
-		}
+	for (int r = 0; r < CH; r++) c.p[r] = pr[r];
+}
+
+// cell += prod_r * TAB[d_r], r in order: the statement
+//   sum += (2*f1*f2) * TAB[hamm_d]   of src/LibHLA.cpp:1786-1813 (ADD_FREQ_MUTANT, src/LibHLA.h:223).
+template <int NWP>
+__device__ __forceinline__ double chunk_apply(double cell, const Chunk<NWP> &c, const LaneMask<NWP> &L,
+	const double *tab_s)
+{
+	double t[CH];
+#pragma unroll
+	for (int r = 0; r < CH; r++) {
+		int d = __popc((c.w[r] ^ L.x[0]) & L.m[0]);
+#pragma unroll
+		for (int w = 1; w < NWP; w++) d = bcnt_acc((c.w[w * CH + r] ^ L.x[w]) & L.m[w], d);
+		t[r] = tab_s[d];
 	}
+#pragma unroll
+	for (int r = 0; r < CH; r++) cell += c.p[r] * t[r];
 	return cell;
 }
+
+// Visit `ncell` consecutive cells in order: cell j owns cnt[j] consecutive
+// chunks starting at cp.  fin(j, cell) receives the strictly ordered cell sum;
+// cells without haplotype pairs are skipped unless `visit_empty` (their sum is
+// +0.0).  The next chunk and the next count are fetched while the current
+// chunk is evaluated (the stream and cnt[] are padded so that reading one
+// element past the range is in bounds).
+template <int NWP, class Fin>
+__device__ __forceinline__ void walk_cells(const uint32_t *__restrict__ cnt, int ncell,
+	const uint32_t *__restrict__ cp, bool visit_empty, const LaneMask<NWP> &L, const double *tab_s, Fin &&fin)
+{
+	Chunk<NWP> cur;
+	load_chunk<NWP>(cur, cp);
+	cp += HIBAG_CHUNK_DWORDS(NWP);
+	uint32_t n = cnt[0];
+	for (int j = 0; j < ncell; j++) {
+		const uint32_t n_next = cnt[j + 1];
+		if (n != 0 || visit_empty) {
+			double cell = 0;
+			for (uint32_t k = 0; k < n; k++) {
+				Chunk<NWP> nxt;
+				load_chunk<NWP>(nxt, cp);
+				cp += HIBAG_CHUNK_DWORDS(NWP);
+				cell = chunk_apply<NWP>(cell, cur, L, tab_s);
+				cur = nxt;
+			}
+			fin(j, cell);
+		}
+		n = n_next;
+	}
+}
+
+// Record widths the kernels are specialised for; the host rounds a classifier's
+// ceil(3k/32) up to the next of these (padding words carry AND mask 0).
+#define HIBAG_DISPATCH_NWP(nwp, CALL)      \
+	switch (nwp) {                         \
+	case 1:  { CALL(1); } break;           \
+	case 2:  { CALL(2); } break;           \
+	case 3:  { CALL(3); } break;           \
+	case 4:  { CALL(4); } break;           \
+	case 6:  { CALL(6); } break;           \
+	case 8:  { CALL(8); } break;           \
+	default: { CALL(12); } break;          \
+	}
 
 __device__ __forceinline__ void stage_table(const HibagModelView &M, double *tab_s)
 {
@@ -109,8 +158,12 @@ __device__ __forceinline__ void stage_table(const HibagModelView &M, double *tab
 
 // ---------------------------------------------------------------------------
 // k_pack: TGenotype::IntToSNP (src/LibHLA.cpp:662-706) for every (sample,
-// classifier) plus the classifier weight from missingness
-// (src/LibHLA.cpp:2418-2431).  grid (n_pad/64, C), block 64, lane = sample.
+// classifier), emitted directly as the lane masks of the packed pair string
+//   bits [0,k)   first haplotype : x = [g==2], m = [g in {0,2}]
+//   bits [k,2k)  second haplotype: same
+//   bits [2k,3k) ~(H1^H2)        : x = 0,      m = [g==1]
+// (missing SNPs have m = 0 everywhere), plus the classifier weight from
+// missingness (src/LibHLA.cpp:2418-2431).  grid (n_pad/64, C), block 64.
 __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatchView B,
 	const int32_t *__restrict__ geno)
 {
@@ -118,28 +171,31 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 	const int s = blockIdx.x * HIBAG_WAVE + threadIdx.x;
 	const bool live = s < B.n_samp;
 	const int k = M.n_snp_c[c];
-	const int nw = M.n_word[c];
+	const int nwp = M.nwp[c];
 	const int *__restrict__ idx = M.snp_index + M.snp_off[c];
 	const int32_t *__restrict__ row = geno + (size_t)(live ? s : 0) * M.n_snp;
-	const int row0 = M.geno_row[c];
+	const int row0 = M.mask_row[c];
 	int num = 0, den = 0;
-	for (int w = 0; w < nw; w++) {
-		uint32_t p1 = 0, p2 = 0xFFFFFFFFu;      // all missing: (S1,S2) = (0,1)
-		const int lim = min(32, k - 32 * w);
-		for (int j = 0; j < lim; j++) {
-			const int snp = idx[32 * w + j];
-			const int wt = M.snp_weight[snp];
-			den += wt;
+	int comp = 0, i = 0;                       // position 32*m+q = comp*k + i
+	for (int m = 0; m < nwp; m++) {
+		uint32_t xw = 0, mw = 0;
+		for (int q = 0; q < 32 && comp < 3 && k > 0; q++) {
+			const int snp = idx[i];
 			const int g = live ? row[snp] : -1;
-			const uint32_t bit = 1u << j;
-			if (g >= 0 && g <= 2) {
-				num += wt;
-				if (g >= 1) p1 |= bit;
-				if (g <= 1) p2 &= ~bit;
+			const uint32_t bit = 1u << q;
+			if (comp == 0) {
+				const int wt = M.snp_weight[snp];
+				den += wt;
+				if (g >= 0 && g <= 2) num += wt;
 			}
+			if (comp < 2) {
+				if (g == 0 || g == 2) mw |= bit;
+				if (g == 2) xw |= bit;
+			} else if (g == 1) mw |= bit;
+			if (++i == k) { i = 0; comp++; }
 		}
-		B.planes[(size_t)(row0 + 2 * w) * B.n_pad + s] = p1;
-		B.planes[(size_t)(row0 + 2 * w + 1) * B.n_pad + s] = p2;
+		B.masks[(size_t)(row0 + m) * B.n_pad + s] = xw;
+		B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s] = mw;
 	}
 	B.cw[(size_t)c * B.n_pad + s] = (live && den > 0) ? ((double)num / den) : 0.0;
 }
@@ -147,24 +203,34 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 // k_unpack_tgeno: plugin path (predict_avg_prob): the host already packed one
 // sample per classifier as TGenotype (48 bytes: int64 S1[2], S2[2], 16 bytes
 // of book-keeping, inst/include/LibHLA_ext.h:311-352) and computed the
-// weights.  One thread per classifier writes lane 0 of the planes; lanes 1..63
-// are padding (missing, weight 0).
+// weights.  One block per classifier; lane 0 carries the sample, lanes 1..63
+// are padding (all missing, weight 0).
 __global__ void k_unpack_tgeno(HibagModelView M, HibagBatchView B,
 	const uint64_t *__restrict__ tgeno, const double *__restrict__ weight)
 {
 	const int c = blockIdx.x;
 	const int lane = threadIdx.x;
-	const int nw = M.n_word[c];
-	const int row0 = M.geno_row[c];
+	const int k = M.n_snp_c[c];
+	const int nwp = M.nwp[c];
+	const int row0 = M.mask_row[c];
 	const uint64_t *g = tgeno + (size_t)c * 6;
-	for (int w = 0; w < nw; w++) {
-		uint32_t p1 = 0, p2 = 0xFFFFFFFFu;
+	int comp = 0, i = 0;
+	for (int m = 0; m < nwp; m++) {
+		uint32_t xw = 0, mw = 0;
 		if (lane == 0) {
-			p1 = (uint32_t)(g[w >> 1] >> (32 * (w & 1)));
-			p2 = (uint32_t)(g[2 + (w >> 1)] >> (32 * (w & 1)));
+			for (int q = 0; q < 32 && comp < 3 && k > 0; q++) {
+				const uint32_t s1 = (uint32_t)(g[i >> 6] >> (i & 63)) & 1u;
+				const uint32_t s2 = (uint32_t)(g[2 + (i >> 6)] >> (i & 63)) & 1u;
+				const uint32_t bit = 1u << q;
+				if (comp < 2) {
+					if (s1 == s2) mw |= bit;           // g = 0 or 2
+					if (s1 & s2) xw |= bit;            // g = 2
+				} else if (s1 & ~s2 & 1u) mw |= bit;   // g = 1
+				if (++i == k) { i = 0; comp++; }
+			}
 		}
-		B.planes[(size_t)(row0 + 2 * w) * B.n_pad + lane] = p1;
-		B.planes[(size_t)(row0 + 2 * w + 1) * B.n_pad + lane] = p2;
+		B.masks[(size_t)(row0 + m) * B.n_pad + lane] = xw;
+		B.masks[(size_t)(row0 + nwp + m) * B.n_pad + lane] = mw;
 	}
 	B.cw[(size_t)c * B.n_pad + lane] = (lane == 0) ? weight[c] : 0.0;
 }
@@ -173,112 +239,97 @@ __global__ void k_unpack_tgeno(HibagModelView M, HibagBatchView B,
 // k_total (pass 1): in-order posterior total of one classifier for 64 samples:
 // cells visited h1 ascending, h2 >= h1 ascending and added as produced
 // (src/LibHLA.cpp:1776-1826).  Empty cells add +0.0 and are skipped.
-// grid (n_pad/64, C) with the heaviest classifiers first, block 64.
-template <int NW>
+// grid (ceil(groups/4), C) with the heaviest classifiers first; each of the 4
+// wavefronts of a block owns one group of 64 samples.
+template <int NWP>
 __device__ __forceinline__ double classifier_total(const HibagModelView &M, const HibagBatchView &B,
 	int c, int s, const double *tab_s)
 {
-	LaneGeno<NW> G;
-	load_geno<NW>(B, M.geno_row[c], s, G);
-	const int H = M.n_hap[c];
-	const uint32_t *__restrict__ hb = M.hbits + M.bits_off[c];
-	const double *__restrict__ hf = M.hfreq + M.hap_off[c];
-	const int *__restrict__ st = M.hla_start + (size_t)c * (M.n_hla + 1);
-	const int n_hla = M.n_hla;
+	LaneMask<NWP> L;
+	load_masks<NWP>(B, M.mask_row[c], s, L);
 	double total = 0;
-	for (int h1 = 0; h1 < n_hla; h1++) {
-		const int a0 = st[h1], a1 = st[h1 + 1];
-		if (a0 == a1) continue;
-		total += cell_value<NW>(hb, hf, H, a0, a1, a0, a1, true, G, tab_s);
-		for (int h2 = h1 + 1; h2 < n_hla; h2++) {
-			const int b0 = st[h2], b1 = st[h2 + 1];
-			if (b0 == b1) continue;
-			total += cell_value<NW>(hb, hf, H, a0, a1, b0, b1, false, G, tab_s);
-		}
-	}
+	walk_cells<NWP>(M.tile_cnt + (size_t)c * M.n_tile * HIBAG_TILE, M.n_tile * HIBAG_TILE,
+		M.stream + M.stream_off[c], false, L, tab_s, [&](int, double cell) { total += cell; });
 	return total;
 }
 
-__global__ __launch_bounds__(HIBAG_WAVE) void k_total(HibagModelView M, HibagBatchView B)
+__global__ __launch_bounds__(BLOCK_THREADS) void k_total(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	stage_table(M, tab_s);
 	const int c = M.c_order[blockIdx.y];
-	const int s = blockIdx.x * HIBAG_WAVE + threadIdx.x;
+	const int group = blockIdx.x * BLOCK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	if (group * HIBAG_WAVE >= B.n_pad) return;
+	const int s = group * HIBAG_WAVE + (threadIdx.x & 63);
 	const size_t at = (size_t)c * B.n_pad + s;
 	const bool active = B.cw[at] > 0;                 // src/LibHLA.cpp:2451
 	if (__ballot(active) == 0) return;                // nobody needs this classifier
 	double total;
-	switch (M.n_word[c]) {
-	case 1:  total = classifier_total<1>(M, B, c, s, tab_s); break;
-	case 2:  total = classifier_total<2>(M, B, c, s, tab_s); break;
-	case 3:  total = classifier_total<3>(M, B, c, s, tab_s); break;
-	default: total = classifier_total<4>(M, B, c, s, tab_s); break;
-	}
+#define CALL(N) total = classifier_total<N>(M, B, c, s, tab_s)
+	HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
+#undef CALL
 	B.tot[at] = total;
 	B.inv[at] = 1 / total;                            // src/LibHLA.cpp:1827 (inf when total == 0)
 }
 
 // ---------------------------------------------------------------------------
-// k_accum (pass 2): for a tile of allele-pair cells and 64 samples, walk the
+// k_accum (pass 2): for one tile of allele-pair cells and 64 samples, walk the
 // classifiers in order and do  S[p] += (cell * (1/total)) * w
-// (src/LibHLA.cpp:1828 then :1497-1507) with S in LDS.  A classifier whose
-// cell is structurally empty contributes (0*inv)*w = +0 unless inv is not
-// finite (total == 0 or denormal), in which case the reference yields NaN/inf;
-// the `poison` ballot keeps that case on the full path.
-// grid n_tile * n_pad/64 (XCD-aware decode), block 64.
-template <int NW, int T>
+// (src/LibHLA.cpp:1828 then :1497-1507) with the tile's S in VGPRs.  A cell
+// that is structurally empty in a classifier contributes (0*inv)*w = +0 unless
+// inv is not finite (total == 0 or denormal), where the reference yields
+// NaN/inf; the `poison` ballot keeps that case on the full path.
+// Each of the 4 wavefronts of a block owns one tile of the same sample group.
+
+// The tile's 16 ensemble sums live in VGPRs as one vector; acc[j] with a
+// wave-uniform j compiles to register-relative moves (M0-indexed v_movrel), not
+// to memory.
+typedef double acc_t __attribute__((ext_vector_type(HIBAG_TILE)));
+
+template <int NWP>
 __device__ __forceinline__ void accumulate_classifier(const HibagModelView &M, const HibagBatchView &B,
-	int c, int s, int tile, bool active, bool poison, double inv, double w,
-	const double *tab_s, double (*acc)[HIBAG_WAVE])
+	int c, int s, int tile, int ncell, bool active, bool poison, double inv, double w,
+	const double *tab_s, acc_t &acc)
 {
-	LaneGeno<NW> G;
-	load_geno<NW>(B, M.geno_row[c], s, G);
-	const int H = M.n_hap[c];
-	const uint32_t *__restrict__ hb = M.hbits + M.bits_off[c];
-	const double *__restrict__ hf = M.hfreq + M.hap_off[c];
-	const int *__restrict__ st = M.hla_start + (size_t)c * (M.n_hla + 1);
-	const int *__restrict__ cells = M.tile_cell + (size_t)tile * T;
-	const int lane = threadIdx.x;
-	for (int j = 0; j < T; j++) {
-		const int p = cells[j];
-		if (p < 0) break;
-		const int h1 = M.cell_h1[p], h2 = M.cell_h2[p];
-		const int a0 = st[h1], a1 = st[h1 + 1], b0 = st[h2], b1 = st[h2 + 1];
-		if ((a0 == a1 || b0 == b1) && !poison) continue;
-		const double cell = cell_value<NW>(hb, hf, H, a0, a1, b0, b1, h1 == h2, G, tab_s);
-		if (active) acc[j][lane] += (cell * inv) * w;
-	}
+	LaneMask<NWP> L;
+	load_masks<NWP>(B, M.mask_row[c], s, L);
+	const size_t ct = (size_t)c * M.n_tile + tile;
+	walk_cells<NWP>(M.tile_cnt + ct * HIBAG_TILE, ncell,
+		M.stream + M.stream_off[c] + (size_t)M.tile_off[ct] * HIBAG_CHUNK_DWORDS(NWP), poison, L, tab_s,
+		[&](int j, double cell) {
+			const double v = (cell * inv) * w;
+			acc[j] += active ? v : 0.0;               // x + 0.0 == x: inactive lanes keep their sum
+		});
 }
 
-template <int T>
-__global__ __launch_bounds__(HIBAG_WAVE) void k_accum(HibagModelView M, HibagBatchView B)
+__global__ __launch_bounds__(BLOCK_THREADS) void k_accum(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
-	__shared__ double acc[T][HIBAG_WAVE];
 	stage_table(M, tab_s);
 
 	// XCD-aware decode: workgroups are dealt round-robin over the 8 XCDs, so
 	// give all tiles of one sample group the same (blockIdx % 8): the group's
-	// planes / weights / totals are then fetched into one XCD's L2 only.
+	// masks / weights / totals are then fetched into one XCD's L2 only.
 	const int n_group = B.n_pad / HIBAG_WAVE;
+	const int n_quad = (M.n_tile + BLOCK_WAVES - 1) / BLOCK_WAVES;   // blocks per sample group
 	const int b = blockIdx.x;
-	int group, tile;
+	int group, quad;
 	{
 		const int groups_full = n_group & ~7;          // groups covered by the swizzle
-		if (b < groups_full * M.n_tile) {
-			const int xcd = b & 7, j = b >> 3, jg = j / M.n_tile;
-			group = jg * 8 + xcd; tile = j - jg * M.n_tile;
+		if (b < groups_full * n_quad) {
+			const int xcd = b & 7, j = b >> 3, jg = j / n_quad;
+			group = jg * 8 + xcd; quad = j - jg * n_quad;
 		} else {                                       // tail (< 8 groups): plain order
-			const int r = b - groups_full * M.n_tile;
-			group = groups_full + r / M.n_tile; tile = r % M.n_tile;
+			const int r = b - groups_full * n_quad;
+			group = groups_full + r / n_quad; quad = r % n_quad;
 		}
 	}
-	const int lane = threadIdx.x;
-	const int s = group * HIBAG_WAVE + lane;
+	const int tile = quad * BLOCK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	if (tile >= M.n_tile) return;
+	const int s = group * HIBAG_WAVE + (threadIdx.x & 63);
+	const int ncell = M.tile_n[tile];
 
-#pragma unroll
-	for (int j = 0; j < T; j++) acc[j][lane] = 0;
+	acc_t acc = 0.0;
 
 	for (int c = 0; c < M.n_classifier; c++) {
 		const size_t at = (size_t)c * B.n_pad + s;
@@ -287,71 +338,56 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_accum(HibagModelView M, HibagBat
 		if (__ballot(active) == 0) continue;
 		const double inv = B.inv[at];
 		const bool poison = __ballot(active && !(fabs(inv) <= 1.79769313486231570815e+308)) != 0;
-		switch (M.n_word[c]) {
-		case 1:  accumulate_classifier<1, T>(M, B, c, s, tile, active, poison, inv, w, tab_s, acc); break;
-		case 2:  accumulate_classifier<2, T>(M, B, c, s, tile, active, poison, inv, w, tab_s, acc); break;
-		case 3:  accumulate_classifier<3, T>(M, B, c, s, tile, active, poison, inv, w, tab_s, acc); break;
-		default: accumulate_classifier<4, T>(M, B, c, s, tile, active, poison, inv, w, tab_s, acc); break;
-		}
+#define CALL(N) accumulate_classifier<N>(M, B, c, s, tile, ncell, active, poison, inv, w, tab_s, acc)
+		HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
+#undef CALL
 	}
 
-	const int *__restrict__ cells = M.tile_cell + (size_t)tile * T;
-	for (int j = 0; j < T; j++) {
-		const int p = cells[j];
-		if (p < 0) break;
-		B.part[(size_t)p * B.n_pad + s] = acc[j][lane];
-	}
+	const int p0 = M.tile_p0[tile];
+#pragma unroll
+	for (int j = 0; j < HIBAG_TILE; j++)
+		if (j < ncell) B.part[(size_t)(p0 + j) * B.n_pad + s] = acc[j];
 }
 
 // ---------------------------------------------------------------------------
-// k_vote_best (majority vote, pass 2 of vote_method = 2): per (sample,
-// classifier) the first strict maximum of the NORMALISED posterior
-// cell*(1/total) in cell order (src/LibHLA.cpp:2468 -> :1549-1566).
-// grid (n_pad/64, C), block 64.  Writes the winning cell index or -1.
-template <int NW>
+// k_vote_best (majority vote, vote_method = 2): per (sample, classifier) the
+// first strict maximum of the NORMALISED posterior cell*(1/total) in cell order
+// (src/LibHLA.cpp:2468 -> :1549-1566).  Empty cells give +0 or NaN, neither of
+// which can replace a maximum that starts at 0, so they are skipped.
+// grid as k_total.  Writes the winning cell index or -1.
+template <int NWP>
 __device__ __forceinline__ int classifier_best(const HibagModelView &M, const HibagBatchView &B,
-	int c, int s, double inv, bool poison, const double *tab_s)
+	int c, int s, double inv, const double *tab_s)
 {
-	LaneGeno<NW> G;
-	load_geno<NW>(B, M.geno_row[c], s, G);
-	const int H = M.n_hap[c];
-	const uint32_t *__restrict__ hb = M.hbits + M.bits_off[c];
-	const double *__restrict__ hf = M.hfreq + M.hap_off[c];
-	const int *__restrict__ st = M.hla_start + (size_t)c * (M.n_hla + 1);
-	const int n_hla = M.n_hla;
+	LaneMask<NWP> L;
+	load_masks<NWP>(B, M.mask_row[c], s, L);
 	double best = 0;
-	int best_p = -1, p = 0;
-	for (int h1 = 0; h1 < n_hla; h1++) {
-		const int a0 = st[h1], a1 = st[h1 + 1];
-		if (a0 == a1 && !poison) { p += n_hla - h1; continue; }
-		for (int h2 = h1; h2 < n_hla; h2++, p++) {
-			const int b0 = st[h2], b1 = st[h2 + 1];
-			if ((a0 == a1 || b0 == b1) && !poison) continue;   // prob = +0 never beats max >= 0
-			const double prob = cell_value<NW>(hb, hf, H, a0, a1, b0, b1, h1 == h2, G, tab_s) * inv;
+	int best_p = -1;
+	walk_cells<NWP>(M.tile_cnt + (size_t)c * M.n_tile * HIBAG_TILE, M.n_tile * HIBAG_TILE,
+		M.stream + M.stream_off[c], false, L, tab_s, [&](int j, double cell) {
+			const double prob = cell * inv;
+			const int p = M.tile_p0[j / HIBAG_TILE] + (j % HIBAG_TILE);
 			if (best < prob) { best = prob; best_p = p; }
-		}
-	}
+		});
 	return best_p;
 }
 
-__global__ __launch_bounds__(HIBAG_WAVE) void k_vote_best(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
+__global__ __launch_bounds__(BLOCK_THREADS) void k_vote_best(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	stage_table(M, tab_s);
 	const int c = M.c_order[blockIdx.y];
-	const int s = blockIdx.x * HIBAG_WAVE + threadIdx.x;
+	const int group = blockIdx.x * BLOCK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	if (group * HIBAG_WAVE >= B.n_pad) return;
+	const int s = group * HIBAG_WAVE + (threadIdx.x & 63);
 	const size_t at = (size_t)c * B.n_pad + s;
 	const bool active = B.cw[at] > 0;
 	if (__ballot(active) == 0) { best_cell[at] = -1; return; }
 	const double inv = B.inv[at];
-	const bool poison = __ballot(active && !(fabs(inv) <= 1.79769313486231570815e+308)) != 0;
 	int bp;
-	switch (M.n_word[c]) {
-	case 1:  bp = classifier_best<1>(M, B, c, s, inv, poison, tab_s); break;
-	case 2:  bp = classifier_best<2>(M, B, c, s, inv, poison, tab_s); break;
-	case 3:  bp = classifier_best<3>(M, B, c, s, inv, poison, tab_s); break;
-	default: bp = classifier_best<4>(M, B, c, s, inv, poison, tab_s); break;
-	}
+#define CALL(N) bp = classifier_best<N>(M, B, c, s, inv, tab_s)
+	HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
+#undef CALL
 	best_cell[at] = active ? bp : -1;
 }
 
@@ -491,25 +527,29 @@ void hibag_launch_unpack_tgeno(const HibagModelView &M, const HibagBatchView &B,
 void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st)
 {
 	if (M.n_classifier == 0) return;
-	hipLaunchKernelGGL(k_total, dim3(B.n_pad / HIBAG_WAVE, M.n_classifier), dim3(HIBAG_WAVE), 0, st, M, B);
+	const unsigned gx = (unsigned)((B.n_pad / HIBAG_WAVE + BLOCK_WAVES - 1) / BLOCK_WAVES);
+	static const int dbg_lds = getenv("HIBAG_DEBUG_LDS") ? atoi(getenv("HIBAG_DEBUG_LDS")) : 0;   // occupancy experiments
+	hipLaunchKernelGGL(k_total, dim3(gx, M.n_classifier), dim3(BLOCK_THREADS), dbg_lds, st, M, B);
 }
 
 void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStream_t st)
 {
-	const unsigned n = (unsigned)(B.n_pad / HIBAG_WAVE) * (unsigned)M.n_tile;
-	if (n == 0) return;
-	switch (M.tile_cells) {
-	case 8:  hipLaunchKernelGGL(k_accum<8>, dim3(n), dim3(HIBAG_WAVE), 0, st, M, B); break;
-	case 16: hipLaunchKernelGGL(k_accum<16>, dim3(n), dim3(HIBAG_WAVE), 0, st, M, B); break;
-	default: hipLaunchKernelGGL(k_accum<32>, dim3(n), dim3(HIBAG_WAVE), 0, st, M, B); break;
+	const unsigned n_quad = (unsigned)((M.n_tile + BLOCK_WAVES - 1) / BLOCK_WAVES);
+	const unsigned n = (unsigned)(B.n_pad / HIBAG_WAVE) * n_quad;
+	if (n == 0 || M.n_classifier == 0) {
+		// no classifier: the ensemble sums are all zero (src/LibHLA.cpp:1491-1495)
+		(void)hipMemsetAsync(B.part, 0, (size_t)M.n_cell * B.n_pad * sizeof(double), st);
+		return;
 	}
+	hipLaunchKernelGGL(k_accum, dim3(n), dim3(BLOCK_THREADS), 0, st, M, B);
 }
 
 void hibag_launch_vote(const HibagModelView &M, const HibagBatchView &B, int *d_best_cell, hipStream_t st)
 {
-	if (M.n_classifier > 0)
-		hipLaunchKernelGGL(k_vote_best, dim3(B.n_pad / HIBAG_WAVE, M.n_classifier), dim3(HIBAG_WAVE), 0, st,
-			M, B, d_best_cell);
+	if (M.n_classifier > 0) {
+		const unsigned gx = (unsigned)((B.n_pad / HIBAG_WAVE + BLOCK_WAVES - 1) / BLOCK_WAVES);
+		hipLaunchKernelGGL(k_vote_best, dim3(gx, M.n_classifier), dim3(BLOCK_THREADS), 0, st, M, B, d_best_cell);
+	}
 	hipLaunchKernelGGL(k_vote_tally, grid1(B.n_pad, 64), dim3(64), 0, st, M, B, (const int *)d_best_cell);
 }
 
