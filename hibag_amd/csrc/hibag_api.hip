@@ -357,20 +357,32 @@ int finalize_model(hibag_hip_model *m)
 	std::vector<int> tile_p0, tile_n;
 	build_tiles(P, cell_work, tile_p0, tile_n);
 	const int n_tile = (int)tile_p0.size();
-	// +1: the walker reads the count after the last cell; see walk_cells()
-	std::vector<uint32_t> tile_cnt((size_t)std::max(C, 1) * n_tile * HIBAG_TILE + 1, 0), tile_off((size_t)std::max(C, 1) * n_tile, 0);
+	// pass 1 lists (non-empty cells per classifier) and pass 2 tile entries
+	std::vector<uint32_t> cls_cnt, cls_cell, tile_meta((size_t)std::max(C, 1) * n_tile * HIBAG_TILE_META + 1, 0);
+	std::vector<int> cls_off(std::max(C, 1), 0), cls_n(std::max(C, 1), 0);
 	for (int c = 0; c < C; c++) {
+		cls_off[c] = (int)cls_cnt.size();
+		for (int p = 0; p < P; p++)
+			if (cell_chunks[c][p]) { cls_cnt.push_back(cell_chunks[c][p]); cls_cell.push_back((uint32_t)p); }
+		cls_n[c] = (int)cls_cnt.size() - cls_off[c];
+		cls_cnt.push_back(0); cls_cell.push_back(0);        // the walker reads one count ahead
 		uint64_t off = 0;
 		for (int t = 0; t < n_tile; t++) {
+			uint32_t *me = &tile_meta[((size_t)c * n_tile + t) * HIBAG_TILE_META];
 			if (off > 0xFFFFFFFFull) return fail(HIBAG_HIP_EINVAL, "classifier %d has too many haplotype pairs", c);
-			tile_off[(size_t)c * n_tile + t] = (uint32_t)off;
+			me[1] = (uint32_t)off;
+			int k = 0;
 			for (int j = 0; j < tile_n[t]; j++) {
 				const uint32_t n = cell_chunks[c][tile_p0[t] + j];
-				tile_cnt[((size_t)c * n_tile + t) * HIBAG_TILE + j] = n;
-				off += n;
+				if (n > 0xFFFFFFu) return fail(HIBAG_HIP_EINVAL, "an allele pair of classifier %d has too many haplotype pairs", c);
+				if (n) { me[2 + k++] = ((uint32_t)j << 24) | n; off += n; }
 			}
+			me[0] = (uint32_t)k;
+			for (int j = 0; j < tile_n[t]; j++)
+				if (!cell_chunks[c][tile_p0[t] + j]) me[2 + k++] = (uint32_t)j << 24;
 		}
 	}
+	if (cls_cnt.empty()) { cls_cnt.push_back(0); cls_cell.push_back(0); }
 
 	// one int arena
 	std::vector<int> arena;
@@ -381,19 +393,22 @@ int finalize_model(hibag_hip_model *m)
 		return off;
 	};
 	const size_t o_nsnp = put(n_snp_c), o_nwp = put(nwp), o_snpoff = put(snp_off), o_snpidx = put(snp_index),
-		o_snpw = put(snp_weight), o_mrow = put(mask_row), o_order = put(c_order), o_tp0 = put(tile_p0), o_tn = put(tile_n);
+		o_snpw = put(snp_weight), o_mrow = put(mask_row), o_order = put(c_order), o_tp0 = put(tile_p0), o_tn = put(tile_n),
+		o_coff = put(cls_off), o_cn = put(cls_n);
 
 	if (int rc = m->d_int.reserve(arena.size() * sizeof(int))) return rc;
 	if (int rc = m->d_stream.reserve(stream.size() * sizeof(uint32_t))) return rc;
-	if (int rc = m->d_tile.reserve((tile_cnt.size() + tile_off.size()) * sizeof(uint32_t) + stream_off.size() * sizeof(uint64_t))) return rc;
+	const size_t tb_off = 0, tb_meta = stream_off.size() * sizeof(uint64_t), tb_cnt = tb_meta + tile_meta.size() * sizeof(uint32_t),
+		tb_cell = tb_cnt + cls_cnt.size() * sizeof(uint32_t), tb_end = tb_cell + cls_cell.size() * sizeof(uint32_t);
+	if (int rc = m->d_tile.reserve(tb_end)) return rc;
 	if (int rc = m->d_tab.reserve(sizeof(m->tab))) return rc;
 	HIP_TRY(hipMemcpy(m->d_int.p, arena.data(), arena.size() * sizeof(int), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(m->d_stream.p, stream.data(), stream.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	char *tbase = m->d_tile.as<char>();
-	const size_t tb_off = 0, tb_cnt = stream_off.size() * sizeof(uint64_t), tb_toff = tb_cnt + tile_cnt.size() * sizeof(uint32_t);
 	HIP_TRY(hipMemcpy(tbase + tb_off, stream_off.data(), stream_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(tbase + tb_cnt, tile_cnt.data(), tile_cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(tbase + tb_toff, tile_off.data(), tile_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(tbase + tb_meta, tile_meta.data(), tile_meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(tbase + tb_cnt, cls_cnt.data(), cls_cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(tbase + tb_cell, cls_cell.data(), cls_cell.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(m->d_tab.p, m->tab, sizeof(m->tab), hipMemcpyHostToDevice));
 
 	HibagModelView &V = m->view;
@@ -403,8 +418,10 @@ int finalize_model(hibag_hip_model *m)
 	V.snp_index = base + o_snpidx; V.snp_weight = base + o_snpw; V.mask_row = base + o_mrow;
 	V.c_order = base + o_order; V.tile_p0 = base + o_tp0; V.tile_n = base + o_tn;
 	V.stream_off = (const uint64_t *)(tbase + tb_off);
-	V.tile_cnt = (const uint32_t *)(tbase + tb_cnt);
-	V.tile_off = (const uint32_t *)(tbase + tb_toff);
+	V.tile_meta = (const uint32_t *)(tbase + tb_meta);
+	V.cls_cnt = (const uint32_t *)(tbase + tb_cnt);
+	V.cls_cell = (const uint32_t *)(tbase + tb_cell);
+	V.cls_off = base + o_coff; V.cls_n = base + o_cn;
 	V.stream = m->d_stream.as<uint32_t>();
 	V.tab = m->d_tab.as<double>();
 	m->mask_rows = rows;

@@ -14,9 +14,12 @@
 //    Records are grouped in CHUNKS of HIBAG_CHUNK, SoA inside a chunk
 //    (W[nwp][CHUNK] then prod[CHUNK]); every allele-pair cell owns whole chunks,
 //    padded with {W=0, prod=+0.0} records (adding +0.0*TAB[d] is exact).
-//    Cells are grouped in TILES of up to HIBAG_TILE consecutive cells with about
-//    equal work; tile_cnt[c][t][j] = chunks of cell j of tile t in classifier c,
-//    tile_off[c][t] = first chunk of the tile in the classifier's stream.
+//    Cells without haplotype pairs own no chunk.  cls_cnt lists, per classifier,
+//    the chunk counts of its non-empty cells in posterior order (pass 1 walks
+//    it).  For pass 2 cells are grouped in TILES of up to HIBAG_TILE consecutive
+//    cells with about equal work; tile_meta[c][t] = { #non-empty cells, first
+//    chunk of the tile, then one entry (j << 24 | chunks) per cell of the tile:
+//    the non-empty ones in order, then the empty ones }.
 //
 //  BATCH ("lane = sample": consecutive samples are consecutive addresses, so
 //  every per-lane access is one coalesced row segment of a wavefront):
@@ -33,8 +36,13 @@
 
 #define HIBAG_WAVE 64
 #define HIBAG_TAB_N 257          // 2*128 + 1 distances (src/LibHLA.cpp:167)
-#define HIBAG_TILE 16            // allele-pair cells per tile (accumulators live in VGPRs)
-#define HIBAG_CHUNK 2            // pair records per chunk
+#ifndef HIBAG_TILE
+#define HIBAG_TILE 8             // allele-pair cells per tile (one LDS accumulator row each)
+#endif
+#ifndef HIBAG_CHUNK
+#define HIBAG_CHUNK 4            // pair records per chunk
+#endif
+#define HIBAG_TILE_META (2 + HIBAG_TILE)   // dwords of one tile_meta entry
 #define HIBAG_MAX_NWP 12         // ceil(3*128/32) words of the packed pair string
 
 // dwords of one chunk for a classifier with nwp words per record
@@ -57,8 +65,11 @@ struct HibagModelView {
 	const int *c_order;          // [C] classifiers sorted by pair count, heaviest first
 	const int *tile_p0;          // [n_tile] first cell (posterior index) of the tile
 	const int *tile_n;           // [n_tile] cells in the tile (1..HIBAG_TILE)
-	const uint32_t *tile_cnt;    // [C][n_tile][HIBAG_TILE] chunks per cell
-	const uint32_t *tile_off;    // [C][n_tile] first chunk of the tile
+	const uint32_t *tile_meta;   // [C][n_tile][HIBAG_TILE_META]
+	const uint32_t *cls_cnt;     // per classifier: chunks of each non-empty cell (+1 pad)
+	const uint32_t *cls_cell;    // same layout: posterior index of each non-empty cell
+	const int *cls_off;          // [C] offset of the classifier's list in cls_cnt / cls_cell
+	const int *cls_n;            // [C] number of non-empty cells
 	const uint64_t *stream_off;  // [C] dword offset of the classifier's stream
 	const uint32_t *stream;      // the pair streams
 	const double *tab;           // [257] exp(d*log(1e-5))

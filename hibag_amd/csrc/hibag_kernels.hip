@@ -58,6 +58,14 @@ __device__ __forceinline__ void load_masks(const HibagBatchView &B, int row0, in
 		L.x[w] = B.masks[(size_t)(row0 + w) * B.n_pad + s];
 		L.m[w] = B.masks[(size_t)(row0 + NWP + w) * B.n_pad + s];
 	}
+	// The masks are used by every instruction of the loops that follow: make the
+	// loads complete here (an empty asm that passes the registers through) instead
+	// of leaving one s_waitcnt vmcnt per mask inside the loop.  It must be a plain
+	// asm: a "memory" clobber, asm volatile or the s_waitcnt builtin all make the
+	// compiler assume the stream may have been written, and the stream loads then
+	// become per-lane VMEM instead of scalar s_load.
+#pragma unroll
+	for (int w = 0; w < NWP; w++) asm("" : "+v"(L.x[w]), "+v"(L.m[w]));
 }
 
 // popc(x) + acc in one VALU op.  Written as asm so that the compiler keeps the
@@ -70,71 +78,39 @@ __device__ __forceinline__ int bcnt_acc(uint32_t x, int acc)
 	return r;
 }
 
-// One chunk of the pair stream, wave-uniform (lives in SGPRs).
-template <int NWP>
-struct Chunk {
-	uint32_t w[NWP * CH];
-	double p[CH];
-};
-
-template <int NWP>
-__device__ __forceinline__ void load_chunk(Chunk<NWP> &c, const uint32_t *__restrict__ cp)
-{
-#pragma unroll
-	for (int i = 0; i < NWP * CH; i++) c.w[i] = cp[i];
-	const double *__restrict__ pr = reinterpret_cast<const double *>(cp + NWP * CH);
-#pragma unroll
-	for (int r = 0; r < CH; r++) c.p[r] = pr[r];
-}
-
-// cell += prod_r * TAB[d_r], r in order: the statement
+// One chunk of CH pair records at cp (wave-uniform: s_load into SGPRs):
+//   cell += prod_r * TAB[d_r], r in order -- the statement
 //   sum += (2*f1*f2) * TAB[hamm_d]   of src/LibHLA.cpp:1786-1813 (ADD_FREQ_MUTANT, src/LibHLA.h:223).
+// The CH table look-ups are independent, so their LDS latencies overlap.
 template <int NWP>
-__device__ __forceinline__ double chunk_apply(double cell, const Chunk<NWP> &c, const LaneMask<NWP> &L,
-	const double *tab_s)
+__device__ __forceinline__ double chunk_apply(double cell, const uint32_t *__restrict__ cp,
+	const LaneMask<NWP> &L, const double *tab_s)
 {
 	double t[CH];
 #pragma unroll
 	for (int r = 0; r < CH; r++) {
-		int d = __popc((c.w[r] ^ L.x[0]) & L.m[0]);
+		int d = __popc((cp[r] ^ L.x[0]) & L.m[0]);
 #pragma unroll
-		for (int w = 1; w < NWP; w++) d = bcnt_acc((c.w[w * CH + r] ^ L.x[w]) & L.m[w], d);
+		for (int w = 1; w < NWP; w++) d = bcnt_acc((cp[w * CH + r] ^ L.x[w]) & L.m[w], d);
 		t[r] = tab_s[d];
 	}
+	const double *__restrict__ pr = reinterpret_cast<const double *>(cp + NWP * CH);
 #pragma unroll
-	for (int r = 0; r < CH; r++) cell += c.p[r] * t[r];
+	for (int r = 0; r < CH; r++) cell += pr[r] * t[r];
 	return cell;
 }
 
-// Visit `ncell` consecutive cells in order: cell j owns cnt[j] consecutive
-// chunks starting at cp.  fin(j, cell) receives the strictly ordered cell sum;
-// cells without haplotype pairs are skipped unless `visit_empty` (their sum is
-// +0.0).  The next chunk and the next count are fetched while the current
-// chunk is evaluated (the stream and cnt[] are padded so that reading one
-// element past the range is in bounds).
-template <int NWP, class Fin>
-__device__ __forceinline__ void walk_cells(const uint32_t *__restrict__ cnt, int ncell,
-	const uint32_t *__restrict__ cp, bool visit_empty, const LaneMask<NWP> &L, const double *tab_s, Fin &&fin)
+// The strictly ordered sum of one allele-pair cell: n consecutive chunks at cp.
+template <int NWP>
+__device__ __forceinline__ double cell_sum(uint32_t n, const uint32_t *__restrict__ &cp,
+	const LaneMask<NWP> &L, const double *tab_s)
 {
-	Chunk<NWP> cur;
-	load_chunk<NWP>(cur, cp);
-	cp += HIBAG_CHUNK_DWORDS(NWP);
-	uint32_t n = cnt[0];
-	for (int j = 0; j < ncell; j++) {
-		const uint32_t n_next = cnt[j + 1];
-		if (n != 0 || visit_empty) {
-			double cell = 0;
-			for (uint32_t k = 0; k < n; k++) {
-				Chunk<NWP> nxt;
-				load_chunk<NWP>(nxt, cp);
-				cp += HIBAG_CHUNK_DWORDS(NWP);
-				cell = chunk_apply<NWP>(cell, cur, L, tab_s);
-				cur = nxt;
-			}
-			fin(j, cell);
-		}
-		n = n_next;
+	double cell = 0;
+	for (; n > 0; n--) {
+		cell = chunk_apply<NWP>(cell, cp, L, tab_s);
+		cp += HIBAG_CHUNK_DWORDS(NWP);
 	}
+	return cell;
 }
 
 // Record widths the kernels are specialised for; the host rounds a classifier's
@@ -247,13 +223,20 @@ __device__ __forceinline__ double classifier_total(const HibagModelView &M, cons
 {
 	LaneMask<NWP> L;
 	load_masks<NWP>(B, M.mask_row[c], s, L);
+	const uint32_t *__restrict__ cnt = M.cls_cnt + M.cls_off[c];
+	const uint32_t *__restrict__ cp = M.stream + M.stream_off[c];
+	const int ncell = M.cls_n[c];
 	double total = 0;
-	walk_cells<NWP>(M.tile_cnt + (size_t)c * M.n_tile * HIBAG_TILE, M.n_tile * HIBAG_TILE,
-		M.stream + M.stream_off[c], false, L, tab_s, [&](int, double cell) { total += cell; });
+	uint32_t n = cnt[0];
+	for (int i = 0; i < ncell; i++) {
+		const uint32_t n_next = cnt[i + 1];           // fetched while this cell is evaluated
+		total += cell_sum<NWP>(n, cp, L, tab_s);
+		n = n_next;
+	}
 	return total;
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS) void k_total(HibagModelView M, HibagBatchView B)
+__global__ __launch_bounds__(BLOCK_THREADS, 8) void k_total(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	stage_table(M, tab_s);
@@ -275,36 +258,38 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_total(HibagModelView M, Hibag
 // ---------------------------------------------------------------------------
 // k_accum (pass 2): for one tile of allele-pair cells and 64 samples, walk the
 // classifiers in order and do  S[p] += (cell * (1/total)) * w
-// (src/LibHLA.cpp:1828 then :1497-1507) with the tile's S in VGPRs.  A cell
-// that is structurally empty in a classifier contributes (0*inv)*w = +0 unless
-// inv is not finite (total == 0 or denormal), where the reference yields
-// NaN/inf; the `poison` ballot keeps that case on the full path.
+// (src/LibHLA.cpp:1828 then :1497-1507) with the tile's S in LDS (one row of 64
+// doubles per cell, conflict-free).  A cell that is structurally empty in a
+// classifier contributes (0*inv)*w = +0 unless inv is not finite (total == 0 or
+// denormal), where the reference yields NaN/inf; the `poison` ballot makes the
+// walk include the empty cells in that case.
 // Each of the 4 wavefronts of a block owns one tile of the same sample group.
-
-// The tile's 16 ensemble sums live in VGPRs as one vector; acc[j] with a
-// wave-uniform j compiles to register-relative moves (M0-indexed v_movrel), not
-// to memory.
-typedef double acc_t __attribute__((ext_vector_type(HIBAG_TILE)));
-
 template <int NWP>
 __device__ __forceinline__ void accumulate_classifier(const HibagModelView &M, const HibagBatchView &B,
 	int c, int s, int tile, int ncell, bool active, bool poison, double inv, double w,
-	const double *tab_s, acc_t &acc)
+	const double *tab_s, double (*acc)[HIBAG_WAVE])
 {
 	LaneMask<NWP> L;
 	load_masks<NWP>(B, M.mask_row[c], s, L);
-	const size_t ct = (size_t)c * M.n_tile + tile;
-	walk_cells<NWP>(M.tile_cnt + ct * HIBAG_TILE, ncell,
-		M.stream + M.stream_off[c] + (size_t)M.tile_off[ct] * HIBAG_CHUNK_DWORDS(NWP), poison, L, tab_s,
-		[&](int j, double cell) {
-			const double v = (cell * inv) * w;
-			acc[j] += active ? v : 0.0;               // x + 0.0 == x: inactive lanes keep their sum
-		});
+	const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + tile) * HIBAG_TILE_META;
+	const int nvisit = poison ? ncell : (int)meta[0];
+	const uint32_t *__restrict__ cp = M.stream + M.stream_off[c] + (size_t)meta[1] * HIBAG_CHUNK_DWORDS(NWP);
+	const int lane = threadIdx.x & 63;
+	uint32_t e = meta[2];
+	for (int i = 0; i < nvisit; i++) {
+		const uint32_t e_next = meta[3 + i];           // fetched while this cell is evaluated (meta is padded)
+		const int j = e >> 24;
+		const double cell = cell_sum<NWP>(e & 0xFFFFFFu, cp, L, tab_s);
+		const double v = (cell * inv) * w;
+		acc[j][lane] += active ? v : 0.0;              // x + 0.0 == x: inactive lanes keep their sum
+		e = e_next;
+	}
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS) void k_accum(HibagModelView M, HibagBatchView B)
+__global__ __launch_bounds__(BLOCK_THREADS, 8) void k_accum(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
+	__shared__ double acc_s[BLOCK_WAVES][HIBAG_TILE][HIBAG_WAVE];
 	stage_table(M, tab_s);
 
 	// XCD-aware decode: workgroups are dealt round-robin over the 8 XCDs, so
@@ -324,12 +309,16 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_accum(HibagModelView M, Hibag
 			group = groups_full + r / n_quad; quad = r % n_quad;
 		}
 	}
-	const int tile = quad * BLOCK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int tile = quad * BLOCK_WAVES + wave;
 	if (tile >= M.n_tile) return;
-	const int s = group * HIBAG_WAVE + (threadIdx.x & 63);
+	const int lane = threadIdx.x & 63;
+	const int s = group * HIBAG_WAVE + lane;
 	const int ncell = M.tile_n[tile];
+	double (*acc)[HIBAG_WAVE] = acc_s[wave];
 
-	acc_t acc = 0.0;
+#pragma unroll
+	for (int j = 0; j < HIBAG_TILE; j++) acc[j][lane] = 0;
 
 	for (int c = 0; c < M.n_classifier; c++) {
 		const size_t at = (size_t)c * B.n_pad + s;
@@ -344,9 +333,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_accum(HibagModelView M, Hibag
 	}
 
 	const int p0 = M.tile_p0[tile];
-#pragma unroll
-	for (int j = 0; j < HIBAG_TILE; j++)
-		if (j < ncell) B.part[(size_t)(p0 + j) * B.n_pad + s] = acc[j];
+	for (int j = 0; j < ncell; j++) B.part[(size_t)(p0 + j) * B.n_pad + s] = acc[j][lane];
 }
 
 // ---------------------------------------------------------------------------
@@ -361,18 +348,20 @@ __device__ __forceinline__ int classifier_best(const HibagModelView &M, const Hi
 {
 	LaneMask<NWP> L;
 	load_masks<NWP>(B, M.mask_row[c], s, L);
+	const uint32_t *__restrict__ cnt = M.cls_cnt + M.cls_off[c];
+	const uint32_t *__restrict__ cell_p = M.cls_cell + M.cls_off[c];
+	const uint32_t *__restrict__ cp = M.stream + M.stream_off[c];
+	const int ncell = M.cls_n[c];
 	double best = 0;
 	int best_p = -1;
-	walk_cells<NWP>(M.tile_cnt + (size_t)c * M.n_tile * HIBAG_TILE, M.n_tile * HIBAG_TILE,
-		M.stream + M.stream_off[c], false, L, tab_s, [&](int j, double cell) {
-			const double prob = cell * inv;
-			const int p = M.tile_p0[j / HIBAG_TILE] + (j % HIBAG_TILE);
-			if (best < prob) { best = prob; best_p = p; }
-		});
+	for (int i = 0; i < ncell; i++) {
+		const double prob = cell_sum<NWP>(cnt[i], cp, L, tab_s) * inv;
+		if (best < prob) { best = prob; best_p = (int)cell_p[i]; }
+	}
 	return best_p;
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS) void k_vote_best(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
+__global__ __launch_bounds__(BLOCK_THREADS, 8) void k_vote_best(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	stage_table(M, tab_s);
