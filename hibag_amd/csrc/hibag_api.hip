@@ -138,7 +138,7 @@ struct hibag_hip_model {
 	size_t stream_bytes = 0;
 
 	// per-batch workspace (grow-only)
-	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out;
+	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes;
 	// plugin staging
 	DevBuf ws_tgeno, ws_weight;
 
@@ -150,7 +150,7 @@ struct hibag_hip_model {
 		(void)hipSetDevice(device);
 		timer.destroy();
 		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
-		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_tgeno, &ws_weight})
+		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_tgeno, &ws_weight})
 			b->release();
 	}
 };
@@ -451,6 +451,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	if (int rc = m->ws_tot.reserve(C * n_pad * sizeof(double))) return rc;
 	if (int rc = m->ws_inv.reserve(C * n_pad * sizeof(double))) return rc;
 	if (int rc = m->ws_part.reserve((size_t)(m->view.n_cell + 3) * n_pad * sizeof(double))) return rc;
+	if (int rc = m->ws_codes.reserve((size_t)std::max(m->n_snp, 1) * n_pad)) return rc;
 	if (need_best)
 		if (int rc = m->ws_best.reserve(C * n_pad * sizeof(int))) return rc;
 	B.n_samp = n_samp; B.n_pad = n_pad;
@@ -507,7 +508,7 @@ int predict_device_locked(hibag_hip_model *m, const int32_t *d_geno, int n_samp,
 		HibagBatchView B;
 		if (int rc = make_batch(m, n, vote_method == 2, B)) return rc;
 		m->timer.begin(HIBAG_HIP_K_PACK, st);
-		hibag_launch_pack(m->view, B, d_geno + (size_t)s0 * m->n_snp, st);
+		hibag_launch_pack(m->view, B, d_geno + (size_t)s0 * m->n_snp, m->ws_codes.as<uint8_t>(), st);
 		m->timer.end(st);
 		run_core(m, B, vote_method, m->ws_part.as<double>(), st);
 		m->timer.begin(HIBAG_HIP_K_FINISH, st);
@@ -721,7 +722,7 @@ int hibag_hip_predict_partial_device(hibag_hip_model *m, const int32_t *d_geno, 
 	HibagBatchView B;
 	if (int rc = make_batch(m, n_samp, false, B)) return rc;
 	m->timer.begin(HIBAG_HIP_K_PACK, st);
-	hibag_launch_pack(m->view, B, d_geno, st);
+	hibag_launch_pack(m->view, B, d_geno, m->ws_codes.as<uint8_t>(), st);
 	m->timer.end(st);
 	run_core(m, B, 1, d_partial, st);
 	HIP_TRY(hipGetLastError());

@@ -7,7 +7,8 @@
 #include <stdint.h>
 #include "hibag_device.h"
 
-void hibag_launch_pack(const HibagModelView &M, const HibagBatchView &B, const int32_t *d_geno, hipStream_t st);
+void hibag_launch_pack(const HibagModelView &M, const HibagBatchView &B, const int32_t *d_geno, uint8_t *d_codes,
+	hipStream_t st);
 void hibag_launch_unpack_tgeno(const HibagModelView &M, const HibagBatchView &B, const uint64_t *d_tgeno,
 	const double *d_weight, hipStream_t st);
 void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st);

@@ -133,23 +133,46 @@ __device__ __forceinline__ void stage_table(const HibagModelView &M, double *tab
 }
 
 // ---------------------------------------------------------------------------
+// k_codes: the raw genotype matrix int32 [n_samp][n_snp] (sample-major, the
+// memory of R's SNP x sample matrix) -> byte codes [n_snp][n_pad] with the
+// sample index fastest: 0/1/2 = genotype, 3 = missing (anything outside 0..2,
+// incl. NA_integer_, src/LibHLA.cpp:662-665).  64x64 transpose through LDS:
+// reads are coalesced along SNPs, writes along samples.
+__global__ __launch_bounds__(256) void k_codes(HibagModelView M, HibagBatchView B,
+	const int32_t *__restrict__ geno, uint8_t *__restrict__ codes)
+{
+	__shared__ uint8_t tile[64][65];
+	const int s0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	for (int r = ty; r < 64; r += 4) {
+		const int s = s0 + r, k = k0 + tx;
+		int g = -1;
+		if (s < B.n_samp && k < M.n_snp) g = geno[(size_t)s * M.n_snp + k];
+		tile[r][tx] = (g >= 0 && g <= 2) ? (uint8_t)g : (uint8_t)3;
+	}
+	__syncthreads();
+	for (int r = ty; r < 64; r += 4) {
+		const int k = k0 + r;
+		if (k < M.n_snp) codes[(size_t)k * B.n_pad + s0 + tx] = tile[tx][r];
+	}
+}
+
 // k_pack: TGenotype::IntToSNP (src/LibHLA.cpp:662-706) for every (sample,
 // classifier), emitted directly as the lane masks of the packed pair string
 //   bits [0,k)   first haplotype : x = [g==2], m = [g in {0,2}]
 //   bits [k,2k)  second haplotype: same
 //   bits [2k,3k) ~(H1^H2)        : x = 0,      m = [g==1]
 // (missing SNPs have m = 0 everywhere), plus the classifier weight from
-// missingness (src/LibHLA.cpp:2418-2431).  grid (n_pad/64, C), block 64.
+// missingness (src/LibHLA.cpp:2418-2431).  grid (n_pad/64, C), block 64,
+// lane = sample: every code load is one coalesced 64-byte row segment.
 __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatchView B,
-	const int32_t *__restrict__ geno)
+	const uint8_t *__restrict__ codes)
 {
 	const int c = blockIdx.y;
 	const int s = blockIdx.x * HIBAG_WAVE + threadIdx.x;
-	const bool live = s < B.n_samp;
 	const int k = M.n_snp_c[c];
 	const int nwp = M.nwp[c];
 	const int *__restrict__ idx = M.snp_index + M.snp_off[c];
-	const int32_t *__restrict__ row = geno + (size_t)(live ? s : 0) * M.n_snp;
 	const int row0 = M.mask_row[c];
 	int num = 0, den = 0;
 	int comp = 0, i = 0;                       // position 32*m+q = comp*k + i
@@ -157,12 +180,12 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 		uint32_t xw = 0, mw = 0;
 		for (int q = 0; q < 32 && comp < 3 && k > 0; q++) {
 			const int snp = idx[i];
-			const int g = live ? row[snp] : -1;
+			const uint32_t g = codes[(size_t)snp * B.n_pad + s];
 			const uint32_t bit = 1u << q;
 			if (comp == 0) {
 				const int wt = M.snp_weight[snp];
 				den += wt;
-				if (g >= 0 && g <= 2) num += wt;
+				if (g != 3) num += wt;
 			}
 			if (comp < 2) {
 				if (g == 0 || g == 2) mw |= bit;
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 		B.masks[(size_t)(row0 + m) * B.n_pad + s] = xw;
 		B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s] = mw;
 	}
-	B.cw[(size_t)c * B.n_pad + s] = (live && den > 0) ? ((double)num / den) : 0.0;
+	B.cw[(size_t)c * B.n_pad + s] = (s < B.n_samp && den > 0) ? ((double)num / den) : 0.0;
 }
 
 // k_unpack_tgeno: plugin path (predict_avg_prob): the host already packed one
@@ -420,35 +443,55 @@ __global__ void k_scalars(HibagModelView M, HibagBatchView B, const int *__restr
 }
 
 // ---------------------------------------------------------------------------
-// k_finish_call: NormalizeSumPostProb (src/LibHLA.cpp:1509-1518) in place,
-// then BestGuessEnsemble (:1549-1566: first strict maximum, NA when nothing is
-// positive), the called pair's probability (:2376-2382) and the matching
-// proportion (:2480).  thread = sample; rows of `part` are coalesced.
-__global__ void k_finish_call(HibagModelView M, HibagBatchView B, double *__restrict__ part,
-	int32_t *__restrict__ H1, int32_t *__restrict__ H2, double *__restrict__ max_prob,
-	double *__restrict__ matching)
+// The ensemble sums in `part` stay un-normalised; every consumer applies
+// NormalizeSumPostProb (src/LibHLA.cpp:1509-1518: S *= 1/sum_w when sum_w > 0)
+// on the fly, which rounds exactly like scaling in place first.
+__device__ __forceinline__ double normalised(double v, bool scale, double ff) { return scale ? v * ff : v; }
+
+// k_finish_call: BestGuessEnsemble (src/LibHLA.cpp:1549-1566: first strict
+// maximum in cell order, NA when nothing is positive), the called pair's
+// probability (:2376-2382) and the matching proportion (:2480).
+// Block = 64 samples x FIN_SEG segments of the cell range; every thread scans
+// its segment in order, then the segments are merged in order with the same
+// strict comparison, which reproduces the sequential scan exactly.
+#define FIN_SEG 16
+__global__ __launch_bounds__(64 * FIN_SEG) void k_finish_call(HibagModelView M, HibagBatchView B,
+	const double *__restrict__ part, int32_t *__restrict__ H1, int32_t *__restrict__ H2,
+	double *__restrict__ max_prob, double *__restrict__ matching)
 {
-	const int s = blockIdx.x * blockDim.x + threadIdx.x;
-	if (s >= B.n_pad) return;
-	const size_t P = (size_t)M.n_cell, np = (size_t)B.n_pad;
-	const double sum_w = part[(P + 0) * np + s];
+	__shared__ double best_s[FIN_SEG][64];
+	__shared__ int cell_s[FIN_SEG][64];
+	const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+	const int s = blockIdx.x * 64 + lane;
+	const int P = M.n_cell;
+	const size_t np = (size_t)B.n_pad;
+	const double sum_w = part[(size_t)P * np + s];
 	const bool scale = sum_w > 0;
 	const double ff = 1.0 / sum_w;
+	const int per = (P + FIN_SEG - 1) / FIN_SEG;
+	const int lo = seg * per, hi = min(P, lo + per);
 	double best = 0;
+	int cell = -1;
+	for (int p = lo; p < hi; p++) {
+		const double v = normalised(part[(size_t)p * np + s], scale, ff);
+		if (best < v) { best = v; cell = p; }
+	}
+	best_s[seg][lane] = best;
+	cell_s[seg][lane] = cell;
+	__syncthreads();
+	if (seg != 0 || s >= B.n_samp) return;
+	for (int g = 1; g < FIN_SEG; g++)
+		if (best < best_s[g][lane]) { best = best_s[g][lane]; cell = cell_s[g][lane]; }
 	int b1 = NA_INTEGER, b2 = NA_INTEGER;
-	size_t p = 0;
-	for (int h1 = 0; h1 < M.n_hla; h1++) {
-		for (int h2 = h1; h2 < M.n_hla; h2++, p++) {
-			double v = part[p * np + s];
-			if (scale) { v *= ff; part[p * np + s] = v; }
-			if (best < v) { best = v; b1 = h1; b2 = h2; }
-		}
+	if (cell >= 0) {
+		// invert p = h2 + h1*(2n-h1-1)/2 (src/LibHLA.cpp:1523)
+		int h1 = 0, row = M.n_hla, rem = cell;
+		while (rem >= row) { rem -= row; row--; h1++; }
+		b1 = h1; b2 = h1 + rem;
 	}
-	if (s < B.n_samp) {
-		if (H1) { H1[s] = b1; H2[s] = b2; }
-		if (max_prob) max_prob[s] = (b1 != NA_INTEGER) ? best : 0.0;
-		if (matching) matching[s] = part[(P + 1) * np + s] / part[(P + 2) * np + s];
-	}
+	if (H1) { H1[s] = b1; H2[s] = b2; }
+	if (max_prob) max_prob[s] = (cell >= 0) ? best : 0.0;
+	if (matching) matching[s] = part[(size_t)(P + 1) * np + s] / part[(size_t)(P + 2) * np + s];
 }
 
 // k_finish_dosage: expected allele dosage (src/LibHLA.cpp:2387-2402).  The
@@ -463,14 +506,17 @@ __global__ void k_finish_dosage(HibagModelView M, HibagBatchView B, const double
 	if (s >= B.n_samp) return;
 	const int n = M.n_hla;
 	const size_t np = (size_t)B.n_pad;
+	const double sum_w = part[(size_t)M.n_cell * np + s];
+	const bool scale = sum_w > 0;
+	const double ff = 1.0 / sum_w;
 	double d = 0;
 	for (int g = 0; g < h; g++) {
 		const size_t p = (size_t)h + (size_t)g * (2 * n - g - 1) / 2;   // index of (g,h), src/LibHLA.cpp:1523
-		d += part[p * np + s];
+		d += normalised(part[p * np + s], scale, ff);
 	}
 	size_t p = (size_t)h + (size_t)h * (2 * n - h - 1) / 2;
-	d += 2 * part[p * np + s];
-	for (int g = h + 1; g < n; g++) { p++; d += part[p * np + s]; }
+	d += 2 * normalised(part[p * np + s], scale, ff);
+	for (int g = h + 1; g < n; g++) { p++; d += normalised(part[p * np + s], scale, ff); }
 	dosage[(size_t)s * n + h] = d;
 }
 
@@ -484,9 +530,12 @@ __global__ __launch_bounds__(256) void k_finish_prob(HibagModelView M, HibagBatc
 	const int s0 = blockIdx.x * 64, p0 = blockIdx.y * 64;
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 	const int P = M.n_cell;
+	const double sum_w = part[(size_t)P * B.n_pad + s0 + tx];
+	const bool scale = sum_w > 0;
+	const double ff = 1.0 / sum_w;
 	for (int r = ty; r < 64; r += 4) {
 		const int p = p0 + r;
-		tile[r][tx] = (p < P) ? part[(size_t)p * B.n_pad + s0 + tx] : 0.0;
+		tile[r][tx] = (p < P) ? normalised(part[(size_t)p * B.n_pad + s0 + tx], scale, ff) : 0.0;
 	}
 	__syncthreads();
 	for (int r = ty; r < 64; r += 4) {
@@ -500,10 +549,13 @@ __global__ __launch_bounds__(256) void k_finish_prob(HibagModelView M, HibagBatc
 
 static inline dim3 grid1(int n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
-void hibag_launch_pack(const HibagModelView &M, const HibagBatchView &B, const int32_t *d_geno, hipStream_t st)
+void hibag_launch_pack(const HibagModelView &M, const HibagBatchView &B, const int32_t *d_geno, uint8_t *d_codes,
+	hipStream_t st)
 {
-	if (M.n_classifier == 0) return;
-	hipLaunchKernelGGL(k_pack, dim3(B.n_pad / HIBAG_WAVE, M.n_classifier), dim3(HIBAG_WAVE), 0, st, M, B, d_geno);
+	if (M.n_classifier == 0 || M.n_snp == 0) return;
+	hipLaunchKernelGGL(k_codes, dim3(B.n_pad / 64, (M.n_snp + 63) / 64), dim3(256), 0, st, M, B, d_geno, d_codes);
+	hipLaunchKernelGGL(k_pack, dim3(B.n_pad / HIBAG_WAVE, M.n_classifier), dim3(HIBAG_WAVE), 0, st, M, B,
+		(const uint8_t *)d_codes);
 }
 
 void hibag_launch_unpack_tgeno(const HibagModelView &M, const HibagBatchView &B, const uint64_t *d_tgeno,
@@ -551,7 +603,7 @@ void hibag_launch_finish(const HibagModelView &M, const HibagBatchView &B, doubl
 	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching,
 	double *d_dosage, double *d_postprob, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_finish_call, grid1(B.n_pad, 64), dim3(64), 0, st, M, B, d_part,
+	hipLaunchKernelGGL(k_finish_call, dim3(B.n_pad / 64), dim3(64 * FIN_SEG), 0, st, M, B, (const double *)d_part,
 		d_H1, d_H2, d_max_prob, d_matching);
 	if (d_dosage)
 		hipLaunchKernelGGL(k_finish_dosage, dim3((B.n_pad + 63) / 64, M.n_hla), dim3(64), 0, st,
