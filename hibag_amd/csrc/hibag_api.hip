@@ -19,6 +19,7 @@
 #include "../../include/hibag_hip.h"
 #include "hibag_device.h"
 #include "hibag_kernels.h"
+#include "hibag_plugin.h"
 
 namespace {
 
@@ -792,19 +793,6 @@ int hibag_hip_reset_timing(hibag_hip_model *m)
 
 namespace {
 
-// Mirrors of the two packed POD types the host hands over (sizes 32 and 48).
-struct PluginHaplotype {            // THaplotype, LibHLA_ext.h:261-299
-	int64_t packed[2];
-	double freq;
-	struct { float freq_f32; int hla_allele; } aux;
-};
-struct PluginGenotype {             // TGenotype, LibHLA_ext.h:311-352
-	int64_t snp1[2], snp2[2];
-	int bootstrap_count, hla1, hla2, pad;
-};
-static_assert(sizeof(PluginHaplotype) == 32, "THaplotype must be 32 bytes");
-static_assert(sizeof(PluginGenotype) == 48, "TGenotype must be 48 bytes");
-
 hibag_hip_model *g_plugin_model = nullptr;
 thread_local char g_plugin_msg[600];
 
@@ -879,21 +867,9 @@ void plugin_predict_avg_prob(const PluginGenotype geno[], const double weight[],
 	if (plugin_avg_prob(g_plugin_model, geno, weight, out_prob, out_match)) plugin_throw("predict_avg_prob");
 }
 
-struct PluginTable {                // TypeGPUExtProc, LibHLA_ext.h:358-388
-	void (*build_init)(int, int);
-	void (*build_done)();
-	void (*build_set_bootstrap)(const int[]);
-	uint32_t *(*build_haplomatch)(const PluginHaplotype[], const size_t[], int, const PluginGenotype[], size_t &);
-	void (*build_set_haplo_geno)(const PluginHaplotype[], int, const PluginGenotype[], int);
-	int (*build_acc_oob)();
-	double (*build_acc_ib)();
-	void (*predict_init)(int, int, const PluginHaplotype *const[], const int[], const int[]);
-	void (*predict_done)();
-	void (*predict_avg_prob)(const PluginGenotype[], const double[], double[], double[]);
-};
-
 const PluginTable g_plugin_table = {
-	nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+	hibag_build_init, hibag_build_done, hibag_build_set_bootstrap, hibag_build_haplomatch,
+	hibag_build_set_haplo_geno, hibag_build_acc_oob, hibag_build_acc_ib,
 	plugin_predict_init, plugin_predict_done, plugin_predict_avg_prob,
 };
 

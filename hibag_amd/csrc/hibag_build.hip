@@ -1,0 +1,457 @@
+// hibag_build.hip -- the training-side kernels of the HIBAG plugin table
+// (build_* entries of TypeGPUExtProc, inst/include/LibHLA_ext.h:358-388): the
+// same haplotype-pair loop as prediction, with the reductions the greedy SNP
+// search needs while it grows a classifier (src/LibHLA.cpp:1981-2122):
+//
+//   build_acc_oob  sum over out-of-bag samples of #alleles called correctly by
+//                  _BestGuess (src/LibHLA.cpp:1639-1704, :1934-1955)
+//   build_acc_ib   -2 * sum over in-bag samples of count * log(_PostProb(true
+//                  pair)) (src/LibHLA.cpp:1706-1767, :1957-1979)
+//   build_haplomatch  per in-bag sample the haplotype pairs of its true alleles
+//                  at distance 0, else at the minimum distance
+//                  (_PrepHaploMatch, src/LibHLA.cpp:1569-1637, consumed at :1037-1063)
+//
+// The haplotype list changes with every candidate SNP, so unlike prediction
+// nothing is flattened on the host: k_build_eval walks the allele-grouped SoA
+// list directly (lane = sample, haplotype words and frequencies through the
+// scalar cache), adding terms in the reference's order.  Sums that the
+// reference forms on the host (log, the in-order log-likelihood) stay on the
+// host so that they round identically.
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "hibag_device.h"
+#include "hibag_plugin.h"
+
+namespace {
+
+constexpr int NW = 4;                       // 32-bit words of a 128-SNP string
+
+struct BuildState {
+	bool active = false;
+	int n_hla = 0, n_sample = 0, n_pad = 0;
+	std::vector<int> boot;                  // bootstrap count per sample (0 = out-of-bag)
+	std::vector<int> inbag, oob;            // sample indices, ascending (src/LibHLA.cpp:1858-1874)
+	// current candidate (build_set_haplo_geno)
+	int n_haplo = 0, n_snp = 0;
+	std::vector<int> true1, true2;          // true allele pair per sample, a1 <= a2
+	bool evaluated = false;
+	std::vector<int> best1, best2;
+	std::vector<double> postprob;
+	// device
+	void *d_hb = nullptr, *d_hf = nullptr, *d_start = nullptr, *d_planes = nullptr, *d_true = nullptr,
+		*d_best = nullptr, *d_post = nullptr, *d_tab = nullptr, *d_match = nullptr;
+	size_t cap_h = 0, cap_s = 0, cap_match = 0;
+};
+BuildState g;
+thread_local char g_msg[400];
+
+[[noreturn]] void build_throw(const char *what, hipError_t e = hipSuccess)
+{
+	if (e != hipSuccess) snprintf(g_msg, sizeof(g_msg), "HIBAG HIP plugin: %s: %s", what, hipGetErrorString(e));
+	else snprintf(g_msg, sizeof(g_msg), "HIBAG HIP plugin: %s", what);
+	throw (const char *)g_msg;
+}
+#define HIP_OK(expr, what) do { hipError_t e_ = (expr); if (e_ != hipSuccess) build_throw(what, e_); } while (0)
+
+void dev_free(void *&p) { if (p) (void)hipFree(p); p = nullptr; }
+
+void reserve(void *&p, size_t &cap, size_t bytes, const char *what)
+{
+	if (bytes <= cap && p) return;
+	dev_free(p);
+	HIP_OK(hipMalloc(&p, bytes), what);
+	cap = bytes;
+}
+
+// ---------------------------------------------------------------------------
+// device side
+
+struct BuildView {
+	int n_hla, n_sample, n_pad, n_haplo, nw;
+	const uint32_t *hb;      // [nw][n_haplo]
+	const double *hf;        // [n_haplo]
+	const int *start;        // [n_hla+1]
+	const uint32_t *planes;  // [2*NW][n_pad]: S1 words then S2 words
+	const int *true_cell;    // [n_pad] posterior index of the true pair
+	const double *tab;
+	int *best;               // [2][n_pad]
+	double *post;            // [n_pad]
+};
+
+template <int W>
+struct LaneG { uint32_t zt[W], t[W], e[W]; int n_het; };
+
+// One allele-pair cell in the reference's order (src/LibHLA.cpp:1653-1668 diagonal,
+// :1680-1691 off-diagonal): d = popc((A^T)&ZT) + popc((B^T)&ZT) + popc(~(A^B)&E),
+// the per-SNP form of hamm_d (:747-819): g=0 -> h1+h2, g=2 -> 2-h1-h2, g=1 -> [h1==h2].
+template <int W>
+__device__ __forceinline__ double build_cell(const BuildView &V, int a0, int a1, int b0, int b1, bool diagonal,
+	const LaneG<W> &G, const double *tab_s)
+{
+	double cell = 0;
+	for (int a = a0; a < a1; a++) {
+		uint32_t A[W];
+		int ca = 0;
+#pragma unroll
+		for (int w = 0; w < W; w++) { A[w] = V.hb[w * V.n_haplo + a]; ca += __popc((A[w] ^ G.t[w]) & G.zt[w]); }
+		const double fa = V.hf[a];
+		int b = b0;
+		if (diagonal) { cell += (fa * fa) * tab_s[2 * ca + G.n_het]; b = a + 1; }
+		const double ff = 2 * fa;
+		for (; b < b1; b++) {
+			int d = ca;
+#pragma unroll
+			for (int w = 0; w < W; w++) {
+				const uint32_t Bw = V.hb[w * V.n_haplo + b];
+				d += __popc((Bw ^ G.t[w]) & G.zt[w]) + __popc(~(A[w] ^ Bw) & G.e[w]);
+			}
+			cell += (ff * V.hf[b]) * tab_s[d];
+		}
+	}
+	return cell;
+}
+
+// lane = sample: strict first maximum over cells (_BestGuess) and
+// cell(true pair) / in-order total (_PostProb) in one walk.
+template <int W>
+__device__ __forceinline__ void build_eval(const BuildView &V, int s, const double *tab_s)
+{
+	LaneG<W> G;
+	G.n_het = 0;
+#pragma unroll
+	for (int w = 0; w < W; w++) {
+		const uint32_t s1 = V.planes[(size_t)w * V.n_pad + s], s2 = V.planes[(size_t)(NW + w) * V.n_pad + s];
+		G.zt[w] = ~(s1 ^ s2); G.t[w] = s1 & s2; G.e[w] = s1 & ~s2;
+		G.n_het += __popc(G.e[w]);
+	}
+	const int want = V.true_cell[s];
+	double best = 0, total = 0, hit = 0;
+	int b1 = -2147483647 - 1, b2 = -2147483647 - 1, p = 0;
+	for (int h1 = 0; h1 < V.n_hla; h1++) {
+		const int a0 = V.start[h1], a1 = V.start[h1 + 1];
+		if (a0 == a1) { p += V.n_hla - h1; continue; }      // empty row: cells are +0.0 (never > max, add nothing)
+		for (int h2 = h1; h2 < V.n_hla; h2++, p++) {
+			const int c0 = V.start[h2], c1 = V.start[h2 + 1];
+			if (c0 == c1) continue;
+			const double cell = build_cell<W>(V, a0, a1, c0, c1, h1 == h2, G, tab_s);
+			if (best < cell) { best = cell; b1 = h1; b2 = h2; }
+			if (p == want) hit = cell;
+			total += cell;
+		}
+	}
+	V.best[s] = b1;
+	V.best[V.n_pad + s] = b2;
+	V.post[s] = hit / total;
+}
+
+__global__ __launch_bounds__(HIBAG_WAVE) void k_build_eval(BuildView V)
+{
+	__shared__ double tab_s[HIBAG_TAB_N];
+	for (int i = threadIdx.x; i < HIBAG_TAB_N; i += blockDim.x) tab_s[i] = V.tab[i];
+	__syncthreads();
+	const int s = blockIdx.x * HIBAG_WAVE + threadIdx.x;
+	switch (V.nw) {
+	case 1:  build_eval<1>(V, s, tab_s); break;
+	case 2:  build_eval<2>(V, s, tab_s); break;
+	case 3:  build_eval<3>(V, s, tab_s); break;
+	default: build_eval<4>(V, s, tab_s); break;
+	}
+}
+
+// One wavefront per in-bag sample, lanes over the haplotype pairs of its true
+// alleles.  Pass 0 finds the minimum distance and counts the pairs at it; pass 1
+// (after the host turned counts into offsets) writes them in the reference's
+// order (i1 outer, i2 inner), compacted with ballots.
+struct MatchView {
+	int n_haplo, nw, n_pad;
+	const uint32_t *hb;
+	const int *start;
+	const uint32_t *planes;
+	const int *samp;         // [n_inbag] sample index
+	const int *a1, *a2;      // [n_inbag] true alleles, a1 <= a2
+	int *min_d;              // [n_inbag]
+	int *count;              // [n_inbag]
+	const int *offset;       // [n_inbag] (pass 1)
+	uint32_t *out;           // pairs: {k, (i2<<16)|i1}
+};
+
+__device__ __forceinline__ int match_dist(const MatchView &V, int s, int i, int j)
+{
+	int d = 0;
+	for (int w = 0; w < V.nw; w++) {
+		const uint32_t s1 = V.planes[(size_t)w * V.n_pad + s], s2 = V.planes[(size_t)(NW + w) * V.n_pad + s];
+		const uint32_t A = V.hb[w * V.n_haplo + i], B = V.hb[w * V.n_haplo + j];
+		d += __popc((A ^ (s1 & s2)) & ~(s1 ^ s2)) + __popc((B ^ (s1 & s2)) & ~(s1 ^ s2)) + __popc(~(A ^ B) & s1 & ~s2);
+	}
+	return d;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(HIBAG_WAVE) void k_build_match(MatchView V)
+{
+	const int k = blockIdx.x, lane = threadIdx.x;
+	const int s = V.samp[k];
+	const int a1 = V.a1[k], a2 = V.a2[k];
+	const int st1 = V.start[a1], n1 = V.start[a1 + 1] - st1;
+	const int st2 = V.start[a2], n2 = V.start[a2 + 1] - st2;
+	const bool same = a1 == a2;
+	const long long npair = (long long)n1 * n2;
+	int best = 0x7FFFFFFF, cnt = 0;
+	const int target = PASS ? V.min_d[k] : 0;
+	int written = PASS ? V.offset[k] : 0;
+	for (long long q0 = 0; q0 < npair; q0 += HIBAG_WAVE) {
+		const long long q = q0 + lane;
+		bool valid = q < npair;
+		int i1 = 0, i2 = 0, d = 0x7FFFFFFF;
+		if (valid) {
+			i1 = (int)(q / n2); i2 = (int)(q - (long long)i1 * n2);
+			if (same && i2 < i1) valid = false;          // triangular: i1 <= i2 (src/LibHLA.cpp:1611-1612)
+		}
+		if (valid) d = match_dist(V, s, st1 + i1, st2 + i2);
+		if (PASS == 0) {
+			if (d < best) { best = d; cnt = 0; }
+			if (valid && d == best) cnt++;
+		} else {
+			const bool hit = valid && d == target;
+			const unsigned long long m = __ballot(hit);
+			if (hit) {
+				const int pos = written + __popcll(m & ((1ull << lane) - 1));
+				V.out[2 * (size_t)pos] = (uint32_t)k;
+				V.out[2 * (size_t)pos + 1] = ((uint32_t)i2 << 16) | (uint32_t)i1;
+			}
+			written += __popcll(m);
+		}
+	}
+	if (PASS == 0) {
+		// wave reduction: global minimum, then the number of pairs at it
+		int gmin = best;
+		for (int off = 32; off > 0; off >>= 1) gmin = min(gmin, __shfl_xor(gmin, off));
+		int c = (best == gmin) ? cnt : 0;
+		for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+		if (lane == 0) { V.min_d[k] = gmin; V.count[k] = c; }
+	}
+}
+
+// ---------------------------------------------------------------------------
+// host side
+
+void upload_haplo(const PluginHaplotype haplo[], int n_haplo, int n_snp, bool alleles_from_aux,
+	const size_t *len_per_hla_or_null)
+{
+	const int nh = g.n_hla;
+	g.n_haplo = n_haplo; g.n_snp = n_snp;
+	const int nw = std::max(1, (n_snp + 31) / 32);
+	std::vector<uint32_t> hb((size_t)NW * std::max(n_haplo, 1), 0);
+	std::vector<double> hf(std::max(n_haplo, 1), 0.0);
+	std::vector<int> start(nh + 1, 0);
+	for (int i = 0; i < n_haplo; i++) {
+		for (int w = 0; w < nw; w++) {
+			uint32_t v = (uint32_t)((uint64_t)haplo[i].packed[w >> 1] >> (32 * (w & 1)));
+			const int lo = 32 * w;                       // clear bits >= n_snp (uninitialised in the reference, src/LibHLA.cpp:287-292)
+			if (n_snp < lo + 32) v &= (n_snp <= lo) ? 0u : ((1u << (n_snp - lo)) - 1);
+			hb[(size_t)w * n_haplo + i] = v;
+		}
+		hf[i] = haplo[i].freq;
+		if (alleles_from_aux) {
+			const int a = haplo[i].aux.hla_allele;
+			if (a < 0 || a >= nh) build_throw("haplotype with an invalid HLA allele index");
+			start[a + 1]++;
+		}
+	}
+	if (len_per_hla_or_null) for (int h = 0; h < nh; h++) start[h + 1] = (int)len_per_hla_or_null[h];
+	for (int h = 0; h < nh; h++) start[h + 1] += start[h];
+	if (start[nh] != n_haplo) build_throw("haplotype counts per allele do not add up");
+	reserve(g.d_hb, g.cap_h, (size_t)NW * std::max(n_haplo, 1) * 4 + std::max(n_haplo, 1) * 8 + 64, "hipMalloc(haplotypes)");
+	g.d_hf = (char *)g.d_hb + (((size_t)NW * std::max(n_haplo, 1) * 4 + 7) & ~(size_t)7);
+	HIP_OK(hipMemcpy(g.d_hb, hb.data(), (size_t)nw * std::max(n_haplo, 1) * 4, hipMemcpyHostToDevice), "copy haplotypes");
+	HIP_OK(hipMemcpy(g.d_hf, hf.data(), hf.size() * 8, hipMemcpyHostToDevice), "copy frequencies");
+	HIP_OK(hipMemcpy(g.d_start, start.data(), (nh + 1) * sizeof(int), hipMemcpyHostToDevice), "copy allele starts");
+}
+
+void upload_geno(const PluginGenotype geno[])
+{
+	const int n = g.n_sample, np = g.n_pad, nh = g.n_hla;
+	std::vector<uint32_t> planes((size_t)2 * NW * np);
+	std::vector<int> true_cell(np, -1);
+	g.true1.assign(n, 0); g.true2.assign(n, 0);
+	for (int w = 0; w < NW; w++)
+		for (int s = 0; s < np; s++) {                     // padding lanes: all missing
+			planes[(size_t)w * np + s] = s < n ? (uint32_t)((uint64_t)geno[s].snp1[w >> 1] >> (32 * (w & 1))) : 0u;
+			planes[(size_t)(NW + w) * np + s] = s < n ? (uint32_t)((uint64_t)geno[s].snp2[w >> 1] >> (32 * (w & 1))) : 0xFFFFFFFFu;
+		}
+	for (int s = 0; s < n; s++) {
+		int a1 = geno[s].hla1, a2 = geno[s].hla2;
+		if (a1 > a2) std::swap(a1, a2);                    // src/LibHLA.cpp:1710, :1863-1868
+		if (a1 < 0 || a2 >= nh) build_throw("genotype with an invalid true HLA pair");
+		g.true1[s] = a1; g.true2[s] = a2;
+		true_cell[s] = a2 + a1 * (2 * nh - a1 - 1) / 2;    // src/LibHLA.cpp:1712
+	}
+	HIP_OK(hipMemcpy(g.d_planes, planes.data(), planes.size() * 4, hipMemcpyHostToDevice), "copy genotypes");
+	HIP_OK(hipMemcpy(g.d_true, true_cell.data(), np * sizeof(int), hipMemcpyHostToDevice), "copy true pairs");
+}
+
+void evaluate()
+{
+	if (g.evaluated) return;
+	BuildView V{g.n_hla, g.n_sample, g.n_pad, g.n_haplo, std::max(1, (g.n_snp + 31) / 32),
+		(const uint32_t *)g.d_hb, (const double *)g.d_hf, (const int *)g.d_start, (const uint32_t *)g.d_planes,
+		(const int *)g.d_true, (const double *)g.d_tab, (int *)g.d_best, (double *)g.d_post};
+	hipLaunchKernelGGL(k_build_eval, dim3(g.n_pad / HIBAG_WAVE), dim3(HIBAG_WAVE), 0, 0, V);
+	HIP_OK(hipGetLastError(), "k_build_eval");
+	std::vector<int> best((size_t)2 * g.n_pad);
+	std::vector<double> post(g.n_pad);
+	HIP_OK(hipMemcpy(best.data(), g.d_best, best.size() * sizeof(int), hipMemcpyDeviceToHost), "read best guesses");
+	HIP_OK(hipMemcpy(post.data(), g.d_post, post.size() * sizeof(double), hipMemcpyDeviceToHost), "read posteriors");
+	g.best1.assign(best.begin(), best.begin() + g.n_sample);
+	g.best2.assign(best.begin() + g.n_pad, best.begin() + g.n_pad + g.n_sample);
+	g.postprob.assign(post.begin(), post.begin() + g.n_sample);
+	g.evaluated = true;
+}
+
+// CHLATypeList::Compare, src/LibHLA.cpp:912-924
+int compare_hla(int p1, int p2, int t1, int t2)
+{
+	int cnt = 0;
+	if (p1 == t1 || p1 == t2) { cnt = 1; if (p1 == t1) t1 = -1; else t2 = -1; }
+	if (p2 == t1 || p2 == t2) cnt++;
+	return cnt;
+}
+
+} // namespace
+
+// build_init(nHLA, nSample): src/LibHLA.cpp:2256-2260
+void hibag_build_init(int n_hla, int n_sample)
+{
+	hibag_build_done();
+	if (n_hla <= 0 || n_sample < 0) build_throw("build_init: invalid dimensions");
+	g.n_hla = n_hla; g.n_sample = n_sample;
+	g.n_pad = (std::max(n_sample, 1) + HIBAG_WAVE - 1) / HIBAG_WAVE * HIBAG_WAVE;
+	g.boot.assign(n_sample, 1);
+	g.inbag.clear(); g.oob.clear();
+	for (int i = 0; i < n_sample; i++) g.inbag.push_back(i);
+	double tab[HIBAG_TAB_N];
+	for (int i = 0; i < HIBAG_TAB_N; i++) tab[i] = std::exp(i * std::log(1e-5));     // src/LibHLA.cpp:166-183
+	tab[0] = 1;
+	for (int i = 0; i < HIBAG_TAB_N; i++) if (!std::isfinite(tab[i])) tab[i] = 0;
+	HIP_OK(hipMalloc(&g.d_tab, sizeof(tab)), "hipMalloc(table)");
+	HIP_OK(hipMemcpy(g.d_tab, tab, sizeof(tab), hipMemcpyHostToDevice), "copy table");
+	HIP_OK(hipMalloc(&g.d_start, (n_hla + 1) * sizeof(int)), "hipMalloc(starts)");
+	HIP_OK(hipMalloc(&g.d_planes, (size_t)2 * NW * g.n_pad * 4), "hipMalloc(genotypes)");
+	HIP_OK(hipMalloc(&g.d_true, (size_t)g.n_pad * sizeof(int)), "hipMalloc(true pairs)");
+	HIP_OK(hipMalloc(&g.d_best, (size_t)2 * g.n_pad * sizeof(int)), "hipMalloc(best)");
+	HIP_OK(hipMalloc(&g.d_post, (size_t)g.n_pad * sizeof(double)), "hipMalloc(post)");
+	g.active = true;
+}
+
+// build_done(): called from a destructor (src/LibHLA.cpp:2262-2266) -- must not throw
+void hibag_build_done()
+{
+	for (void **p : {&g.d_hb, &g.d_start, &g.d_planes, &g.d_true, &g.d_best, &g.d_post, &g.d_tab, &g.d_match}) dev_free(*p);
+	g.d_hf = nullptr;
+	g.cap_h = g.cap_s = g.cap_match = 0;
+	g.active = false; g.evaluated = false;
+}
+
+// build_set_bootstrap(counts[nSample]): src/LibHLA.cpp:2290-2293; 0 = out-of-bag
+void hibag_build_set_bootstrap(const int oob_cnt[])
+{
+	if (!g.active) build_throw("build_set_bootstrap before build_init");
+	g.boot.assign(oob_cnt, oob_cnt + g.n_sample);
+	g.inbag.clear(); g.oob.clear();
+	for (int i = 0; i < g.n_sample; i++) (g.boot[i] > 0 ? g.inbag : g.oob).push_back(i);
+	g.evaluated = false;
+}
+
+// build_set_haplo_geno(haplo, n_haplo, geno, n_snp): src/LibHLA.cpp:1916-1920
+void hibag_build_set_haplo_geno(const PluginHaplotype haplo[], int n_haplo, const PluginGenotype geno[], int n_snp)
+{
+	if (!g.active) build_throw("build_set_haplo_geno before build_init");
+	if (n_snp < 0 || n_snp > 128 || n_haplo < 0) build_throw("build_set_haplo_geno: invalid sizes");
+	upload_haplo(haplo, n_haplo, n_snp, true, nullptr);
+	upload_geno(geno);
+	g.evaluated = false;
+}
+
+// build_acc_oob(): src/LibHLA.cpp:1938-1941 -- number of correct alleles over the out-of-bag samples
+int hibag_build_acc_oob()
+{
+	if (!g.active) build_throw("build_acc_oob before build_init");
+	evaluate();
+	int correct = 0;
+	for (int s : g.oob) correct += compare_hla(g.best1[s], g.best2[s], g.true1[s], g.true2[s]);
+	return correct;
+}
+
+// build_acc_ib(): src/LibHLA.cpp:1961-1977 -- -2 * sum_i count_i * log(p_i), in-bag order, host libm
+double hibag_build_acc_ib()
+{
+	if (!g.active) build_throw("build_acc_ib before build_init");
+	evaluate();
+	double loglik = 0;
+	for (int s : g.inbag) loglik += g.boot[s] * std::log(g.postprob[s]);
+	loglik *= -2;
+	return loglik;
+}
+
+// build_haplomatch(haplo, nHaplo[nHLA], n_snp, geno, out_n): src/LibHLA.cpp:1037-1063.
+// Returns a malloc()ed buffer the host free()s: buf[0] = 2*npairs, then npairs x
+// {in-bag sample index, (i2 << 16) | i1} with i1/i2 inside the allele-specific sub-lists.
+uint32_t *hibag_build_haplomatch(const PluginHaplotype haplo[], const size_t n_haplo[], int n_snp,
+	const PluginGenotype geno[], size_t &out_n)
+{
+	if (!g.active) build_throw("build_haplomatch before build_init");
+	size_t H = 0;
+	for (int h = 0; h < g.n_hla; h++) {
+		if (n_haplo[h] > 65535) build_throw("There are too many HLA allele-specific haplotypes (# > 65535).");
+		H += n_haplo[h];
+	}
+	upload_haplo(haplo, (int)H, n_snp, false, n_haplo);
+	upload_geno(geno);
+	g.evaluated = false;
+	const int nib = (int)g.inbag.size();
+	if (nib == 0) {
+		uint32_t *buf = (uint32_t *)malloc(sizeof(uint32_t));
+		if (!buf) build_throw("out of memory");
+		buf[0] = 0; out_n = 1;
+		return buf;
+	}
+	std::vector<int> samp(g.inbag), a1(nib), a2(nib);
+	for (int k = 0; k < nib; k++) { a1[k] = g.true1[samp[k]]; a2[k] = g.true2[samp[k]]; }
+	// layout of the scratch buffer: samp, a1, a2, min_d, count, offset (ints), then the pairs
+	const size_t ints = (size_t)6 * nib;
+	reserve(g.d_match, g.cap_match, ints * sizeof(int) + 64, "hipMalloc(match)");
+	int *d_i = (int *)g.d_match;
+	HIP_OK(hipMemcpy(d_i, samp.data(), nib * sizeof(int), hipMemcpyHostToDevice), "copy match args");
+	HIP_OK(hipMemcpy(d_i + nib, a1.data(), nib * sizeof(int), hipMemcpyHostToDevice), "copy match args");
+	HIP_OK(hipMemcpy(d_i + 2 * nib, a2.data(), nib * sizeof(int), hipMemcpyHostToDevice), "copy match args");
+	MatchView V{(int)H, std::max(1, (n_snp + 31) / 32), g.n_pad, (const uint32_t *)g.d_hb, (const int *)g.d_start,
+		(const uint32_t *)g.d_planes, d_i, d_i + nib, d_i + 2 * nib, d_i + 3 * nib, d_i + 4 * nib, d_i + 5 * nib, nullptr};
+	hipLaunchKernelGGL(k_build_match<0>, dim3(nib), dim3(HIBAG_WAVE), 0, 0, V);
+	std::vector<int> count(nib), offset(nib);
+	HIP_OK(hipMemcpy(count.data(), d_i + 4 * nib, nib * sizeof(int), hipMemcpyDeviceToHost), "read match counts");
+	size_t total = 0;
+	for (int k = 0; k < nib; k++) { offset[k] = (int)total; total += (size_t)count[k]; }
+	uint32_t *buf = (uint32_t *)malloc((1 + 2 * total) * sizeof(uint32_t));
+	if (!buf) build_throw("out of memory");
+	buf[0] = (uint32_t)(2 * total);
+	if (total > 0) {
+		void *d_out = nullptr;
+		if (hipMalloc(&d_out, 2 * total * sizeof(uint32_t)) != hipSuccess) { free(buf); build_throw("hipMalloc(pairs)"); }
+		V.out = (uint32_t *)d_out;
+		hipError_t e = hipMemcpy(d_i + 5 * nib, offset.data(), nib * sizeof(int), hipMemcpyHostToDevice);
+		if (e == hipSuccess) {
+			hipLaunchKernelGGL(k_build_match<1>, dim3(nib), dim3(HIBAG_WAVE), 0, 0, V);
+			e = hipMemcpy(buf + 1, d_out, 2 * total * sizeof(uint32_t), hipMemcpyDeviceToHost);
+		}
+		(void)hipFree(d_out);
+		if (e != hipSuccess) { free(buf); build_throw("build_haplomatch", e); }
+	}
+	out_n = 1 + 2 * total;
+	return buf;
+}

@@ -1,0 +1,45 @@
+// hibag_plugin.h -- layout mirrors of the types HIBAG shares with a GPU plugin
+// (inst/include/LibHLA_ext.h) and the entry points behind the plugin table.
+#ifndef HIBAG_PLUGIN_H_
+#define HIBAG_PLUGIN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+struct PluginHaplotype {            // THaplotype, LibHLA_ext.h:261-299 (32 bytes)
+	int64_t packed[2];
+	double freq;
+	struct { float freq_f32; int hla_allele; } aux;   // filled by SetHaploAux_GPU, src/LibHLA.cpp:565-578
+};
+struct PluginGenotype {             // TGenotype, LibHLA_ext.h:311-352 (48 bytes)
+	int64_t snp1[2], snp2[2];
+	int bootstrap_count, hla1, hla2, pad;
+};
+static_assert(sizeof(PluginHaplotype) == 32, "THaplotype must be 32 bytes");
+static_assert(sizeof(PluginGenotype) == 48, "TGenotype must be 48 bytes");
+
+struct PluginTable {                // TypeGPUExtProc, LibHLA_ext.h:358-388
+	void (*build_init)(int, int);
+	void (*build_done)();
+	void (*build_set_bootstrap)(const int[]);
+	uint32_t *(*build_haplomatch)(const PluginHaplotype[], const size_t[], int, const PluginGenotype[], size_t &);
+	void (*build_set_haplo_geno)(const PluginHaplotype[], int, const PluginGenotype[], int);
+	int (*build_acc_oob)();
+	double (*build_acc_ib)();
+	void (*predict_init)(int, int, const PluginHaplotype *const[], const int[], const int[]);
+	void (*predict_done)();
+	void (*predict_avg_prob)(const PluginGenotype[], const double[], double[], double[]);
+};
+
+// training-side entries (hibag_build.hip); failures throw `const char *` like the
+// predict entries (the host's CORE_CATCH turns that into an R error, src/HIBAG.cpp:41-60)
+void hibag_build_init(int n_hla, int n_sample);
+void hibag_build_done();
+void hibag_build_set_bootstrap(const int oob_cnt[]);
+uint32_t *hibag_build_haplomatch(const PluginHaplotype haplo[], const size_t n_haplo[], int n_snp,
+	const PluginGenotype geno[], size_t &out_n);
+void hibag_build_set_haplo_geno(const PluginHaplotype haplo[], int n_haplo, const PluginGenotype geno[], int n_snp);
+int hibag_build_acc_oob();
+double hibag_build_acc_ib();
+
+#endif

@@ -177,7 +177,7 @@ def test_plugin_table_per_sample_path(hib, oracle, hapmap_geno, model_a):
     from hibag_amd import _lib
     assert C.sizeof(_THaplotype) == 32 and C.sizeof(_TGenotype) == 48
     tab = _Table.from_address(_lib.lib().hibag_hip_gpu_ext_proc())
-    assert all(getattr(tab, n) is None for n, _ in _Table._fields_[:7])       # build_* are NULL
+    assert all(getattr(tab, n) is not None for n, _ in _Table._fields_[:7])   # build_* are implemented too
     fm = oracle.flatten(model_a)
     G = align_geno(model_a, hapmap_geno, hapmap_geno.sample_id)[:8].copy()
     G[2, ::3] = hib.NA_INTEGER
