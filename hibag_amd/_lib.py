@@ -13,7 +13,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libhibag_hip.so")
+# HIBAG_HIP_LIBRARY selects another build of the same library (tuning experiments)
+LIB_PATH = os.environ.get("HIBAG_HIP_LIBRARY") or os.path.join(CSRC, "libhibag_hip.so")
 
 K_PACK, K_TOTAL, K_ACCUM, K_FINISH, K_COUNT = 0, 1, 2, 3, 4
 KERNEL_NAMES = {K_PACK: "pack", K_TOTAL: "total", K_ACCUM: "accum", K_FINISH: "finish"}

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -127,19 +128,20 @@ struct hibag_hip_model {
 	int n_hla = 0, n_snp = 0;
 	bool finalized = false;
 	bool have_snpidx = true;
+	bool use_mfma = true;                  // matrix-core engine for classifiers with <= 32 SNPs (HIBAG_ENGINE=valu disables)
 	std::vector<HostClassifier> cls;
 	std::vector<int> snp_weight_override;   // classifier-sharded runs
 	int64_t pair_evals = 0;
 	double tab[HIBAG_TAB_N];
 
 	// device model
-	DevBuf d_int, d_stream, d_tile, d_tab;
+	DevBuf d_int, d_stream, d_tile, d_tab, d_blk;
 	HibagModelView view{};
-	int mask_rows = 0;
+	int mask_rows = 0, bt_rows = 0;
 	size_t stream_bytes = 0;
 
 	// per-batch workspace (grow-only)
-	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes;
+	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias;
 	// plugin staging
 	DevBuf ws_tgeno, ws_weight;
 
@@ -150,7 +152,7 @@ struct hibag_hip_model {
 	{
 		(void)hipSetDevice(device);
 		timer.destroy();
-		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
+		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
 		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_tgeno, &ws_weight})
 			b->release();
 	}
@@ -230,8 +232,15 @@ void or_bits(uint32_t *dst, const uint64_t src[2], int nbits, int pos)
 // per cell in `cell_chunks[P]`.  The frequency factor is rounded exactly as the
 // reference does: f1*f1 for the leading diagonal term (:1786), (2*f1)*f2 else
 // (:1789-1793, :1808-1812); this file is compiled with -ffp-contract=off.
+// `raw` (optional) keeps every record un-chunked: raw->w (nwp words each), raw->p, raw->n[cell].
+struct RawRecords {
+	std::vector<uint32_t> w;
+	std::vector<double> p;
+	std::vector<uint32_t> n;
+};
+
 void build_pair_stream(const HostClassifier &k, int n_hla, int nwp, const int *st,
-	std::vector<uint32_t> &stream, std::vector<uint32_t> &cell_chunks)
+	std::vector<uint32_t> &stream, std::vector<uint32_t> &cell_chunks, RawRecords *raw)
 {
 	const int ks = k.n_snp;
 	const uint64_t lowmask[2] = {
@@ -251,6 +260,11 @@ void build_pair_stream(const HostClassifier &k, int n_hla, int nwp, const int *s
 	};
 	auto flush = [&]() -> uint32_t {
 		const size_t n = recp.size();
+		if (raw) {
+			raw->w.insert(raw->w.end(), recw.begin(), recw.end());
+			raw->p.insert(raw->p.end(), recp.begin(), recp.end());
+			raw->n.push_back((uint32_t)n);
+		}
 		const size_t nchunk = (n + HIBAG_CHUNK - 1) / HIBAG_CHUNK;
 		for (size_t ch = 0; ch < nchunk; ch++) {
 			const size_t base = stream.size();
@@ -285,6 +299,57 @@ void build_pair_stream(const HostClassifier &k, int n_hla, int nwp, const int *s
 			}
 			cell_chunks[p++] = flush();
 		}
+	}
+}
+
+// Matrix-core engine: regroup one classifier's records per tile into blocks of
+// 32 (W[nkb][32], prod[32], end mask, pad).  Cells are padded to an even number
+// of records with {W = 0, prod = +0.0}; bit i of the end mask marks the record
+// that closes a cell.  Returns per tile {first block, #blocks} in `blk_tile`.
+void build_block_stream(const RawRecords &raw, int nwp, int nkb, const std::vector<int> &tile_p0,
+	const std::vector<int> &tile_n, std::vector<uint32_t> &out, uint32_t *blk_tile, int &n_blocks)
+{
+	std::vector<size_t> first(raw.n.size() + 1, 0);          // first record of each cell
+	for (size_t p = 0; p < raw.n.size(); p++) first[p + 1] = first[p] + raw.n[p];
+	n_blocks = 0;
+	const size_t BD = HIBAG_BLOCK_DWORDS(nkb);
+	for (size_t t = 0; t < tile_p0.size(); t++) {
+		std::vector<uint32_t> w;            // nkb words per slot
+		std::vector<double> pr;
+		std::vector<uint8_t> end;
+		for (int j = 0; j < tile_n[t]; j++) {
+			const size_t p = (size_t)tile_p0[t] + j;
+			const uint32_t n = raw.n[p];
+			if (!n) continue;
+			for (uint32_t i = 0; i < n; i++) {
+				for (int q = 0; q < nkb; q++) w.push_back(raw.w[(first[p] + i) * nwp + q]);
+				pr.push_back(raw.p[first[p] + i]);
+				end.push_back(0);
+			}
+			if (n & 1) { w.insert(w.end(), (size_t)nkb, 0u); pr.push_back(0.0); end.push_back(0); }
+			end.back() = 1;
+		}
+		const size_t nb = (pr.size() + 31) / 32;
+		blk_tile[2 * t] = (uint32_t)n_blocks;
+		blk_tile[2 * t + 1] = (uint32_t)nb;
+		for (size_t b = 0; b < nb; b++) {
+			const size_t base = out.size();
+			out.resize(base + BD, 0);
+			uint32_t mask = 0;
+			for (int i = 0; i < 32; i++) {
+				const size_t r = b * 32 + i;
+				double prod = 0.0;
+				if (r < pr.size()) {
+					for (int q = 0; q < nkb; q++) out[base + (size_t)q * 32 + i] = w[r * nkb + q];
+					prod = pr[r];
+					if (end[r]) mask |= 1u << i;
+				}
+				memcpy(&out[base + 32 * (size_t)nkb + 2 * (size_t)i], &prod, sizeof(double));
+			}
+			out[base + 32 * (size_t)nkb + 64] = mask;
+			out[base + 32 * (size_t)nkb + 65] = (uint32_t)std::min<size_t>(32, pr.size() - b * 32);
+		}
+		n_blocks += (int)nb;
 	}
 }
 
@@ -324,7 +389,10 @@ int finalize_model(hibag_hip_model *m)
 	std::vector<uint64_t> stream_off(std::max(C, 1), 0), cell_work(P, 0);
 	std::vector<uint32_t> stream;
 	std::vector<std::vector<uint32_t>> cell_chunks(C);
+	std::vector<RawRecords> raw(C);
+	std::vector<int> mfma_nkb(std::max(C, 1), 0), bt_row(std::max(C, 1), 0), cls_nblk(std::max(C, 1), 0);
 	std::vector<int64_t> pairs(C);
+	int bt_rows = 0;
 	int rows = 0;
 	m->pair_evals = 0;
 	for (int c = 0; c < C; c++) {
@@ -343,7 +411,11 @@ int finalize_model(hibag_hip_model *m)
 		if (stream.size() & 1) stream.push_back(0);          // 8-byte alignment of the doubles inside
 		stream_off[c] = stream.size();
 		cell_chunks[c].assign(P, 0);
-		build_pair_stream(k, nh, nwp[c], st.data(), stream, cell_chunks[c]);
+		const int nkb_true = std::max(1, (3 * k.n_snp + 31) / 32);
+		mfma_nkb[c] = (m->use_mfma && nkb_true <= 3) ? nkb_true : 0;
+		bt_row[c] = bt_rows;
+		bt_rows += 2 * mfma_nkb[c];
+		build_pair_stream(k, nh, nwp[c], st.data(), stream, cell_chunks[c], mfma_nkb[c] ? &raw[c] : nullptr);
 		for (int p = 0; p < P; p++) cell_work[p] += (uint64_t)cell_chunks[c][p] * (nwp[c] + 2);
 		pairs[c] = (int64_t)H * (H + 1) / 2;
 		m->pair_evals += pairs[c];
@@ -385,6 +457,19 @@ int finalize_model(hibag_hip_model *m)
 	}
 	if (cls_cnt.empty()) { cls_cnt.push_back(0); cls_cell.push_back(0); }
 
+	// block streams of the matrix-core engine
+	std::vector<uint32_t> blk_stream, blk_tile((size_t)std::max(C, 1) * n_tile * 2 + 2, 0);
+	std::vector<uint64_t> blk_off(std::max(C, 1), 0);
+	for (int c = 0; c < C; c++) {
+		if (!mfma_nkb[c]) continue;
+		if (blk_stream.size() & 1) blk_stream.push_back(0);
+		blk_off[c] = blk_stream.size();
+		build_block_stream(raw[c], nwp[c], mfma_nkb[c], tile_p0, tile_n, blk_stream,
+			&blk_tile[(size_t)c * n_tile * 2], cls_nblk[c]);
+		raw[c] = RawRecords();
+	}
+	blk_stream.insert(blk_stream.end(), 2 * HIBAG_BLOCK_DWORDS(3), 0);   // look-ahead slack of the block walker
+
 	// one int arena
 	std::vector<int> arena;
 	auto put = [&](const std::vector<int> &v) {
@@ -395,12 +480,14 @@ int finalize_model(hibag_hip_model *m)
 	};
 	const size_t o_nsnp = put(n_snp_c), o_nwp = put(nwp), o_snpoff = put(snp_off), o_snpidx = put(snp_index),
 		o_snpw = put(snp_weight), o_mrow = put(mask_row), o_order = put(c_order), o_tp0 = put(tile_p0), o_tn = put(tile_n),
-		o_coff = put(cls_off), o_cn = put(cls_n);
+		o_coff = put(cls_off), o_cn = put(cls_n), o_nkb = put(mfma_nkb), o_btrow = put(bt_row), o_nblk = put(cls_nblk);
 
 	if (int rc = m->d_int.reserve(arena.size() * sizeof(int))) return rc;
 	if (int rc = m->d_stream.reserve(stream.size() * sizeof(uint32_t))) return rc;
 	const size_t tb_off = 0, tb_meta = stream_off.size() * sizeof(uint64_t), tb_cnt = tb_meta + tile_meta.size() * sizeof(uint32_t),
-		tb_cell = tb_cnt + cls_cnt.size() * sizeof(uint32_t), tb_end = tb_cell + cls_cell.size() * sizeof(uint32_t);
+		tb_cell = tb_cnt + cls_cnt.size() * sizeof(uint32_t),
+		tb_boff = (tb_cell + cls_cell.size() * sizeof(uint32_t) + 7) & ~(size_t)7, tb_btile = tb_boff + blk_off.size() * sizeof(uint64_t),
+		tb_end = tb_btile + blk_tile.size() * sizeof(uint32_t);
 	if (int rc = m->d_tile.reserve(tb_end)) return rc;
 	if (int rc = m->d_tab.reserve(sizeof(m->tab))) return rc;
 	HIP_TRY(hipMemcpy(m->d_int.p, arena.data(), arena.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -410,6 +497,10 @@ int finalize_model(hibag_hip_model *m)
 	HIP_TRY(hipMemcpy(tbase + tb_meta, tile_meta.data(), tile_meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_cnt, cls_cnt.data(), cls_cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_cell, cls_cell.data(), cls_cell.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(tbase + tb_boff, blk_off.data(), blk_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(tbase + tb_btile, blk_tile.data(), blk_tile.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	if (int rc = m->d_blk.reserve(blk_stream.size() * sizeof(uint32_t))) return rc;
+	HIP_TRY(hipMemcpy(m->d_blk.p, blk_stream.data(), blk_stream.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(m->d_tab.p, m->tab, sizeof(m->tab), hipMemcpyHostToDevice));
 
 	HibagModelView &V = m->view;
@@ -423,6 +514,11 @@ int finalize_model(hibag_hip_model *m)
 	V.cls_cnt = (const uint32_t *)(tbase + tb_cnt);
 	V.cls_cell = (const uint32_t *)(tbase + tb_cell);
 	V.cls_off = base + o_coff; V.cls_n = base + o_cn;
+	V.mfma_nkb = base + o_nkb; V.bt_row = base + o_btrow; V.cls_nblk = base + o_nblk;
+	V.blk_off = (const uint64_t *)(tbase + tb_boff);
+	V.blk_tile = (const uint32_t *)(tbase + tb_btile);
+	V.blk_stream = m->d_blk.as<uint32_t>();
+	m->bt_rows = bt_rows;
 	V.stream = m->d_stream.as<uint32_t>();
 	V.tab = m->d_tab.as<double>();
 	m->mask_rows = rows;
@@ -437,7 +533,7 @@ int finalize_model(hibag_hip_model *m)
 int batch_limit(const hibag_hip_model *m)
 {
 	const double per_sample = 8.0 * (m->view.n_cell + 3) + 24.0 * m->view.n_classifier +
-		4.0 * m->mask_rows + 4.0 * m->view.n_classifier;
+		4.0 * m->mask_rows + 4.0 * m->view.n_classifier + 16.0 * m->bt_rows + 8.0 * m->view.n_classifier;
 	int lim = (int)(1.5e9 / std::max(per_sample, 1.0));
 	lim = std::max(64, std::min(lim, 1 << 17));
 	return lim / 64 * 64;
@@ -453,12 +549,15 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	if (int rc = m->ws_inv.reserve(C * n_pad * sizeof(double))) return rc;
 	if (int rc = m->ws_part.reserve((size_t)(m->view.n_cell + 3) * n_pad * sizeof(double))) return rc;
 	if (int rc = m->ws_codes.reserve((size_t)std::max(m->n_snp, 1) * n_pad)) return rc;
+	if (int rc = m->ws_bt.reserve((size_t)std::max(m->bt_rows, 1) * n_pad * sizeof(uint4))) return rc;
+	if (int rc = m->ws_bias.reserve(2 * C * n_pad * sizeof(int))) return rc;
 	if (need_best)
 		if (int rc = m->ws_best.reserve(C * n_pad * sizeof(int))) return rc;
 	B.n_samp = n_samp; B.n_pad = n_pad;
 	B.masks = m->ws_planes.as<uint32_t>();
 	B.cw = m->ws_cw.as<double>(); B.tot = m->ws_tot.as<double>(); B.inv = m->ws_inv.as<double>();
 	B.part = m->ws_part.as<double>();
+	B.bt = m->ws_bt.as<uint4>(); B.bias = m->ws_bias.as<int>();
 	return 0;
 }
 
@@ -576,6 +675,8 @@ hibag_hip_model *hibag_hip_model_new(int n_hla, int n_snp)
 	hibag_hip_model *m = new (std::nothrow) hibag_hip_model;
 	if (!m) { fail(HIBAG_HIP_ENOMEM, "out of host memory"); return nullptr; }
 	m->device = g_device;
+	const char *engine = getenv("HIBAG_ENGINE");         // "valu": bit logic + popcount on the vector ALU for every classifier
+	m->use_mfma = !(engine && strcmp(engine, "valu") == 0);
 	m->n_hla = n_hla;
 	m->n_snp = n_snp;
 	build_table(m->tab);
@@ -830,6 +931,7 @@ void plugin_predict_init(int n_hla, int n_classifier, const PluginHaplotype *con
 			plugin_throw("predict_init");
 		}
 	}
+	m->use_mfma = false;      // one live lane per call: the per-sample path packs masks only (k_unpack_tgeno)
 	if (hibag_hip_model_finalize(m)) { hibag_hip_model_free(m); plugin_throw("predict_init"); }
 	g_plugin_model = m;
 }

@@ -21,6 +21,10 @@
 //    chunk of the tile, then one entry (j << 24 | chunks) per cell of the tile:
 //    the non-empty ones in order, then the empty ones }.
 //
+//    The matrix-core engine reads the same records regrouped per (classifier,
+//    tile) into BLOCKS of 32 (blk_stream): W[nkb][32] then prod[32] then a mask
+//    of the records that close a cell; cells are padded to an even record count.
+//
 //  BATCH ("lane = sample": consecutive samples are consecutive addresses, so
 //  every per-lane access is one coalesced row segment of a wavefront):
 //    masks : uint32 [mask_rows][n_pad]; classifier c owns rows mask_row[c] +
@@ -33,6 +37,7 @@
 #define HIBAG_DEVICE_H_
 
 #include <stdint.h>
+#include <hip/hip_vector_types.h>
 
 #define HIBAG_WAVE 64
 #define HIBAG_TAB_N 257          // 2*128 + 1 distances (src/LibHLA.cpp:167)
@@ -47,6 +52,8 @@
 
 // dwords of one chunk for a classifier with nwp words per record
 #define HIBAG_CHUNK_DWORDS(nwp) (HIBAG_CHUNK * ((nwp) + 2))
+// dwords of one 32-record block of the matrix-core engine
+#define HIBAG_BLOCK_DWORDS(nkb) (32 * (nkb) + 66)
 
 struct HibagModelView {
 	int n_hla;
@@ -73,6 +80,14 @@ struct HibagModelView {
 	const uint64_t *stream_off;  // [C] dword offset of the classifier's stream
 	const uint32_t *stream;      // the pair streams
 	const double *tab;           // [257] exp(d*log(1e-5))
+
+	// matrix-core engine (classifiers with at most 32 SNPs; hibag_kernels.hip "MFMA engine")
+	const int *mfma_nkb;         // [C] 32-wide K blocks of the distance dot product, 0 = use the VALU engine
+	const int *bt_row;           // [C] first operand row of the classifier in HibagBatchView::bt
+	const uint64_t *blk_off;     // [C] dword offset of the classifier's block stream
+	const int *cls_nblk;         // [C] blocks of the classifier (all tiles)
+	const uint32_t *blk_tile;    // [C][n_tile][2] = {first block of the tile, blocks of the tile}
+	const uint32_t *blk_stream;  // blocks of 32 records: W[nkb][32], prod[32] (f64), end mask, pad
 };
 
 struct HibagBatchView {
@@ -83,6 +98,10 @@ struct HibagBatchView {
 	double *tot;        // [C][n_pad]
 	double *inv;        // [C][n_pad]
 	double *part;       // [P+3][n_pad]
+	// matrix-core engine: per classifier and sample group the B operand tiles
+	// (int8 +1/-1/0 per packed bit, MFMA lane layout) and the distance offsets
+	uint4 *bt;          // [(bt_row[c] + n*nkb + kb)][n_pad/64][64]
+	int *bias;          // [(2c + n)][n_pad/64][64]
 };
 
 #endif

@@ -113,6 +113,152 @@ __device__ __forceinline__ double cell_sum(uint32_t n, const uint32_t *__restric
 	return cell;
 }
 
+// ---------------------------------------------------------------------------
+// MFMA engine.  The distance is an integer dot product,
+//     d = sum_k ((W_k ^ x_k) & m_k) = sum_k W_k * a_k + sum_k m_k x_k,   a_k = m_k (1 - 2 x_k) in {-1,0,+1},
+// over the 3k packed bit positions, i.e. D[record][sample] = W[record][:] . a[:][sample] + bias[sample]:
+// a small int8 GEMM with K = 32*nkb.  One v_mfma_i32_32x32x32_i8 gives the exact
+// distances of 32 records x 32 samples; two (sample halves) cover the wavefront's
+// 64 samples, and 16 v_permlane32_swap move every lane's own-sample column into
+// its registers.  This takes the bit logic and popcounts (the dominant VALU cost,
+// tools/ubench_valu.hip) off the vector ALU; the FP64 accumulation below is
+// unchanged -- per lane, in the reference's order -- so results stay bit-identical.
+// Used for classifiers with at most 32 SNPs (nkb <= 3); wider ones use the VALU
+// engine above.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+template <int NKB>
+struct LaneOperand {
+	v4i b[2][NKB];      // B operand of sample half n, K block kb (MFMA lane layout)
+	int bias[2];
+};
+
+template <int NKB>
+__device__ __forceinline__ void load_operand(const HibagModelView &M, const HibagBatchView &B, int c, int group,
+	int lane, LaneOperand<NKB> &T)
+{
+	const size_t n_group = (size_t)(B.n_pad / HIBAG_WAVE);
+#pragma unroll
+	for (int n = 0; n < 2; n++) {
+#pragma unroll
+		for (int kb = 0; kb < NKB; kb++) {
+			const uint4 v = B.bt[((size_t)(M.bt_row[c] + n * NKB + kb) * n_group + group) * HIBAG_WAVE + lane];
+			T.b[n][kb] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+		}
+		T.bias[n] = B.bias[((size_t)(2 * c + n) * n_group + group) * HIBAG_WAVE + lane];
+	}
+}
+
+// 16 bits -> 16 bytes (bit i -> byte i = 0/1): per nibble (n * 0x00204081) & 0x01010101
+__device__ __forceinline__ v4i expand_bits16(uint32_t x)
+{
+	v4i r;
+#pragma unroll
+	for (int q = 0; q < 4; q++) r[q] = (int)((((x >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u);
+	return r;
+}
+
+// Issue the MFMAs of one block: acc_n[r] of lane l = distance of record
+// 8(r/4) + 4(l/32) + r%4 to sample (l%32) of sample half n.
+// w[kb] = word kb of record (lane % 32), already in a register.
+template <int NKB>
+__device__ __forceinline__ void block_mfma(const uint32_t (&w)[NKB], int sh, const LaneOperand<NKB> &T,
+	v16i &acc0, v16i &acc1)
+{
+#pragma unroll
+	for (int r = 0; r < 16; r++) { acc0[r] = T.bias[0]; acc1[r] = T.bias[1]; }
+#pragma unroll
+	for (int kb = 0; kb < NKB; kb++) {
+		// A operand: lane l holds record l%32, K bytes 16*(l/32)..+15 of this K block
+		const v4i a = expand_bits16((w[kb] >> sh) & 0xFFFFu);
+		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, T.b[0][kb], acc0, 0, 0, 0);
+		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, T.b[1][kb], acc1, 0, 0, 0);
+	}
+}
+
+// Swap the upper lanes of half 0 with the lower lanes of half 1: afterwards every
+// lane holds its OWN sample: record i = 8g + q  ->  q < 4 ? D0[4g + q] : D1[4g + q - 4].
+__device__ __forceinline__ void block_own_sample(const v16i &acc0, const v16i &acc1, v16i &D0, v16i &D1)
+{
+#pragma unroll
+	for (int r = 0; r < 16; r++) {
+		const auto sw = __builtin_amdgcn_permlane32_swap(acc0[r], acc1[r], false, false);
+		D0[r] = sw[0]; D1[r] = sw[1];
+	}
+}
+
+// cell += prod_i * TAB[d_i] for the first n_valid records of a block, in order;
+// `fin(cell)` at every record that closes a cell (end mask; cells are padded to
+// an even number of records, so only odd positions can close one).  Eight table
+// look-ups are in flight per wait.
+template <class Fin>
+__device__ __forceinline__ void block_accumulate(const double *__restrict__ pr, uint32_t endmask, int n_valid,
+	const v16i &D0, const v16i &D1, double &cell, const double *tab_s, Fin &&fin)
+{
+#pragma unroll
+	for (int g = 0; g < 4; g++) {
+		if (8 * g >= n_valid) break;
+		// the 8 frequency factors of the group as one vector load (one s_load_dwordx16), so
+		// that they are not re-fetched piecemeal behind every cell-end branch
+		typedef double f64x8 __attribute__((ext_vector_type(8)));
+		const f64x8 pv = *reinterpret_cast<const f64x8 *>(pr + 8 * g);
+		double t[8];
+#pragma unroll
+		for (int q = 0; q < 8; q++) t[q] = tab_s[q < 4 ? D0[4 * g + q] : D1[4 * g + q - 4]];
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			cell += pv[q] * t[q];
+			if ((q & 1) && (endmask & (1u << (8 * g + q)))) { fin(cell); cell = 0; }
+		}
+	}
+}
+
+// Walk `nblk` consecutive blocks (wave-uniform pointer), software-pipelined
+// inside the wavefront: while the vector ALU accumulates block b, the matrix
+// core already computes the distances of block b+1 and the record words of
+// block b+2 are in flight (per-lane VMEM).  The stream is padded by two blocks
+// so that the look-ahead stays in bounds.
+template <int NKB, class Fin>
+__device__ __forceinline__ void walk_blocks(const uint32_t *__restrict__ blk, int nblk, int lane,
+	const LaneOperand<NKB> &T, const double *tab_s, Fin &&fin)
+{
+	double cell = 0;
+	const int sh = (lane >> 5) * 16, li = lane & 31;
+	uint32_t w[NKB];
+	v16i acc0, acc1;
+#pragma unroll
+	for (int kb = 0; kb < NKB; kb++) w[kb] = blk[kb * 32 + li];
+	block_mfma<NKB>(w, sh, T, acc0, acc1);
+#pragma unroll
+	for (int kb = 0; kb < NKB; kb++) w[kb] = blk[HIBAG_BLOCK_DWORDS(NKB) + kb * 32 + li];
+	for (int b = 0; b < nblk; b++) {
+		v16i D0, D1;
+#if defined(HIBAG_ABLATE) && HIBAG_ABLATE == 1      // timing experiment: no distance computation at all
+		for (int r = 0; r < 16; r++) { D0[r] = (T.bias[0] + r) & 63; D1[r] = (T.bias[1] + w[0] + r) & 63; }
+#else
+		block_own_sample(acc0, acc1, D0, D1);
+		block_mfma<NKB>(w, sh, T, acc0, acc1);
+#endif
+#pragma unroll
+		for (int kb = 0; kb < NKB; kb++) w[kb] = blk[2 * HIBAG_BLOCK_DWORDS(NKB) + kb * 32 + li];
+#if defined(HIBAG_ABLATE) && HIBAG_ABLATE == 2      // timing experiment: distances only, no accumulation
+		{ int z = 0; for (int r = 0; r < 16; r++) z += D0[r] ^ D1[r]; cell += z; }
+#else
+		block_accumulate(reinterpret_cast<const double *>(blk + 32 * NKB), blk[32 * NKB + 64], (int)blk[32 * NKB + 65],
+			D0, D1, cell, tab_s, fin);
+#endif
+		blk += HIBAG_BLOCK_DWORDS(NKB);
+	}
+}
+
+#define HIBAG_DISPATCH_NKB(nkb, CALL)      \
+	switch (nkb) {                         \
+	case 1:  { CALL(1); } break;           \
+	case 2:  { CALL(2); } break;           \
+	default: { CALL(3); } break;           \
+	}
+
 // Record widths the kernels are specialised for; the host rounds a classifier's
 // ceil(3k/32) up to the next of these (padding words carry AND mask 0).
 #define HIBAG_DISPATCH_NWP(nwp, CALL)      \
@@ -174,7 +320,8 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 	const int nwp = M.nwp[c];
 	const int *__restrict__ idx = M.snp_index + M.snp_off[c];
 	const int row0 = M.mask_row[c];
-	int num = 0, den = 0;
+	const int nkb = M.mfma_nkb[c];
+	int num = 0, den = 0, bias = 0;
 	int comp = 0, i = 0;                       // position 32*m+q = comp*k + i
 	for (int m = 0; m < nwp; m++) {
 		uint32_t xw = 0, mw = 0;
@@ -195,6 +342,27 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 		}
 		B.masks[(size_t)(row0 + m) * B.n_pad + s] = xw;
 		B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s] = mw;
+		if (m < nkb) {
+			// matrix-core engine: this sample's column of the B operand, a_k = +1 / -1 / 0 as int8,
+			// written to the two lanes (K halves) that own it in the MFMA layout
+			bias += __popc(xw & mw);
+			const int n = threadIdx.x >> 5;
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				const uint32_t xs = (xw >> (16 * h)) & 0xFFFFu, ms = (mw >> (16 * h)) & 0xFFFFu;
+				const v4i pos = expand_bits16(ms & ~xs), neg = expand_bits16(ms & xs);
+				uint4 a;
+				a.x = (uint32_t)pos[0] | ((uint32_t)neg[0] * 0xFFu); a.y = (uint32_t)pos[1] | ((uint32_t)neg[1] * 0xFFu);
+				a.z = (uint32_t)pos[2] | ((uint32_t)neg[2] * 0xFFu); a.w = (uint32_t)pos[3] | ((uint32_t)neg[3] * 0xFFu);
+				B.bt[((size_t)(M.bt_row[c] + n * nkb + m) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (threadIdx.x & 31)] = a;
+			}
+		}
+	}
+	if (nkb > 0) {
+		const int n = threadIdx.x >> 5;
+		const size_t at = ((size_t)(2 * c + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + (threadIdx.x & 31);
+		B.bias[at] = bias;
+		B.bias[at + 32] = bias;
 	}
 	B.cw[(size_t)c * B.n_pad + s] = (s < B.n_samp && den > 0) ? ((double)num / den) : 0.0;
 }
@@ -259,7 +427,7 @@ __device__ __forceinline__ double classifier_total(const HibagModelView &M, cons
 	return total;
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS, 8) void k_total(HibagModelView M, HibagBatchView B)
+__global__ __launch_bounds__(BLOCK_THREADS, 3) void k_total(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	stage_table(M, tab_s);
@@ -270,10 +438,19 @@ __global__ __launch_bounds__(BLOCK_THREADS, 8) void k_total(HibagModelView M, Hi
 	const size_t at = (size_t)c * B.n_pad + s;
 	const bool active = B.cw[at] > 0;                 // src/LibHLA.cpp:2451
 	if (__ballot(active) == 0) return;                // nobody needs this classifier
-	double total;
-#define CALL(N) total = classifier_total<N>(M, B, c, s, tab_s)
-	HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
+	double total = 0;
+	const int nkb = M.mfma_nkb[c];
+	if (nkb > 0) {
+#define CALL(N) { LaneOperand<N> T; load_operand<N>(M, B, c, group, threadIdx.x & 63, T);                         \
+		walk_blocks<N>(M.blk_stream + M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, T, tab_s,                    \
+			[&](double cell) { total += cell; asm("" : "+v"(total)); /* keeps the cell end a scalar branch */ }); }
+		HIBAG_DISPATCH_NKB(nkb, CALL)
 #undef CALL
+	} else {
+#define CALL(N) total = classifier_total<N>(M, B, c, s, tab_s)
+		HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
+#undef CALL
+	}
 	B.tot[at] = total;
 	B.inv[at] = 1 / total;                            // src/LibHLA.cpp:1827 (inf when total == 0)
 }
@@ -309,7 +486,7 @@ __device__ __forceinline__ void accumulate_classifier(const HibagModelView &M, c
 	}
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS, 8) void k_accum(HibagModelView M, HibagBatchView B)
+__global__ __launch_bounds__(BLOCK_THREADS, 3) void k_accum(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double acc_s[BLOCK_WAVES][HIBAG_TILE][HIBAG_WAVE];
@@ -350,9 +527,31 @@ __global__ __launch_bounds__(BLOCK_THREADS, 8) void k_accum(HibagModelView M, Hi
 		if (__ballot(active) == 0) continue;
 		const double inv = B.inv[at];
 		const bool poison = __ballot(active && !(fabs(inv) <= 1.79769313486231570815e+308)) != 0;
-#define CALL(N) accumulate_classifier<N>(M, B, c, s, tile, ncell, active, poison, inv, w, tab_s, acc)
-		HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
+		const int nkb = M.mfma_nkb[c];
+		if (nkb > 0) {
+			const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + tile) * HIBAG_TILE_META;
+			const uint32_t *__restrict__ bt = M.blk_tile + ((size_t)c * M.n_tile + tile) * 2;
+			int e = 0;                                   // cells close in the order of the tile's non-empty entries
+			auto fin = [&](double cell) {
+				const int j = meta[2 + e] >> 24;
+				e++;
+				const double v = (cell * inv) * w;
+				acc[j][lane] += active ? v : 0.0;
+			};
+#define CALL(N) { LaneOperand<N> T; load_operand<N>(M, B, c, group, lane, T);                                      \
+			walk_blocks<N>(M.blk_stream + M.blk_off[c] + (size_t)bt[0] * HIBAG_BLOCK_DWORDS(N), (int)bt[1], lane, T, tab_s, fin); }
+			HIBAG_DISPATCH_NKB(nkb, CALL)
 #undef CALL
+			if (poison)                                  // empty cells: (0 * inv) * w is NaN where inv is not finite
+				for (int i = (int)meta[0]; i < ncell; i++) {
+					const double v = (0.0 * inv) * w;
+					acc[meta[2 + i] >> 24][lane] += active ? v : 0.0;
+				}
+		} else {
+#define CALL(N) accumulate_classifier<N>(M, B, c, s, tile, ncell, active, poison, inv, w, tab_s, acc)
+			HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
+#undef CALL
+		}
 	}
 
 	const int p0 = M.tile_p0[tile];
