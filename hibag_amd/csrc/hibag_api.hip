@@ -445,14 +445,16 @@ int finalize_model(hibag_hip_model *m)
 			if (off > 0xFFFFFFFFull) return fail(HIBAG_HIP_EINVAL, "classifier %d has too many haplotype pairs", c);
 			me[1] = (uint32_t)off;
 			int k = 0;
+			uint64_t jpack = 0;
 			for (int j = 0; j < tile_n[t]; j++) {
 				const uint32_t n = cell_chunks[c][tile_p0[t] + j];
 				if (n > 0xFFFFFFu) return fail(HIBAG_HIP_EINVAL, "an allele pair of classifier %d has too many haplotype pairs", c);
-				if (n) { me[2 + k++] = ((uint32_t)j << 24) | n; off += n; }
+				if (n) { jpack |= (uint64_t)j << (4 * k); me[4 + k++] = ((uint32_t)j << 24) | n; off += n; }
 			}
 			me[0] = (uint32_t)k;
+			me[2] = (uint32_t)jpack; me[3] = (uint32_t)(jpack >> 32);
 			for (int j = 0; j < tile_n[t]; j++)
-				if (!cell_chunks[c][tile_p0[t] + j]) me[2 + k++] = (uint32_t)j << 24;
+				if (!cell_chunks[c][tile_p0[t] + j]) me[4 + k++] = (uint32_t)j << 24;
 		}
 	}
 	if (cls_cnt.empty()) { cls_cnt.push_back(0); cls_cell.push_back(0); }

@@ -18,8 +18,9 @@
 //    the chunk counts of its non-empty cells in posterior order (pass 1 walks
 //    it).  For pass 2 cells are grouped in TILES of up to HIBAG_TILE consecutive
 //    cells with about equal work; tile_meta[c][t] = { #non-empty cells, first
-//    chunk of the tile, then one entry (j << 24 | chunks) per cell of the tile:
-//    the non-empty ones in order, then the empty ones }.
+//    chunk of the tile, the row numbers j of the non-empty cells packed 4 bits each
+//    (2 dwords), then one entry (j << 24 | chunks) per cell of the tile: the
+//    non-empty ones in order, then the empty ones }.
 //
 //    The matrix-core engine reads the same records regrouped per (classifier,
 //    tile) into BLOCKS of 32 (blk_stream): W[nkb][32] then prod[32] then a mask
@@ -42,12 +43,13 @@
 #define HIBAG_WAVE 64
 #define HIBAG_TAB_N 257          // 2*128 + 1 distances (src/LibHLA.cpp:167)
 #ifndef HIBAG_TILE
-#define HIBAG_TILE 8             // allele-pair cells per tile (one LDS accumulator row each)
+#define HIBAG_TILE 16            // allele-pair cells per tile (one LDS accumulator row each; at most 16)
 #endif
 #ifndef HIBAG_CHUNK
 #define HIBAG_CHUNK 4            // pair records per chunk
 #endif
-#define HIBAG_TILE_META (2 + HIBAG_TILE)   // dwords of one tile_meta entry
+#define HIBAG_TILE_META (4 + HIBAG_TILE)   // dwords of one tile_meta entry
+static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 #define HIBAG_MAX_NWP 12         // ceil(3*128/32) words of the packed pair string
 
 // dwords of one chunk for a classifier with nwp words per record

@@ -191,7 +191,11 @@ __device__ __forceinline__ void block_own_sample(const v16i &acc0, const v16i &a
 // cell += prod_i * TAB[d_i] for the first n_valid records of a block, in order;
 // `fin(cell)` at every record that closes a cell (end mask; cells are padded to
 // an even number of records, so only odd positions can close one).  Eight table
-// look-ups are in flight per wait.
+// look-ups are in flight per wait; the 8 frequency factors of a group come as one
+// vector load (one s_load_dwordx16) so that they are not re-fetched piecemeal
+// behind every cell-end branch.
+typedef double f64x8 __attribute__((ext_vector_type(8)));
+
 template <class Fin>
 __device__ __forceinline__ void block_accumulate(const double *__restrict__ pr, uint32_t endmask, int n_valid,
 	const v16i &D0, const v16i &D1, double &cell, const double *tab_s, Fin &&fin)
@@ -199,9 +203,6 @@ __device__ __forceinline__ void block_accumulate(const double *__restrict__ pr, 
 #pragma unroll
 	for (int g = 0; g < 4; g++) {
 		if (8 * g >= n_valid) break;
-		// the 8 frequency factors of the group as one vector load (one s_load_dwordx16), so
-		// that they are not re-fetched piecemeal behind every cell-end branch
-		typedef double f64x8 __attribute__((ext_vector_type(8)));
 		const f64x8 pv = *reinterpret_cast<const f64x8 *>(pr + 8 * g);
 		double t[8];
 #pragma unroll
@@ -214,11 +215,9 @@ __device__ __forceinline__ void block_accumulate(const double *__restrict__ pr, 
 	}
 }
 
-// Walk `nblk` consecutive blocks (wave-uniform pointer), software-pipelined
-// inside the wavefront: while the vector ALU accumulates block b, the matrix
-// core already computes the distances of block b+1 and the record words of
-// block b+2 are in flight (per-lane VMEM).  The stream is padded by two blocks
-// so that the look-ahead stays in bounds.
+// Walk `nblk` consecutive blocks (wave-uniform pointer).  The record words of
+// the next block are fetched (per-lane VMEM) while the current one is evaluated;
+// the stream is padded so that the look-ahead stays in bounds.
 template <int NKB, class Fin>
 __device__ __forceinline__ void walk_blocks(const uint32_t *__restrict__ blk, int nblk, int lane,
 	const LaneOperand<NKB> &T, const double *tab_s, Fin &&fin)
@@ -226,29 +225,18 @@ __device__ __forceinline__ void walk_blocks(const uint32_t *__restrict__ blk, in
 	double cell = 0;
 	const int sh = (lane >> 5) * 16, li = lane & 31;
 	uint32_t w[NKB];
-	v16i acc0, acc1;
 #pragma unroll
 	for (int kb = 0; kb < NKB; kb++) w[kb] = blk[kb * 32 + li];
-	block_mfma<NKB>(w, sh, T, acc0, acc1);
-#pragma unroll
-	for (int kb = 0; kb < NKB; kb++) w[kb] = blk[HIBAG_BLOCK_DWORDS(NKB) + kb * 32 + li];
 	for (int b = 0; b < nblk; b++) {
-		v16i D0, D1;
-#if defined(HIBAG_ABLATE) && HIBAG_ABLATE == 1      // timing experiment: no distance computation at all
-		for (int r = 0; r < 16; r++) { D0[r] = (T.bias[0] + r) & 63; D1[r] = (T.bias[1] + w[0] + r) & 63; }
-#else
-		block_own_sample(acc0, acc1, D0, D1);
+		v16i acc0, acc1, D0, D1;
 		block_mfma<NKB>(w, sh, T, acc0, acc1);
-#endif
+		const uint32_t *__restrict__ nxt = blk + HIBAG_BLOCK_DWORDS(NKB);
 #pragma unroll
-		for (int kb = 0; kb < NKB; kb++) w[kb] = blk[2 * HIBAG_BLOCK_DWORDS(NKB) + kb * 32 + li];
-#if defined(HIBAG_ABLATE) && HIBAG_ABLATE == 2      // timing experiment: distances only, no accumulation
-		{ int z = 0; for (int r = 0; r < 16; r++) z += D0[r] ^ D1[r]; cell += z; }
-#else
+		for (int kb = 0; kb < NKB; kb++) w[kb] = nxt[kb * 32 + li];
+		block_own_sample(acc0, acc1, D0, D1);
 		block_accumulate(reinterpret_cast<const double *>(blk + 32 * NKB), blk[32 * NKB + 64], (int)blk[32 * NKB + 65],
 			D0, D1, cell, tab_s, fin);
-#endif
-		blk += HIBAG_BLOCK_DWORDS(NKB);
+		blk = nxt;
 	}
 }
 
@@ -427,7 +415,7 @@ __device__ __forceinline__ double classifier_total(const HibagModelView &M, cons
 	return total;
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS, 3) void k_total(HibagModelView M, HibagBatchView B)
+__global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	stage_table(M, tab_s);
@@ -475,18 +463,19 @@ __device__ __forceinline__ void accumulate_classifier(const HibagModelView &M, c
 	const int nvisit = poison ? ncell : (int)meta[0];
 	const uint32_t *__restrict__ cp = M.stream + M.stream_off[c] + (size_t)meta[1] * HIBAG_CHUNK_DWORDS(NWP);
 	const int lane = threadIdx.x & 63;
-	uint32_t e = meta[2];
+	uint32_t e = meta[4];
 	for (int i = 0; i < nvisit; i++) {
-		const uint32_t e_next = meta[3 + i];           // fetched while this cell is evaluated (meta is padded)
+		const uint32_t e_next = meta[5 + i];           // fetched while this cell is evaluated (meta is padded)
 		const int j = e >> 24;
+		const double a = acc[j][lane];                 // LDS read in flight during the cell
 		const double cell = cell_sum<NWP>(e & 0xFFFFFFu, cp, L, tab_s);
 		const double v = (cell * inv) * w;
-		acc[j][lane] += active ? v : 0.0;              // x + 0.0 == x: inactive lanes keep their sum
+		acc[j][lane] = a + (active ? v : 0.0);         // x + 0.0 == x: inactive lanes keep their sum
 		e = e_next;
 	}
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS, 3) void k_accum(HibagModelView M, HibagBatchView B)
+__global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double acc_s[BLOCK_WAVES][HIBAG_TILE][HIBAG_WAVE];
@@ -531,12 +520,18 @@ __global__ __launch_bounds__(BLOCK_THREADS, 3) void k_accum(HibagModelView M, Hi
 		if (nkb > 0) {
 			const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + tile) * HIBAG_TILE_META;
 			const uint32_t *__restrict__ bt = M.blk_tile + ((size_t)c * M.n_tile + tile) * 2;
-			int e = 0;                                   // cells close in the order of the tile's non-empty entries
+			// Cells close in the order of the tile's non-empty entries; their row numbers j come
+			// packed 4 bits each in two SGPRs, so closing a cell needs no memory access, and the
+			// LDS row of the NEXT cell to close is read while that cell is still being summed.
+			uint64_t jpack = ((uint64_t)meta[3] << 32) | meta[2];
+			int j = (int)(jpack & 15);
+			double a = acc[j][lane];
 			auto fin = [&](double cell) {
-				const int j = meta[2 + e] >> 24;
-				e++;
 				const double v = (cell * inv) * w;
-				acc[j][lane] += active ? v : 0.0;
+				acc[j][lane] = a + (active ? v : 0.0);
+				jpack >>= 4;
+				j = (int)(jpack & 15);
+				a = acc[j][lane];
 			};
 #define CALL(N) { LaneOperand<N> T; load_operand<N>(M, B, c, group, lane, T);                                      \
 			walk_blocks<N>(M.blk_stream + M.blk_off[c] + (size_t)bt[0] * HIBAG_BLOCK_DWORDS(N), (int)bt[1], lane, T, tab_s, fin); }
@@ -545,7 +540,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 3) void k_accum(HibagModelView M, Hi
 			if (poison)                                  // empty cells: (0 * inv) * w is NaN where inv is not finite
 				for (int i = (int)meta[0]; i < ncell; i++) {
 					const double v = (0.0 * inv) * w;
-					acc[meta[2 + i] >> 24][lane] += active ? v : 0.0;
+					acc[meta[4 + i] >> 24][lane] += active ? v : 0.0;
 				}
 		} else {
 #define CALL(N) accumulate_classifier<N>(M, B, c, s, tile, ncell, active, poison, inv, w, tab_s, acc)
