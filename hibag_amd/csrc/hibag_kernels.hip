@@ -115,7 +115,8 @@ __device__ __forceinline__ double cell_sum(uint32_t n, const uint32_t *__restric
 
 // ---------------------------------------------------------------------------
 // MFMA engine.  The distance is an integer dot product,
-//     d = sum_k ((W_k ^ x_k) & m_k) = sum_k W_k * a_k + sum_k m_k x_k,   a_k = m_k (1 - 2 x_k) in {-1,0,+1},
+//     d = sum_k ((W_k ^ x_k) & m_k) = sum_k W_k * a_k + sum_k m_k x_k,   a_k = m_k (1 - 2 x_k) in {-1,0,+1}
+// (both sides are scaled by 8 in the operands, so the MFMA delivers the byte offset of TAB[d] directly),
 // over the 3k packed bit positions, i.e. D[record][sample] = W[record][:] . a[:][sample] + bias[sample]:
 // a small int8 GEMM with K = 32*nkb.  One v_mfma_i32_32x32x32_i8 gives the exact
 // distances of 32 records x 32 samples; two (sample halves) cover the wavefront's
@@ -190,52 +191,77 @@ __device__ __forceinline__ void block_own_sample(const v16i &acc0, const v16i &a
 
 // cell += prod_i * TAB[d_i] for the first n_valid records of a block, in order;
 // `fin(cell)` at every record that closes a cell (end mask; cells are padded to
-// an even number of records, so only odd positions can close one).  Eight table
-// look-ups are in flight per wait; the 8 frequency factors of a group come as one
-// vector load (one s_load_dwordx16) so that they are not re-fetched piecemeal
-// behind every cell-end branch.
-typedef double f64x8 __attribute__((ext_vector_type(8)));
+// an even number of records, so only odd positions can close one).  Per group of
+// 8 records: 8 table look-ups (per-lane LDS gathers) and the 8 frequency factors
+// (4 wave-uniform 16-byte LDS reads, broadcast to all lanes) are in flight before
+// the first wait.  `stage` = this wavefront's copy of the block's factors in LDS.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 template <class Fin>
-__device__ __forceinline__ void block_accumulate(const double *__restrict__ pr, uint32_t endmask, int n_valid,
+__device__ __forceinline__ void block_accumulate(const double *stage, uint32_t endmask, int n_valid,
 	const v16i &D0, const v16i &D1, double &cell, const double *tab_s, Fin &&fin)
 {
 #pragma unroll
 	for (int g = 0; g < 4; g++) {
 		if (8 * g >= n_valid) break;
-		const f64x8 pv = *reinterpret_cast<const f64x8 *>(pr + 8 * g);
+		f64x2 pv[4];
 		double t[8];
 #pragma unroll
-		for (int q = 0; q < 8; q++) t[q] = tab_s[q < 4 ? D0[4 * g + q] : D1[4 * g + q - 4]];
+		for (int q = 0; q < 4; q++) pv[q] = *reinterpret_cast<const f64x2 *>(stage + 8 * g + 2 * q);
+#pragma unroll
+		for (int q = 0; q < 8; q++)           // D = 8*d: already the byte offset into the table
+			t[q] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab_s) + (q < 4 ? D0[4 * g + q] : D1[4 * g + q - 4]));
 #pragma unroll
 		for (int q = 0; q < 8; q++) {
-			cell += pv[q] * t[q];
+			cell += pv[q >> 1][q & 1] * t[q];
 			if ((q & 1) && (endmask & (1u << (8 * g + q)))) { fin(cell); cell = 0; }
 		}
 	}
 }
 
-// Walk `nblk` consecutive blocks (wave-uniform pointer).  The record words of
-// the next block are fetched (per-lane VMEM) while the current one is evaluated;
-// the stream is padded so that the look-ahead stays in bounds.
+// LDS staging area of one wavefront: two buffers of 32 factors + {end mask, count}
+#define STAGE_DOUBLES 34
+#define STAGE_BYTES (2 * STAGE_DOUBLES * 8)
+
+// Walk `nblk` consecutive blocks (wave-uniform pointer).
+//
+// Latency plan.  Nothing in this loop goes through the scalar cache: scalar loads
+// share the lgkmcnt counter with the LDS table look-ups and return out of order,
+// so every wait for table values would also wait for the scalar load just issued
+// (~600 cycles on a miss; measured with s_memtime stamps, the accumulation phase
+// was 80 % of a block's time that way).  Instead lanes 0..32 fetch the NEXT
+// block's 32 frequency factors + {end mask, count} with one per-lane VMEM load
+// (264 contiguous bytes) while this block is evaluated, park them in the
+// wavefront's LDS staging buffer, and the accumulation reads them back with
+// wave-uniform (broadcast) LDS reads, which are in-order with the table look-ups.
+// The record words of the next block travel the same way (VMEM, one block ahead).
+// The stream is padded so that the look-ahead stays in bounds.
 template <int NKB, class Fin>
 __device__ __forceinline__ void walk_blocks(const uint32_t *__restrict__ blk, int nblk, int lane,
-	const LaneOperand<NKB> &T, const double *tab_s, Fin &&fin)
+	const LaneOperand<NKB> &T, const double *tab_s, double *stage, Fin &&fin)
 {
 	double cell = 0;
 	const int sh = (lane >> 5) * 16, li = lane & 31;
+	const int ls = lane < 33 ? lane : 0;             // staging lane: 32 factors + the meta pair
 	uint32_t w[NKB];
 #pragma unroll
 	for (int kb = 0; kb < NKB; kb++) w[kb] = blk[kb * 32 + li];
+	double pf = reinterpret_cast<const double *>(blk + 32 * NKB)[ls];
 	for (int b = 0; b < nblk; b++) {
+		double *buf = stage + (b & 1) * STAGE_DOUBLES;
+		if (lane < 33) buf[lane] = pf;
+		const uint32_t *__restrict__ nxt = blk + HIBAG_BLOCK_DWORDS(NKB);
+
 		v16i acc0, acc1, D0, D1;
 		block_mfma<NKB>(w, sh, T, acc0, acc1);
-		const uint32_t *__restrict__ nxt = blk + HIBAG_BLOCK_DWORDS(NKB);
 #pragma unroll
 		for (int kb = 0; kb < NKB; kb++) w[kb] = nxt[kb * 32 + li];
+		pf = reinterpret_cast<const double *>(nxt + 32 * NKB)[ls];
 		block_own_sample(acc0, acc1, D0, D1);
-		block_accumulate(reinterpret_cast<const double *>(blk + 32 * NKB), blk[32 * NKB + 64], (int)blk[32 * NKB + 65],
-			D0, D1, cell, tab_s, fin);
+		const uint2 meta = *reinterpret_cast<const uint2 *>(buf + 32);
+		const uint32_t endmask = __builtin_amdgcn_readfirstlane(meta.x);
+		const int n_valid = __builtin_amdgcn_readfirstlane(meta.y);
+		block_accumulate(buf, endmask, n_valid, D0, D1, cell, tab_s, fin);
 		blk = nxt;
 	}
 }
@@ -340,8 +366,9 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 				const uint32_t xs = (xw >> (16 * h)) & 0xFFFFu, ms = (mw >> (16 * h)) & 0xFFFFu;
 				const v4i pos = expand_bits16(ms & ~xs), neg = expand_bits16(ms & xs);
 				uint4 a;
-				a.x = (uint32_t)pos[0] | ((uint32_t)neg[0] * 0xFFu); a.y = (uint32_t)pos[1] | ((uint32_t)neg[1] * 0xFFu);
-				a.z = (uint32_t)pos[2] | ((uint32_t)neg[2] * 0xFFu); a.w = (uint32_t)pos[3] | ((uint32_t)neg[3] * 0xFFu);
+				// +8 -> 0x08, -8 -> 0xF8: the MFMA then yields 8*d, the byte offset of TAB[d]
+				a.x = (uint32_t)pos[0] * 0x08u | (uint32_t)neg[0] * 0xF8u; a.y = (uint32_t)pos[1] * 0x08u | (uint32_t)neg[1] * 0xF8u;
+				a.z = (uint32_t)pos[2] * 0x08u | (uint32_t)neg[2] * 0xF8u; a.w = (uint32_t)pos[3] * 0x08u | (uint32_t)neg[3] * 0xF8u;
 				B.bt[((size_t)(M.bt_row[c] + n * nkb + m) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (threadIdx.x & 31)] = a;
 			}
 		}
@@ -349,8 +376,8 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 	if (nkb > 0) {
 		const int n = threadIdx.x >> 5;
 		const size_t at = ((size_t)(2 * c + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + (threadIdx.x & 31);
-		B.bias[at] = bias;
-		B.bias[at + 32] = bias;
+		B.bias[at] = 8 * bias;
+		B.bias[at + 32] = 8 * bias;
 	}
 	B.cw[(size_t)c * B.n_pad + s] = (s < B.n_samp && den > 0) ? ((double)num / den) : 0.0;
 }
@@ -415,9 +442,10 @@ __device__ __forceinline__ double classifier_total(const HibagModelView &M, cons
 	return total;
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, HibagBatchView B)
+__global__ __launch_bounds__(BLOCK_THREADS, 3) void k_total(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
+	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
 	stage_table(M, tab_s);
 	const int c = M.c_order[blockIdx.y];
 	const int group = blockIdx.x * BLOCK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -431,6 +459,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, Hi
 	if (nkb > 0) {
 #define CALL(N) { LaneOperand<N> T; load_operand<N>(M, B, c, group, threadIdx.x & 63, T);                         \
 		walk_blocks<N>(M.blk_stream + M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, T, tab_s,                    \
+			stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)],                                             \
 			[&](double cell) { total += cell; asm("" : "+v"(total)); /* keeps the cell end a scalar branch */ }); }
 		HIBAG_DISPATCH_NKB(nkb, CALL)
 #undef CALL
@@ -475,10 +504,11 @@ __device__ __forceinline__ void accumulate_classifier(const HibagModelView &M, c
 	}
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, HibagBatchView B)
+__global__ __launch_bounds__(BLOCK_THREADS, 3) void k_accum(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double acc_s[BLOCK_WAVES][HIBAG_TILE][HIBAG_WAVE];
+	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
 	stage_table(M, tab_s);
 
 	// XCD-aware decode: workgroups are dealt round-robin over the 8 XCDs, so
@@ -534,7 +564,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 				a = acc[j][lane];
 			};
 #define CALL(N) { LaneOperand<N> T; load_operand<N>(M, B, c, group, lane, T);                                      \
-			walk_blocks<N>(M.blk_stream + M.blk_off[c] + (size_t)bt[0] * HIBAG_BLOCK_DWORDS(N), (int)bt[1], lane, T, tab_s, fin); }
+			walk_blocks<N>(M.blk_stream + M.blk_off[c] + (size_t)bt[0] * HIBAG_BLOCK_DWORDS(N), (int)bt[1], lane, T, tab_s, \
+				stage_s[wave], fin); }
 			HIBAG_DISPATCH_NKB(nkb, CALL)
 #undef CALL
 			if (poison)                                  // empty cells: (0 * inv) * w is NaN where inv is not finite
