@@ -471,6 +471,19 @@ int finalize_model(hibag_hip_model *m)
 		raw[c] = RawRecords();
 	}
 	blk_stream.insert(blk_stream.end(), 2 * HIBAG_BLOCK_DWORDS(3), 0);   // look-ahead slack of the block walker
+	// per (classifier, tile) record of pass 2 (one s_load_dwordx8)
+	std::vector<uint32_t> ctile((size_t)std::max(C, 1) * n_tile * 8 + 8, 0);
+	for (int c = 0; c < C; c++)
+		for (int t = 0; t < n_tile; t++) {
+			uint32_t *r = &ctile[((size_t)c * n_tile + t) * 8];
+			const uint32_t *me = &tile_meta[((size_t)c * n_tile + t) * HIBAG_TILE_META];
+			const uint64_t off = blk_off[c] + (uint64_t)blk_tile[((size_t)c * n_tile + t) * 2] * HIBAG_BLOCK_DWORDS(std::max(mfma_nkb[c], 1));
+			r[0] = (uint32_t)mfma_nkb[c]; r[1] = (uint32_t)bt_row[c];
+			r[2] = (uint32_t)off; r[3] = (uint32_t)(off >> 32);
+			r[4] = blk_tile[((size_t)c * n_tile + t) * 2 + 1];
+			r[5] = me[0]; r[6] = me[2]; r[7] = me[3];
+		}
+
 
 	// one int arena
 	std::vector<int> arena;
@@ -489,7 +502,8 @@ int finalize_model(hibag_hip_model *m)
 	const size_t tb_off = 0, tb_meta = stream_off.size() * sizeof(uint64_t), tb_cnt = tb_meta + tile_meta.size() * sizeof(uint32_t),
 		tb_cell = tb_cnt + cls_cnt.size() * sizeof(uint32_t),
 		tb_boff = (tb_cell + cls_cell.size() * sizeof(uint32_t) + 7) & ~(size_t)7, tb_btile = tb_boff + blk_off.size() * sizeof(uint64_t),
-		tb_end = tb_btile + blk_tile.size() * sizeof(uint32_t);
+		tb_ctile = (tb_btile + blk_tile.size() * sizeof(uint32_t) + 31) & ~(size_t)31,
+		tb_end = tb_ctile + ctile.size() * sizeof(uint32_t);
 	if (int rc = m->d_tile.reserve(tb_end)) return rc;
 	if (int rc = m->d_tab.reserve(sizeof(m->tab))) return rc;
 	HIP_TRY(hipMemcpy(m->d_int.p, arena.data(), arena.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -501,6 +515,7 @@ int finalize_model(hibag_hip_model *m)
 	HIP_TRY(hipMemcpy(tbase + tb_cell, cls_cell.data(), cls_cell.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_boff, blk_off.data(), blk_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_btile, blk_tile.data(), blk_tile.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(tbase + tb_ctile, ctile.data(), ctile.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	if (int rc = m->d_blk.reserve(blk_stream.size() * sizeof(uint32_t))) return rc;
 	HIP_TRY(hipMemcpy(m->d_blk.p, blk_stream.data(), blk_stream.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(m->d_tab.p, m->tab, sizeof(m->tab), hipMemcpyHostToDevice));
@@ -519,6 +534,7 @@ int finalize_model(hibag_hip_model *m)
 	V.mfma_nkb = base + o_nkb; V.bt_row = base + o_btrow; V.cls_nblk = base + o_nblk;
 	V.blk_off = (const uint64_t *)(tbase + tb_boff);
 	V.blk_tile = (const uint32_t *)(tbase + tb_btile);
+	V.ctile = (const uint32_t *)(tbase + tb_ctile);
 	V.blk_stream = m->d_blk.as<uint32_t>();
 	m->bt_rows = bt_rows;
 	V.stream = m->d_stream.as<uint32_t>();

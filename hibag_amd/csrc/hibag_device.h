@@ -90,6 +90,8 @@ struct HibagModelView {
 	const int *cls_nblk;         // [C] blocks of the classifier (all tiles)
 	const uint32_t *blk_tile;    // [C][n_tile][2] = {first block of the tile, blocks of the tile}
 	const uint32_t *blk_stream;  // blocks of 32 records: W[nkb][32], prod[32] (f64), end mask, pad
+	const uint32_t *ctile;       // [C][n_tile][8]: everything pass 2 needs per (classifier, tile) in one s_load_dwordx8:
+	                             // {nkb, bt_row, block stream dword offset lo/hi, #blocks, #non-empty cells, row list lo/hi}
 };
 
 struct HibagBatchView {

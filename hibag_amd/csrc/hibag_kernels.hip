@@ -136,7 +136,18 @@ struct LaneOperand {
 };
 
 template <int NKB>
+__device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt_row, int c, int group,
+	int lane, LaneOperand<NKB> &T);
+
+template <int NKB>
 __device__ __forceinline__ void load_operand(const HibagModelView &M, const HibagBatchView &B, int c, int group,
+	int lane, LaneOperand<NKB> &T)
+{
+	load_operand_row<NKB>(B, M.bt_row[c], c, group, lane, T);
+}
+
+template <int NKB>
+__device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt_row, int c, int group,
 	int lane, LaneOperand<NKB> &T)
 {
 	const size_t n_group = (size_t)(B.n_pad / HIBAG_WAVE);
@@ -144,7 +155,7 @@ __device__ __forceinline__ void load_operand(const HibagModelView &M, const Hiba
 	for (int n = 0; n < 2; n++) {
 #pragma unroll
 		for (int kb = 0; kb < NKB; kb++) {
-			const uint4 v = B.bt[((size_t)(M.bt_row[c] + n * NKB + kb) * n_group + group) * HIBAG_WAVE + lane];
+			const uint4 v = B.bt[((size_t)(bt_row + n * NKB + kb) * n_group + group) * HIBAG_WAVE + lane];
 			T.b[n][kb] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
 		}
 		T.bias[n] = B.bias[((size_t)(2 * c + n) * n_group + group) * HIBAG_WAVE + lane];
@@ -163,16 +174,30 @@ __device__ __forceinline__ v4i expand_bits16(uint32_t x)
 // Issue the MFMAs of one block: acc_n[r] of lane l = distance of record
 // 8(r/4) + 4(l/32) + r%4 to sample (l%32) of sample half n.
 // w[kb] = word kb of record (lane % 32), already in a register.
+// 8 bits -> 8 bytes (bit i -> byte i = 0/1) for all 256 byte values: the A operand
+// is expanded with two 8-byte LDS look-ups per K block instead of ~13 VALU ops.
+__device__ __forceinline__ void stage_expand_table(uint2 *exp_s)
+{
+	for (int v = threadIdx.x; v < 256; v += blockDim.x) {
+		uint2 e;
+		e.x = (((uint32_t)v & 0xFu) * 0x00204081u) & 0x01010101u;
+		e.y = ((((uint32_t)v >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
+		exp_s[v] = e;
+	}
+}
+
 template <int NKB>
 __device__ __forceinline__ void block_mfma(const uint32_t (&w)[NKB], int sh, const LaneOperand<NKB> &T,
-	v16i &acc0, v16i &acc1)
+	const uint2 *exp_s, v16i &acc0, v16i &acc1)
 {
 #pragma unroll
 	for (int r = 0; r < 16; r++) { acc0[r] = T.bias[0]; acc1[r] = T.bias[1]; }
 #pragma unroll
 	for (int kb = 0; kb < NKB; kb++) {
 		// A operand: lane l holds record l%32, K bytes 16*(l/32)..+15 of this K block
-		const v4i a = expand_bits16((w[kb] >> sh) & 0xFFFFu);
+		const uint32_t x = w[kb] >> sh;
+		const uint2 lo = exp_s[x & 0xFFu], hi = exp_s[(x >> 8) & 0xFFu];
+		const v4i a = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
 		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, T.b[0][kb], acc0, 0, 0, 0);
 		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, T.b[1][kb], acc1, 0, 0, 0);
 	}
@@ -238,7 +263,7 @@ __device__ __forceinline__ void block_accumulate(const double *stage, uint32_t e
 // The stream is padded so that the look-ahead stays in bounds.
 template <int NKB, class Fin>
 __device__ __forceinline__ void walk_blocks(const uint32_t *__restrict__ blk, int nblk, int lane,
-	const LaneOperand<NKB> &T, const double *tab_s, double *stage, Fin &&fin)
+	const LaneOperand<NKB> &T, const double *tab_s, const uint2 *exp_s, double *stage, Fin &&fin)
 {
 	double cell = 0;
 	const int sh = (lane >> 5) * 16, li = lane & 31;
@@ -253,7 +278,7 @@ __device__ __forceinline__ void walk_blocks(const uint32_t *__restrict__ blk, in
 		const uint32_t *__restrict__ nxt = blk + HIBAG_BLOCK_DWORDS(NKB);
 
 		v16i acc0, acc1, D0, D1;
-		block_mfma<NKB>(w, sh, T, acc0, acc1);
+		block_mfma<NKB>(w, sh, T, exp_s, acc0, acc1);
 #pragma unroll
 		for (int kb = 0; kb < NKB; kb++) w[kb] = nxt[kb * 32 + li];
 		pf = reinterpret_cast<const double *>(nxt + 32 * NKB)[ls];
@@ -446,6 +471,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 3) void k_total(HibagModelView M, Hi
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
+	__shared__ uint2 exp_s[256];
+	stage_expand_table(exp_s);
 	stage_table(M, tab_s);
 	const int c = M.c_order[blockIdx.y];
 	const int group = blockIdx.x * BLOCK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -458,7 +485,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 3) void k_total(HibagModelView M, Hi
 	const int nkb = M.mfma_nkb[c];
 	if (nkb > 0) {
 #define CALL(N) { LaneOperand<N> T; load_operand<N>(M, B, c, group, threadIdx.x & 63, T);                         \
-		walk_blocks<N>(M.blk_stream + M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, T, tab_s,                    \
+		walk_blocks<N>(M.blk_stream + M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, T, tab_s, exp_s,             \
 			stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)],                                             \
 			[&](double cell) { total += cell; asm("" : "+v"(total)); /* keeps the cell end a scalar branch */ }); }
 		HIBAG_DISPATCH_NKB(nkb, CALL)
@@ -509,6 +536,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 3) void k_accum(HibagModelView M, Hi
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double acc_s[BLOCK_WAVES][HIBAG_TILE][HIBAG_WAVE];
 	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
+	__shared__ uint2 exp_s[256];
+	stage_expand_table(exp_s);
 	stage_table(M, tab_s);
 
 	// XCD-aware decode: workgroups are dealt round-robin over the 8 XCDs, so
@@ -539,21 +568,33 @@ __global__ __launch_bounds__(BLOCK_THREADS, 3) void k_accum(HibagModelView M, Hi
 #pragma unroll
 	for (int j = 0; j < HIBAG_TILE; j++) acc[j][lane] = 0;
 
+	// Everything classifier c+1 needs that does not cost many registers is requested while
+	// classifier c is evaluated: its (classifier, tile) record (one s_load_dwordx8) and the
+	// lane's weight and 1/total.  Without this every classifier starts with a chain of
+	// dependent scalar and vector loads (~3000 cycles per classifier, measured with stamps).
+	typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+	const u32x8 *__restrict__ ct = reinterpret_cast<const u32x8 *>(M.ctile) + tile;
+	u32x8 rec_n = ct[0];
+	double w_n = B.cw[s], inv_n = B.inv[s];
 	for (int c = 0; c < M.n_classifier; c++) {
-		const size_t at = (size_t)c * B.n_pad + s;
-		const double w = B.cw[at];
+		const u32x8 rec = rec_n;
+		const double w = w_n, inv = inv_n;
+		{
+			const int cn = (c + 1 < M.n_classifier) ? c + 1 : c;
+			rec_n = ct[(size_t)cn * M.n_tile];
+			w_n = B.cw[(size_t)cn * B.n_pad + s];
+			inv_n = B.inv[(size_t)cn * B.n_pad + s];
+		}
+		__builtin_amdgcn_sched_barrier(0);            // keep the requests above at the top of the iteration
 		const bool active = w > 0;
 		if (__ballot(active) == 0) continue;
-		const double inv = B.inv[at];
 		const bool poison = __ballot(active && !(fabs(inv) <= 1.79769313486231570815e+308)) != 0;
-		const int nkb = M.mfma_nkb[c];
+		const int nkb = (int)rec[0];
 		if (nkb > 0) {
-			const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + tile) * HIBAG_TILE_META;
-			const uint32_t *__restrict__ bt = M.blk_tile + ((size_t)c * M.n_tile + tile) * 2;
 			// Cells close in the order of the tile's non-empty entries; their row numbers j come
 			// packed 4 bits each in two SGPRs, so closing a cell needs no memory access, and the
 			// LDS row of the NEXT cell to close is read while that cell is still being summed.
-			uint64_t jpack = ((uint64_t)meta[3] << 32) | meta[2];
+			uint64_t jpack = ((uint64_t)rec[7] << 32) | rec[6];
 			int j = (int)(jpack & 15);
 			double a = acc[j][lane];
 			auto fin = [&](double cell) {
@@ -563,16 +604,18 @@ __global__ __launch_bounds__(BLOCK_THREADS, 3) void k_accum(HibagModelView M, Hi
 				j = (int)(jpack & 15);
 				a = acc[j][lane];
 			};
-#define CALL(N) { LaneOperand<N> T; load_operand<N>(M, B, c, group, lane, T);                                      \
-			walk_blocks<N>(M.blk_stream + M.blk_off[c] + (size_t)bt[0] * HIBAG_BLOCK_DWORDS(N), (int)bt[1], lane, T, tab_s, \
-				stage_s[wave], fin); }
+			const uint32_t *__restrict__ blk = M.blk_stream + (((uint64_t)rec[3] << 32) | rec[2]);
+#define CALL(N) { LaneOperand<N> T; load_operand_row<N>(B, (int)rec[1], c, group, lane, T);                        \
+			walk_blocks<N>(blk, (int)rec[4], lane, T, tab_s, exp_s, stage_s[wave], fin); }
 			HIBAG_DISPATCH_NKB(nkb, CALL)
 #undef CALL
-			if (poison)                                  // empty cells: (0 * inv) * w is NaN where inv is not finite
-				for (int i = (int)meta[0]; i < ncell; i++) {
+			if (poison) {                                // empty cells: (0 * inv) * w is NaN where inv is not finite
+				const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + tile) * HIBAG_TILE_META;
+				for (int i = (int)rec[5]; i < ncell; i++) {
 					const double v = (0.0 * inv) * w;
 					acc[meta[4 + i] >> 24][lane] += active ? v : 0.0;
 				}
+			}
 		} else {
 #define CALL(N) accumulate_classifier<N>(M, B, c, s, tile, ncell, active, poison, inv, w, tab_s, acc)
 			HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
