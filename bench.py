@@ -186,6 +186,26 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores():
+    """Threads worth starting: the CPU affinity mask capped by the cgroup CPU quota (the GPU box
+    exposes all hardware threads but limits the container's CPU time)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    note = f"{n} hardware threads visible"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period) + 0.5))
+            if q < n:
+                note += f", cgroup CPU quota {q}"
+                n = q
+    except (OSError, ValueError):
+        pass
+    return n, note
+
+
 def cpu_baseline(model_obj, geno, gpu_h1, gpu_h2):
     """AVX2 + threads port of the reference's CPU kernel (oracle/hibag_oracle_avx2.c) on all host
     cores.  The timed sample is the benchmark batch repeated until it holds about 12 s of CPU work
@@ -195,7 +215,7 @@ def cpu_baseline(model_obj, geno, gpu_h1, gpu_h2):
     from oracle import oracle as O
     O.build()
     fm = O.flatten(model_obj)
-    cores = os.cpu_count() or 1
+    cores, cores_note = usable_cores()
     n = len(geno)
     t = time.perf_counter()
     ref = O.predict(fm, geno, avx2=True, n_threads=cores, want_dosage=True, want_prob=False)
@@ -208,7 +228,7 @@ def cpu_baseline(model_obj, geno, gpu_h1, gpu_h2):
     dt = time.perf_counter() - t
     return {"value": len(big) / dt, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"the {n} samples of the timed batch repeated {reps}x ({len(big)} samples, {dt:.1f} s), same model, "
-                      f"same outputs; AVX2 4-wide inner loop + {cores} threads over samples",
+                      f"same outputs; AVX2 4-wide inner loop + {cores} threads over samples ({cores_note})",
             "calls_identical_to_gpu": same}
 
 
