@@ -190,8 +190,13 @@ template <int NKB>
 __device__ __forceinline__ void block_mfma(const uint32_t (&w)[NKB], int sh, const LaneOperand<NKB> &T,
 	const uint2 *exp_s, v16i &acc0, v16i &acc1)
 {
+	// The accumulators start at the lane's distance offset.  The empty asm makes the offsets
+	// opaque per block: otherwise the two 16-register splats are hoisted out of the block loop
+	// and cost 32 VGPRs for its whole duration (one wavefront per SIMD less).
+	int b0 = T.bias[0], b1 = T.bias[1];
+	asm("" : "+v"(b0), "+v"(b1));
 #pragma unroll
-	for (int r = 0; r < 16; r++) { acc0[r] = T.bias[0]; acc1[r] = T.bias[1]; }
+	for (int r = 0; r < 16; r++) { acc0[r] = b0; acc1[r] = b1; }
 #pragma unroll
 	for (int kb = 0; kb < NKB; kb++) {
 		// A operand: lane l holds record l%32, K bytes 16*(l/32)..+15 of this K block
@@ -205,11 +210,11 @@ __device__ __forceinline__ void block_mfma(const uint32_t (&w)[NKB], int sh, con
 
 // Swap the upper lanes of half 0 with the lower lanes of half 1: afterwards every
 // lane holds its OWN sample: record i = 8g + q  ->  q < 4 ? D0[4g + q] : D1[4g + q - 4].
-__device__ __forceinline__ void block_own_sample(const v16i &acc0, const v16i &acc1, v16i &D0, v16i &D1)
+__device__ __forceinline__ void block_own_sample(v16i &D0, v16i &D1)    // in place: (acc0, acc1) -> (D0, D1)
 {
 #pragma unroll
 	for (int r = 0; r < 16; r++) {
-		const auto sw = __builtin_amdgcn_permlane32_swap(acc0[r], acc1[r], false, false);
+		const auto sw = __builtin_amdgcn_permlane32_swap(D0[r], D1[r], false, false);
 		D0[r] = sw[0]; D1[r] = sw[1];
 	}
 }
@@ -277,12 +282,12 @@ __device__ __forceinline__ void walk_blocks(const uint32_t *__restrict__ blk, in
 		if (lane < 33) buf[lane] = pf;
 		const uint32_t *__restrict__ nxt = blk + HIBAG_BLOCK_DWORDS(NKB);
 
-		v16i acc0, acc1, D0, D1;
-		block_mfma<NKB>(w, sh, T, exp_s, acc0, acc1);
+		v16i D0, D1;
+		block_mfma<NKB>(w, sh, T, exp_s, D0, D1);
 #pragma unroll
 		for (int kb = 0; kb < NKB; kb++) w[kb] = nxt[kb * 32 + li];
 		pf = reinterpret_cast<const double *>(nxt + 32 * NKB)[ls];
-		block_own_sample(acc0, acc1, D0, D1);
+		block_own_sample(D0, D1);
 		const uint2 meta = *reinterpret_cast<const uint2 *>(buf + 32);
 		const uint32_t endmask = __builtin_amdgcn_readfirstlane(meta.x);
 		const int n_valid = __builtin_amdgcn_readfirstlane(meta.y);
@@ -467,7 +472,7 @@ __device__ __forceinline__ double classifier_total(const HibagModelView &M, cons
 	return total;
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS, 3) void k_total(HibagModelView M, HibagBatchView B)
+__global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
@@ -531,7 +536,7 @@ __device__ __forceinline__ void accumulate_classifier(const HibagModelView &M, c
 	}
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS, 3) void k_accum(HibagModelView M, HibagBatchView B)
+__global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double acc_s[BLOCK_WAVES][HIBAG_TILE][HIBAG_WAVE];
