@@ -256,3 +256,37 @@ def test_full_size_hla_b_properties(hib, oracle):
     sub = np.sort(np.random.default_rng(5).choice(N, 160, replace=False))
     want = oracle.predict(oracle.flatten(model), G[sub], avx2=True, n_threads=8)
     assert_same({k: v[sub] for k, v in out.items()}, want)
+
+
+def test_both_engines_give_the_same_bits(hib, oracle, monkeypatch):
+    """The matrix-core engine (int8 MFMA distances) and the vector-ALU engine (bit logic +
+    popcount) compute the same integers; everything downstream is shared."""
+    from hibag_amd import synth
+    model, founders, af = synth.make_model("hla-b", n_classifier=30)
+    G, _ = synth.make_samples(founders, af, 700)
+    G[9, :] = hib.NA_INTEGER
+    monkeypatch.setenv("HIBAG_ENGINE", "mfma")
+    a = hib.hlaModelFromObj(model).predict_raw(G, 1, want_dosage=True, want_prob=True)
+    monkeypatch.setenv("HIBAG_ENGINE", "valu")
+    b = hib.hlaModelFromObj(model).predict_raw(G, 1, want_dosage=True, want_prob=True)
+    assert_same(a, b)
+    assert_same({k: v[:96] for k, v in a.items()}, oracle.predict(oracle.flatten(model), G[:96], avx2=True, n_threads=8))
+
+
+def test_more_samples_than_one_batch(hib, oracle):
+    """The driver cuts the cohort into batches (<= 131,072 samples); results must not depend on
+    where the cuts fall."""
+    from hibag_amd import synth
+    model, founders, af = synth.make_model("hla-a-small", n_classifier=8)
+    N = 140_000
+    G, _ = synth.make_samples(founders, af, N)
+    dev = hib.hlaModelFromObj(model)
+    out = dev.predict_raw(G, 1, want_dosage=True, want_prob=False)
+    lo, hi = 131_072 - 100, 131_072 + 100            # straddles the batch boundary
+    part = dev.predict_raw(G[lo:hi], 1, want_dosage=True, want_prob=False)
+    for k in part:
+        assert np.array_equal(part[k], out[k][lo:hi], equal_nan=True), k
+    sub = np.sort(np.random.default_rng(11).choice(N, 200, replace=False))
+    want = oracle.predict(oracle.flatten(model), G[sub], want_prob=False, avx2=True, n_threads=8)
+    for k in want:
+        assert np.array_equal(out[k][sub], want[k], equal_nan=True), k
