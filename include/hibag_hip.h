@@ -162,11 +162,15 @@ int hibag_hip_reset_timing(hibag_hip_model *m);
 
 /* Returns a pointer to a static struct laid out exactly like
  * HLA_LIB::TypeGPUExtProc (inst/include/LibHLA_ext.h:358-388): ten function
- * pointers.  predict_init / predict_done / predict_avg_prob are implemented
- * (src/LibHLA.cpp:2498-2531, :2433-2441); the seven build_* entries are NULL
- * (the host NULL-checks each one, e.g. src/LibHLA.cpp:2258, :2290, :1916).
- * An R package hands it to hlaPredict() as attr(cl, "proc_ptr")
- * (R/HIBAG.R:707); see INTEGRATION.md. */
+ * pointers, all implemented.
+ *   predict_init / predict_done / predict_avg_prob  (src/LibHLA.cpp:2498-2531, :2433-2441)
+ *   build_init / build_done / build_set_bootstrap    (src/LibHLA.cpp:2256-2266, :2290-2293)
+ *   build_haplomatch                                 (src/LibHLA.cpp:1037-1063)
+ *   build_set_haplo_geno / build_acc_oob / build_acc_ib (src/LibHLA.cpp:1916-1920, :1938-1941, :1961-1964)
+ * An R package hands it to hlaPredict() as attr(cl, "proc_ptr") (R/HIBAG.R:707) or
+ * to HIBAG_NewClassifiers as its last argument (src/HIBAG.cpp:601-602); see
+ * INTEGRATION.md.  Failures inside these void entries throw `const char *`, which
+ * the host's CORE_CATCH turns into an R error (src/HIBAG.cpp:41-60). */
 const void *hibag_hip_gpu_ext_proc(void);
 
 #ifdef __cplusplus

@@ -128,3 +128,17 @@ def test_snp_matching_subset_and_flip(model_a, hapmap_geno):
     with pytest.raises(ValueError, match="no overlapping"):
         none = HlaSNPGeno(sub.genotype[:3], sub.sample_id, ["x1", "x2", "x3"], np.array([1., 2., 3.]), ["A/G"] * 3, "hg19")
         match_snps_for_predict(model_a, none, "RefSNP", True, False, False, False)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """On a machine without an MI355X the product refuses to compute (there is no CPU path)."""
+    import hibag_amd
+    from hibag_amd import _lib, synth
+    if _lib.lib().hibag_hip_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(hibag_amd.HibagHipError) as e:
+        hibag_amd.hlaSetKernelTarget("hip")
+    assert e.value.code == -2                                   # HIBAG_HIP_ENODEV
+    model, _, _ = synth.make_model("hla-a-small", n_classifier=2)
+    with pytest.raises(hibag_amd.HibagHipError):                # finalize needs the device
+        hibag_amd.hlaModelFromObj(model)
