@@ -10,8 +10,10 @@ from .model import (NA_INTEGER, Classifier, HlaAttrBagObj, HlaSNPGeno, load_geno
 from .hibag import (HlaAlleleClass, HlaAttrBagClass, hlaClose, hlaModelFromObj, hlaModelToObj,   # noqa: F401
                     hlaPredict, hlaSetKernelTarget)
 from .snpmatch import hlaGenoSwitchStrand, hlaSNPID  # noqa: F401
+from .bed import HlaBEDGeno, hlaBED2Geno, hlaLociInfo  # noqa: F401
 from ._lib import HibagHipError  # noqa: F401
 
 __all__ = ["NA_INTEGER", "Classifier", "HlaAttrBagObj", "HlaSNPGeno", "load_geno", "load_model",
            "HlaAlleleClass", "HlaAttrBagClass", "hlaClose", "hlaModelFromObj", "hlaModelToObj",
-           "hlaPredict", "hlaSetKernelTarget", "hlaGenoSwitchStrand", "hlaSNPID", "HibagHipError"]
+           "hlaPredict", "hlaSetKernelTarget", "hlaGenoSwitchStrand", "hlaSNPID", "HibagHipError",
+           "HlaBEDGeno", "hlaBED2Geno", "hlaLociInfo"]

@@ -27,7 +27,7 @@ EXPORTS = [
     "hibag_hip_model_pair_evals", "hibag_hip_model_mutation_table", "hibag_hip_predict",
     "hibag_hip_predict_device", "hibag_hip_model_set_snp_weights", "hibag_hip_predict_partial_device",
     "hibag_hip_finish_device", "hibag_hip_set_timing", "hibag_hip_get_timing", "hibag_hip_reset_timing",
-    "hibag_hip_gpu_ext_proc",
+    "hibag_hip_gpu_ext_proc", "hibag_hip_bed_flag", "hibag_hip_conv_bed", "hibag_hip_predict_bed",
 ]
 
 
@@ -85,6 +85,9 @@ def lib() -> C.CDLL:
     L.hibag_hip_get_timing.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(i64)]
     L.hibag_hip_reset_timing.argtypes = [vp]
     L.hibag_hip_gpu_ext_proc.restype = vp
+    L.hibag_hip_bed_flag.argtypes = [C.c_char_p]
+    L.hibag_hip_conv_bed.argtypes = [C.c_char_p, i32, i32, i32, vp, vp]
+    L.hibag_hip_predict_bed.argtypes = [vp, C.c_char_p, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 

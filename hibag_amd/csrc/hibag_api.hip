@@ -144,6 +144,8 @@ struct hibag_hip_model {
 	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias;
 	// plugin staging
 	DevBuf ws_tgeno, ws_weight;
+	// PLINK BED payload + SNP map of hibag_hip_predict_bed
+	DevBuf ws_bed, ws_bedidx;
 
 	KernelTimer timer;
 	std::mutex lock;
@@ -153,7 +155,7 @@ struct hibag_hip_model {
 		(void)hipSetDevice(device);
 		timer.destroy();
 		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
-		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_tgeno, &ws_weight})
+		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_tgeno, &ws_weight, &ws_bed, &ws_bedidx})
 			b->release();
 	}
 };
@@ -614,7 +616,17 @@ int check_predict_args(hibag_hip_model *m, const void *geno, int n_samp, int vot
 	return 0;
 }
 
-int predict_device_locked(hibag_hip_model *m, const int32_t *d_geno, int n_samp, int vote_method,
+// Where a batch's genotypes come from: the int32 matrix, or a PLINK BED payload.
+struct PackSource {
+	const int32_t *d_geno = nullptr;       // [n_samp][n_snp]
+	const uint8_t *d_bed = nullptr;        // payload rows (see k_bed_codes)
+	int mode = 0;
+	size_t stride = 0;
+	int samp0 = 0;                         // BED sample index of the call's sample 0
+	const int32_t *d_row = nullptr, *d_flip = nullptr;
+};
+
+int predict_device_locked(hibag_hip_model *m, const PackSource &src, int n_samp, int vote_method,
 	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching, double *d_dosage,
 	double *d_postprob, hipStream_t st)
 {
@@ -626,7 +638,11 @@ int predict_device_locked(hibag_hip_model *m, const int32_t *d_geno, int n_samp,
 		HibagBatchView B;
 		if (int rc = make_batch(m, n, vote_method == 2, B)) return rc;
 		m->timer.begin(HIBAG_HIP_K_PACK, st);
-		hibag_launch_pack(m->view, B, d_geno + (size_t)s0 * m->n_snp, m->ws_codes.as<uint8_t>(), st);
+		if (src.d_bed)
+			hibag_launch_pack_bed(m->view, B, src.d_bed, src.mode, src.stride, src.samp0 + s0, src.d_row, src.d_flip,
+				m->ws_codes.as<uint8_t>(), st);
+		else
+			hibag_launch_pack(m->view, B, src.d_geno + (size_t)s0 * m->n_snp, m->ws_codes.as<uint8_t>(), st);
 		m->timer.end(st);
 		run_core(m, B, vote_method, m->ws_part.as<double>(), st);
 		m->timer.begin(HIBAG_HIP_K_FINISH, st);
@@ -638,6 +654,109 @@ int predict_device_locked(hibag_hip_model *m, const int32_t *d_geno, int n_samp,
 		m->timer.end(st);
 	}
 	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// Host-pointer driver: slices the cohort so that the posterior matrix never
+// needs more than a slice on the device; genotypes come from the host int32
+// matrix (uploaded slice by slice) or from a BED payload already on the device.
+int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSource *bed, int n_samp, int vote_method,
+	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob)
+{
+	const size_t P = (size_t)m->view.n_cell, nh = (size_t)m->n_hla, S = (size_t)m->n_snp;
+	const int slice = batch_limit(m);
+	const size_t geno_bytes = (size_t)slice * std::max<size_t>(S, 1) * sizeof(int32_t);
+	const size_t o_h1 = 0, o_h2 = o_h1 + (size_t)slice * 4, o_mp = (o_h2 + (size_t)slice * 4 + 7) / 8 * 8,
+		o_mt = o_mp + (size_t)slice * 8, o_ds = o_mt + (size_t)slice * 8, o_pp = o_ds + (size_t)slice * nh * 8,
+		out_bytes = o_pp + (postprob ? (size_t)slice * P * 8 : 0);
+	if (!bed)
+		if (int rc = m->ws_geno.reserve(geno_bytes)) return rc;
+	if (int rc = m->ws_out.reserve(out_bytes)) return rc;
+	char *o = m->ws_out.as<char>();
+	for (int s0 = 0; s0 < n_samp; s0 += slice) {
+		const int n = std::min(slice, n_samp - s0);
+		PackSource src;
+		if (bed) {
+			src = *bed;
+			src.samp0 = bed->samp0 + s0;
+		} else {
+			HIP_TRY(hipMemcpyAsync(m->ws_geno.p, geno + (size_t)s0 * S, (size_t)n * S * sizeof(int32_t),
+				hipMemcpyHostToDevice, 0));
+			src.d_geno = m->ws_geno.as<int32_t>();
+		}
+		if (int rc = predict_device_locked(m, src, n, vote_method,
+				H1 ? (int32_t *)(o + o_h1) : nullptr, H2 ? (int32_t *)(o + o_h2) : nullptr,
+				max_prob ? (double *)(o + o_mp) : nullptr, matching ? (double *)(o + o_mt) : nullptr,
+				dosage ? (double *)(o + o_ds) : nullptr, postprob ? (double *)(o + o_pp) : nullptr, 0))
+			return rc;
+		if (H1) {
+			HIP_TRY(hipMemcpyAsync(H1 + s0, o + o_h1, (size_t)n * 4, hipMemcpyDeviceToHost, 0));
+			HIP_TRY(hipMemcpyAsync(H2 + s0, o + o_h2, (size_t)n * 4, hipMemcpyDeviceToHost, 0));
+		}
+		if (max_prob) HIP_TRY(hipMemcpyAsync(max_prob + s0, o + o_mp, (size_t)n * 8, hipMemcpyDeviceToHost, 0));
+		if (matching) HIP_TRY(hipMemcpyAsync(matching + s0, o + o_mt, (size_t)n * 8, hipMemcpyDeviceToHost, 0));
+		if (dosage) HIP_TRY(hipMemcpyAsync(dosage + (size_t)s0 * nh, o + o_ds, (size_t)n * nh * 8, hipMemcpyDeviceToHost, 0));
+		if (postprob) HIP_TRY(hipMemcpyAsync(postprob + (size_t)s0 * P, o + o_pp, (size_t)n * P * 8, hipMemcpyDeviceToHost, 0));
+		HIP_TRY(hipStreamSynchronize(0));
+	}
+	return 0;
+}
+
+// ---------------------------------------------------------------------------
+// PLINK BED files (HIBAG_BEDFlag / HIBAG_ConvBED, src/HIBAG.cpp:1068-1191)
+
+// Host image of the part of a BED file a call needs.  SNP-major files keep only
+// the rows of the wanted SNPs (a cohort file holds the whole genome, a model
+// ~10^2-10^3 SNPs); individual-major files are kept whole.
+struct BedImage {
+	int mode = 0;
+	size_t stride = 0;                 // bytes per row
+	std::vector<uint8_t> rows;         // payload
+	std::vector<int32_t> index;        // per wanted SNP: row (SNP-major) / column (individual-major) in `rows`, -1 = absent
+};
+
+int read_bed_prefix(FILE *f, int *mode)
+{
+	unsigned char prefix[3];
+	if (fread(prefix, 1, 3, f) != 3 || prefix[0] != 0x6C || prefix[1] != 0x1B)
+		return fail(HIBAG_HIP_EINVAL, "Invalid prefix in the PLINK BED file.");   // src/HIBAG.cpp:1077-1078, :1112-1113
+	*mode = prefix[2];
+	return 0;
+}
+
+// want[n_want]: BED SNP indices (0-based, -1 = none).
+int load_bed(const char *fn, int n_samp, int n_snp, const int32_t *want, int n_want, BedImage &img)
+{
+	if (!fn) return fail(HIBAG_HIP_EINVAL, "bed file name is NULL");
+	if (n_samp < 0 || n_snp < 0) return fail(HIBAG_HIP_EINVAL, "negative dimensions (n_samp=%d, n_snp=%d)", n_samp, n_snp);
+	FILE *f = fopen(fn, "rb");
+	if (!f) return fail(HIBAG_HIP_EINVAL, "Fail to open the file \"%s\".", fn);   // src/HIBAG.cpp:1106-1107
+	struct Closer { FILE *f; ~Closer() { fclose(f); } } closer{f};
+	if (int rc = read_bed_prefix(f, &img.mode)) return rc;
+	for (int j = 0; j < n_want; j++)
+		if (want[j] >= n_snp) return fail(HIBAG_HIP_EINVAL, "SNP index %d outside the BED file's %d SNPs", want[j], n_snp);
+	img.index.assign(n_want, -1);
+	const char *short_msg = "the PLINK BED file holds fewer than %d x %d genotypes";
+	if (img.mode == 0) {
+		img.stride = ((size_t)n_snp + 3) / 4;
+		img.rows.resize(img.stride * (size_t)n_samp);
+		if (!img.rows.empty() && fread(img.rows.data(), 1, img.rows.size(), f) != img.rows.size())
+			return fail(HIBAG_HIP_EINVAL, short_msg, n_samp, n_snp);
+		for (int j = 0; j < n_want; j++) img.index[j] = want[j];
+	} else {
+		img.stride = ((size_t)n_samp + 3) / 4;
+		int n_row = 0;
+		for (int j = 0; j < n_want; j++) if (want[j] >= 0) n_row++;
+		img.rows.resize(img.stride * (size_t)n_row);
+		int r = 0;
+		for (int j = 0; j < n_want; j++) {
+			if (want[j] < 0) continue;
+			if (fseeko(f, (off_t)3 + (off_t)img.stride * want[j], SEEK_SET) != 0 ||
+				(img.stride && fread(img.rows.data() + img.stride * (size_t)r, 1, img.stride, f) != img.stride))
+				return fail(HIBAG_HIP_EINVAL, short_msg, n_samp, n_snp);
+			img.index[j] = r++;
+		}
+	}
 	return 0;
 }
 
@@ -785,7 +904,9 @@ int hibag_hip_predict_device(hibag_hip_model *m, const int32_t *d_geno, int n_sa
 {
 	if (int rc = check_predict_args(m, d_geno, n_samp, vote_method, d_H1, d_H2)) return rc;
 	std::lock_guard<std::mutex> g(m->lock);
-	return predict_device_locked(m, d_geno, n_samp, vote_method, d_H1, d_H2, d_max_prob, d_matching,
+	PackSource src;
+	src.d_geno = d_geno;
+	return predict_device_locked(m, src, n_samp, vote_method, d_H1, d_H2, d_max_prob, d_matching,
 		d_dosage, d_postprob, (hipStream_t)stream);
 }
 
@@ -796,36 +917,81 @@ int hibag_hip_predict(hibag_hip_model *m, const int32_t *geno, int n_samp, int v
 	if (n_samp == 0) return 0;
 	std::lock_guard<std::mutex> g(m->lock);
 	HIP_TRY(hipSetDevice(m->device));
-	const size_t P = (size_t)m->view.n_cell, nh = (size_t)m->n_hla, S = (size_t)m->n_snp;
-	// stage in slices so that the posterior matrix never needs more than a slice on the device
-	const int slice = batch_limit(m);
-	const size_t geno_bytes = (size_t)slice * std::max<size_t>(S, 1) * sizeof(int32_t);
-	const size_t o_h1 = 0, o_h2 = o_h1 + (size_t)slice * 4, o_mp = (o_h2 + (size_t)slice * 4 + 7) / 8 * 8,
-		o_mt = o_mp + (size_t)slice * 8, o_ds = o_mt + (size_t)slice * 8, o_pp = o_ds + (size_t)slice * nh * 8,
-		out_bytes = o_pp + (postprob ? (size_t)slice * P * 8 : 0);
-	if (int rc = m->ws_geno.reserve(geno_bytes)) return rc;
-	if (int rc = m->ws_out.reserve(out_bytes)) return rc;
-	char *o = m->ws_out.as<char>();
-	for (int s0 = 0; s0 < n_samp; s0 += slice) {
-		const int n = std::min(slice, n_samp - s0);
-		HIP_TRY(hipMemcpyAsync(m->ws_geno.p, geno + (size_t)s0 * S, (size_t)n * S * sizeof(int32_t),
-			hipMemcpyHostToDevice, 0));
-		if (int rc = predict_device_locked(m, m->ws_geno.as<int32_t>(), n, vote_method,
-				H1 ? (int32_t *)(o + o_h1) : nullptr, H2 ? (int32_t *)(o + o_h2) : nullptr,
-				max_prob ? (double *)(o + o_mp) : nullptr, matching ? (double *)(o + o_mt) : nullptr,
-				dosage ? (double *)(o + o_ds) : nullptr, postprob ? (double *)(o + o_pp) : nullptr, 0))
-			return rc;
-		if (H1) {
-			HIP_TRY(hipMemcpyAsync(H1 + s0, o + o_h1, (size_t)n * 4, hipMemcpyDeviceToHost, 0));
-			HIP_TRY(hipMemcpyAsync(H2 + s0, o + o_h2, (size_t)n * 4, hipMemcpyDeviceToHost, 0));
-		}
-		if (max_prob) HIP_TRY(hipMemcpyAsync(max_prob + s0, o + o_mp, (size_t)n * 8, hipMemcpyDeviceToHost, 0));
-		if (matching) HIP_TRY(hipMemcpyAsync(matching + s0, o + o_mt, (size_t)n * 8, hipMemcpyDeviceToHost, 0));
-		if (dosage) HIP_TRY(hipMemcpyAsync(dosage + (size_t)s0 * nh, o + o_ds, (size_t)n * nh * 8, hipMemcpyDeviceToHost, 0));
-		if (postprob) HIP_TRY(hipMemcpyAsync(postprob + (size_t)s0 * P, o + o_pp, (size_t)n * P * 8, hipMemcpyDeviceToHost, 0));
-		HIP_TRY(hipStreamSynchronize(0));
-	}
+	return predict_staged_locked(m, geno, nullptr, n_samp, vote_method, H1, H2, max_prob, matching, dosage, postprob);
+}
+
+// ---- PLINK BED ------------------------------------------------------------
+
+int hibag_hip_bed_flag(const char *bed_fn)
+{
+	if (!bed_fn) return fail(HIBAG_HIP_EINVAL, "bed file name is NULL");
+	FILE *f = fopen(bed_fn, "rb");
+	if (!f) return fail(HIBAG_HIP_EINVAL, "Cannot open the file %s.", bed_fn);   // src/HIBAG.cpp:1073-1074
+	int mode = 0;
+	const int rc = read_bed_prefix(f, &mode);
+	fclose(f);
+	return rc ? rc : mode;
+}
+
+int hibag_hip_conv_bed(const char *bed_fn, int n_samp, int n_snp, int n_save_snp, const int32_t *snp_flag,
+	int32_t *geno)
+{
+	if (!snp_flag && n_snp > 0) return fail(HIBAG_HIP_EINVAL, "snp_flag is NULL");
+	std::vector<int32_t> want;
+	for (int j = 0; j < n_snp; j++) if (snp_flag[j]) want.push_back(j);
+	if ((int)want.size() != n_save_snp)
+		return fail(HIBAG_HIP_EINVAL, "snp_flag selects %zu SNPs, n_save_snp is %d", want.size(), n_save_snp);
+	BedImage img;
+	if (int rc = load_bed(bed_fn, n_samp, n_snp, want.data(), n_save_snp, img)) return rc;
+	if (n_samp == 0 || n_save_snp == 0) return 0;
+	if (!geno) return fail(HIBAG_HIP_EINVAL, "geno is NULL");
+	if (hibag_hip_device_count() <= g_device) return fail(HIBAG_HIP_ENODEV, "no HIP device available");
+	HIP_TRY(hipSetDevice(g_device));
+	DevBuf d_rows, d_sel, d_geno;
+	struct Free { DevBuf &a, &b, &c; ~Free() { a.release(); b.release(); c.release(); } } fr{d_rows, d_sel, d_geno};
+	const size_t out_bytes = (size_t)n_samp * n_save_snp * sizeof(int32_t);
+	if (int rc = d_rows.reserve(std::max<size_t>(img.rows.size(), 1))) return rc;
+	if (int rc = d_sel.reserve((size_t)n_save_snp * sizeof(int32_t))) return rc;
+	if (int rc = d_geno.reserve(out_bytes)) return rc;
+	HIP_TRY(hipMemcpyAsync(d_rows.p, img.rows.data(), img.rows.size(), hipMemcpyHostToDevice, 0));
+	HIP_TRY(hipMemcpyAsync(d_sel.p, img.index.data(), (size_t)n_save_snp * sizeof(int32_t), hipMemcpyHostToDevice, 0));
+	hibag_launch_bed_geno(d_rows.as<uint8_t>(), img.mode, img.stride, n_samp, n_save_snp, d_sel.as<int32_t>(),
+		d_geno.as<int32_t>(), 0);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(geno, d_geno.p, out_bytes, hipMemcpyDeviceToHost, 0));
+	HIP_TRY(hipStreamSynchronize(0));
 	return 0;
+}
+
+int hibag_hip_predict_bed(hibag_hip_model *m, const char *bed_fn, int n_samp, int n_snp,
+	const int32_t *snp_col, const int32_t *flip, int vote_method,
+	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob)
+{
+	if (int rc = check_predict_args(m, bed_fn, n_samp, vote_method, H1, H2)) return rc;
+	if (!snp_col && m->n_snp > 0) return fail(HIBAG_HIP_EINVAL, "snp_col is NULL");
+	BedImage img;
+	if (int rc = load_bed(bed_fn, n_samp, n_snp, snp_col, m->n_snp, img)) return rc;
+	if (n_samp == 0) return 0;
+	std::lock_guard<std::mutex> g(m->lock);
+	HIP_TRY(hipSetDevice(m->device));
+	const size_t S = (size_t)std::max(m->n_snp, 1);
+	std::vector<int32_t> idx(2 * S, 0);
+	for (int k = 0; k < m->n_snp; k++) {
+		idx[k] = img.index[k];
+		idx[S + k] = flip ? (flip[k] != 0) : 0;
+	}
+	if (int rc = m->ws_bed.reserve(std::max<size_t>(img.rows.size(), 1))) return rc;
+	if (int rc = m->ws_bedidx.reserve(idx.size() * sizeof(int32_t))) return rc;
+	HIP_TRY(hipMemcpyAsync(m->ws_bed.p, img.rows.data(), img.rows.size(), hipMemcpyHostToDevice, 0));
+	HIP_TRY(hipMemcpyAsync(m->ws_bedidx.p, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, 0));
+	HIP_TRY(hipStreamSynchronize(0));            // `img` and `idx` are pageable host memory about to go out of scope
+	PackSource src;
+	src.d_bed = m->ws_bed.as<uint8_t>();
+	src.mode = img.mode;
+	src.stride = img.stride;
+	src.d_row = m->ws_bedidx.as<int32_t>();
+	src.d_flip = m->ws_bedidx.as<int32_t>() + S;
+	return predict_staged_locked(m, nullptr, &src, n_samp, vote_method, H1, H2, max_prob, matching, dosage, postprob);
 }
 
 int hibag_hip_predict_partial_device(hibag_hip_model *m, const int32_t *d_geno, int n_samp,

@@ -9,6 +9,11 @@
 
 void hibag_launch_pack(const HibagModelView &M, const HibagBatchView &B, const int32_t *d_geno, uint8_t *d_codes,
 	hipStream_t st);
+// PLINK BED sources: `d_bed` is the payload after the 3-byte prefix, rows of `stride` bytes
+void hibag_launch_pack_bed(const HibagModelView &M, const HibagBatchView &B, const uint8_t *d_bed, int mode,
+	size_t stride, int samp0, const int32_t *d_snp_row, const int32_t *d_flip, uint8_t *d_codes, hipStream_t st);
+void hibag_launch_bed_geno(const uint8_t *d_bed, int mode, size_t stride, int n_samp, int n_save,
+	const int32_t *d_sel, int32_t *d_geno, hipStream_t st);
 void hibag_launch_unpack_tgeno(const HibagModelView &M, const HibagBatchView &B, const uint64_t *d_tgeno,
 	const double *d_weight, hipStream_t st);
 void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st);

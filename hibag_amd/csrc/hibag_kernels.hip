@@ -347,6 +347,69 @@ __global__ __launch_bounds__(256) void k_codes(HibagModelView M, HibagBatchView 
 	}
 }
 
+// ---------------------------------------------------------------------------
+// PLINK BED sources (HIBAG_ConvBED, src/HIBAG.cpp:1094-1191).  `bed` is the
+// payload after the 3-byte prefix: rows of `stride` bytes, 4 two-bit codes per
+// byte, lowest bits first.  mode 0 = individual-major (row = sample, column =
+// SNP), otherwise SNP-major.  Code -> genotype {2, NA, 1, 0} (:1135), returned
+// here as the byte code 0/1/2 or 3 = missing.
+__device__ __forceinline__ uint32_t bed_code(const uint8_t *__restrict__ bed, int mode, size_t stride, int snp_row, int samp)
+{
+	const size_t row = mode == 0 ? (size_t)samp : (size_t)snp_row;
+	const int col = mode == 0 ? snp_row : samp;
+	const uint32_t two = ((uint32_t)bed[row * stride + (size_t)(col >> 2)] >> (2 * (col & 3))) & 3u;
+	return (0x0132u >> (4 * two)) & 0xFu;
+}
+
+// k_bed_codes: BED payload -> the byte codes [n_snp][n_pad] k_pack consumes,
+// skipping the int32 matrix.  snp_row[k] = row (SNP-major) / column
+// (individual-major) of model SNP k inside `bed`, or -1 if the cohort lacks it
+// (-> missing); flip[k] != 0 swaps the allele count, g -> 2 - g (the strand /
+// allele-order fix-up of hlaPredict, R/HIBAG.R:640-676).  Block = 4 wavefronts,
+// one SNP each, lane = sample: SNP-major rows are read as 16 contiguous bytes
+// per wavefront and written as 64 contiguous codes.
+__global__ __launch_bounds__(256) void k_bed_codes(HibagModelView M, HibagBatchView B,
+	const uint8_t *__restrict__ bed, int mode, size_t stride, int samp0,
+	const int32_t *__restrict__ snp_row, const int32_t *__restrict__ flip, uint8_t *__restrict__ codes)
+{
+	const int k = blockIdx.y * 4 + (threadIdx.x >> 6);
+	const int s = blockIdx.x * 64 + (threadIdx.x & 63);
+	if (k >= M.n_snp) return;
+	uint32_t g = 3;
+	const int r = snp_row[k];
+	if (s < B.n_samp && r >= 0) {
+		g = bed_code(bed, mode, stride, r, samp0 + s);
+		if (flip[k] && g != 3) g = 2 - g;
+	}
+	codes[(size_t)k * B.n_pad + s] = (uint8_t)g;
+}
+
+// k_bed_geno: HIBAG_ConvBED itself -- the int32 matrix [n_samp][n_save]
+// (sample-major = R's n_save x n_samp matrix) of the selected SNPs, NA_integer_
+// for the missing code.  64 x 64 tiles; SNP-major sources go through an LDS
+// transpose so that both the byte reads (along samples) and the int32 writes
+// (along SNPs) are contiguous.
+__global__ __launch_bounds__(256) void k_bed_geno(const uint8_t *__restrict__ bed, int mode, size_t stride,
+	int n_samp, int n_save, const int32_t *__restrict__ sel, int32_t *__restrict__ geno)
+{
+	__shared__ uint8_t tile[64][65];
+	const int s0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	if (mode != 0) {
+		for (int r = ty; r < 64; r += 4) {           // r = SNP, tx = sample
+			const int j = j0 + r, s = s0 + tx;
+			tile[r][tx] = (j < n_save && s < n_samp) ? (uint8_t)bed_code(bed, mode, stride, sel[j], s) : (uint8_t)3;
+		}
+		__syncthreads();
+	}
+	for (int r = ty; r < 64; r += 4) {               // r = sample, tx = SNP
+		const int s = s0 + r, j = j0 + tx;
+		if (s >= n_samp || j >= n_save) continue;
+		const uint32_t g = mode != 0 ? tile[tx][r] : bed_code(bed, mode, stride, sel[j], s);
+		geno[(size_t)s * n_save + j] = g == 3 ? (int32_t)0x80000000 : (int32_t)g;
+	}
+}
+
 // k_pack: TGenotype::IntToSNP (src/LibHLA.cpp:662-706) for every (sample,
 // classifier), emitted directly as the lane masks of the packed pair string
 //   bits [0,k)   first haplotype : x = [g==2], m = [g in {0,2}]
@@ -829,6 +892,24 @@ void hibag_launch_pack(const HibagModelView &M, const HibagBatchView &B, const i
 	hipLaunchKernelGGL(k_codes, dim3(B.n_pad / 64, (M.n_snp + 63) / 64), dim3(256), 0, st, M, B, d_geno, d_codes);
 	hipLaunchKernelGGL(k_pack, dim3(B.n_pad / HIBAG_WAVE, M.n_classifier), dim3(HIBAG_WAVE), 0, st, M, B,
 		(const uint8_t *)d_codes);
+}
+
+void hibag_launch_pack_bed(const HibagModelView &M, const HibagBatchView &B, const uint8_t *d_bed, int mode,
+	size_t stride, int samp0, const int32_t *d_snp_row, const int32_t *d_flip, uint8_t *d_codes, hipStream_t st)
+{
+	if (M.n_classifier == 0 || M.n_snp == 0) return;
+	hipLaunchKernelGGL(k_bed_codes, dim3(B.n_pad / 64, (M.n_snp + 3) / 4), dim3(256), 0, st, M, B, d_bed, mode, stride,
+		samp0, d_snp_row, d_flip, d_codes);
+	hipLaunchKernelGGL(k_pack, dim3(B.n_pad / HIBAG_WAVE, M.n_classifier), dim3(HIBAG_WAVE), 0, st, M, B,
+		(const uint8_t *)d_codes);
+}
+
+void hibag_launch_bed_geno(const uint8_t *d_bed, int mode, size_t stride, int n_samp, int n_save,
+	const int32_t *d_sel, int32_t *d_geno, hipStream_t st)
+{
+	if (n_samp <= 0 || n_save <= 0) return;
+	hipLaunchKernelGGL(k_bed_geno, dim3((n_samp + 63) / 64, (n_save + 63) / 64), dim3(256), 0, st, d_bed, mode, stride,
+		n_samp, n_save, d_sel, d_geno);
 }
 
 void hibag_launch_unpack_tgeno(const HibagModelView &M, const HibagBatchView &B, const uint64_t *d_tgeno,

@@ -14,6 +14,7 @@ hands over device tensors.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import sys
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Union
@@ -22,6 +23,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import HibagHipError
+from .bed import HlaBEDGeno
 from .model import (NA_INTEGER, Classifier, HlaAttrBagObj, HlaSNPGeno)
 
 _TARGETS_CPU = ("max", "auto.avx2", "base", "sse2", "sse4", "avx", "avx2", "avx512f", "avx512bw",
@@ -149,6 +151,28 @@ class HlaAttrBagClass:
             _as_ptr(out["prob"]), _as_ptr(out["matching"]), _as_ptr(out.get("dosage")), _as_ptr(out.get("postprob"))))
         return out
 
+    def predict_bed(self, bed_fn: str, n_samp: int, n_snp: int, snp_col: np.ndarray, flip: Optional[np.ndarray] = None,
+                    vote_method: int = 1, want_dosage: bool = True, want_prob: bool = False) -> dict:
+        """``PredictHLA`` on every sample of a PLINK BED file (``hibag_hip_predict_bed``):
+        ``snp_col[k]`` = 0-based .bim index of model SNP k (-1 = absent), ``flip[k]`` =
+        reverse the allele count of SNP k."""
+        col = np.ascontiguousarray(snp_col, np.int32)
+        if col.shape != (self.obj.n_snp,):
+            raise ValueError("snp_col must have one entry per model SNP")
+        fl = None if flip is None else np.ascontiguousarray(np.asarray(flip) != 0, np.int32)
+        n = int(n_samp)
+        out = dict(h1=np.zeros(n, np.int32), h2=np.zeros(n, np.int32),
+                   prob=np.zeros(n, np.float64), matching=np.zeros(n, np.float64))
+        if want_dosage:
+            out["dosage"] = np.zeros((n, self.obj.n_hla), np.float64)
+        if want_prob:
+            out["postprob"] = np.zeros((n, self.obj.n_cell), np.float64)
+        _lib.check(_lib.lib().hibag_hip_predict_bed(
+            self.handle, os.fsencode(bed_fn), n, int(n_snp), _as_ptr(col), _as_ptr(fl), int(vote_method),
+            _as_ptr(out["h1"]), _as_ptr(out["h2"]), _as_ptr(out["prob"]), _as_ptr(out["matching"]),
+            _as_ptr(out.get("dosage")), _as_ptr(out.get("postprob"))))
+        return out
+
     def predict_device(self, d_geno, n_samp: int, vote_method: int = 1, d_h1=None, d_h2=None, d_prob=None,
                        d_matching=None, d_dosage=None, d_postprob=None, stream=None):
         """Device-pointer form; arguments are ints (``tensor.data_ptr()``) or None."""
@@ -231,7 +255,7 @@ _TYPES = ("response+dosage", "response", "prob", "response+prob")
 _VOTES = ("prob", "majority")
 
 
-def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, np.ndarray], cl=False,
+def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, HlaBEDGeno, np.ndarray], cl=False,
                type: str = "response+dosage", vote: str = "prob", allele_check: bool = True,
                match_type: str = "Position", same_strand: bool = False, verbose: bool = True,
                verbose_match: bool = True):
@@ -264,7 +288,17 @@ def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, np.ndarray], cl=F
         print("Prediction:\n    " + ("based on the averaged posterior probabilities" if vote_method == 1
                                       else "by voting from all individual classifiers"), file=out)
 
-    if not isinstance(snp, HlaSNPGeno):
+    bed_plan = None
+    if isinstance(snp, HlaBEDGeno):
+        # extension: the genotypes stay in the PLINK BED file; the SNP matching / strand check
+        # (R/HIBAG.R:550-686) runs on the annotation and the device decodes the file directly
+        from .snpmatch import plan_snps_for_predict
+        bed_plan = plan_snps_for_predict(obj, snp, snp.allele_freq, match_type, allele_check, same_strand,
+                                         verbose, verbose_match)
+        assembly = bed_plan.assembly
+        geno_sampid = list(snp.sample_id)
+        mat = None
+    elif not isinstance(snp, HlaSNPGeno):
         g = np.asarray(snp)
         if g.ndim == 1:
             if g.shape[0] != obj.n_snp:
@@ -281,24 +315,28 @@ def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, np.ndarray], cl=F
                                                verbose, verbose_match)
         geno_sampid = list(snp.sample_id)
 
-    if mat.shape[0] != obj.n_snp:
+    if bed_plan is None and mat.shape[0] != obj.n_snp:
         raise ValueError("The number of SNPs is not valid, and it maybe due to duplicated 'snp.id' "
                          "or incorrect dimension of genotype matrix.")
-    n_samp = mat.shape[1]
+    n_samp = len(geno_sampid) if bed_plan is not None else mat.shape[1]
     if verbose:
         print(f"# of samples: {n_samp}", file=out)
         print(f"Kernel target: {_kernel_info or 'hip'}", file=out)
 
-    # as.integer(snp): R's NA -> NA_integer_ ; the C side treats anything outside 0..2 as missing
-    if mat.dtype.kind == "f":
-        gi = np.where(np.isfinite(mat), mat, NA_INTEGER).astype(np.int64)
-    else:
-        gi = mat.astype(np.int64)
-    genomat = np.ascontiguousarray(gi.T.astype(np.int32))     # [n_samp, n_snp]
-
     want_prob = type in ("prob", "response+prob")
     want_dosage = type != "response"
-    rv = object.predict_raw(genomat, vote_method, want_dosage=want_dosage, want_prob=want_prob)
+    if bed_plan is not None:
+        col = np.where(bed_plan.sel >= 0, snp.bed_index[np.maximum(bed_plan.sel, 0)], -1)
+        rv = object.predict_bed(snp.bed_fn, snp.n_bed_samp, snp.n_bed_snp, col, bed_plan.flip, vote_method,
+                                want_dosage=want_dosage, want_prob=want_prob)
+    else:
+        # as.integer(snp): R's NA -> NA_integer_ ; the C side treats anything outside 0..2 as missing
+        if mat.dtype.kind == "f":
+            gi = np.where(np.isfinite(mat), mat, NA_INTEGER).astype(np.int64)
+        else:
+            gi = mat.astype(np.int64)
+        genomat = np.ascontiguousarray(gi.T.astype(np.int32))     # [n_samp, n_snp]
+        rv = object.predict_raw(genomat, vote_method, want_dosage=want_dosage, want_prob=want_prob)
 
     names = _pair_names(obj.hla_allele)
     if type == "prob":

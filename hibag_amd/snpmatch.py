@@ -11,7 +11,8 @@ from __future__ import annotations
 
 import sys
 import warnings
-from typing import List, Optional, Sequence, Tuple
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -175,11 +176,25 @@ def hlaGenoSwitchStrand(target: HlaSNPGeno, template, match_type: str = "Positio
                       assembly=getattr(template, "assembly", "unknown"))
 
 
-def match_snps_for_predict(obj: HlaAttrBagObj, snp: HlaSNPGeno, match_type: str, allele_check: bool,
-                           same_strand: bool, verbose: bool, verbose_match: bool):
-    """The ``hlaSNPGenoClass`` branch of ``hlaPredict`` (``R/HIBAG.R:550-686``):
-    returns ``(genotype matrix [n.snp, n.samp] in model SNP order, assembly)``;
-    model SNPs absent from the data become all-missing rows."""
+@dataclass
+class SNPPlan:
+    """What the SNP-matching step of ``hlaPredict`` decides: for every model SNP
+    the row of the user's data that supplies it (-1 = absent -> all missing) and
+    whether its allele count is reversed (``g -> 2 - g``)."""
+    sel: np.ndarray          # int64 [n.snp]
+    flip: np.ndarray         # bool  [n.snp]
+    assembly: str
+
+
+def plan_snps_for_predict(obj: HlaAttrBagObj, snp, afreq_of_rows: Callable[[np.ndarray], np.ndarray],
+                          match_type: str, allele_check: bool, same_strand: bool, verbose: bool,
+                          verbose_match: bool) -> SNPPlan:
+    """The ``hlaSNPGenoClass`` branch of ``hlaPredict`` (``R/HIBAG.R:550-686``) up to, but
+    not including, the construction of the genotype matrix.  ``snp`` only needs the
+    annotation (``snp_id``, ``snp_position``, ``snp_allele``, ``assembly``);
+    ``afreq_of_rows(rows)`` returns the A-allele frequency of the given data rows
+    (``rowMeans(genotype, na.rm=TRUE) * 0.5``), which the strand check consults for
+    ambiguous SNPs (``hlaGenoSwitchStrand``, ``R/DataUtilities.R:415-505``)."""
     if match_type not in MATCH_TYPES:
         raise ValueError("'arg' should be one of " + ", ".join(f'"{t}"' for t in MATCH_TYPES))
     out = sys.stdout
@@ -212,38 +227,72 @@ def match_snps_for_predict(obj: HlaAttrBagObj, snp: HlaSNPGeno, match_type: str,
     obj_id = hlaSNPID(obj, match_type)
     geno_id = hlaSNPID(snp, match_type)
     if len(obj_id) == len(geno_id) and all(a == b for a, b in zip(obj_id, geno_id)):
-        mat = hlaGenoSwitchStrand(snp, obj, match_type, same_strand, verbose).genotype if allele_check \
-            else snp.genotype
-        return mat, assembly
-
-    first = {}
-    for j, v in enumerate(geno_id):
-        first.setdefault(v, j)
-    sel, used = [], set()
-    for v in obj_id:                       # match(); duplicated selections -> NA
-        j = first.get(v)
-        if j is not None and j in used:
-            j = None
-        if j is not None:
-            used.add(j)
-        sel.append(j)
-    n_missing = sum(1 for j in sel if j is None)
-    if n_missing == len(obj_id):
-        raise ValueError("There is no overlapping of SNPs!")
-    if n_missing > 0.5 * len(obj_id):
-        warnings.warn("More than 50% of SNPs are missing!")
-    n_samp = snp.genotype.shape[1]
-    g = np.full((len(obj_id), n_samp), NA_INTEGER, np.int32)
-    alleles = []
-    for i, j in enumerate(sel):
-        if j is None:
-            alleles.append(obj.snp_allele[i])
-        else:
-            g[i] = snp.genotype[j]
-            a = snp.snp_allele[j] if j < len(snp.snp_allele) else None
+        sel = np.arange(len(obj_id), dtype=np.int64)
+        alleles = list(snp.snp_allele)
+    else:
+        first = {}
+        for j, v in enumerate(geno_id):
+            first.setdefault(v, j)
+        picked, used = [], set()
+        for v in obj_id:                       # match(); duplicated selections -> NA
+            j = first.get(v)
+            if j is not None and j in used:
+                j = None
+            if j is not None:
+                used.add(j)
+            picked.append(j)
+        n_missing = sum(1 for j in picked if j is None)
+        if n_missing == len(obj_id):
+            raise ValueError("There is no overlapping of SNPs!")
+        if n_missing > 0.5 * len(obj_id):
+            warnings.warn("More than 50% of SNPs are missing!")
+        sel = np.array([-1 if j is None else j for j in picked], np.int64)
+        alleles = []
+        for i, j in enumerate(picked):
+            a = None if j is None or j >= len(snp.snp_allele) else snp.snp_allele[j]
             alleles.append(obj.snp_allele[i] if a is None else a)
-    tmp = HlaSNPGeno(genotype=g, sample_id=list(snp.sample_id), snp_id=list(obj.snp_id),
-                     snp_position=obj.snp_position, snp_allele=alleles, assembly=snp.assembly)
+
+    flip = np.zeros(len(obj_id), bool)
     if allele_check:
-        tmp = hlaGenoSwitchStrand(tmp, obj, match_type, same_strand, verbose)
-    return tmp.genotype, assembly
+        if match_type != "Pos+Allele":
+            af = np.full(len(obj_id), np.nan)
+            have = sel >= 0
+            if have.any():
+                af[have] = afreq_of_rows(sel[have])
+            flip, n_amb, n_mis, n_swap = allele_strand_flags(obj.snp_allele, _model_afreq(obj), alleles, af, same_strand)
+            if verbose:
+                x = int(flip.sum())
+                print(f"# of SNP loci with flipped alleles: {x}" if x > 0
+                      else "No allelic strand or A/B allele is flipped.", file=out)
+                if n_swap > 0:
+                    print(f"# of SNP loci with swapped strands: {n_swap}", file=out)
+                if n_amb > 0:
+                    print(f"# of SNP loci with strand ambiguity (e.g., C/G): {n_amb} (comparing allele frequencies)", file=out)
+                if n_mis > 0:
+                    print(f"# of SNP loci with mismatched alleles: {n_mis} (comparing allele frequencies)", file=out)
+        elif verbose:
+            print("No allele is flipped since match.type='Pos+Allele'.", file=out)
+    return SNPPlan(sel=sel, flip=np.asarray(flip, bool), assembly=assembly)
+
+
+def _model_afreq(obj):
+    af = getattr(obj, "snp_allele_freq", None)
+    return _row_afreq(obj.genotype) if af is None else af
+
+
+def match_snps_for_predict(obj: HlaAttrBagObj, snp: HlaSNPGeno, match_type: str, allele_check: bool,
+                           same_strand: bool, verbose: bool, verbose_match: bool):
+    """:func:`plan_snps_for_predict` applied to an in-memory genotype object: returns
+    ``(genotype matrix [n.snp, n.samp] in model SNP order, assembly)``; model SNPs
+    absent from the data become all-missing rows (``R/HIBAG.R:640-660``)."""
+    plan = plan_snps_for_predict(obj, snp, lambda rows: _row_afreq(snp.genotype[rows]), match_type,
+                                 allele_check, same_strand, verbose, verbose_match)
+    n_samp = snp.genotype.shape[1]
+    g = np.full((len(plan.sel), n_samp), NA_INTEGER, np.int32)
+    have = plan.sel >= 0
+    g[have] = snp.genotype[plan.sel[have]]
+    rows = np.where(plan.flip & have)[0]
+    if len(rows):
+        sub = g[rows]
+        g[rows] = np.where(sub == NA_INTEGER, NA_INTEGER, 2 - sub)
+    return g, plan.assembly

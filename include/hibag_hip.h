@@ -133,8 +133,9 @@ int hibag_hip_predict_device(hibag_hip_model *m, const int32_t *d_geno, int n_sa
  * which the classifier weights depend on).  Writes the un-normalised partial
  * ensemble sums so that one sum all-reduce merges ranks:
  *   d_partial [n_hla(n_hla+1)/2 + 3][n_pad]  (n_pad = n_samp rounded up to 64):
- *   rows 0..P-1 sum_c w_c*prob_c, row P sum_c w_c, row P+1 sum_c w_c*total_c,
- *   row P+2 unused.  hibag_hip_finish_device() turns merged partials into the
+ *   rows 0..P-1 sum_c w_c*prob_c, row P sum_c w_c (_Sum_Weight), row P+1
+ *   sum_c w_c*total_c (sum_matching), row P+2 sum_c w_c (num_matching,
+ *   src/LibHLA.cpp:2458-2459).  hibag_hip_finish_device() turns merged partials into the
  *   PredictHLA outputs. */
 int hibag_hip_model_set_snp_weights(hibag_hip_model *m, const int32_t *snp_weight);
 int hibag_hip_predict_partial_device(hibag_hip_model *m, const int32_t *d_geno,
@@ -142,6 +143,41 @@ int hibag_hip_predict_partial_device(hibag_hip_model *m, const int32_t *d_geno,
 int hibag_hip_finish_device(hibag_hip_model *m, const double *d_partial, int n_samp,
 	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching,
 	double *d_dosage, double *d_postprob, void *stream);
+
+/* ---- PLINK BED input: replaces HIBAG_BEDFlag + HIBAG_ConvBED --------------- */
+
+/* HIBAG_BEDFlag(bed.fn) (src/HIBAG.cpp:1068-1081): returns the storage-mode byte
+ * of the file (0 = individual-major, otherwise SNP-major) or a negative error
+ * with the reference's messages ("Cannot open the file %s.", "Invalid prefix in
+ * the PLINK BED file.").  Host only. */
+int hibag_hip_bed_flag(const char *bed_fn);
+
+/* HIBAG_ConvBED(bed.fn, n.samp, n.snp, n.save.snp, snp.flag) (src/HIBAG.cpp:1094-1191):
+ * decodes the 2-bit genotypes of the SNPs with snp_flag[j] != 0 (R logical
+ * vector, n_snp entries, n_save_snp of them set) on the device into
+ *   geno  int32 [n_samp][n_save_snp]  (the memory of R's n_save_snp x n_samp matrix),
+ * values 2 / NA_integer_ / 1 / 0 for the codes 0 / 1 / 2 / 3 (:1135).  Only the
+ * selected SNP rows of a SNP-major file are read and uploaded.  Unlike the
+ * reference, a file shorter than n_samp x n_snp genotypes is an error (EINVAL)
+ * rather than a silent reuse of the previous row. */
+int hibag_hip_conv_bed(const char *bed_fn, int n_samp, int n_snp, int n_save_snp,
+	const int32_t *snp_flag, int32_t *geno);
+
+/* hlaBED2Geno() + hlaPredict() fused: PredictHLA (as hibag_hip_predict) with the
+ * genotypes decoded on the device straight from the BED file into the packed
+ * form the kernels use, without materialising the int32 matrix (16x less
+ * host->device traffic).
+ *   n_samp, n_snp   dimensions of the BED file (.fam / .bim line counts)
+ *   snp_col[model n_snp]  0-based BED SNP index of each model SNP, -1 = the
+ *                   cohort lacks it (treated as missing, like the NA rows
+ *                   hlaPredict builds, R/HIBAG.R:640-660)
+ *   flip[model n_snp]     NULL, or != 0 where the allele count must be
+ *                   reversed, g -> 2 - g (A/B order or strand differs between
+ *                   cohort and model, R/HIBAG.R:661-676, src/HIBAG.cpp:221-342)
+ * All samples of the file are predicted, in file order. */
+int hibag_hip_predict_bed(hibag_hip_model *m, const char *bed_fn, int n_samp, int n_snp,
+	const int32_t *snp_col, const int32_t *flip, int vote_method,
+	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob);
 
 /* ---- kernel timing (HIP events on the launch stream) --------------------- */
 

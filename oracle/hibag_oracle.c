@@ -371,3 +371,36 @@ int oracle_predict(int n_hla, int n_classifier, int n_snp_total,
 	free(snp_weight);
 	return 0;
 }
+
+/* ---------------------------------------------------------------------------
+ * PLINK BED decoding: HIBAG_ConvBED (src/HIBAG.cpp:1094-1191) on a memory
+ * image of the file (3-byte prefix included).  snp_flag[n_snp] selects the
+ * n_save SNPs to keep; out is int[n_samp][n_save] (R's n_save x n_samp matrix).
+ * Returns 0, -1 on a bad prefix, -2 when the image is too short.
+ * Pinned by the reference's own pair of fixtures: inst/extdata/HapMap_CEU.bed
+ * decoded with this function reproduces data/HapMap_CEU_Geno.rdata. */
+int oracle_conv_bed(const unsigned char *image, size_t n_bytes, int n_samp, int n_snp,
+	int n_save, const int *snp_flag, int *out)
+{
+	static const int cvt[4] = { 2, ORACLE_NA_INTEGER, 1, 0 };      /* :1135 */
+	if (n_bytes < 3 || image[0] != 0x6C || image[1] != 0x1B) return -1;   /* :1112-1113 */
+	const int mode = image[2];
+	const int n_row = (mode == 0) ? n_samp : n_snp;               /* :1118-1131 */
+	const int n_col = (mode == 0) ? n_snp : n_samp;
+	const size_t stride = ((size_t)n_col + 3) / 4;
+	if (n_bytes < 3 + stride * (size_t)n_row) return -2;
+	int i_snp = 0;
+	for (int i = 0; i < n_row; i++) {
+		const unsigned char *src = image + 3 + stride * (size_t)i;
+		if (mode == 0) {                                           /* row = individual, :1166-1174 */
+			int *dst = out + (size_t)i * n_save;
+			for (int j = 0; j < n_snp; j++)
+				if (snp_flag[j]) *dst++ = cvt[(src[j >> 2] >> (2 * (j & 3))) & 3];
+		} else if (snp_flag[i]) {                                  /* row = SNP, :1175-1186 */
+			for (int j = 0; j < n_samp; j++)
+				out[(size_t)j * n_save + i_snp] = cvt[(src[j >> 2] >> (2 * (j & 3))) & 3];
+			i_snp++;
+		}
+	}
+	return 0;
+}

@@ -216,3 +216,17 @@ def predict(fm: FlatModel, genomat: np.ndarray, vote_method: int = 1, want_dosag
     if rc != 0:
         raise RuntimeError(f"oracle_predict failed ({rc})")
     return out
+
+
+def conv_bed(image: bytes, n_samp: int, n_snp: int, snp_flag) -> np.ndarray:
+    """``HIBAG_ConvBED`` on the bytes of a BED file -> int32 [n_samp, n_save]."""
+    L = lib()
+    L.oracle_conv_bed.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, _i32p, _i32p]
+    flag = np.ascontiguousarray(np.asarray(snp_flag) != 0, np.int32)
+    n_save = int(flag.sum())
+    out = np.zeros((n_samp, max(n_save, 1)), np.int32)
+    rc = L.oracle_conv_bed(image, len(image), n_samp, n_snp, n_save, flag, out)
+    if rc != 0:
+        raise ValueError({-1: "Invalid prefix in the PLINK BED file.", -2: "BED image too short"}[rc])
+    return out[:, :n_save]
+

@@ -59,3 +59,34 @@ def align_geno(model, geno, samples=None):
     si = {s: i for i, s in enumerate(geno.sample_id)}
     ids = model.sample_id if samples is None else samples
     return np.ascontiguousarray(geno.sample_major(sel)[[si[s] for s in ids]])
+
+
+def write_bed(path, geno, mode):
+    """PLINK BED file from genotypes [n_snp, n_samp] (0/1/2, anything else = missing):
+    mode 0 = individual-major, 1 = SNP-major.  Codes: 2 -> 0, missing -> 1, 1 -> 2, 0 -> 3."""
+    import numpy as np
+    g = np.asarray(geno)
+    code = np.full(g.shape, 1, np.uint8)
+    code[g == 2] = 0
+    code[g == 1] = 2
+    code[g == 0] = 3
+    rows = code if mode != 0 else code.T                  # [row, col]
+    n_col = rows.shape[1]
+    pad = np.zeros((rows.shape[0], (n_col + 3) // 4 * 4), np.uint8)
+    pad[:, :n_col] = rows
+    q = pad.reshape(rows.shape[0], -1, 4)
+    packed = (q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).astype(np.uint8)
+    with open(path, "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 1 if mode != 0 else 0]))
+        f.write(packed.tobytes())
+    return path
+
+
+def write_fam_bim(prefix, sample_id, snp_id, chrom, pos, alleles):
+    with open(prefix + ".fam", "w") as f:
+        for s in sample_id:
+            f.write(f"F{s} {s} 0 0 1 -9\n")
+    with open(prefix + ".bim", "w") as f:
+        for i, c, p, a in zip(snp_id, chrom, pos, alleles):
+            a1, a2 = a.split("/")
+            f.write(f"{c}\t{i}\t0\t{int(p)}\t{a1}\t{a2}\n")
