@@ -308,9 +308,14 @@ void build_pair_stream(const HostClassifier &k, int n_hla, int nwp, const int *s
 // 32 (W[nkb][32], prod[32], end mask, pad).  Cells are padded to an even number
 // of records with {W = 0, prod = +0.0}; bit i of the end mask marks the record
 // that closes a cell.  Returns per tile {first block, #blocks} in `blk_tile`.
-void build_block_stream(const RawRecords &raw, int nwp, int nkb, const std::vector<int> &tile_p0,
+// `spare_pos` >= 0: bits spare_pos..spare_pos+3 are set in EVERY record slot (padding included):
+// the K positions through which k_pack feeds the lane's distance offset into the dot product.
+void build_block_stream(const RawRecords &raw, int nwp, int nkb, int spare_pos, const std::vector<int> &tile_p0,
 	const std::vector<int> &tile_n, std::vector<uint32_t> &out, uint32_t *blk_tile, int &n_blocks)
 {
+	std::vector<uint32_t> spare((size_t)nkb, 0u);
+	if (spare_pos >= 0)
+		for (int j = 0; j < 4; j++) spare[(size_t)(spare_pos + j) >> 5] |= 1u << ((spare_pos + j) & 31);
 	std::vector<size_t> first(raw.n.size() + 1, 0);          // first record of each cell
 	for (size_t p = 0; p < raw.n.size(); p++) first[p + 1] = first[p] + raw.n[p];
 	n_blocks = 0;
@@ -324,7 +329,7 @@ void build_block_stream(const RawRecords &raw, int nwp, int nkb, const std::vect
 			const uint32_t n = raw.n[p];
 			if (!n) continue;
 			for (uint32_t i = 0; i < n; i++) {
-				for (int q = 0; q < nkb; q++) w.push_back(raw.w[(first[p] + i) * nwp + q]);
+				for (int q = 0; q < nkb; q++) w.push_back(q < nwp ? raw.w[(first[p] + i) * nwp + q] : 0u);
 				pr.push_back(raw.p[first[p] + i]);
 				end.push_back(0);
 			}
@@ -346,6 +351,7 @@ void build_block_stream(const RawRecords &raw, int nwp, int nkb, const std::vect
 					prod = pr[r];
 					if (end[r]) mask |= 1u << i;
 				}
+				for (int q = 0; q < nkb; q++) out[base + (size_t)q * 32 + i] |= spare[q];
 				memcpy(&out[base + 32 * (size_t)nkb + 2 * (size_t)i], &prod, sizeof(double));
 			}
 			out[base + 32 * (size_t)nkb + 64] = mask;
@@ -392,7 +398,7 @@ int finalize_model(hibag_hip_model *m)
 	std::vector<uint32_t> stream;
 	std::vector<std::vector<uint32_t>> cell_chunks(C);
 	std::vector<RawRecords> raw(C);
-	std::vector<int> mfma_nkb(std::max(C, 1), 0), bt_row(std::max(C, 1), 0), cls_nblk(std::max(C, 1), 0);
+	std::vector<int> mfma_nkb(std::max(C, 1), 0), mfma_bik(std::max(C, 1), 0), bt_row(std::max(C, 1), 0), cls_nblk(std::max(C, 1), 0);
 	std::vector<int64_t> pairs(C);
 	int bt_rows = 0;
 	int rows = 0;
@@ -413,8 +419,12 @@ int finalize_model(hibag_hip_model *m)
 		if (stream.size() & 1) stream.push_back(0);          // 8-byte alignment of the doubles inside
 		stream_off[c] = stream.size();
 		cell_chunks[c].assign(P, 0);
-		const int nkb_true = std::max(1, (3 * k.n_snp + 31) / 32);
-		mfma_nkb[c] = (m->use_mfma && nkb_true <= 3) ? nkb_true : 0;
+		// matrix-core engine: K = the 3k bit positions + 4 spare positions that carry the distance
+		// offset (8*popc(x&m) <= 16k <= 4*120 as four int8 terms); k = 31, 32 have no room for them
+		// within 3 K blocks and start the accumulators at the offset instead
+		const int nkb_true = std::max(1, (3 * k.n_snp + 31) / 32), nkb_bik = (3 * k.n_snp + 4 + 31) / 32;
+		mfma_bik[c] = (m->use_mfma && nkb_bik <= 3) ? 1 : 0;
+		mfma_nkb[c] = mfma_bik[c] ? nkb_bik : ((m->use_mfma && nkb_true <= 3) ? nkb_true : 0);
 		bt_row[c] = bt_rows;
 		bt_rows += 2 * mfma_nkb[c];
 		build_pair_stream(k, nh, nwp[c], st.data(), stream, cell_chunks[c], mfma_nkb[c] ? &raw[c] : nullptr);
@@ -468,7 +478,7 @@ int finalize_model(hibag_hip_model *m)
 		if (!mfma_nkb[c]) continue;
 		if (blk_stream.size() & 1) blk_stream.push_back(0);
 		blk_off[c] = blk_stream.size();
-		build_block_stream(raw[c], nwp[c], mfma_nkb[c], tile_p0, tile_n, blk_stream,
+		build_block_stream(raw[c], nwp[c], mfma_nkb[c], mfma_bik[c] ? 3 * n_snp_c[c] : -1, tile_p0, tile_n, blk_stream,
 			&blk_tile[(size_t)c * n_tile * 2], cls_nblk[c]);
 		raw[c] = RawRecords();
 	}
@@ -480,7 +490,7 @@ int finalize_model(hibag_hip_model *m)
 			uint32_t *r = &ctile[((size_t)c * n_tile + t) * 8];
 			const uint32_t *me = &tile_meta[((size_t)c * n_tile + t) * HIBAG_TILE_META];
 			const uint64_t off = blk_off[c] + (uint64_t)blk_tile[((size_t)c * n_tile + t) * 2] * HIBAG_BLOCK_DWORDS(std::max(mfma_nkb[c], 1));
-			r[0] = (uint32_t)mfma_nkb[c]; r[1] = (uint32_t)bt_row[c];
+			r[0] = (uint32_t)(mfma_nkb[c] == 0 ? 0 : (mfma_bik[c] ? mfma_nkb[c] : 4)); r[1] = (uint32_t)bt_row[c];
 			r[2] = (uint32_t)off; r[3] = (uint32_t)(off >> 32);
 			r[4] = blk_tile[((size_t)c * n_tile + t) * 2 + 1];
 			r[5] = me[0]; r[6] = me[2]; r[7] = me[3];
@@ -497,7 +507,7 @@ int finalize_model(hibag_hip_model *m)
 	};
 	const size_t o_nsnp = put(n_snp_c), o_nwp = put(nwp), o_snpoff = put(snp_off), o_snpidx = put(snp_index),
 		o_snpw = put(snp_weight), o_mrow = put(mask_row), o_order = put(c_order), o_tp0 = put(tile_p0), o_tn = put(tile_n),
-		o_coff = put(cls_off), o_cn = put(cls_n), o_nkb = put(mfma_nkb), o_btrow = put(bt_row), o_nblk = put(cls_nblk);
+		o_coff = put(cls_off), o_cn = put(cls_n), o_nkb = put(mfma_nkb), o_btrow = put(bt_row), o_nblk = put(cls_nblk), o_bik = put(mfma_bik);
 
 	if (int rc = m->d_int.reserve(arena.size() * sizeof(int))) return rc;
 	if (int rc = m->d_stream.reserve(stream.size() * sizeof(uint32_t))) return rc;
@@ -533,7 +543,7 @@ int finalize_model(hibag_hip_model *m)
 	V.cls_cnt = (const uint32_t *)(tbase + tb_cnt);
 	V.cls_cell = (const uint32_t *)(tbase + tb_cell);
 	V.cls_off = base + o_coff; V.cls_n = base + o_cn;
-	V.mfma_nkb = base + o_nkb; V.bt_row = base + o_btrow; V.cls_nblk = base + o_nblk;
+	V.mfma_nkb = base + o_nkb; V.bt_row = base + o_btrow; V.cls_nblk = base + o_nblk; V.mfma_bik = base + o_bik;
 	V.blk_off = (const uint64_t *)(tbase + tb_boff);
 	V.blk_tile = (const uint32_t *)(tbase + tb_btile);
 	V.ctile = (const uint32_t *)(tbase + tb_ctile);

@@ -86,12 +86,14 @@ struct HibagModelView {
 	// matrix-core engine (classifiers with at most 32 SNPs; hibag_kernels.hip "MFMA engine")
 	const int *mfma_nkb;         // [C] 32-wide K blocks of the distance dot product, 0 = use the VALU engine
 	const int *bt_row;           // [C] first operand row of the classifier in HibagBatchView::bt
+	const int *mfma_bik;         // [C] 1: the lane's distance offset rides in 4 spare K positions (3k..3k+3) of the dot
+	                             //     product (W bits set by the host, B bytes by k_pack); 0: it initialises the accumulators
 	const uint64_t *blk_off;     // [C] dword offset of the classifier's block stream
 	const int *cls_nblk;         // [C] blocks of the classifier (all tiles)
 	const uint32_t *blk_tile;    // [C][n_tile][2] = {first block of the tile, blocks of the tile}
 	const uint32_t *blk_stream;  // blocks of 32 records: W[nkb][32], prod[32] (f64), end mask, pad
 	const uint32_t *ctile;       // [C][n_tile][8]: everything pass 2 needs per (classifier, tile) in one s_load_dwordx8:
-	                             // {nkb, bt_row, block stream dword offset lo/hi, #blocks, #non-empty cells, row list lo/hi}
+	                             // {engine code (1..3 = nkb with the offset in K, 4 = nkb 3 with accumulator offset, 0 = VALU), bt_row, block stream dword offset lo/hi, #blocks, #non-empty cells, row list lo/hi}
 };
 
 struct HibagBatchView {

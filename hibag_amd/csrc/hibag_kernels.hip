@@ -135,18 +135,8 @@ struct LaneOperand {
 	int bias[2];
 };
 
-template <int NKB>
-__device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt_row, int c, int group,
-	int lane, LaneOperand<NKB> &T);
-
-template <int NKB>
-__device__ __forceinline__ void load_operand(const HibagModelView &M, const HibagBatchView &B, int c, int group,
-	int lane, LaneOperand<NKB> &T)
-{
-	load_operand_row<NKB>(B, M.bt_row[c], c, group, lane, T);
-}
-
-template <int NKB>
+// BIK ("bias in K"): the distance offset is part of the dot product, T.bias is not used.
+template <int NKB, bool BIK>
 __device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt_row, int c, int group,
 	int lane, LaneOperand<NKB> &T)
 {
@@ -158,8 +148,15 @@ __device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt
 			const uint4 v = B.bt[((size_t)(bt_row + n * NKB + kb) * n_group + group) * HIBAG_WAVE + lane];
 			T.b[n][kb] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
 		}
-		T.bias[n] = B.bias[((size_t)(2 * c + n) * n_group + group) * HIBAG_WAVE + lane];
+		T.bias[n] = BIK ? 0 : B.bias[((size_t)(2 * c + n) * n_group + group) * HIBAG_WAVE + lane];
 	}
+}
+
+template <int NKB, bool BIK>
+__device__ __forceinline__ void load_operand(const HibagModelView &M, const HibagBatchView &B, int c, int group,
+	int lane, LaneOperand<NKB> &T)
+{
+	load_operand_row<NKB, BIK>(B, M.bt_row[c], c, group, lane, T);
 }
 
 // 16 bits -> 16 bytes (bit i -> byte i = 0/1): per nibble (n * 0x00204081) & 0x01010101
@@ -186,17 +183,23 @@ __device__ __forceinline__ void stage_expand_table(uint2 *exp_s)
 	}
 }
 
-template <int NKB>
+template <int NKB, bool BIK>
 __device__ __forceinline__ void block_mfma(const uint32_t (&w)[NKB], int sh, const LaneOperand<NKB> &T,
 	const uint2 *exp_s, v16i &acc0, v16i &acc1)
 {
-	// The accumulators start at the lane's distance offset.  The empty asm makes the offsets
-	// opaque per block: otherwise the two 16-register splats are hoisted out of the block loop
-	// and cost 32 VGPRs for its whole duration (one wavefront per SIMD less).
-	int b0 = T.bias[0], b1 = T.bias[1];
-	asm("" : "+v"(b0), "+v"(b1));
+	if (BIK) {
+		// the offset is one of the K terms: the accumulators start at the inline constant 0
 #pragma unroll
-	for (int r = 0; r < 16; r++) { acc0[r] = b0; acc1[r] = b1; }
+		for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
+	} else {
+		// The accumulators start at the lane's distance offset.  The empty asm makes the offsets
+		// opaque per block: otherwise the two 16-register splats are hoisted out of the block loop
+		// and cost 32 VGPRs for its whole duration (one wavefront per SIMD less).
+		int b0 = T.bias[0], b1 = T.bias[1];
+		asm("" : "+v"(b0), "+v"(b1));
+#pragma unroll
+		for (int r = 0; r < 16; r++) { acc0[r] = b0; acc1[r] = b1; }
+	}
 #pragma unroll
 	for (int kb = 0; kb < NKB; kb++) {
 		// A operand: lane l holds record l%32, K bytes 16*(l/32)..+15 of this K block
@@ -237,10 +240,21 @@ __device__ __forceinline__ void block_accumulate(const double *stage, uint32_t e
 		f64x2 pv[4];
 		double t[8];
 #pragma unroll
-		for (int q = 0; q < 4; q++) pv[q] = *reinterpret_cast<const f64x2 *>(stage + 8 * g + 2 * q);
+		for (int q = 0; q < 4; q++) {
+#ifdef HIBAG_ABL_NOFAC
+			pv[q] = f64x2{1.0 + g, 2.0 + q};
+#else
+			pv[q] = *reinterpret_cast<const f64x2 *>(stage + 8 * g + 2 * q);
+#endif
+		}
 #pragma unroll
-		for (int q = 0; q < 8; q++)           // D = 8*d: already the byte offset into the table
+		for (int q = 0; q < 8; q++) {         // D = 8*d: already the byte offset into the table
+#ifdef HIBAG_ABL_NOTAB
+			t[q] = __hiloint2double(0x3ff00000, (q < 4 ? D0[4 * g + q] : D1[4 * g + q - 4]));
+#else
 			t[q] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab_s) + (q < 4 ? D0[4 * g + q] : D1[4 * g + q - 4]));
+#endif
+		}
 #pragma unroll
 		for (int q = 0; q < 8; q++) {
 			cell += pv[q >> 1][q & 1] * t[q];
@@ -266,7 +280,7 @@ __device__ __forceinline__ void block_accumulate(const double *stage, uint32_t e
 // wave-uniform (broadcast) LDS reads, which are in-order with the table look-ups.
 // The record words of the next block travel the same way (VMEM, one block ahead).
 // The stream is padded so that the look-ahead stays in bounds.
-template <int NKB, class Fin>
+template <int NKB, bool BIK, class Fin>
 __device__ __forceinline__ void walk_blocks(const uint32_t *__restrict__ blk, int nblk, int lane,
 	const LaneOperand<NKB> &T, const double *tab_s, const uint2 *exp_s, double *stage, Fin &&fin)
 {
@@ -283,11 +297,18 @@ __device__ __forceinline__ void walk_blocks(const uint32_t *__restrict__ blk, in
 		const uint32_t *__restrict__ nxt = blk + HIBAG_BLOCK_DWORDS(NKB);
 
 		v16i D0, D1;
-		block_mfma<NKB>(w, sh, T, exp_s, D0, D1);
+#ifdef HIBAG_ABL_NOMFMA
+#pragma unroll
+		for (int r = 0; r < 16; r++) { D0[r] = (int)((w[0] >> r) & 7u) * 8; D1[r] = (int)((w[NKB - 1] >> (r + 3)) & 7u) * 8; }
+#else
+		block_mfma<NKB, BIK>(w, sh, T, exp_s, D0, D1);
+#endif
 #pragma unroll
 		for (int kb = 0; kb < NKB; kb++) w[kb] = nxt[kb * 32 + li];
 		pf = reinterpret_cast<const double *>(nxt + 32 * NKB)[ls];
+#ifndef HIBAG_ABL_NOMFMA
 		block_own_sample(D0, D1);
+#endif
 		const uint2 meta = *reinterpret_cast<const uint2 *>(buf + 32);
 		const uint32_t endmask = __builtin_amdgcn_readfirstlane(meta.x);
 		const int n_valid = __builtin_amdgcn_readfirstlane(meta.y);
@@ -296,11 +317,13 @@ __device__ __forceinline__ void walk_blocks(const uint32_t *__restrict__ blk, in
 	}
 }
 
-#define HIBAG_DISPATCH_NKB(nkb, CALL)      \
-	switch (nkb) {                         \
-	case 1:  { CALL(1); } break;           \
-	case 2:  { CALL(2); } break;           \
-	default: { CALL(3); } break;           \
+// engine code: 1..3 = K blocks with the distance offset in K, 4 = 3 K blocks, accumulator offset (k = 31, 32)
+#define HIBAG_DISPATCH_NKB(code, CALL)     \
+	switch (code) {                        \
+	case 1:  { CALL(1, true); } break;     \
+	case 2:  { CALL(2, true); } break;     \
+	case 3:  { CALL(3, true); } break;     \
+	default: { CALL(3, false); } break;    \
 	}
 
 // Record widths the kernels are specialised for; the host rounds a classifier's
@@ -428,7 +451,7 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 	const int *__restrict__ idx = M.snp_index + M.snp_off[c];
 	const int row0 = M.mask_row[c];
 	const int nkb = M.mfma_nkb[c];
-	int num = 0, den = 0, bias = 0;
+	int num = 0, den = 0;
 	int comp = 0, i = 0;                       // position 32*m+q = comp*k + i
 	for (int m = 0; m < nwp; m++) {
 		uint32_t xw = 0, mw = 0;
@@ -449,28 +472,55 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 		}
 		B.masks[(size_t)(row0 + m) * B.n_pad + s] = xw;
 		B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s] = mw;
-		if (m < nkb) {
-			// matrix-core engine: this sample's column of the B operand, a_k = +1 / -1 / 0 as int8,
-			// written to the two lanes (K halves) that own it in the MFMA layout
-			bias += __popc(xw & mw);
-			const int n = threadIdx.x >> 5;
-#pragma unroll
-			for (int h = 0; h < 2; h++) {
-				const uint32_t xs = (xw >> (16 * h)) & 0xFFFFu, ms = (mw >> (16 * h)) & 0xFFFFu;
-				const v4i pos = expand_bits16(ms & ~xs), neg = expand_bits16(ms & xs);
-				uint4 a;
-				// +8 -> 0x08, -8 -> 0xF8: the MFMA then yields 8*d, the byte offset of TAB[d]
-				a.x = (uint32_t)pos[0] * 0x08u | (uint32_t)neg[0] * 0xF8u; a.y = (uint32_t)pos[1] * 0x08u | (uint32_t)neg[1] * 0xF8u;
-				a.z = (uint32_t)pos[2] * 0x08u | (uint32_t)neg[2] * 0xF8u; a.w = (uint32_t)pos[3] * 0x08u | (uint32_t)neg[3] * 0xF8u;
-				B.bt[((size_t)(M.bt_row[c] + n * nkb + m) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (threadIdx.x & 31)] = a;
-			}
-		}
 	}
 	if (nkb > 0) {
+		// matrix-core engine: this sample's column of the B operand, a_k = +1 / -1 / 0 as int8 scaled
+		// by 8 (+8 -> 0x08, -8 -> 0xF8: the MFMA then yields 8*d, the byte offset of TAB[d]), written
+		// to the two lanes (K halves) that own it in the MFMA layout.  The distance offset
+		// 8*popc(x & m) either rides in the spare K positions 3k..3k+3 (terms of at most 120) or
+		// goes to B.bias for the accumulator start.
+		uint32_t xs[3] = {0, 0, 0}, ms[3] = {0, 0, 0};
+		int bias = 0;
+#pragma unroll
+		for (int m = 0; m < 3; m++)
+			if (m < nkb && m < nwp) {
+				xs[m] = B.masks[(size_t)(row0 + m) * B.n_pad + s];
+				ms[m] = B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s];
+				bias += __popc(xs[m] & ms[m]);
+			}
+		const bool bik = M.mfma_bik[c] != 0;
 		const int n = threadIdx.x >> 5;
-		const size_t at = ((size_t)(2 * c + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + (threadIdx.x & 31);
-		B.bias[at] = 8 * bias;
-		B.bias[at + 32] = 8 * bias;
+#pragma unroll
+		for (int m = 0; m < 3; m++) {
+			if (m >= nkb) break;
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				const uint32_t xh = (xs[m] >> (16 * h)) & 0xFFFFu, mh = (ms[m] >> (16 * h)) & 0xFFFFu;
+				const v4i pos = expand_bits16(mh & ~xh), neg = expand_bits16(mh & xh);
+				uint32_t a[4];
+#pragma unroll
+				for (int q = 0; q < 4; q++) a[q] = (uint32_t)pos[q] * 0x08u | (uint32_t)neg[q] * 0xF8u;
+				if (bik) {
+#pragma unroll
+					for (int j = 0; j < 4; j++) {
+						const int p = 3 * k + j;                       // spare K position j
+						const int term = min(max(8 * bias - 120 * j, 0), 120);
+						if ((p >> 5) == m && ((p >> 4) & 1) == h) {
+#pragma unroll
+							for (int q = 0; q < 4; q++)
+								if (((p & 15) >> 2) == q) a[q] |= (uint32_t)term << (8 * (p & 3));
+						}
+					}
+				}
+				B.bt[((size_t)(M.bt_row[c] + n * nkb + m) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (threadIdx.x & 31)] =
+					uint4{a[0], a[1], a[2], a[3]};
+			}
+		}
+		if (!bik) {
+			const size_t at = ((size_t)(2 * c + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + (threadIdx.x & 31);
+			B.bias[at] = 8 * bias;
+			B.bias[at + 32] = 8 * bias;
+		}
 	}
 	B.cw[(size_t)c * B.n_pad + s] = (s < B.n_samp && den > 0) ? ((double)num / den) : 0.0;
 }
@@ -552,11 +602,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, Hi
 	double total = 0;
 	const int nkb = M.mfma_nkb[c];
 	if (nkb > 0) {
-#define CALL(N) { LaneOperand<N> T; load_operand<N>(M, B, c, group, threadIdx.x & 63, T);                         \
-		walk_blocks<N>(M.blk_stream + M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, T, tab_s, exp_s,             \
+#define CALL(N, BIK) { LaneOperand<N> T; load_operand<N, BIK>(M, B, c, group, threadIdx.x & 63, T);               \
+		walk_blocks<N, BIK>(M.blk_stream + M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, T, tab_s, exp_s,        \
 			stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)],                                             \
 			[&](double cell) { total += cell; asm("" : "+v"(total)); /* keeps the cell end a scalar branch */ }); }
-		HIBAG_DISPATCH_NKB(nkb, CALL)
+		HIBAG_DISPATCH_NKB(M.mfma_bik[c] ? nkb : 4, CALL)
 #undef CALL
 	} else {
 #define CALL(N) total = classifier_total<N>(M, B, c, s, tab_s)
@@ -673,8 +723,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 				a = acc[j][lane];
 			};
 			const uint32_t *__restrict__ blk = M.blk_stream + (((uint64_t)rec[3] << 32) | rec[2]);
-#define CALL(N) { LaneOperand<N> T; load_operand_row<N>(B, (int)rec[1], c, group, lane, T);                        \
-			walk_blocks<N>(blk, (int)rec[4], lane, T, tab_s, exp_s, stage_s[wave], fin); }
+#define CALL(N, BIK) { LaneOperand<N> T; load_operand_row<N, BIK>(B, (int)rec[1], c, group, lane, T);              \
+			walk_blocks<N, BIK>(blk, (int)rec[4], lane, T, tab_s, exp_s, stage_s[wave], fin); }
 			HIBAG_DISPATCH_NKB(nkb, CALL)
 #undef CALL
 			if (poison) {                                // empty cells: (0 * inv) * w is NaN where inv is not finite

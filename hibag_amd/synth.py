@@ -55,6 +55,8 @@ def make_model(shape: str = "hla-b", seed: int = DEFAULT_SEED, wide_classifier: 
         k = int(rng.integers(lo, hi + 1))
         if wide_classifier and c == C // 2:
             k = min(100, S)                      # exercises the multi-word bit planes
+        if p.get("snp_counts") is not None:      # explicit SNP count per classifier (tests)
+            k = int(p["snp_counts"][c])
         snpidx = rng.choice(S, size=k, replace=False).astype(np.int32)
         cnt = _allele_counts(rng, n_hla, H)
         hla = np.repeat(np.arange(n_hla), cnt).astype(np.int32)

@@ -88,6 +88,23 @@ def test_synthetic_models(hib, oracle, shape, n, vote):
     assert_same(got, want)
 
 
+@pytest.mark.parametrize("vote", [1, 2])
+def test_every_classifier_width(hib, oracle, vote):
+    """One classifier per SNP count 1..40 and 63..66, 127, 128: every engine variant
+    (1, 2, 3 K blocks with the distance offset inside the dot product, k = 31/32 with
+    the accumulator offset, the VALU engine's word counts) and their boundaries."""
+    from hibag_amd import synth
+    ks = list(range(1, 41)) + [63, 64, 65, 66, 96, 127, 128]
+    model, founders, af = synth.make_model("hla-a-small", seed=77, n_classifier=len(ks), n_snp=160,
+                                           snp_counts=ks, wide_classifier=False)
+    assert sorted(len(c.snpidx) for c in model.classifiers) == sorted(ks)
+    G, _ = synth.make_samples(founders, af, 150, seed=78, miss=0.05)
+    G[3, :] = hib.NA_INTEGER
+    want = oracle.predict(oracle.flatten(model), G, vote_method=vote, avx2=True, n_threads=8)
+    got = hib.hlaModelFromObj(model).predict_raw(G, vote, want_dosage=True, want_prob=True)
+    assert_same(got, want)
+
+
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 130])
 def test_ragged_batch_sizes(hib, oracle, n):
     from hibag_amd import synth
