@@ -15,9 +15,9 @@ torch.distributed.run, rendezvous over RCCL.
 Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
   roofline     : the dominant kernel against the HBM roof the metric names,
                  from HIP events recorded on the launch stream inside the timed
-                 region (and, under "valu", the SIMD cycles per wavefront-pair,
-                 the figure that tracks the vector-ALU / LDS issue ceiling that
-                 actually binds this path -- DESIGN.md section 5);
+                 region (and, under "issue", the SIMD time per wavefront-pair
+                 against the measured FP64 + matrix-core issue floor, the ceiling
+                 that actually binds this path -- DESIGN.md section 5);
   cpu_baseline : the AVX2 + threads CPU port of the reference's kernel
                  (oracle/, kind "port") timed on this box's host cores on a
                  bounded sample of the same workload (rank 0, N = 1 only).
@@ -35,10 +35,13 @@ sys.path.insert(0, ROOT)
 SAMPLES_PER_GPU = 10_000
 SHAPE = "hla-b"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-# vector-ALU issue ceiling used for the "valu" block (DESIGN.md "Rooflines"):
-# 256 CUs x 4 SIMDs x 2.4 GHz wave-instruction issue slots (a wave64 int32 op
-# holds a SIMD for 2 cycles, an FP64 op for 4).
-SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
+# Issue floor used for the "issue" block (DESIGN.md "Rooflines"), measured on MI355X
+# with tools/ubench_mfma.hip: a wave64 FP64 mul or add holds its SIMD for 2.29 ns, a
+# v_mfma_i32_32x32x32_i8 for 16.0 ns, and the two do not overlap across wavefronts of
+# one SIMD (half/half mix runs at 86 % of the serial sum).
+N_SIMD = 256 * 4
+FP64_OP_NS = 2.29
+MFMA_NS = 16.0
 
 
 def main():
@@ -145,17 +148,29 @@ def main():
         except Exception:
             traffic = None
     pairs_per_s_kernel = pair_evals * n / (avg_ms * 1e-3)
-    cyc_per_pair_wave = SIMD_CYCLES_PER_S / (pairs_per_s_kernel / 64.0)
+    # SIMD time per wavefront-pair (64 samples x one haplotype pair) against the issue floor:
+    # two FP64 ops per pair, plus the int8 MFMAs of the distance dot product (2 per 32-record
+    # block and 32-wide K block; K = 3k bit positions + 4 offset positions) on the matrix engine
+    ns_per_wave_pair = N_SIMD * avg_ms * 1e6 / (pair_evals * n / 64.0)
+    mfma_ns, w = 0.0, 0
+    for c in model_obj.classifiers:
+        k, h = len(c.snpidx), len(c.freq)
+        nkb = -(-(3 * k + 4) // 32) if 3 * k + 4 <= 96 else (-(-3 * k // 32) if 3 * k <= 96 else 0)
+        mfma_ns += h * (h + 1) // 2 * (2 * nkb * MFMA_NS / 32.0)
+        w += h * (h + 1) // 2
+    floor_ns = 2 * FP64_OP_NS + (mfma_ns / max(w, 1) if os.environ.get("HIBAG_ENGINE", "mfma") == "mfma" else 0.0)
     roofline = {
         "kernel": f"k_{dom}", "bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
         "avg_launch_ms": round(avg_ms, 4), "launches": int(dom_launches),
         "algorithmic_bytes_per_launch": int(alg_bytes),
-        "valu": {"pair_evals_per_s": pairs_per_s_kernel,
-                 "simd_cycles_per_wave_pair": round(cyc_per_pair_wave, 2),
-                 "floor_cycles_per_wave_pair": 8.0,
-                 "note": "binding ceiling is vector-ALU issue (FP64 mul+add per pair = 8 SIMD cycles at 2.4 GHz, "
-                         "plus table look-ups through LDS), not HBM (DESIGN.md section 5); lower is better"},
+        "issue": {"pair_evals_per_s": pairs_per_s_kernel,
+                  "simd_ns_per_wave_pair": round(ns_per_wave_pair, 2),
+                  "floor_ns_per_wave_pair": round(floor_ns, 2),
+                  "frac": round(floor_ns / ns_per_wave_pair, 4),
+                  "note": "the binding ceiling is SIMD issue, not HBM: per pair one FP64 mul + one FP64 add in the "
+                          "reference's order (2 x 2.29 ns) plus its share of the int8 MFMAs (16 ns each), which "
+                          "serialise on a SIMD (tools/ubench_mfma.hip, DESIGN.md section 5)"},
         "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in timing.items()},
     }
 

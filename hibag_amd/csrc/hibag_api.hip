@@ -473,13 +473,22 @@ int finalize_model(hibag_hip_model *m)
 
 	// block streams of the matrix-core engine
 	std::vector<uint32_t> blk_stream, blk_tile((size_t)std::max(C, 1) * n_tile * 2 + 2, 0);
-	std::vector<uint64_t> blk_off(std::max(C, 1), 0);
+	// Two layouts per classifier: per tile (pass 2: a wavefront walks one tile's blocks) and
+	// all cells back to back (pass 1: no block is left half empty at a tile boundary).
+	std::vector<uint64_t> blk_off(std::max(C, 1), 0), blk_off_tiled(std::max(C, 1), 0);
+	const std::vector<int> all_p0(1, 0), all_n(1, P);
 	for (int c = 0; c < C; c++) {
 		if (!mfma_nkb[c]) continue;
+		const int spare = mfma_bik[c] ? 3 * n_snp_c[c] : -1;
+		if (blk_stream.size() & 1) blk_stream.push_back(0);
+		blk_off_tiled[c] = blk_stream.size();
+		int n_tiled = 0;
+		build_block_stream(raw[c], nwp[c], mfma_nkb[c], spare, tile_p0, tile_n, blk_stream,
+			&blk_tile[(size_t)c * n_tile * 2], n_tiled);
 		if (blk_stream.size() & 1) blk_stream.push_back(0);
 		blk_off[c] = blk_stream.size();
-		build_block_stream(raw[c], nwp[c], mfma_nkb[c], mfma_bik[c] ? 3 * n_snp_c[c] : -1, tile_p0, tile_n, blk_stream,
-			&blk_tile[(size_t)c * n_tile * 2], cls_nblk[c]);
+		uint32_t whole[2];
+		build_block_stream(raw[c], nwp[c], mfma_nkb[c], spare, all_p0, all_n, blk_stream, whole, cls_nblk[c]);
 		raw[c] = RawRecords();
 	}
 	blk_stream.insert(blk_stream.end(), 2 * HIBAG_BLOCK_DWORDS(3), 0);   // look-ahead slack of the block walker
@@ -489,7 +498,7 @@ int finalize_model(hibag_hip_model *m)
 		for (int t = 0; t < n_tile; t++) {
 			uint32_t *r = &ctile[((size_t)c * n_tile + t) * 8];
 			const uint32_t *me = &tile_meta[((size_t)c * n_tile + t) * HIBAG_TILE_META];
-			const uint64_t off = blk_off[c] + (uint64_t)blk_tile[((size_t)c * n_tile + t) * 2] * HIBAG_BLOCK_DWORDS(std::max(mfma_nkb[c], 1));
+			const uint64_t off = blk_off_tiled[c] + (uint64_t)blk_tile[((size_t)c * n_tile + t) * 2] * HIBAG_BLOCK_DWORDS(std::max(mfma_nkb[c], 1));
 			r[0] = (uint32_t)(mfma_nkb[c] == 0 ? 0 : (mfma_bik[c] ? mfma_nkb[c] : 4)); r[1] = (uint32_t)bt_row[c];
 			r[2] = (uint32_t)off; r[3] = (uint32_t)(off >> 32);
 			r[4] = blk_tile[((size_t)c * n_tile + t) * 2 + 1];

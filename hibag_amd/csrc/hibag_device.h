@@ -88,8 +88,8 @@ struct HibagModelView {
 	const int *bt_row;           // [C] first operand row of the classifier in HibagBatchView::bt
 	const int *mfma_bik;         // [C] 1: the lane's distance offset rides in 4 spare K positions (3k..3k+3) of the dot
 	                             //     product (W bits set by the host, B bytes by k_pack); 0: it initialises the accumulators
-	const uint64_t *blk_off;     // [C] dword offset of the classifier's block stream
-	const int *cls_nblk;         // [C] blocks of the classifier (all tiles)
+	const uint64_t *blk_off;     // [C] dword offset of the classifier's pass-1 block stream (all cells back to back)
+	const int *cls_nblk;         // [C] blocks in that stream
 	const uint32_t *blk_tile;    // [C][n_tile][2] = {first block of the tile, blocks of the tile}
 	const uint32_t *blk_stream;  // blocks of 32 records: W[nkb][32], prod[32] (f64), end mask, pad
 	const uint32_t *ctile;       // [C][n_tile][8]: everything pass 2 needs per (classifier, tile) in one s_load_dwordx8:

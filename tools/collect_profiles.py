@@ -32,7 +32,8 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    f = sorted(glob.glob(os.path.join(src, pattern)))
+    # gpurun MERGES into gpurun_out/, so files of earlier calls linger: take the newest
+    f = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
     return f[-1] if f else None
 
 
