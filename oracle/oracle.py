@@ -30,7 +30,7 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (``make -C oracle``)."""
-    srcs = [os.path.join(_HERE, f) for f in ("hibag_oracle.c", "hibag_oracle_avx2.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("hibag_oracle.c", "hibag_oracle_avx2.c", "hibag_oracle_train.c", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if force or stale:
@@ -229,4 +229,42 @@ def conv_bed(image: bytes, n_samp: int, n_snp: int, snp_flag) -> np.ndarray:
     if rc != 0:
         raise ValueError({-1: "Invalid prefix in the PLINK BED file.", -2: "BED image too short"}[rc])
     return out[:, :n_save]
+
+
+def train(genomat: np.ndarray, h1, h2, n_hla: int, nclassifier: int, mtry: int, prune: bool = True, seed: int = 100):
+    """``set.seed(seed)`` + ``CAttrBag_Model::BuildClassifiers`` (hibag_oracle_train.c).
+    ``genomat`` int32 [n_samp, n_snp]; ``h1``/``h2`` 0-based allele indices.  Returns one dict per
+    classifier: snpidx (0-based), samp_num, freq, hla, bits [n_haplo, 2] uint64, haplo strings, acc."""
+    L = lib()
+    L.oracle_train_new.restype = C.c_void_p
+    L.oracle_train_new.argtypes = [C.c_int, C.c_int, _i32p, C.c_int, _i32p, _i32p, C.c_uint]
+    L.oracle_train_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.oracle_train_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.oracle_train_get.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, _f64p, _i32p, _u64p]
+    L.oracle_train_free.argtypes = [C.c_void_p]
+    g = np.ascontiguousarray(genomat, np.int32)
+    a1 = np.ascontiguousarray(h1, np.int32)
+    a2 = np.ascontiguousarray(h2, np.int32)
+    n_samp, n_snp = g.shape
+    h = C.c_void_p(L.oracle_train_new(n_snp, n_samp, g, n_hla, a1, a2, seed & 0xFFFFFFFF))
+    try:
+        n = L.oracle_train_run(h, nclassifier, mtry, int(bool(prune)))
+        out = []
+        for i in range(n):
+            ns, nh, acc = C.c_int(0), C.c_int(0), C.c_double(0)
+            L.oracle_train_info(h, i, C.byref(ns), C.byref(nh), C.byref(acc))
+            snpidx = np.zeros(max(ns.value, 1), np.int32)
+            samp = np.zeros(n_samp, np.int32)
+            freq = np.zeros(max(nh.value, 1), np.float64)
+            hla = np.zeros(max(nh.value, 1), np.int32)
+            bits = np.zeros((max(nh.value, 1), 2), np.uint64)
+            L.oracle_train_get(h, i, snpidx, samp, freq, hla, bits)
+            k = ns.value
+            bits = bits[:nh.value]
+            haplo = ["".join("1" if (int(b[j >> 6]) >> (j & 63)) & 1 else "0" for j in range(k)) for b in bits]
+            out.append(dict(snpidx=snpidx[:k], samp_num=samp, freq=freq[:nh.value], hla=hla[:nh.value], bits=bits,
+                            haplo=haplo, acc=acc.value))
+        return out
+    finally:
+        L.oracle_train_free(h)
 
