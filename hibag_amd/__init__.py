@@ -11,9 +11,11 @@ from .hibag import (HlaAlleleClass, HlaAttrBagClass, hlaClose, hlaModelFromObj, 
                     hlaPredict, hlaSetKernelTarget)
 from .snpmatch import hlaGenoSwitchStrand, hlaSNPID  # noqa: F401
 from .bed import HlaBEDGeno, hlaBED2Geno, hlaLociInfo  # noqa: F401
+from .train import RRandom, hlaAllele, hlaAttrBagging, hlaUniqueAllele, set_seed  # noqa: F401
 from ._lib import HibagHipError  # noqa: F401
 
 __all__ = ["NA_INTEGER", "Classifier", "HlaAttrBagObj", "HlaSNPGeno", "load_geno", "load_model",
            "HlaAlleleClass", "HlaAttrBagClass", "hlaClose", "hlaModelFromObj", "hlaModelToObj",
            "hlaPredict", "hlaSetKernelTarget", "hlaGenoSwitchStrand", "hlaSNPID", "HibagHipError",
-           "HlaBEDGeno", "hlaBED2Geno", "hlaLociInfo"]
+           "HlaBEDGeno", "hlaBED2Geno", "hlaLociInfo", "RRandom", "hlaAllele", "hlaAttrBagging", "hlaUniqueAllele",
+           "set_seed"]

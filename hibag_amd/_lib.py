@@ -28,6 +28,9 @@ EXPORTS = [
     "hibag_hip_predict_device", "hibag_hip_model_set_snp_weights", "hibag_hip_predict_partial_device",
     "hibag_hip_finish_device", "hibag_hip_set_timing", "hibag_hip_get_timing", "hibag_hip_reset_timing",
     "hibag_hip_gpu_ext_proc", "hibag_hip_bed_flag", "hibag_hip_conv_bed", "hibag_hip_predict_bed",
+    "hibag_hip_trainer_new", "hibag_hip_trainer_free", "hibag_hip_trainer_set_rng", "hibag_hip_trainer_set_seed",
+    "hibag_hip_trainer_new_classifiers", "hibag_hip_trainer_n_classifier", "hibag_hip_trainer_classifier_dims",
+    "hibag_hip_trainer_classifier_get",
 ]
 
 
@@ -85,6 +88,16 @@ def lib() -> C.CDLL:
     L.hibag_hip_get_timing.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(i64)]
     L.hibag_hip_reset_timing.argtypes = [vp]
     L.hibag_hip_gpu_ext_proc.restype = vp
+    L.hibag_hip_trainer_new.argtypes = [i32, i32, vp, i32, vp, vp]
+    L.hibag_hip_trainer_new.restype = vp
+    L.hibag_hip_trainer_free.argtypes = [vp]
+    L.hibag_hip_trainer_free.restype = None
+    L.hibag_hip_trainer_set_rng.argtypes = [vp, vp, vp]
+    L.hibag_hip_trainer_set_seed.argtypes = [vp, C.c_uint32]
+    L.hibag_hip_trainer_new_classifiers.argtypes = [vp, i32, i32, i32, i32, i32]
+    L.hibag_hip_trainer_n_classifier.argtypes = [vp]
+    L.hibag_hip_trainer_classifier_dims.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.hibag_hip_trainer_classifier_get.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.POINTER(dbl)]
     L.hibag_hip_bed_flag.argtypes = [C.c_char_p]
     L.hibag_hip_conv_bed.argtypes = [C.c_char_p, i32, i32, i32, vp, vp]
     L.hibag_hip_predict_bed.argtypes = [vp, C.c_char_p, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]

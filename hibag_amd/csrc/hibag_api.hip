@@ -123,6 +123,18 @@ struct KernelTimer {
 
 } // namespace
 
+// for the other translation units of the library (hibag_train.hip)
+int hibag_fail(int code, const char *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	g_last_error = buf;
+	return code;
+}
+
 struct hibag_hip_model {
 	int device = 0;
 	int n_hla = 0, n_snp = 0;

@@ -1,0 +1,595 @@
+// hibag_train.hip -- host driver of hlaAttrBagging()'s native side:
+// CAttrBag_Model::BuildClassifiers (src/LibHLA.cpp:2268-2305) with
+// NewClassifierBootstrap (:2220-2245), CVariableSelection::Search (:1981-2122) and
+// CAlg_EM (:1000-1255), as reached from HIBAG_Training + HIBAG_NewClassifiers
+// (src/HIBAG.cpp:516-634).
+//
+// Division of labour, as in the reference when a GPU plugin is installed: the
+// haplotype-pair kernels run on the device -- candidate pair lists
+// (build_haplomatch), out-of-bag calls (build_acc_oob) and in-bag posteriors
+// (build_acc_ib), hibag_build.hip -- while bootstrap draws, the EM iterations
+// (tiny, strictly ordered sums over a few pairs per sample) and the selection
+// logic stay on the host.  Unlike the reference's GPU branch the pair lists are
+// put into the order of its CPU branch (_PrepHaploMatch_def, :1569-1637), so a
+// model trained here is bit-identical to one trained by the reference on the CPU
+// from the same random stream (tests/test_hip_training.py reproduces the
+// reference's inst/extdata/OutOfBag.RData).
+//
+// There is no CPU scoring path in this file: without a device the build entries
+// throw and the C ABI returns HIBAG_HIP_ENODEV.
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hibag_hip.h"
+#include "hibag_plugin.h"
+
+int hibag_fail(int code, const char *fmt, ...);       // hibag_api.hip: sets the thread's last error
+
+namespace {
+
+// src/LibHLA.cpp:98-116
+const int EM_MAX_ITER = 500;
+const double EM_INIT_VAL_FRAC = 0.001;
+const double MIN_RARE_FREQ = 1e-5;                    // inst/include/LibHLA_ext.h:230
+const double FRACTION_HAPLO = 1.0 / 10;
+const double STOP_RELTOL_LOGLIK_ADDSNP = 0.001;
+const double PRUNE_RELTOL_LOGLIK = 0.1;
+const int MAX_SNP = HIBAG_HIP_MAX_SNP_IN_CLASSIFIER;
+
+// R's default generator (Mersenne-Twister + the scrambling of set.seed(), R src/main/RNG.c),
+// for hosts that are not R; an R binding hands in R's own unif_rand instead.
+struct RMersenne {
+	uint32_t mt[624];
+	int mti = 625;
+	void set_seed(uint32_t seed)
+	{
+		for (int j = 0; j < 50; j++) seed = 69069u * seed + 1u;
+		for (int j = 0; j < 625; j++) {
+			seed = 69069u * seed + 1u;
+			if (j > 0) mt[j - 1] = seed;
+		}
+		mti = 624;
+	}
+	double unif()
+	{
+		const int N = 624, M = 397;
+		uint32_t y;
+		if (mti >= N) {
+			if (mti == N + 1) set_seed(4357);          // never seeded
+			int kk;
+			for (kk = 0; kk < N - M; kk++) {
+				y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+				mt[kk] = mt[kk + M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+			}
+			for (; kk < N - 1; kk++) {
+				y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+				mt[kk] = mt[kk + (M - N)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+			}
+			y = (mt[N - 1] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+			mt[N - 1] = mt[M - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+			mti = 0;
+		}
+		y = mt[mti++];
+		y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+		const double v = (double)y * 2.3283064365386963e-10, eps = 2.328306437080797e-10;
+		if (v <= 0.0) return 0.5 * eps;
+		if (1.0 - v <= 0.0) return 1.0 - 0.5 * eps;
+		return v;
+	}
+};
+
+// CHaplotypeList (src/LibHLA.h:85-140): haplotypes grouped by allele, in the layout the
+// build entries take (THaplotype) plus the EM's previous frequency.
+struct HapList {
+	std::vector<PluginHaplotype> list;
+	std::vector<double> old_freq;
+	std::vector<size_t> len;          // [n_hla]
+	int n_snp = 0;
+};
+
+struct HapPair { int h1, h2; bool flag; double gfreq; };                // CAlg_EM::THaploPair
+struct PairList { int boot, samp; std::vector<HapPair> p; };           // CAlg_EM::THaploPairList
+
+struct OutClassifier {
+	std::vector<int32_t> snpidx, samp_num, hla;
+	std::vector<double> freq;
+	std::vector<uint64_t> bits;       // [n_haplo][2]
+	double acc = 0;
+};
+
+inline void set_allele(PluginHaplotype &h, int idx, int v)              // THaplotype::_SetAllele, :339-345
+{
+	const uint64_t bit = (uint64_t)1 << (idx & 63);
+	uint64_t w = (uint64_t)h.packed[idx >> 6];
+	w = v ? (w | bit) : (w & ~bit);
+	h.packed[idx >> 6] = (int64_t)w;
+}
+inline int get_allele(const PluginHaplotype &h, int idx) { return (int)(((uint64_t)h.packed[idx >> 6] >> (idx & 63)) & 1); }
+
+inline void geno_set(PluginGenotype &g, int idx, int val)               // TGenotype::_SetSNP, :609-622
+{
+	const uint64_t bit = (uint64_t)1 << (idx & 63);
+	const int w = idx >> 6;
+	const bool b1 = val == 1 || val == 2, b2 = !(val == 0 || val == 1);
+	uint64_t s1 = (uint64_t)g.snp1[w], s2 = (uint64_t)g.snp2[w];
+	s1 = b1 ? (s1 | bit) : (s1 & ~bit);
+	s2 = b2 ? (s2 | bit) : (s2 & ~bit);
+	g.snp1[w] = (int64_t)s1; g.snp2[w] = (int64_t)s2;
+}
+
+// CSamplingWithoutReplace, :930-993
+struct Sampling {
+	std::vector<int> a;
+	int m_try = 0;
+	void init(int m_total) { a.resize(m_total); for (int i = 0; i < m_total; i++) a[i] = i; m_try = 0; }
+	int &at(int idx) { return a[a.size() - m_try + idx]; }
+	void remove(int idx) { a.erase(a.begin() + (a.size() - m_try + idx)); }
+	void remove_selection() { a.resize(a.size() - m_try); }
+	void remove_flag()
+	{
+		const int n = (int)a.size();
+		for (int i = n - 1; i >= n - m_try; i--)
+			if (a[i] < 0) a.erase(a.begin() + i);
+	}
+};
+
+} // namespace
+
+struct hibag_hip_trainer {
+	int n_snp = 0, n_samp = 0, n_hla = 0;
+	std::vector<int32_t> geno, h1, h2;          // geno [n_samp][n_snp]
+	RMersenne rng;
+	double (*unif_fn)(void *) = nullptr;
+	void *unif_ctx = nullptr;
+	std::vector<OutClassifier> out;
+	std::mutex lock;
+
+	// CVariableSelection state
+	std::vector<PluginGenotype> g;
+	int g_nsnp = 0;
+	std::vector<int> inbag, outbag;
+	std::vector<PairList> pl;
+	std::vector<double> log_buf;
+
+	double unif() { return unif_fn ? unif_fn(unif_ctx) : rng.unif(); }
+	int random_num(int n)                                               // :120-126
+	{
+		int v = (int)(n * unif());
+		if (v >= n) v = n - 1;
+		return v;
+	}
+};
+
+namespace {
+
+typedef hibag_hip_trainer T;
+
+void select(T &t, Sampling &s, int m_try)                               // RandomSelect, :949-962
+{
+	const int n = (int)s.a.size();
+	if (m_try > n) m_try = n;
+	if (m_try < n)
+		for (int i = 0; i < m_try; i++) {
+			const int I = t.random_num(n - i);
+			std::swap(s.a[I], s.a[n - i - 1]);
+		}
+	s.m_try = m_try;
+}
+
+void init_selection(T &t, const std::vector<int> &boot)                 // InitSelection, :1843-1878
+{
+	t.inbag.clear(); t.outbag.clear();
+	for (int i = 0; i < t.n_samp; i++) {
+		PluginGenotype &g = t.g[i];
+		g.bootstrap_count = boot[i];
+		g.hla1 = t.h1[i]; g.hla2 = t.h2[i];
+		if (g.hla2 < g.hla1) std::swap(g.hla1, g.hla2);
+		(boot[i] > 0 ? t.inbag : t.outbag).push_back(i);
+		g.snp1[0] = g.snp1[1] = 0;                                      // SetAllMissing, :883-891
+		g.snp2[0] = g.snp2[1] = -1;
+	}
+	t.g_nsnp = 0;
+}
+
+void init_haplotype(T &t, HapList &h)                                   // _InitHaplotype, :1880-1911
+{
+	std::vector<int> tmp(t.n_hla, 0);
+	int sum = 0;
+	for (int k : t.inbag) {
+		const PluginGenotype &g = t.g[k];
+		tmp[g.hla1] += g.bootstrap_count; tmp[g.hla2] += g.bootstrap_count;
+		sum += g.bootstrap_count;
+	}
+	h.len.assign(t.n_hla, 0);
+	h.list.clear();
+	h.n_snp = 0;
+	const double scale = 0.5 / sum;
+	for (int i = 0; i < t.n_hla; i++)
+		if (tmp[i] > 0) {
+			h.len[i] = 1;
+			PluginHaplotype p{};
+			p.freq = tmp[i] * scale;
+			h.list.push_back(p);
+		}
+}
+
+void set_aux(HapList &h)                                                // SetHaploAux_GPU, :565-578
+{
+	size_t i = 0;
+	for (size_t a = 0; a < h.len.size(); a++)
+		for (size_t m = h.len[a]; m > 0; m--, i++) {
+			h.list[i].aux.freq_f32 = (float)h.list[i].freq;
+			h.list[i].aux.hla_allele = (int)a;
+		}
+}
+
+void add_snp(T &t, int snp)                                             // CGenotypeList::AddSNP, :860-874
+{
+	for (int i = 0; i < t.n_samp; i++) geno_set(t.g[i], t.g_nsnp, t.geno[(size_t)i * t.n_snp + snp]);
+	t.g_nsnp++;
+}
+
+// CAlg_EM::PrepareHaplotypes (:1002-1125): the device lists, per in-bag sample, the pairs of
+// CURRENT haplotypes of its two true alleles at distance 0 (or at the minimum distance);
+// each becomes the 4 (3 on the diagonal) pairs of its doubled copies, ordered like the
+// reference's CPU branch: ascending (first, second) index in the doubled list.
+void prepare_haplotypes(T &t, const HapList &cur, HapList &next)
+{
+	next.n_snp = cur.n_snp + 1;                                         // DoubleHaplos, :416-442
+	next.list.resize(cur.list.size() * 2);
+	next.old_freq.assign(next.list.size(), 0.0);
+	for (size_t i = 0; i < cur.list.size(); i++) {
+		next.list[2 * i] = cur.list[i]; set_allele(next.list[2 * i], cur.n_snp, 0);
+		next.list[2 * i + 1] = cur.list[i]; set_allele(next.list[2 * i + 1], cur.n_snp, 1);
+	}
+	next.len.resize(t.n_hla);
+	std::vector<size_t> start(t.n_hla, 0);
+	for (int h = 0, st = 0; h < t.n_hla; h++) {
+		if (cur.len[h] > 65535) throw "There are too many HLA allele-specific haplotypes (# > 65535).";
+		next.len[h] = cur.len[h] * 2;
+		start[h] = st; st += (int)cur.len[h];
+	}
+	const size_t n_ib = t.inbag.size();
+	t.pl.assign(n_ib, PairList());
+	for (size_t i = 0; i < n_ib; i++) { t.pl[i].boot = t.g[t.inbag[i]].bootstrap_count; t.pl[i].samp = t.inbag[i]; }
+
+	size_t n_buf = 0;
+	uint32_t *buf = hibag_build_haplomatch(cur.list.data(), cur.len.data(), cur.n_snp, t.g.data(), n_buf);
+	if (buf) {
+		uint32_t n = buf[0] >> 1;
+		for (const uint32_t *p = buf + 1; n > 0; n--, p += 2) {
+			const size_t k = p[0];
+			if (k >= n_ib) { free(buf); throw "build_haplomatch returned an invalid sample index"; }
+			const PluginGenotype &g = t.g[t.inbag[k]];
+			const int a = (int)(2 * (start[g.hla1] + (p[1] & 0xFFFF))), b = (int)(2 * (start[g.hla2] + (p[1] >> 16)));
+			std::vector<HapPair> &PL = t.pl[k].p;
+			PL.push_back(HapPair{a, b, false, 0.0});
+			PL.push_back(HapPair{a, b + 1, false, 0.0});
+			if (a + 1 <= b) PL.push_back(HapPair{a + 1, b, false, 0.0});
+			PL.push_back(HapPair{a + 1, b + 1, false, 0.0});
+		}
+		free(buf);
+	}
+	for (PairList &pl : t.pl) {
+		if (pl.p.empty()) throw "PairList should not be empty in PrepareHaplotypes().";   // :1070-1071
+		std::sort(pl.p.begin(), pl.p.end(), [](const HapPair &x, const HapPair &y) {
+			return x.h1 != y.h1 ? x.h1 < y.h1 : x.h2 < y.h2; });
+	}
+}
+
+bool prepare_new_snp(T &t, int snp, const HapList &cur, HapList &next)  // PrepareNewSNP, :1127-1183
+{
+	int allele_cnt = 0, valid_cnt = 0;
+	for (int i : t.inbag) {
+		const int dup = t.g[i].bootstrap_count;
+		const int g = t.geno[(size_t)i * t.n_snp + snp];
+		if (0 <= g && g <= 2) { allele_cnt += g * dup; valid_cnt += 2 * dup; }
+	}
+	if (allele_cnt == 0 || allele_cnt == valid_cnt) return false;
+	const double afreq = (double)allele_cnt / valid_cnt, p0 = 1 - afreq, p1 = afreq;   // DoubleHaplosInitFreq, :444-459
+	for (size_t i = 0; i < cur.list.size(); i++) {
+		next.list[2 * i].freq = p0 * cur.list[i].freq + EM_INIT_VAL_FRAC;
+		next.list[2 * i + 1].freq = p1 * cur.list[i].freq + EM_INIT_VAL_FRAC;
+	}
+	const int idx_new = next.n_snp - 1;
+	for (PairList &pl : t.pl) {
+		const int geno = t.geno[(size_t)pl.samp * t.n_snp + snp];
+		for (HapPair &p : pl.p)
+			p.flag = (0 <= geno && geno <= 2) ?
+				(get_allele(next.list[p.h1], idx_new) + get_allele(next.list[p.h2], idx_new) == geno) : true;
+	}
+	return true;
+}
+
+void expectation_maximization(T &t, HapList &next)                      // ExpectationMaximization, :1185-1255
+{
+	const int total = t.n_samp;
+	const double em_reltol = std::sqrt(DBL_EPSILON);                    // :102
+	double conv_tol = 0, loglik = -1e+30;
+	const size_t num = t.pl.size();
+	if (t.log_buf.size() < num) t.log_buf.resize(num);
+	for (int iter = 0; iter <= EM_MAX_ITER; iter++) {
+		const double old_loglik = loglik;
+		for (size_t i = 0; i < next.list.size(); i++) { next.old_freq[i] = next.list[i].freq; next.list[i].freq = 0; }
+		for (size_t i = 0; i < num; i++) {
+			PairList &pl = t.pl[i];
+			double psum = 0;
+			for (HapPair &p : pl.p)
+				if (p.flag) {
+					p.gfreq = (p.h1 != p.h2) ? (2 * next.old_freq[p.h1] * next.old_freq[p.h2])
+					                         : (next.old_freq[p.h1] * next.old_freq[p.h2]);
+					psum += p.gfreq;
+				}
+			t.log_buf[i] = pl.boot * std::log(psum);
+			psum = pl.boot / psum;
+			for (HapPair &p : pl.p) if (p.flag) p.gfreq *= psum;
+		}
+		loglik = 0;
+		for (size_t i = 0; i < num; i++) {
+			loglik += t.log_buf[i];
+			for (const HapPair &p : t.pl[i].p)
+				if (p.flag) { next.list[p.h1].freq += p.gfreq; next.list[p.h2].freq += p.gfreq; }
+		}
+		const double scale = 0.5 / total;
+		for (PluginHaplotype &h : next.list) h.freq *= scale;
+		if (iter > 0) {
+			if (std::fabs(loglik - old_loglik) <= conv_tol) break;
+		} else {
+			conv_tol = em_reltol * (std::fabs(loglik) + em_reltol);
+			if (conv_tol < 0) conv_tol = 0;
+		}
+	}
+}
+
+void erase_double_haplos(const HapList &in, double rare_prob, HapList &out)   // EraseDoubleHaplos, :461-515
+{
+	out.n_snp = in.n_snp;
+	out.list.clear();
+	out.len.assign(in.len.size(), 0);
+	const PluginHaplotype *p = in.list.data();
+	double sum = 0;
+	for (size_t h = 0; h < in.len.size(); h++) {
+		size_t num = 0;
+		for (size_t n = in.len[h]; n > 0; n -= 2, p += 2) {
+			const double sumfreq = p[0].freq + p[1].freq;
+			if (p[0].freq < rare_prob || p[1].freq < rare_prob) {
+				if (sumfreq >= MIN_RARE_FREQ) {
+					out.list.push_back(p[0].freq >= p[1].freq ? p[0] : p[1]);
+					out.list.back().freq = sumfreq;
+					sum += sumfreq;
+					num++;
+				}
+			} else {
+				out.list.push_back(p[0]); out.list.push_back(p[1]);
+				sum += sumfreq;
+				num += 2;
+			}
+		}
+		out.len[h] = num;
+	}
+	const double scale = 1 / sum;
+	for (PluginHaplotype &h : out.list) h.freq *= scale;
+}
+
+const char *date_text()
+{
+	static char buf[64];
+	const time_t now = time(nullptr);
+	strftime(buf, sizeof buf, "%Y-%m-%d %H:%M:%S", localtime(&now));
+	return buf;
+}
+
+// CVariableSelection::Search, :1981-2122
+void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool verbose_detail)
+{
+	const double rare_prob = std::max(FRACTION_HAPLO / (2 * t.n_samp), MIN_RARE_FREQ);
+	HapList out_haplo, next, reduced, minh;
+	init_haplotype(t, out_haplo);
+	o.snpidx.clear();
+	const int num_oob = (int)t.outbag.size();
+	int global_max_acc = 0;
+	double global_min_loss = 1e+30;
+
+	while (!vs.a.empty() && (int)o.snpidx.size() < MAX_SNP) {
+		prepare_haplotypes(t, out_haplo, next);
+		int max_acc = global_max_acc, min_i = -1;
+		double min_loss = global_min_loss;
+		select(t, vs, mtry);
+		for (int i = 0; i < vs.m_try; i++) {
+			if (!prepare_new_snp(t, vs.at(i), out_haplo, next)) continue;
+			expectation_maximization(t, next);
+			erase_double_haplos(next, rare_prob, reduced);
+			add_snp(t, vs.at(i));
+			set_aux(reduced);                                           // _Init_EvalAcc, :1913-1929
+			hibag_build_set_haplo_geno(reduced.list.data(), (int)reduced.list.size(), t.g.data(), reduced.n_snp);
+			double loss = 0;
+			const int acc = hibag_build_acc_oob();
+			if (acc >= max_acc) loss = hibag_build_acc_ib();
+			t.g_nsnp--;                                                 // ReduceSNP
+			if (acc > max_acc) { min_i = i; min_loss = loss; max_acc = acc; minh = reduced; }
+			else if (acc == max_acc && loss < min_loss) { min_i = i; min_loss = loss; minh = reduced; }
+			if (prune) {
+				if (acc < global_max_acc) vs.at(i) = -1;
+				else if (acc == global_max_acc && loss > global_min_loss * (1 + PRUNE_RELTOL_LOGLIK) && min_i != i) vs.at(i) = -1;
+			}
+		}
+		bool sign = false;
+		if (max_acc > global_max_acc) sign = true;
+		else if (max_acc == global_max_acc && min_i >= 0)
+			sign = min_loss >= STOP_RELTOL_LOGLIK_ADDSNP && min_loss < global_min_loss * (1 - STOP_RELTOL_LOGLIK_ADDSNP);
+		if (sign) {
+			global_max_acc = max_acc;
+			global_min_loss = min_loss;
+			out_haplo = minh;
+			o.snpidx.push_back(vs.at(min_i));
+			add_snp(t, vs.at(min_i));
+			if (prune) { vs.at(min_i) = -1; vs.remove_flag(); } else vs.remove(min_i);
+			if (verbose_detail)
+				printf("    %2d, SNP: %d, loss: %g, oob acc: %0.2f%%, # of haplo: %d\n", (int)o.snpidx.size(),
+					o.snpidx.back() + 1, global_min_loss, double(global_max_acc) / num_oob * 50, (int)out_haplo.list.size());
+		} else {
+			vs.remove_selection();
+			for (int i = 0; i < t.n_samp; i++) geno_set(t.g[i], t.g_nsnp, -1);    // SetMissing, :893-903
+		}
+	}
+	o.acc = 0.5 * global_max_acc / num_oob;
+	const size_t H = out_haplo.list.size();
+	o.freq.resize(H); o.hla.resize(H); o.bits.resize(2 * H);
+	size_t i = 0;
+	for (size_t a = 0; a < out_haplo.len.size(); a++)
+		for (size_t m = out_haplo.len[a]; m > 0; m--, i++) {
+			o.freq[i] = out_haplo.list[i].freq;
+			o.hla[i] = (int32_t)a;
+			for (int w = 0; w < 2; w++) {                               // report defined bits only
+				const int lo = 64 * w, k = (int)o.snpidx.size();
+				const uint64_t mask = k >= lo + 64 ? ~(uint64_t)0 : (k <= lo ? 0 : (((uint64_t)1 << (k - lo)) - 1));
+				o.bits[2 * i + w] = (uint64_t)out_haplo.list[i].packed[w] & mask;
+			}
+		}
+}
+
+// BuildClassifiers, :2268-2305
+void build_classifiers(T &t, int nclassifier, int mtry, bool prune, bool verbose, bool verbose_detail)
+{
+	struct Scope {                                                      // try_final_train_gpu, :2256-2266
+		Scope(int nh, int ns) { hibag_build_init(nh, ns); }
+		~Scope() { hibag_build_done(); }
+	} scope(t.n_hla, t.n_samp);
+	Sampling vs;
+	const int n = t.n_samp;
+	for (int k = 0; k < nclassifier; k++) {
+		vs.init(t.n_snp);
+		std::vector<int> S(n);                                          // NewClassifierBootstrap, :2220-2245
+		int n_unique;
+		do {
+			std::fill(S.begin(), S.end(), 0);
+			n_unique = 0;
+			for (int i = 0; i < n; i++) {
+				const int j = t.random_num(n);
+				if (S[j] == 0) n_unique++;
+				S[j]++;
+			}
+		} while (n_unique >= n);
+		if (verbose) {
+			int n_oob = 0;
+			for (int v : S) if (v == 0) n_oob++;
+			printf("=== building individual classifier %d, out-of-bag (%d/%.1f%%) ===\n", (int)t.out.size() + 1, n_oob, 100.0 * n_oob / n);
+		}
+		hibag_build_set_bootstrap(S.data());
+		init_selection(t, S);
+		OutClassifier o;
+		o.samp_num.assign(S.begin(), S.end());
+		search(t, vs, o, mtry, prune, verbose_detail);
+		t.out.push_back(std::move(o));
+		if (verbose) {
+			const OutClassifier &c = t.out.back();
+			printf("[%d] %s, oob acc: %0.2f%%, # of SNPs: %d, # of haplo: %d\n", (int)t.out.size(), date_text(),
+				c.acc * 100, (int)c.snpidx.size(), (int)c.freq.size());
+			fflush(stdout);
+		}
+	}
+}
+
+} // namespace
+
+// ===========================================================================
+// C ABI
+
+extern "C" {
+
+hibag_hip_trainer *hibag_hip_trainer_new(int n_snp, int n_samp, const int32_t *snp_geno, int n_hla,
+	const int32_t *H1, const int32_t *H2)
+{
+	// messages of HIBAG_Training (src/HIBAG.cpp:516-535) and InitTraining (src/LibHLA.cpp:2196-2218)
+	if (n_samp <= 0) { hibag_fail(HIBAG_HIP_EINVAL, "Invalid number of samples: %d.", n_samp); return nullptr; }
+	if (n_snp <= 0) { hibag_fail(HIBAG_HIP_EINVAL, "Invalid number of SNPs: %d.", n_snp); return nullptr; }
+	if (n_hla <= 0) { hibag_fail(HIBAG_HIP_EINVAL, "Invalid number of unique HLA alleles: %d.", n_hla); return nullptr; }
+	if (!snp_geno || !H1 || !H2) { hibag_fail(HIBAG_HIP_EINVAL, "NULL argument"); return nullptr; }
+	for (int i = 0; i < n_samp; i++) {
+		if (H1[i] < 0 || H1[i] >= n_hla) { hibag_fail(HIBAG_HIP_EINVAL, "CAttrBag_Model::InitTraining, H1 error."); return nullptr; }
+		if (H2[i] < 0 || H2[i] >= n_hla) { hibag_fail(HIBAG_HIP_EINVAL, "CAttrBag_Model::InitTraining, H2 error."); return nullptr; }
+	}
+	hibag_hip_trainer *t = new (std::nothrow) hibag_hip_trainer;
+	if (!t) { hibag_fail(HIBAG_HIP_ENOMEM, "out of host memory"); return nullptr; }
+	t->n_snp = n_snp; t->n_samp = n_samp; t->n_hla = n_hla;
+	t->geno.assign(snp_geno, snp_geno + (size_t)n_samp * n_snp);
+	t->h1.assign(H1, H1 + n_samp); t->h2.assign(H2, H2 + n_samp);
+	t->g.assign(n_samp, PluginGenotype{});
+	return t;
+}
+
+void hibag_hip_trainer_free(hibag_hip_trainer *t) { delete t; }
+
+int hibag_hip_trainer_set_seed(hibag_hip_trainer *t, uint32_t seed)
+{
+	if (!t) return hibag_fail(HIBAG_HIP_EINVAL, "trainer is NULL");
+	t->rng.set_seed(seed);
+	t->unif_fn = nullptr;
+	return 0;
+}
+
+int hibag_hip_trainer_set_rng(hibag_hip_trainer *t, double (*unif_rand)(void *), void *ctx)
+{
+	if (!t) return hibag_fail(HIBAG_HIP_EINVAL, "trainer is NULL");
+	t->unif_fn = unif_rand; t->unif_ctx = ctx;
+	return 0;
+}
+
+int hibag_hip_trainer_new_classifiers(hibag_hip_trainer *t, int nclassifier, int mtry, int prune, int verbose,
+	int verbose_detail)
+{
+	if (!t) return hibag_fail(HIBAG_HIP_EINVAL, "trainer is NULL");
+	if (nclassifier < 0 || mtry < 1) return hibag_fail(HIBAG_HIP_EINVAL, "invalid nclassifier / mtry");
+	std::lock_guard<std::mutex> g(t->lock);
+	static std::mutex device_state;                    // the build entries keep one device state per process
+	std::lock_guard<std::mutex> g2(device_state);
+	const size_t before = t->out.size();
+	try {
+		build_classifiers(*t, nclassifier, mtry, prune != 0, verbose != 0 || verbose_detail != 0, verbose_detail != 0);
+	} catch (const char *msg) {
+		t->out.resize(before);                         // a failed call adds nothing
+		return hibag_fail(hibag_hip_device_count() <= 0 ? HIBAG_HIP_ENODEV : HIBAG_HIP_EINVAL, "%s", msg);
+	} catch (const std::bad_alloc &) {
+		t->out.resize(before);
+		return hibag_fail(HIBAG_HIP_ENOMEM, "out of host memory");
+	}
+	return 0;
+}
+
+int hibag_hip_trainer_n_classifier(const hibag_hip_trainer *t) { return t ? (int)t->out.size() : 0; }
+
+int hibag_hip_trainer_classifier_dims(const hibag_hip_trainer *t, int idx, int *n_snp_c, int *n_haplo)
+{
+	if (!t || idx < 0 || idx >= (int)t->out.size()) return hibag_fail(HIBAG_HIP_EINVAL, "invalid classifier index");
+	if (n_snp_c) *n_snp_c = (int)t->out[idx].snpidx.size();
+	if (n_haplo) *n_haplo = (int)t->out[idx].freq.size();
+	return 0;
+}
+
+int hibag_hip_trainer_classifier_get(const hibag_hip_trainer *t, int idx, int32_t *snpidx, int32_t *samp_num,
+	double *freq, int32_t *hla, uint64_t *bits, double *outofbag_acc)
+{
+	if (!t || idx < 0 || idx >= (int)t->out.size()) return hibag_fail(HIBAG_HIP_EINVAL, "invalid classifier index");
+	const OutClassifier &o = t->out[idx];
+	if (snpidx) std::copy(o.snpidx.begin(), o.snpidx.end(), snpidx);
+	if (samp_num) std::copy(o.samp_num.begin(), o.samp_num.end(), samp_num);
+	if (freq) std::copy(o.freq.begin(), o.freq.end(), freq);
+	if (hla) std::copy(o.hla.begin(), o.hla.end(), hla);
+	if (bits) std::copy(o.bits.begin(), o.bits.end(), bits);
+	if (outofbag_acc) *outofbag_acc = o.acc;
+	return 0;
+}
+
+} // extern "C"

@@ -221,8 +221,8 @@ class HlaAlleleClass:
     sample_id: List
     allele1: List[Optional[str]]
     allele2: List[Optional[str]]
-    prob: np.ndarray
-    matching: np.ndarray
+    prob: Optional[np.ndarray] = None
+    matching: Optional[np.ndarray] = None
     assembly: str = "unknown"
     dosage: Optional[np.ndarray] = None        # [n_hla, n_samp], rows = hla.allele
     postprob: Optional[np.ndarray] = None      # [n_cell, n_samp], rows = pair_names

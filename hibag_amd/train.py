@@ -1,0 +1,314 @@
+"""Host-side mirror of the reference's training entry ``hlaAttrBagging``
+(``R/HIBAG.R:48-275``): sample / SNP preparation in front of the native driver
+(``hibag_hip_trainer_*`` in ``include/hibag_hip.h`` -- bootstrap, greedy SNP selection
+and EM on the host in C++, haplotype-pair scoring on the device), and the assembly of the
+resulting ``hlaAttrBagObj``.
+
+The reference draws from R's global random stream; :func:`set_seed` /
+:class:`RRandom` reproduce ``set.seed()`` and R's default Mersenne-Twister, so
+``set_seed(100); hlaAttrBagging(...)`` gives the model R gives (the reference's
+``inst/extdata/OutOfBag.RData`` is reproduced bit for bit in the tests).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+import sys
+import warnings
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import HibagHipError
+from .hibag import HlaAlleleClass, HlaAttrBagClass, hlaPredict
+from .model import NA_INTEGER, Classifier, HlaAttrBagObj, HlaSNPGeno
+
+
+class RRandom:
+    """R's default uniform generator: Mersenne-Twister MT19937 seeded like ``set.seed()``
+    (R ``src/main/RNG.c``: ``Randomize`` scrambling, ``MT_genrand``, ``fixup``)."""
+
+    def __init__(self, seed: Optional[int] = None):
+        self.mt = [0] * 624
+        self.mti = 625
+        if seed is not None:
+            self.set_seed(seed)
+
+    def set_seed(self, seed: int) -> None:
+        seed &= 0xFFFFFFFF
+        for _ in range(50):
+            seed = (69069 * seed + 1) & 0xFFFFFFFF
+        for j in range(625):
+            seed = (69069 * seed + 1) & 0xFFFFFFFF
+            if j > 0:
+                self.mt[j - 1] = seed
+        self.mti = 624
+
+    def unif_rand(self) -> float:
+        mt = self.mt
+        if self.mti >= 624:
+            if self.mti == 625:
+                self.set_seed(4357)
+            for kk in range(624):
+                y = (mt[kk] & 0x80000000) | (mt[(kk + 1) % 624] & 0x7FFFFFFF)
+                mt[kk] = mt[(kk + 397) % 624] ^ (y >> 1) ^ (0x9908B0DF if y & 1 else 0)
+            self.mti = 0
+        y = mt[self.mti]
+        self.mti += 1
+        y ^= y >> 11
+        y ^= (y << 7) & 0x9D2C5680
+        y ^= (y << 15) & 0xEFC60000
+        y ^= y >> 18
+        v = y * 2.3283064365386963e-10
+        eps = 2.328306437080797e-10
+        if v <= 0.0:
+            return 0.5 * eps
+        if 1.0 - v <= 0.0:
+            return 1.0 - 0.5 * eps
+        return v
+
+
+_R = RRandom()
+
+
+def set_seed(seed: int) -> None:
+    """``set.seed(seed)`` for the stream :func:`hlaAttrBagging` draws from."""
+    _R.set_seed(int(seed))
+
+
+def _allele_key(s: str):
+    """Sort key of ``HIBAG_SortAlleleStr`` (``src/HIBAG.cpp:79-148``): fields split at ':',
+    each compared as (leading integer, suffix); a missing number sorts last."""
+    key = []
+    for f in s.split(":"):
+        i = 0
+        while i < len(f) and f[i].isdigit():
+            i += 1
+        key.append((int(f[:i]) if i else 2 ** 31 - 1, f[i:]))
+    return key
+
+
+def hlaUniqueAllele(hla: Sequence[Optional[str]]) -> List[str]:
+    """``hlaUniqueAllele`` for a character vector (``R/DataUtilities.R:1139-1150``)."""
+    seen, out = set(), []
+    for a in hla:
+        if a is not None and a not in seen:
+            seen.add(a)
+            out.append(a)
+    return sorted(out, key=_allele_key)
+
+
+def hlaAllele(sample_id: Sequence, H1: Sequence[Optional[str]], H2: Sequence[Optional[str]], locus: str = "any",
+              assembly: str = "auto-silent") -> HlaAlleleClass:
+    """``hlaAllele`` (``R/DataUtilities.R:1176-1240``), the part training needs."""
+    if not (len(sample_id) == len(H1) == len(H2)):
+        raise ValueError("length(sample.id) == length(H1) is not TRUE")
+    from .bed import _hla_assembly
+    return HlaAlleleClass(locus=locus, sample_id=list(sample_id), allele1=list(H1), allele2=list(H2),
+                          assembly=_hla_assembly(assembly))
+
+
+def _mtry(mtry, n_snp: int) -> int:
+    """``R/HIBAG.R:180-208``."""
+    if isinstance(mtry, str):
+        if mtry == "sqrt":
+            m = math.ceil(math.sqrt(n_snp))
+        elif mtry == "all":
+            m = n_snp
+        elif mtry == "one":
+            m = 1
+        else:
+            raise ValueError("Invalid mtry!")
+    else:
+        v = float(mtry)
+        if math.isfinite(v):
+            if 0 < v < 1:
+                v = n_snp * v
+            m = min(math.ceil(v), n_snp)
+        else:
+            m = math.ceil(math.sqrt(n_snp))
+    return max(int(m), 1)
+
+
+_UNIF = C.CFUNCTYPE(C.c_double, C.c_void_p)
+
+
+class _Trainer:
+    """``hibag_hip_trainer`` handle (``HIBAG_Training`` ... ``HIBAG_Close``)."""
+
+    def __init__(self, genomat: np.ndarray, h1: np.ndarray, h2: np.ndarray, n_hla: int):
+        L = _lib.lib()
+        g = np.ascontiguousarray(genomat, np.int32)
+        self.n_samp, self.n_snp = g.shape
+        a1 = np.ascontiguousarray(h1, np.int32)
+        a2 = np.ascontiguousarray(h2, np.int32)
+        h = L.hibag_hip_trainer_new(self.n_snp, self.n_samp, g.ctypes.data_as(C.c_void_p), int(n_hla),
+                                    a1.ctypes.data_as(C.c_void_p), a2.ctypes.data_as(C.c_void_p))
+        if not h:
+            raise HibagHipError(-1, L.hibag_hip_last_error().decode())
+        self._h = C.c_void_p(h)
+        self._cb = None
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().hibag_hip_trainer_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_seed(self, seed: int):
+        _lib.check(_lib.lib().hibag_hip_trainer_set_seed(self._h, C.c_uint32(int(seed) & 0xFFFFFFFF)))
+
+    def set_rng(self, rng: RRandom):
+        self._cb = _UNIF(lambda _ctx: rng.unif_rand())
+        _lib.check(_lib.lib().hibag_hip_trainer_set_rng(self._h, self._cb, None))
+
+    def new_classifiers(self, nclassifier: int, mtry: int, prune: bool, verbose: bool, verbose_detail: bool):
+        sys.stdout.flush()
+        _lib.check(_lib.lib().hibag_hip_trainer_new_classifiers(self._h, int(nclassifier), int(mtry), int(bool(prune)),
+                                                                int(bool(verbose)), int(bool(verbose_detail))))
+
+    def classifiers(self) -> List[Classifier]:
+        L = _lib.lib()
+        out = []
+        for i in range(L.hibag_hip_trainer_n_classifier(self._h)):
+            k, nh = C.c_int(0), C.c_int(0)
+            _lib.check(L.hibag_hip_trainer_classifier_dims(self._h, i, C.byref(k), C.byref(nh)))
+            snpidx = np.zeros(max(k.value, 1), np.int32)
+            samp = np.zeros(self.n_samp, np.int32)
+            freq = np.zeros(max(nh.value, 1), np.float64)
+            hla = np.zeros(max(nh.value, 1), np.int32)
+            bits = np.zeros((max(nh.value, 1), 2), np.uint64)
+            acc = C.c_double(0)
+            _lib.check(L.hibag_hip_trainer_classifier_get(
+                self._h, i, snpidx.ctypes.data_as(C.c_void_p), samp.ctypes.data_as(C.c_void_p),
+                freq.ctypes.data_as(C.c_void_p), hla.ctypes.data_as(C.c_void_p), bits.ctypes.data_as(C.c_void_p),
+                C.byref(acc)))
+            kk = k.value
+            haplo = ["".join("1" if (int(b[j >> 6]) >> (j & 63)) & 1 else "0" for j in range(kk)) for b in bits[:nh.value]]
+            out.append(Classifier(snpidx=snpidx[:kk], freq=freq[:nh.value], hla=hla[:nh.value], haplo=haplo,
+                                  samp_num=samp, outofbag_acc=acc.value))
+        return out
+
+
+def _row_mean_half(g: np.ndarray) -> np.ndarray:
+    ok = (g >= 0) & (g <= 2) if g.dtype.kind != "f" else np.isfinite(g)
+    cnt = ok.sum(axis=1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.where(cnt > 0, np.where(ok, g, 0).sum(axis=1) / cnt, np.nan) * 0.5
+
+
+def hlaAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,
+                   mtry: Union[str, float, int] = "sqrt", prune: bool = True, na_rm: bool = True,
+                   mono_rm: bool = True, maf: float = float("nan"), nthread: int = 1, verbose: bool = True,
+                   verbose_detail: bool = False, rng: Optional[RRandom] = None) -> HlaAttrBagClass:
+    """``hlaAttrBagging`` (``R/HIBAG.R:48-275``).  ``nthread`` is accepted for signature
+    compatibility (the scoring runs on the device).  ``rng`` defaults to the module's
+    R-compatible stream (see :func:`set_seed`)."""
+    if not isinstance(hla, HlaAlleleClass):
+        raise TypeError("inherits(hla, \"hlaAlleleClass\") is not TRUE")
+    if not isinstance(snp, HlaSNPGeno):
+        raise TypeError("inherits(snp, \"hlaSNPGenoClass\") is not TRUE")
+    if verbose_detail:
+        verbose = True
+    nclassifier = 0 if nclassifier is None else int(nclassifier)
+    with_matching = nclassifier > 0
+    if not with_matching:
+        nclassifier = -nclassifier or 1
+
+    in_snp = {s: i for i, s in enumerate(snp.sample_id)}
+    samp_id = [s for s in dict.fromkeys(hla.sample_id) if s in in_snp]          # intersect()
+    pos = {}
+    for i, s in enumerate(hla.sample_id):
+        pos.setdefault(s, i)
+    a1 = [hla.allele1[pos[s]] for s in samp_id]
+    a2 = [hla.allele2[pos[s]] for s in samp_id]
+    if any(x is None or y is None for x, y in zip(a1, a2)):
+        if not na_rm:
+            raise ValueError("There are missing HLA alleles!")
+        warnings.warn("There are missing HLA alleles, and the corresponding samples have been removed.")
+        keep = [x is not None and y is not None for x, y in zip(a1, a2)]
+        samp_id = [s for s, k in zip(samp_id, keep) if k]
+        a1 = [x for x, k in zip(a1, keep) if k]
+        a2 = [x for x, k in zip(a2, keep) if k]
+    if not samp_id:
+        raise ValueError("There is no common sample between 'hla' and 'snp'.")
+
+    geno = np.asarray(snp.genotype)[:, [in_snp[s] for s in samp_id]]
+    if geno.dtype.kind == "f":
+        geno = np.where(np.isfinite(geno), geno, NA_INTEGER)
+    geno = geno.astype(np.int32)
+    snp_id, snp_pos, snp_allele = list(snp.snp_id), snp.snp_position, list(snp.snp_allele)
+
+    msg = ""
+    if mono_rm or math.isfinite(maf):
+        msg = f"    MAF threshold: {'NaN' if math.isnan(maf) else maf}\n"
+        mf = _row_mean_half(geno)
+        mf = np.minimum(mf, 1 - mf)
+        mf[~np.isfinite(mf)] = 0
+        sel = np.ones(len(mf), bool)
+        if mono_rm:
+            n0 = int(sel.sum())
+            sel &= mf > 0
+            a = n0 - int(sel.sum())
+            if a > 0:
+                msg += f"    excluding {a} monomorphic SNP{'s' if a > 1 else ''}\n"
+        if math.isfinite(maf):
+            n0 = int(sel.sum())
+            sel &= mf >= maf
+            a = n0 - int(sel.sum())
+            if a > 0:
+                msg += f"    excluding {a} SNP{'s' if a > 1 else ''} for MAF threshold\n"
+        if not sel.all():
+            ix = np.where(sel)[0]
+            snp_id = [snp_id[i] for i in ix]
+            snp_pos = None if snp_pos is None else np.asarray(snp_pos)[ix]
+            snp_allele = [snp_allele[i] for i in ix]
+            geno = geno[ix]
+
+    n_snp, n_samp = geno.shape
+    if n_snp <= 0:
+        raise ValueError("There is no valid SNP markers.")
+    HUA = hlaUniqueAllele(a1 + a2)
+    lut = {a: i for i, a in enumerate(HUA)}
+    H1 = np.array([lut[a] for a in a1], np.int32)
+    H2 = np.array([lut[a] for a in a2], np.int32)
+    m = _mtry(mtry, n_snp)
+
+    if verbose:
+        print(f"Build a HIBAG model with {nclassifier} individual classifier{'s' if nclassifier > 1 else ''}:")
+        print(msg, end="")
+        print(f"    # of SNPs randomly sampled as candidates for each selection: {m}")
+        print(f"    # of SNPs: {n_snp}\n    # of samples: {n_samp}")
+        print(f"    # of unique {'KIR' if hla.locus.startswith('KIR') else 'HLA'} alleles: {len(HUA)}")
+
+    tr = _Trainer(np.ascontiguousarray(geno.T), H1, H2, len(HUA))
+    try:
+        tr.set_rng(_R if rng is None else rng)
+        tr.new_classifiers(nclassifier, m, prune, verbose, verbose_detail)
+        classifiers = tr.classifiers()
+    finally:
+        tr.close()
+
+    counts = np.bincount(np.concatenate([H1, H2]), minlength=len(HUA)).astype(np.float64)
+    obj = HlaAttrBagObj(
+        n_samp=n_samp, n_snp=n_snp, hla_allele=HUA, classifiers=classifiers, hla_locus=hla.locus,
+        sample_id=samp_id, snp_id=snp_id, snp_position=snp_pos, snp_allele=snp_allele,
+        snp_allele_freq=_row_mean_half(geno), hla_freq=counts / counts.sum(),
+        assembly=snp.assembly or "unknown", matching=None, appendix=None)
+    mod = HlaAttrBagClass(obj)
+    if with_matching:
+        if verbose:
+            print("Calculating matching proportion:")
+        pd = hlaPredict(mod, snp, match_type="Pos+Allele", verbose=False)
+        obj.matching = np.asarray(pd.matching)
+        if verbose:
+            acc = np.mean([c.outofbag_acc for c in classifiers]) * 100
+            print(f"Out-of-bag accuracy: {acc:.2f}%")
+    return mod

@@ -179,6 +179,46 @@ int hibag_hip_predict_bed(hibag_hip_model *m, const char *bed_fn, int n_samp, in
 	const int32_t *snp_col, const int32_t *flip, int vote_method,
 	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob);
 
+/* ---- training: replaces HIBAG_Training + HIBAG_NewClassifiers ---------------- */
+
+typedef struct hibag_hip_trainer hibag_hip_trainer;  /* opaque handle */
+
+/* HIBAG_Training(n.snp, n.samp, snp.geno, n.hla, H1, H2) (src/HIBAG.cpp:516-535 ->
+ * CAttrBag_Model::InitTraining, src/LibHLA.cpp:2196-2218): snp_geno int32
+ * [n_samp][n_snp] (the memory of R's SNP x sample matrix; values outside 0..2 are
+ * missing), H1/H2[n_samp] 0-based allele indices < n_hla.  The arrays are copied.
+ * Errors carry the reference's messages ("Invalid number of samples: %d.", ...). */
+hibag_hip_trainer *hibag_hip_trainer_new(int n_snp, int n_samp, const int32_t *snp_geno, int n_hla,
+	const int32_t *H1, const int32_t *H2);
+void hibag_hip_trainer_free(hibag_hip_trainer *t);
+
+/* Source of the uniform draws the reference takes from R's unif_rand()
+ * (src/LibHLA.cpp:120-126; bootstrap :2236, SNP sampling :957).  An R binding
+ * passes a trampoline to unif_rand between GetRNGstate()/PutRNGstate()
+ * (src/HIBAG.cpp:611, :632); other hosts call set_seed, which reproduces R's
+ * set.seed(seed) + default Mersenne-Twister stream exactly. */
+int hibag_hip_trainer_set_rng(hibag_hip_trainer *t, double (*unif_rand)(void *ctx), void *ctx);
+int hibag_hip_trainer_set_seed(hibag_hip_trainer *t, uint32_t seed);
+
+/* HIBAG_NewClassifiers(model, nclassifier, mtry, prune, nthread, verbose,
+ * verbose.detail, proc_ptr) (src/HIBAG.cpp:599-634 -> CAttrBag_Model::BuildClassifiers,
+ * src/LibHLA.cpp:2268-2305): grows `nclassifier` more individual classifiers -- bootstrap,
+ * greedy SNP selection, EM haplotype fit -- with the haplotype-pair scoring
+ * (build_haplomatch / build_acc_oob / build_acc_ib) on the device.  Given the same
+ * random stream the result is bit-identical to the reference's CPU training. */
+int hibag_hip_trainer_new_classifiers(hibag_hip_trainer *t, int nclassifier, int mtry, int prune,
+	int verbose, int verbose_detail);
+
+/* HIBAG_GetNumClassifiers / HIBAG_GetClassifierList / HIBAG_Classifier_GetHaplos
+ * (src/HIBAG.cpp:843-953): read the grown classifiers back.
+ *   snpidx[n_snp_c] 0-based, samp_num[n_samp] bootstrap counts, freq/hla[n_haplo],
+ *   bits[n_haplo][2] packed haplotypes (bit s = allele of SNP snpidx[s]).
+ * Feed them to hibag_hip_model_add_classifier_packed to predict with the new model. */
+int hibag_hip_trainer_n_classifier(const hibag_hip_trainer *t);
+int hibag_hip_trainer_classifier_dims(const hibag_hip_trainer *t, int idx, int *n_snp_c, int *n_haplo);
+int hibag_hip_trainer_classifier_get(const hibag_hip_trainer *t, int idx, int32_t *snpidx, int32_t *samp_num,
+	double *freq, int32_t *hla, uint64_t *bits, double *outofbag_acc);
+
 /* ---- kernel timing (HIP events on the launch stream) --------------------- */
 
 #define HIBAG_HIP_K_PACK     0   /* genotype packing + classifier weights        */

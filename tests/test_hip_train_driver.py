@@ -1,0 +1,104 @@
+"""GPU parity of the training driver (hibag_hip_trainer_* / hlaAttrBagging): bootstrap,
+greedy SNP selection and EM on the host, haplotype-pair scoring on the device.
+
+Known answer: the reference's own fixture inst/extdata/OutOfBag.RData is what
+    set.seed(100); hlaAttrBagging(hlatab$training, train.geno, nclassifier=100)
+gave in R (vignettes/HIBAG.Rmd:218-220); re-running that call here must return every
+stored classifier and the stored `matching` vector bit for bit.  Further cases compare the
+device-scored driver with the CPU oracle's restatement on data with missing genotypes."""
+
+import math
+
+import numpy as np
+import pytest
+
+from test_oracle_train import assert_same_classifier, training_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hib():
+    import hibag_amd
+    hibag_amd.hlaSetKernelTarget("hip")
+    return hibag_amd
+
+
+def _as_dict(c):
+    return dict(samp_num=c.samp_num, snpidx=c.snpidx, haplo=c.haplo, hla=c.hla, freq=c.freq, acc=c.outofbag_acc)
+
+
+def test_hlaAttrBagging_reproduces_the_reference_model(hib, hapmap_geno, hla_type_table, model_oob, capsys):
+    """The vignette's call: 34 training samples, the 275 SNPs within 500 kb of HLA-A (9 of them
+    monomorphic in the training set and dropped by mono.rm), mtry = ceil(sqrt(266)), prune."""
+    ti = {s: i for i, s in enumerate(hla_type_table["sample.id"])}
+    ids = list(model_oob.sample_id)
+    hla = hib.hlaAllele(ids, [hla_type_table["A.1"][ti[s]] for s in ids], [hla_type_table["A.2"][ti[s]] for s in ids],
+                        locus="A", assembly="hg19")
+    start, end = hib.hlaLociInfo("hg19")["A"][1:]
+    pos = np.asarray(hapmap_geno.snp_position)
+    flank = np.where((pos >= start - 500000) & (pos <= end + 500000))[0]          # hlaFlankingSNP, R/DataUtilities.R:1732-1780
+    assert len(flank) == 275                                                      # man/hlaAttrBagging.Rd:108
+    cols = [hapmap_geno.sample_id.index(s) for s in ids]
+    train_geno = hib.HlaSNPGeno(genotype=hapmap_geno.genotype[np.ix_(flank, cols)], sample_id=ids,
+                                snp_id=[hapmap_geno.snp_id[i] for i in flank], snp_position=pos[flank],
+                                snp_allele=[hapmap_geno.snp_allele[i] for i in flank], assembly="hg19")
+    hib.set_seed(100)
+    model = hib.hlaAttrBagging(hla, train_geno, nclassifier=100, verbose=True)
+    text = capsys.readouterr().out
+    assert "excluding 9 monomorphic SNPs" in text and "# of SNPs: 266" in text
+    obj = model.obj
+    assert obj.snp_id == list(model_oob.snp_id) and obj.hla_allele == list(model_oob.hla_allele)
+    assert obj.sample_id == ids and obj.n_snp == 266 and obj.n_samp == 34
+    assert np.array_equal(obj.snp_allele_freq, model_oob.snp_allele_freq)
+    assert np.allclose(obj.hla_freq, model_oob.hla_freq, rtol=0, atol=1e-15)
+    assert len(obj.classifiers) == 100
+    for i, (got, want) in enumerate(zip(obj.classifiers, model_oob.classifiers)):
+        assert_same_classifier(_as_dict(got), want, i)
+    assert np.array_equal(obj.matching, model_oob.matching)                      # hlaPredict() on the new model
+
+
+@pytest.mark.parametrize("prune", [True, False])
+def test_driver_equals_oracle_with_missing_genotypes(hib, oracle, prune):
+    """Synthetic cohort drawn from a model (with missing genotypes), both random-stream routes
+    (library's set_seed, host callback) against the oracle's CPU restatement."""
+    from hibag_amd import synth, train
+    model, founders, af = synth.make_model("hla-a-small", seed=5, n_snp=60)
+    G, truth = synth.make_samples(founders, af, 150, seed=6, miss=0.03)
+    n_hla = model.n_hla
+    want = oracle.train(G, truth[:, 0], truth[:, 1], n_hla, nclassifier=4, mtry=8, prune=prune, seed=42)
+    for route in ("seed", "callback"):
+        tr = train._Trainer(G, truth[:, 0], truth[:, 1], n_hla)
+        if route == "seed":
+            tr.set_seed(42)
+        else:
+            tr.set_rng(hib.RRandom(42))
+        tr.new_classifiers(2, 8, prune, False, False)
+        tr.new_classifiers(2, 8, prune, False, False)        # the stream continues across calls
+        got = tr.classifiers()
+        tr.close()
+        assert len(got) == 4
+        for i, (g, w) in enumerate(zip(got, want)):
+            c = hib.Classifier(snpidx=w["snpidx"], freq=w["freq"], hla=w["hla"], haplo=w["haplo"], samp_num=w["samp_num"],
+                               outofbag_acc=w["acc"])
+            assert_same_classifier(_as_dict(g), c, i)
+            assert len(g.snpidx) > 0
+
+
+def test_trainer_argument_errors(hib):
+    import ctypes as C
+    from hibag_amd import _lib
+    L = _lib.lib()
+    g = np.zeros((4, 3), np.int32)
+    h = np.zeros(4, np.int32)
+    def new(n_snp, n_samp, n_hla, h1=h):
+        return L.hibag_hip_trainer_new(n_snp, n_samp, g.ctypes.data, n_hla, h1.ctypes.data, h.ctypes.data)
+    assert not new(3, 0, 2) and L.hibag_hip_last_error() == b"Invalid number of samples: 0."          # src/HIBAG.cpp:520-521
+    assert not new(0, 4, 2) and L.hibag_hip_last_error() == b"Invalid number of SNPs: 0."
+    assert not new(3, 4, 0) and L.hibag_hip_last_error() == b"Invalid number of unique HLA alleles: 0."
+    bad = np.array([0, 5, 0, 0], np.int32)
+    assert not new(3, 4, 2, bad) and L.hibag_hip_last_error() == b"CAttrBag_Model::InitTraining, H1 error."
+    t = C.c_void_p(new(3, 4, 2))
+    assert t and L.hibag_hip_trainer_n_classifier(t) == 0
+    assert L.hibag_hip_trainer_new_classifiers(t, 1, 0, 1, 0, 0) == -1
+    L.hibag_hip_trainer_free(t)
