@@ -50,3 +50,12 @@ def test_training_reproduces_the_stored_model(oracle, hapmap_geno, hla_type_tabl
     assert len(out) == 100
     for i, (got, want) in enumerate(zip(out, model_oob.classifiers)):
         assert_same_classifier(got, want, i)
+
+
+def test_training_reproduces_the_second_stored_model(oracle, hapmap_geno, hla_type_table, model_a):
+    """inst/extdata/ModelList.RData, modellist$A: all 60 typed HapMap CEU samples, same seed."""
+    G, a1, a2 = training_inputs(model_a, hapmap_geno, hla_type_table)
+    assert G.shape == (60, 266)
+    out = oracle.train(G, a1, a2, model_a.n_hla, nclassifier=100, mtry=17, prune=True, seed=100)
+    for i, (got, want) in enumerate(zip(out, model_a.classifiers)):
+        assert_same_classifier(got, want, i)
