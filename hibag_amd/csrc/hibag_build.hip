@@ -45,8 +45,8 @@ struct BuildState {
 	std::vector<double> postprob;
 	// device
 	void *d_hb = nullptr, *d_hf = nullptr, *d_start = nullptr, *d_planes = nullptr, *d_true = nullptr,
-		*d_best = nullptr, *d_post = nullptr, *d_tab = nullptr, *d_match = nullptr;
-	size_t cap_h = 0, cap_s = 0, cap_match = 0;
+		*d_best = nullptr, *d_post = nullptr, *d_tab = nullptr, *d_match = nullptr, *d_batch = nullptr;
+	size_t cap_h = 0, cap_s = 0, cap_match = 0, cap_batch = 0;
 };
 BuildState g;
 thread_local char g_msg[400];
@@ -162,6 +162,93 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_build_eval(BuildView V)
 	case 3:  build_eval<3>(V, s, tab_s); break;
 	default: build_eval<4>(V, s, tab_s); break;
 	}
+}
+
+// ---------------------------------------------------------------------------
+// Batched evaluation for the library's own training driver (hibag_train.hip): all candidate
+// SNPs of one growth step in one pass, parallel over allele-pair cells as well as samples
+// (a training cohort is ~10^3 samples -- 16 wavefronts if only samples were spread out).
+//   k_batch_cells  (sample group, cell segment, candidate): lane = sample, walks the
+//                  segment's non-empty cells, stores each cell sum
+//   k_batch_scan   (sample group, candidate): lane = sample, scans the candidate's cell
+//                  sums in posterior order: first strict maximum (_BestGuess), in-order
+//                  total and the true pair's cell (_PostProb)
+// Cell sums are formed exactly as in k_build_eval, and added in the same order.
+struct BatchView {
+	int n_hla, n_pad, nw, n_cand, n_seg, word;      // word = 32-bit word that holds the candidate SNP's bit
+	const uint32_t *hb;        // [nw][n_haplo_total], candidates back to back
+	const double *hf;          // [n_haplo_total]
+	int n_haplo_total;
+	const int *start;          // [n_cand][n_hla+1], absolute haplotype indices
+	const uint32_t *planes;    // [2*NW][n_pad] base genotypes (candidate position missing)
+	const uint32_t *cand_w;    // [n_cand][2][n_pad]: words `word` of S1 / S2 with the candidate SNP set
+	const int *cells;          // [n_cand][max_cells] packed (h1 << 16 | h2) of the non-empty cells, posterior order
+	const int *seg;            // [n_cand][n_seg+1] segment bounds in that list
+	int max_cells;
+	const int *true_cell;      // [n_pad]
+	const double *tab;
+	double *cellv;             // [n_cand][max_cells][n_pad]
+	int *best;                 // [n_cand][2][n_pad]
+	double *post;              // [n_cand][n_pad]
+};
+
+template <int W>
+__device__ __forceinline__ void batch_cells(const BatchView &B, int c, int sg, int s, const double *tab_s)
+{
+	LaneG<W> G;
+	G.n_het = 0;
+#pragma unroll
+	for (int w = 0; w < W; w++) {
+		uint32_t s1 = B.planes[(size_t)w * B.n_pad + s], s2 = B.planes[(size_t)(NW + w) * B.n_pad + s];
+		if (w == B.word) { s1 = B.cand_w[((size_t)c * 2) * B.n_pad + s]; s2 = B.cand_w[((size_t)c * 2 + 1) * B.n_pad + s]; }
+		G.zt[w] = ~(s1 ^ s2); G.t[w] = s1 & s2; G.e[w] = s1 & ~s2;
+		G.n_het += __popc(G.e[w]);
+	}
+	BuildView V{};
+	V.n_haplo = B.n_haplo_total; V.hb = B.hb; V.hf = B.hf;
+	const int *st = B.start + (size_t)c * (B.n_hla + 1);
+	const int *cl = B.cells + (size_t)c * B.max_cells;
+	const int i0 = B.seg[c * (B.n_seg + 1) + sg], i1 = B.seg[c * (B.n_seg + 1) + sg + 1];
+	for (int i = i0; i < i1; i++) {
+		const int h1 = cl[i] >> 16, h2 = cl[i] & 0xFFFF;
+		const double cell = build_cell<W>(V, st[h1], st[h1 + 1], st[h2], st[h2 + 1], h1 == h2, G, tab_s);
+		B.cellv[((size_t)c * B.max_cells + i) * B.n_pad + s] = cell;
+	}
+}
+
+__global__ __launch_bounds__(HIBAG_WAVE) void k_batch_cells(BatchView B)
+{
+	__shared__ double tab_s[HIBAG_TAB_N];
+	for (int i = threadIdx.x; i < HIBAG_TAB_N; i += blockDim.x) tab_s[i] = B.tab[i];
+	__syncthreads();
+	const int s = blockIdx.x * HIBAG_WAVE + threadIdx.x;
+	switch (B.nw) {
+	case 1:  batch_cells<1>(B, blockIdx.z, blockIdx.y, s, tab_s); break;
+	case 2:  batch_cells<2>(B, blockIdx.z, blockIdx.y, s, tab_s); break;
+	case 3:  batch_cells<3>(B, blockIdx.z, blockIdx.y, s, tab_s); break;
+	default: batch_cells<4>(B, blockIdx.z, blockIdx.y, s, tab_s); break;
+	}
+}
+
+__global__ __launch_bounds__(HIBAG_WAVE) void k_batch_scan(BatchView B)
+{
+	const int c = blockIdx.y;
+	const int s = blockIdx.x * HIBAG_WAVE + threadIdx.x;
+	const int *cl = B.cells + (size_t)c * B.max_cells;
+	const int n = B.seg[c * (B.n_seg + 1) + B.n_seg];
+	const int want = B.true_cell[s];
+	double best = 0, total = 0, hit = 0;
+	int b1 = -2147483647 - 1, b2 = -2147483647 - 1;
+	for (int i = 0; i < n; i++) {
+		const int h1 = cl[i] >> 16, h2 = cl[i] & 0xFFFF;
+		const double cell = B.cellv[((size_t)c * B.max_cells + i) * B.n_pad + s];
+		if (best < cell) { best = cell; b1 = h1; b2 = h2; }
+		if (h2 + h1 * (2 * B.n_hla - h1 - 1) / 2 == want) hit = cell;
+		total += cell;
+	}
+	B.best[((size_t)c * 2) * B.n_pad + s] = b1;
+	B.best[((size_t)c * 2 + 1) * B.n_pad + s] = b2;
+	B.post[(size_t)c * B.n_pad + s] = hit / total;
 }
 
 // One wavefront per in-bag sample, lanes over the haplotype pairs of its true
@@ -352,9 +439,9 @@ void hibag_build_init(int n_hla, int n_sample)
 // build_done(): called from a destructor (src/LibHLA.cpp:2262-2266) -- must not throw
 void hibag_build_done()
 {
-	for (void **p : {&g.d_hb, &g.d_start, &g.d_planes, &g.d_true, &g.d_best, &g.d_post, &g.d_tab, &g.d_match}) dev_free(*p);
+	for (void **p : {&g.d_hb, &g.d_start, &g.d_planes, &g.d_true, &g.d_best, &g.d_post, &g.d_tab, &g.d_match, &g.d_batch}) dev_free(*p);
 	g.d_hf = nullptr;
-	g.cap_h = g.cap_s = g.cap_match = 0;
+	g.cap_h = g.cap_s = g.cap_match = g.cap_batch = 0;
 	g.active = false; g.evaluated = false;
 }
 
@@ -454,4 +541,129 @@ uint32_t *hibag_build_haplomatch(const PluginHaplotype haplo[], const size_t n_h
 	}
 	out_n = 1 + 2 * total;
 	return buf;
+}
+
+// ---------------------------------------------------------------------------
+// hibag_build_eval_batch: what a sequence of build_set_haplo_geno + build_acc_oob +
+// build_acc_ib calls returns for n_cand candidate SNPs that extend the same genotype list
+// (src/LibHLA.cpp:2018-2038), evaluated together.  base_geno holds the committed SNPs
+// (position n_snp-1 missing); cand[i].column is the raw genotype of candidate i per sample.
+void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const HibagBuildCandidate cand[], int n_cand,
+	int acc_oob[], double loss_ib[])
+{
+	if (!g.active) build_throw("build_eval_batch before build_init");
+	if (n_snp < 1 || n_snp > 128 || n_cand < 0) build_throw("build_eval_batch: invalid sizes");
+	if (n_cand == 0) return;
+	const int nh = g.n_hla, n = g.n_sample, np = g.n_pad;
+	const int nw = (n_snp + 31) / 32, word = (n_snp - 1) >> 5, bit = (n_snp - 1) & 31;
+	upload_geno(base_geno);
+
+	size_t H = 0;
+	for (int c = 0; c < n_cand; c++) H += (size_t)cand[c].n_haplo;
+	const size_t Hs = std::max<size_t>(H, 1);
+	std::vector<uint32_t> hb((size_t)nw * Hs, 0), cw((size_t)n_cand * 2 * np);
+	std::vector<double> hf(Hs, 0.0);
+	std::vector<int> start((size_t)n_cand * (nh + 1), 0), cells, seg;
+	const int n_seg = std::max(1, std::min(64, 2048 / std::max(1, (np / HIBAG_WAVE) * n_cand)));
+	int max_cells = 1;
+	std::vector<std::vector<int>> cell_list(n_cand);
+	std::vector<std::vector<uint64_t>> cell_work(n_cand);
+	size_t off = 0;
+	for (int c = 0; c < n_cand; c++) {
+		const PluginHaplotype *hp = cand[c].haplo;
+		int *st = &start[(size_t)c * (nh + 1)];
+		for (int i = 0; i < cand[c].n_haplo; i++) {
+			for (int w = 0; w < nw; w++) {
+				uint32_t v = (uint32_t)((uint64_t)hp[i].packed[w >> 1] >> (32 * (w & 1)));
+				const int lo = 32 * w;
+				if (n_snp < lo + 32) v &= (n_snp <= lo) ? 0u : ((1u << (n_snp - lo)) - 1);
+				hb[(size_t)w * Hs + off + i] = v;
+			}
+			hf[off + i] = hp[i].freq;
+			const int a = hp[i].aux.hla_allele;
+			if (a < 0 || a >= nh) build_throw("haplotype with an invalid HLA allele index");
+			st[a + 1]++;
+		}
+		st[0] = (int)off;
+		for (int h = 0; h < nh; h++) st[h + 1] += st[h];
+		off += (size_t)cand[c].n_haplo;
+		for (int h1 = 0; h1 < nh; h1++) {
+			const uint64_t n1 = (uint64_t)(st[h1 + 1] - st[h1]);
+			if (!n1) continue;
+			for (int h2 = h1; h2 < nh; h2++) {
+				const uint64_t n2 = (uint64_t)(st[h2 + 1] - st[h2]);
+				if (!n2) continue;
+				cell_list[c].push_back((h1 << 16) | h2);
+				cell_work[c].push_back(h1 == h2 ? n1 * (n1 + 1) / 2 : n1 * n2);
+			}
+		}
+		max_cells = std::max(max_cells, (int)cell_list[c].size());
+		// the candidate SNP's bit in the two planes of its word
+		for (int s = 0; s < np; s++) {
+			uint32_t s1 = s < n ? (uint32_t)((uint64_t)base_geno[s].snp1[word >> 1] >> (32 * (word & 1))) : 0u;
+			uint32_t s2 = s < n ? (uint32_t)((uint64_t)base_geno[s].snp2[word >> 1] >> (32 * (word & 1))) : 0xFFFFFFFFu;
+			if (s < n) {
+				const int v = cand[c].column[s];
+				const bool b1 = v == 1 || v == 2, b2 = !(v == 0 || v == 1);          // TGenotype::_SetSNP, src/LibHLA.cpp:609-622
+				s1 = b1 ? (s1 | (1u << bit)) : (s1 & ~(1u << bit));
+				s2 = b2 ? (s2 | (1u << bit)) : (s2 & ~(1u << bit));
+			}
+			cw[((size_t)c * 2) * np + s] = s1;
+			cw[((size_t)c * 2 + 1) * np + s] = s2;
+		}
+	}
+	cells.assign((size_t)n_cand * max_cells, 0);
+	seg.assign((size_t)n_cand * (n_seg + 1), 0);
+	for (int c = 0; c < n_cand; c++) {
+		std::copy(cell_list[c].begin(), cell_list[c].end(), cells.begin() + (size_t)c * max_cells);
+		uint64_t total = 0;
+		for (uint64_t w : cell_work[c]) total += w + 4;
+		int *sg = &seg[(size_t)c * (n_seg + 1)];
+		uint64_t acc = 0;
+		int k = 1;
+		for (size_t i = 0; i < cell_list[c].size(); i++) {            // equal work per segment, contiguous cells
+			while (k < n_seg && acc * n_seg >= total * k) sg[k++] = (int)i;
+			acc += cell_work[c][i] + 4;
+		}
+		while (k <= n_seg) sg[k++] = (int)cell_list[c].size();
+	}
+
+	// one device arena: ints first, then doubles
+	const size_t b_hb = hb.size() * 4, b_cw = cw.size() * 4, b_start = start.size() * 4, b_cells = cells.size() * 4,
+		b_seg = seg.size() * 4, b_best = (size_t)n_cand * 2 * np * 4;
+	size_t o = 0;
+	auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
+	const size_t o_hb = take(b_hb), o_cw = take(b_cw), o_start = take(b_start), o_cells = take(b_cells), o_seg = take(b_seg),
+		o_best = take(b_best), o_hf = take(hf.size() * 8), o_post = take((size_t)n_cand * np * 8),
+		o_cellv = take((size_t)n_cand * max_cells * np * 8);
+	reserve(g.d_batch, g.cap_batch, o, "hipMalloc(batch)");
+	char *d = (char *)g.d_batch;
+	HIP_OK(hipMemcpyAsync(d + o_hb, hb.data(), b_hb, hipMemcpyHostToDevice, 0), "copy batch");
+	HIP_OK(hipMemcpyAsync(d + o_cw, cw.data(), b_cw, hipMemcpyHostToDevice, 0), "copy batch");
+	HIP_OK(hipMemcpyAsync(d + o_start, start.data(), b_start, hipMemcpyHostToDevice, 0), "copy batch");
+	HIP_OK(hipMemcpyAsync(d + o_cells, cells.data(), b_cells, hipMemcpyHostToDevice, 0), "copy batch");
+	HIP_OK(hipMemcpyAsync(d + o_seg, seg.data(), b_seg, hipMemcpyHostToDevice, 0), "copy batch");
+	HIP_OK(hipMemcpyAsync(d + o_hf, hf.data(), hf.size() * 8, hipMemcpyHostToDevice, 0), "copy batch");
+	BatchView B{nh, np, nw, n_cand, n_seg, word, (const uint32_t *)(d + o_hb), (const double *)(d + o_hf), (int)Hs,
+		(const int *)(d + o_start), (const uint32_t *)g.d_planes, (const uint32_t *)(d + o_cw), (const int *)(d + o_cells),
+		(const int *)(d + o_seg), max_cells, (const int *)g.d_true, (const double *)g.d_tab, (double *)(d + o_cellv),
+		(int *)(d + o_best), (double *)(d + o_post)};
+	hipLaunchKernelGGL(k_batch_cells, dim3(np / HIBAG_WAVE, n_seg, n_cand), dim3(HIBAG_WAVE), 0, 0, B);
+	hipLaunchKernelGGL(k_batch_scan, dim3(np / HIBAG_WAVE, n_cand), dim3(HIBAG_WAVE), 0, 0, B);
+	HIP_OK(hipGetLastError(), "k_batch");
+	std::vector<int> best((size_t)n_cand * 2 * np);
+	std::vector<double> post((size_t)n_cand * np);
+	HIP_OK(hipMemcpyAsync(best.data(), d + o_best, b_best, hipMemcpyDeviceToHost, 0), "read batch");
+	HIP_OK(hipMemcpyAsync(post.data(), d + o_post, post.size() * 8, hipMemcpyDeviceToHost, 0), "read batch");
+	HIP_OK(hipStreamSynchronize(0), "batch");
+	for (int c = 0; c < n_cand; c++) {
+		int correct = 0;                                               // build_acc_oob
+		for (int s : g.oob)
+			correct += compare_hla(best[((size_t)c * 2) * np + s], best[((size_t)c * 2 + 1) * np + s], g.true1[s], g.true2[s]);
+		acc_oob[c] = correct;
+		double loglik = 0;                                             // build_acc_ib
+		for (int s : g.inbag) loglik += g.boot[s] * std::log(post[(size_t)c * np + s]);
+		loss_ib[c] = loglik * -2;
+	}
+	g.evaluated = false;
 }

@@ -42,4 +42,15 @@ void hibag_build_set_haplo_geno(const PluginHaplotype haplo[], int n_haplo, cons
 int hibag_build_acc_oob();
 double hibag_build_acc_ib();
 
+
+// batched scoring of the candidate SNPs of one growth step, for the library's own driver
+// (hibag_train.hip); same results as set_haplo_geno + acc_oob + acc_ib per candidate
+struct HibagBuildCandidate {
+	const PluginHaplotype *haplo;   // aux.hla_allele filled (SetHaploAux_GPU)
+	int n_haplo;
+	const int32_t *column;          // [n_sample] raw genotype of the candidate SNP
+};
+void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const HibagBuildCandidate cand[], int n_cand,
+	int acc_oob[], double loss_ib[]);
+
 #endif

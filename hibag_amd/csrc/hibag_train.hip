@@ -20,6 +20,8 @@
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -27,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <sched.h>
 #include <mutex>
 #include <new>
 #include <string>
@@ -161,7 +164,7 @@ struct hibag_hip_trainer {
 	int g_nsnp = 0;
 	std::vector<int> inbag, outbag;
 	std::vector<PairList> pl;
-	std::vector<double> log_buf;
+	int n_threads = 1;                          // host threads that fit candidate SNPs concurrently
 
 	double unif() { return unif_fn ? unif_fn(unif_ctx) : rng.unif(); }
 	int random_num(int n)                                               // :120-126
@@ -175,6 +178,18 @@ struct hibag_hip_trainer {
 namespace {
 
 typedef hibag_hip_trainer T;
+
+// wall-clock split of a training call, printed when HIBAG_TRAIN_PROFILE is set
+struct Profile {
+	double t[5] = {0, 0, 0, 0, 0};
+	static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+};
+Profile g_prof;
+struct Tick {
+	int k; double t0;
+	explicit Tick(int k_) : k(k_), t0(Profile::now()) {}
+	~Tick() { g_prof.t[k] += Profile::now() - t0; }
+};
 
 void select(T &t, Sampling &s, int m_try)                               // RandomSelect, :949-962
 {
@@ -289,7 +304,9 @@ void prepare_haplotypes(T &t, const HapList &cur, HapList &next)
 	}
 }
 
-bool prepare_new_snp(T &t, int snp, const HapList &cur, HapList &next)  // PrepareNewSNP, :1127-1183
+// PrepareNewSNP, :1127-1183.  `pl` / `next` are the caller's working copies: candidates of one
+// growth step are fitted concurrently, each on its own copy.
+bool prepare_new_snp(const T &t, int snp, const HapList &cur, HapList &next, std::vector<PairList> &pls)
 {
 	int allele_cnt = 0, valid_cnt = 0;
 	for (int i : t.inbag) {
@@ -304,7 +321,7 @@ bool prepare_new_snp(T &t, int snp, const HapList &cur, HapList &next)  // Prepa
 		next.list[2 * i + 1].freq = p1 * cur.list[i].freq + EM_INIT_VAL_FRAC;
 	}
 	const int idx_new = next.n_snp - 1;
-	for (PairList &pl : t.pl) {
+	for (PairList &pl : pls) {
 		const int geno = t.geno[(size_t)pl.samp * t.n_snp + snp];
 		for (HapPair &p : pl.p)
 			p.flag = (0 <= geno && geno <= 2) ?
@@ -313,18 +330,18 @@ bool prepare_new_snp(T &t, int snp, const HapList &cur, HapList &next)  // Prepa
 	return true;
 }
 
-void expectation_maximization(T &t, HapList &next)                      // ExpectationMaximization, :1185-1255
+void expectation_maximization(const T &t, HapList &next, std::vector<PairList> &pls, std::vector<double> &log_buf)   // :1185-1255
 {
 	const int total = t.n_samp;
 	const double em_reltol = std::sqrt(DBL_EPSILON);                    // :102
 	double conv_tol = 0, loglik = -1e+30;
-	const size_t num = t.pl.size();
-	if (t.log_buf.size() < num) t.log_buf.resize(num);
+	const size_t num = pls.size();
+	if (log_buf.size() < num) log_buf.resize(num);
 	for (int iter = 0; iter <= EM_MAX_ITER; iter++) {
 		const double old_loglik = loglik;
 		for (size_t i = 0; i < next.list.size(); i++) { next.old_freq[i] = next.list[i].freq; next.list[i].freq = 0; }
 		for (size_t i = 0; i < num; i++) {
-			PairList &pl = t.pl[i];
+			PairList &pl = pls[i];
 			double psum = 0;
 			for (HapPair &p : pl.p)
 				if (p.flag) {
@@ -332,14 +349,14 @@ void expectation_maximization(T &t, HapList &next)                      // Expec
 					                         : (next.old_freq[p.h1] * next.old_freq[p.h2]);
 					psum += p.gfreq;
 				}
-			t.log_buf[i] = pl.boot * std::log(psum);
+			log_buf[i] = pl.boot * std::log(psum);
 			psum = pl.boot / psum;
 			for (HapPair &p : pl.p) if (p.flag) p.gfreq *= psum;
 		}
 		loglik = 0;
 		for (size_t i = 0; i < num; i++) {
-			loglik += t.log_buf[i];
-			for (const HapPair &p : t.pl[i].p)
+			loglik += log_buf[i];
+			for (const HapPair &p : pls[i].p)
 				if (p.flag) { next.list[p.h1].freq += p.gfreq; next.list[p.h2].freq += p.gfreq; }
 		}
 		const double scale = 0.5 / total;
@@ -383,6 +400,23 @@ void erase_double_haplos(const HapList &in, double rare_prob, HapList &out)   //
 	for (PluginHaplotype &h : out.list) h.freq *= scale;
 }
 
+// CPUs this process may use: affinity mask capped by the cgroup quota; HIBAG_TRAIN_THREADS overrides
+int usable_threads()
+{
+	if (const char *e = getenv("HIBAG_TRAIN_THREADS")) return std::max(1, atoi(e));
+	int n = (int)std::thread::hardware_concurrency();
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char quota[32];
+		long period = 0;
+		if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+			n = std::min(n, std::max(1, (int)((atol(quota) + period / 2) / period)));
+		fclose(f);
+	}
+	return std::max(1, std::min(n, 64));
+}
+
 const char *date_text()
 {
 	static char buf[64];
@@ -395,7 +429,7 @@ const char *date_text()
 void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool verbose_detail)
 {
 	const double rare_prob = std::max(FRACTION_HAPLO / (2 * t.n_samp), MIN_RARE_FREQ);
-	HapList out_haplo, next, reduced, minh;
+	HapList out_haplo, next, minh;
 	init_haplotype(t, out_haplo);
 	o.snpidx.clear();
 	const int num_oob = (int)t.outbag.size();
@@ -403,23 +437,65 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 	double global_min_loss = 1e+30;
 
 	while (!vs.a.empty() && (int)o.snpidx.size() < MAX_SNP) {
-		prepare_haplotypes(t, out_haplo, next);
+		{ Tick tk(0); prepare_haplotypes(t, out_haplo, next); }
 		int max_acc = global_max_acc, min_i = -1;
 		double min_loss = global_min_loss;
 		select(t, vs, mtry);
-		for (int i = 0; i < vs.m_try; i++) {
-			if (!prepare_new_snp(t, vs.at(i), out_haplo, next)) continue;
-			expectation_maximization(t, next);
-			erase_double_haplos(next, rare_prob, reduced);
-			add_snp(t, vs.at(i));
-			set_aux(reduced);                                           // _Init_EvalAcc, :1913-1929
-			hibag_build_set_haplo_geno(reduced.list.data(), (int)reduced.list.size(), t.g.data(), reduced.n_snp);
-			double loss = 0;
-			const int acc = hibag_build_acc_oob();
-			if (acc >= max_acc) loss = hibag_build_acc_ib();
-			t.g_nsnp--;                                                 // ReduceSNP
-			if (acc > max_acc) { min_i = i; min_loss = loss; max_acc = acc; minh = reduced; }
-			else if (acc == max_acc && loss < min_loss) { min_i = i; min_loss = loss; minh = reduced; }
+
+		// The candidates of a step are independent until they are compared (each starts from
+		// OutHaplo, :2020-2025): fit them concurrently on the host, score them in one device
+		// pass, then apply the reference's sequential comparison to the results.
+		const int m = vs.m_try;
+		std::vector<HapList> cand(m);
+		std::vector<char> valid(m, 0);
+		{
+			Tick tk(1);
+			std::atomic<int> next_i(0);
+			auto work = [&]() {
+				HapList nx;
+				std::vector<PairList> pls;
+				std::vector<double> log_buf;
+				for (int i; (i = next_i.fetch_add(1)) < m;) {
+					nx = next; pls = t.pl;
+					if (!prepare_new_snp(t, vs.at(i), out_haplo, nx, pls)) continue;
+					expectation_maximization(t, nx, pls, log_buf);
+					erase_double_haplos(nx, rare_prob, cand[i]);
+					set_aux(cand[i]);                                   // _Init_EvalAcc, :1913-1929
+					valid[i] = 1;
+				}
+			};
+			const int n_thr = std::max(1, std::min(m, t.n_threads));
+			std::vector<std::thread> pool;
+			for (int k = 1; k < n_thr; k++) pool.emplace_back(work);
+			work();
+			for (std::thread &th : pool) th.join();
+		}
+		std::vector<int> accv(m, 0);
+		std::vector<double> lossv(m, 0.0);
+		{
+			Tick tk(2);
+			std::vector<HibagBuildCandidate> bc;
+			std::vector<std::vector<int32_t>> cols;
+			std::vector<int> which;
+			for (int i = 0; i < m; i++) {
+				if (!valid[i]) continue;
+				cols.emplace_back(t.n_samp);
+				for (int k = 0; k < t.n_samp; k++) cols.back()[k] = t.geno[(size_t)k * t.n_snp + vs.at(i)];
+				which.push_back(i);
+			}
+			for (size_t j = 0; j < which.size(); j++)
+				bc.push_back(HibagBuildCandidate{cand[which[j]].list.data(), (int)cand[which[j]].list.size(), cols[j].data()});
+			std::vector<int> a(bc.size());
+			std::vector<double> l(bc.size());
+			hibag_build_eval_batch(t.g.data(), t.g_nsnp + 1, bc.data(), (int)bc.size(), a.data(), l.data());
+			for (size_t j = 0; j < which.size(); j++) { accv[which[j]] = a[j]; lossv[which[j]] = l[j]; }
+		}
+		for (int i = 0; i < m; i++) {                                   // :2018-2069
+			if (!valid[i]) continue;
+			const int acc = accv[i];
+			const double loss = acc >= max_acc ? lossv[i] : 0;          // the in-bag loss is only looked at then (:2033-2034)
+			if (acc > max_acc) { min_i = i; min_loss = loss; max_acc = acc; minh = cand[i]; }
+			else if (acc == max_acc && loss < min_loss) { min_i = i; min_loss = loss; minh = cand[i]; }
 			if (prune) {
 				if (acc < global_max_acc) vs.at(i) = -1;
 				else if (acc == global_max_acc && loss > global_min_loss * (1 + PRUNE_RELTOL_LOGLIK) && min_i != i) vs.at(i) = -1;
@@ -527,6 +603,7 @@ hibag_hip_trainer *hibag_hip_trainer_new(int n_snp, int n_samp, const int32_t *s
 	t->geno.assign(snp_geno, snp_geno + (size_t)n_samp * n_snp);
 	t->h1.assign(H1, H1 + n_samp); t->h2.assign(H2, H2 + n_samp);
 	t->g.assign(n_samp, PluginGenotype{});
+	t->n_threads = usable_threads();
 	return t;
 }
 
@@ -557,7 +634,12 @@ int hibag_hip_trainer_new_classifiers(hibag_hip_trainer *t, int nclassifier, int
 	std::lock_guard<std::mutex> g2(device_state);
 	const size_t before = t->out.size();
 	try {
+		g_prof = Profile();
+		const double t0 = Profile::now();
 		build_classifiers(*t, nclassifier, mtry, prune != 0, verbose != 0 || verbose_detail != 0, verbose_detail != 0);
+		if (getenv("HIBAG_TRAIN_PROFILE"))
+			fprintf(stderr, "[hibag train] total %.3f s: pair lists (device) %.3f, EM (host) %.3f, scoring (device) %.3f\n",
+				Profile::now() - t0, g_prof.t[0], g_prof.t[1], g_prof.t[2]);
 	} catch (const char *msg) {
 		t->out.resize(before);                         // a failed call adds nothing
 		return hibag_fail(hibag_hip_device_count() <= 0 ? HIBAG_HIP_ENODEV : HIBAG_HIP_EINVAL, "%s", msg);
