@@ -11,11 +11,12 @@ from .hibag import (HlaAlleleClass, HlaAttrBagClass, hlaClose, hlaModelFromObj, 
                     hlaPredict, hlaSetKernelTarget)
 from .snpmatch import hlaGenoSwitchStrand, hlaSNPID  # noqa: F401
 from .bed import HlaBEDGeno, hlaBED2Geno, hlaLociInfo  # noqa: F401
-from .train import RRandom, hlaAllele, hlaAttrBagging, hlaUniqueAllele, set_seed  # noqa: F401
+from .train import (RRandom, hlaAllele, hlaAttrBagging, hlaParallelAttrBagging, hlaUniqueAllele,  # noqa: F401
+                    set_seed)
 from ._lib import HibagHipError  # noqa: F401
 
 __all__ = ["NA_INTEGER", "Classifier", "HlaAttrBagObj", "HlaSNPGeno", "load_geno", "load_model",
            "HlaAlleleClass", "HlaAttrBagClass", "hlaClose", "hlaModelFromObj", "hlaModelToObj",
            "hlaPredict", "hlaSetKernelTarget", "hlaGenoSwitchStrand", "hlaSNPID", "HibagHipError",
-           "HlaBEDGeno", "hlaBED2Geno", "hlaLociInfo", "RRandom", "hlaAllele", "hlaAttrBagging", "hlaUniqueAllele",
+           "HlaBEDGeno", "hlaBED2Geno", "hlaLociInfo", "RRandom", "hlaAllele", "hlaAttrBagging", "hlaParallelAttrBagging", "hlaUniqueAllele",
            "set_seed"]

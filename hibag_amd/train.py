@@ -207,10 +207,11 @@ def _row_mean_half(g: np.ndarray) -> np.ndarray:
 def hlaAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,
                    mtry: Union[str, float, int] = "sqrt", prune: bool = True, na_rm: bool = True,
                    mono_rm: bool = True, maf: float = float("nan"), nthread: int = 1, verbose: bool = True,
-                   verbose_detail: bool = False, rng: Optional[RRandom] = None) -> HlaAttrBagClass:
+                   verbose_detail: bool = False, rng: Optional[RRandom] = None, grow=None) -> HlaAttrBagClass:
     """``hlaAttrBagging`` (``R/HIBAG.R:48-275``).  ``nthread`` is accepted for signature
     compatibility (the scoring runs on the device).  ``rng`` defaults to the module's
-    R-compatible stream (see :func:`set_seed`)."""
+    R-compatible stream (see :func:`set_seed`).  ``grow`` (internal) replaces the single-device
+    call of the native driver, see :func:`hlaParallelAttrBagging`."""
     if not isinstance(hla, HlaAlleleClass):
         raise TypeError("inherits(hla, \"hlaAlleleClass\") is not TRUE")
     if not isinstance(snp, HlaSNPGeno):
@@ -288,13 +289,16 @@ def hlaAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,
         print(f"    # of SNPs: {n_snp}\n    # of samples: {n_samp}")
         print(f"    # of unique {'KIR' if hla.locus.startswith('KIR') else 'HLA'} alleles: {len(HUA)}")
 
-    tr = _Trainer(np.ascontiguousarray(geno.T), H1, H2, len(HUA))
-    try:
-        tr.set_rng(_R if rng is None else rng)
-        tr.new_classifiers(nclassifier, m, prune, verbose, verbose_detail)
-        classifiers = tr.classifiers()
-    finally:
-        tr.close()
+    if grow is None:
+        tr = _Trainer(np.ascontiguousarray(geno.T), H1, H2, len(HUA))
+        try:
+            tr.set_rng(_R if rng is None else rng)
+            tr.new_classifiers(nclassifier, m, prune, verbose, verbose_detail)
+            classifiers = tr.classifiers()
+        finally:
+            tr.close()
+    else:
+        classifiers = grow(np.ascontiguousarray(geno.T), H1, H2, len(HUA), nclassifier, m, prune)
 
     counts = np.bincount(np.concatenate([H1, H2]), minlength=len(HUA)).astype(np.float64)
     obj = HlaAttrBagObj(
@@ -312,3 +316,57 @@ def hlaAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,
             acc = np.mean([c.outofbag_acc for c in classifiers]) * 100
             print(f"Out-of-bag accuracy: {acc:.2f}%")
     return mod
+
+
+def grow_classifier_sharded(grow_fn, nclassifier: int, group=None) -> List[Classifier]:
+    """Classifiers are independent given their random draws (``src/LibHLA.cpp:2274-2304``):
+    every rank grows its share with ``grow_fn(count, rank)`` and the shares are concatenated
+    in rank order on every rank (one ``all_gather_object`` of the small classifier records --
+    the counterpart of ``hlaCombineModelObj``, ``R/HIBAG.R:1069-1114``).  No collective on the
+    compute path."""
+    import torch.distributed as dist
+    from .dist import shard_bounds
+
+    live = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if live else 1
+    rank = dist.get_rank(group) if live else 0
+    lo, hi = shard_bounds(int(nclassifier), world, rank)
+    mine = grow_fn(hi - lo, rank)
+    if world == 1:
+        return list(mine)
+    parts: List = [None] * world
+    dist.all_gather_object(parts, list(mine), group=group)
+    return [c for part in parts for c in part]
+
+
+def hlaParallelAttrBagging(cl, hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,
+                           mtry: Union[str, float, int] = "sqrt", prune: bool = True, na_rm: bool = True,
+                           mono_rm: bool = True, maf: float = float("nan"), verbose: bool = True,
+                           verbose_detail: bool = False, seed: Optional[int] = None, group=None) -> HlaAttrBagClass:
+    """``hlaParallelAttrBagging`` (``R/HIBAG.R:293-440``) for one process per GPU: ``cl`` is
+    accepted for signature compatibility; the "cluster" is the initialised
+    ``torch.distributed`` process group (RCCL on a GPU box).  Like the reference's workers
+    (``clusterSetRNGStream``) every rank draws from its own stream: R's Mersenne-Twister seeded
+    with ``seed + rank`` -- so the model differs from a serial run with the same seed, as it
+    does in the reference.  Every rank returns the complete model."""
+    import torch.distributed as dist
+    live = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if live else 0
+    base = 0 if seed is None else int(seed)
+
+    def grow(genomat, h1, h2, n_hla, n, m, pr):
+        def grow_fn(count, r):
+            if count <= 0:
+                return []
+            tr = _Trainer(genomat, h1, h2, n_hla)
+            try:
+                tr.set_seed(base + r)
+                tr.new_classifiers(count, m, pr, verbose and rank == 0, verbose_detail and rank == 0)
+                return tr.classifiers()
+            finally:
+                tr.close()
+        return grow_classifier_sharded(grow_fn, n, group)
+
+    return hlaAttrBagging(hla, snp, nclassifier=nclassifier, mtry=mtry, prune=prune, na_rm=na_rm, mono_rm=mono_rm,
+                          maf=maf, verbose=verbose and rank == 0, verbose_detail=verbose_detail, grow=grow)
+

@@ -149,3 +149,53 @@ def test_classifier_sharded_entry_points_on_one_gpu(oracle):
     same = ff(pf(G))
     for k in same:
         assert np.array_equal(same[k], full[k], equal_nan=True), k
+
+
+def _train_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from hibag_amd import synth, train
+    from hibag_amd.model import Classifier
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model, founders, af = synth.make_model("hla-a-small", seed=5, n_snp=40)
+    G, truth = synth.make_samples(founders, af, 80, seed=6)
+
+    def grow_fn(count, r):          # the oracle's CPU trainer stands in for the device-scored driver
+        out = O.train(G, truth[:, 0], truth[:, 1], model.n_hla, count, 6, True, 300 + r)
+        return [Classifier(snpidx=o["snpidx"], freq=o["freq"], hla=o["hla"], haplo=o["haplo"], samp_num=o["samp_num"],
+                           outofbag_acc=o["acc"]) for o in out]
+
+    got = train.grow_classifier_sharded(grow_fn, 5)
+    if rank == 0:
+        q.put([(c.snpidx.tolist(), c.freq.tolist(), c.haplo, c.samp_num.tolist()) for c in got])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_training_shards(oracle):
+    """hlaParallelAttrBagging's orchestration: ranks grow 3 + 2 classifiers from their own streams,
+    every rank ends up with all 5 in rank order."""
+    import torch.multiprocessing as mp
+    from hibag_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    model, founders, af = synth.make_model("hla-a-small", seed=5, n_snp=40)
+    G, truth = synth.make_samples(founders, af, 80, seed=6)
+    want = oracle.train(G, truth[:, 0], truth[:, 1], model.n_hla, 3, 6, True, 300) + \
+        oracle.train(G, truth[:, 0], truth[:, 1], model.n_hla, 2, 6, True, 301)
+    assert len(got) == 5
+    for (snpidx, freq, haplo, samp), w in zip(got, want):
+        assert snpidx == w["snpidx"].tolist() and freq == w["freq"].tolist() and haplo == w["haplo"]
+        assert samp == w["samp_num"].tolist()

@@ -105,3 +105,27 @@ def test_trainer_argument_errors(hib):
     assert t and L.hibag_hip_trainer_n_classifier(t) == 0
     assert L.hibag_hip_trainer_new_classifiers(t, 1, 0, 1, 0, 0) == -1
     L.hibag_hip_trainer_free(t)
+
+
+def test_parallel_entry_single_rank(hib, oracle):
+    """hlaParallelAttrBagging without a process group = one rank: stream seed + 0."""
+    from hibag_amd import synth
+    model, founders, af = synth.make_model("hla-a-small", seed=5, n_snp=40)
+    G, truth = synth.make_samples(founders, af, 80, seed=6)
+    ids = [f"S{i}" for i in range(80)]
+    hla = hib.hlaAllele(ids, [model.hla_allele[a] for a in truth[:, 0]], [model.hla_allele[a] for a in truth[:, 1]], locus="A",
+                        assembly="hg19")
+    snp = hib.HlaSNPGeno(genotype=np.ascontiguousarray(G.T), sample_id=ids, snp_id=list(model.snp_id),
+                         snp_position=model.snp_position, snp_allele=list(model.snp_allele), assembly="hg19")
+    mod = hib.hlaParallelAttrBagging(None, hla, snp, nclassifier=3, mtry=6, mono_rm=False, verbose=False, seed=300)
+    used = sorted(set(truth.ravel().tolist()))
+    remap = {a: i for i, a in enumerate(used)}            # the model only knows the alleles that occur
+    assert mod.obj.hla_allele == hib.hlaUniqueAllele([model.hla_allele[a] for a in used])
+    order = {a: i for i, a in enumerate(mod.obj.hla_allele)}
+    h1 = np.array([order[model.hla_allele[a]] for a in truth[:, 0]], np.int32)
+    h2 = np.array([order[model.hla_allele[a]] for a in truth[:, 1]], np.int32)
+    want = oracle.train(G, h1, h2, len(used), 3, 6, True, 300)
+    assert len(mod.obj.classifiers) == 3 and mod.obj.matching is not None and len(mod.obj.matching) == 80
+    for i, (g, w) in enumerate(zip(mod.obj.classifiers, want)):
+        assert np.array_equal(g.snpidx, w["snpidx"]) and np.array_equal(g.freq, w["freq"]) and g.haplo == w["haplo"], i
+    del remap
