@@ -13,10 +13,11 @@ from .snpmatch import hlaGenoSwitchStrand, hlaSNPID  # noqa: F401
 from .bed import HlaBEDGeno, hlaBED2Geno, hlaLociInfo  # noqa: F401
 from .train import (RRandom, hlaAllele, hlaAttrBagging, hlaParallelAttrBagging, hlaUniqueAllele,  # noqa: F401
                     set_seed)
+from .merge import hlaAlleleDigit, hlaPredMerge  # noqa: F401
 from ._lib import HibagHipError  # noqa: F401
 
 __all__ = ["NA_INTEGER", "Classifier", "HlaAttrBagObj", "HlaSNPGeno", "load_geno", "load_model",
            "HlaAlleleClass", "HlaAttrBagClass", "hlaClose", "hlaModelFromObj", "hlaModelToObj",
            "hlaPredict", "hlaSetKernelTarget", "hlaGenoSwitchStrand", "hlaSNPID", "HibagHipError",
-           "HlaBEDGeno", "hlaBED2Geno", "hlaLociInfo", "RRandom", "hlaAllele", "hlaAttrBagging", "hlaParallelAttrBagging", "hlaUniqueAllele",
+           "HlaBEDGeno", "hlaBED2Geno", "hlaLociInfo", "RRandom", "hlaAllele", "hlaAttrBagging", "hlaParallelAttrBagging", "hlaUniqueAllele", "hlaAlleleDigit", "hlaPredMerge",
            "set_seed"]

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIBAG_HIP_ABI_VERSION 1
+#define HIBAG_HIP_ABI_VERSION 2   /* 2: + PLINK BED entries, training driver */
 
 /* error codes */
 #define HIBAG_HIP_OK          0

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.hibag_hip_abi_version() == 1
+    assert L.hibag_hip_abi_version() == 2
 
 
 def test_no_cpu_fallback_in_product():
@@ -142,3 +142,37 @@ def test_no_gpu_means_loud_failure_not_fallback():
     model, _, _ = synth.make_model("hla-a-small", n_classifier=2)
     with pytest.raises(hibag_amd.HibagHipError):                # finalize needs the device
         hibag_amd.hlaModelFromObj(model)
+
+
+def test_pred_merge_host_logic():
+    """hlaPredMerge (R/HIBAG.R:825-1023): weighted, matching-scaled sum of posterior matrices over
+    the union of alleles, renormalised per sample."""
+    import numpy as np
+    import hibag_amd as hb
+    from hibag_amd.hibag import HlaAlleleClass, _pair_names
+    rng = np.random.default_rng(1)
+
+    def fake(alleles, n=5):
+        names = _pair_names(alleles)
+        p = rng.random((len(names), n))
+        p /= p.sum(axis=0)
+        return HlaAlleleClass(locus="A", sample_id=list(range(n)), allele1=[None] * n, allele2=[None] * n,
+                              prob=p.max(axis=0), matching=rng.random(n), assembly="hg19", postprob=p, pair_names=names)
+
+    a = fake(["01:01", "02:01", "03:01"])
+    b = fake(["02:01", "03:01", "24:02"])
+    same = hb.hlaPredMerge(a, verbose=False, ret_postprob=True)
+    assert same.pair_names == a.pair_names and np.allclose(same.postprob, a.postprob, rtol=1e-15)
+    assert [f"{y}/{x}" for x, y in zip(same.allele1, same.allele2)] == [a.pair_names[j] for j in a.postprob.argmax(axis=0)]
+    m = hb.hlaPredMerge(a, b, weight=[3, 1], verbose=False, ret_postprob=True)
+    assert m.pair_names == _pair_names(["01:01", "02:01", "03:01", "24:02"])
+    assert np.allclose(m.postprob.sum(axis=0), 1) and np.allclose(m.dosage.sum(axis=0), 2)
+    j = m.pair_names.index("03:01/02:01")
+    want = 0.75 * a.matching * a.postprob[a.pair_names.index("03:01/02:01")] + 0.25 * b.matching * b.postprob[b.pair_names.index("03:01/02:01")]
+    tot = 0.75 * a.matching * 1 + 0.25 * b.matching * 1
+    assert np.allclose(m.postprob[j], want / tot) and np.allclose(m.matching, 0.75 * a.matching + 0.25 * b.matching)
+    low = hb.hlaPredMerge(a, b, max_resolution="2-digit", verbose=False, ret_postprob=True)
+    assert low.pair_names == _pair_names(["01", "02", "03", "24"]) and np.allclose(low.postprob.sum(axis=0), 1)
+    assert hb.hlaAlleleDigit(["01:01:01G", "02:01N", None], "4-digit", rm_suffix=True) == ["01:01", "02:01", None]
+    with pytest.raises(ValueError, match="sample IDs"):
+        hb.hlaPredMerge(a, fake(["01:01"], n=4), verbose=False)
