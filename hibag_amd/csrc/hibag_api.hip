@@ -149,11 +149,11 @@ struct hibag_hip_model {
 	// device model
 	DevBuf d_int, d_stream, d_tile, d_tab, d_blk;
 	HibagModelView view{};
-	int mask_rows = 0, bt_rows = 0;
+	int mask_rows = 0, bt_rows = 0, cellsum_rows = 0;
 	size_t stream_bytes = 0;
 
 	// per-batch workspace (grow-only)
-	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias;
+	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias, ws_cellsum;
 	// plugin staging
 	DevBuf ws_tgeno, ws_weight;
 	// PLINK BED payload + SNP map of hibag_hip_predict_bed
@@ -166,7 +166,7 @@ struct hibag_hip_model {
 	{
 		(void)hipSetDevice(device);
 		timer.destroy();
-		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
+		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_cellsum, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
 		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_tgeno, &ws_weight, &ws_bed, &ws_bedidx})
 			b->release();
 	}
@@ -483,6 +483,61 @@ int finalize_model(hibag_hip_model *m)
 	}
 	if (cls_cnt.empty()) { cls_cnt.push_back(0); cls_cell.push_back(0); }
 
+	// pass-1 work items.  One per classifier, except VALU-engine classifiers (more than 32 SNPs)
+	// whose work dwarfs the typical one: a single wavefront per sample group would walk them for
+	// many times the duration of the rest of the pass, so they are cut into items of typical size
+	// that store per-cell sums, added in order afterwards (k_total_scan).
+	std::vector<int> item, item_whole, split_row(std::max(C, 1), -1), split_cls;
+	int cellsum_rows = 0;
+	double split_heavy_ns = 0, split_rest_ns = 0;
+	{
+		// rough wavefront-time per record: matrix engine 50 ns at full occupancy, VALU engine 12 ns per
+		// 32-bit word when few wavefronts share a SIMD (the situation in which a tail forms), 4x that otherwise
+		std::vector<double> work(C, 0.0);
+		double typical = 0;
+		int n_typ = 0;
+		for (int c = 0; c < C; c++) {
+			work[c] = (double)pairs[c] * (mfma_nkb[c] ? 50.0 : 48.0 * nwp[c]);
+			if (mfma_nkb[c]) { typical += work[c]; n_typ++; }
+			split_rest_ns += work[c];
+		}
+		typical = n_typ ? typical / n_typ : 0;
+		std::vector<std::pair<double, std::vector<int>>> items, whole;
+		for (int c = 0; c < C; c++) {
+			whole.push_back({work[c], {c, 0, cls_n[c], 0}});
+			int nseg = 1;
+			if (!mfma_nkb[c] && typical > 0 && work[c] > 3 * typical)
+				nseg = (int)std::min<double>(64, std::max(2.0, std::floor(work[c] / typical)));
+			if (nseg == 1 || cls_n[c] < 2) {
+				items.push_back({work[c], {c, 0, cls_n[c], 0}});
+				continue;
+			}
+			split_heavy_ns = std::max(split_heavy_ns, (double)pairs[c] * 12.0 * nwp[c]);
+			split_row[c] = cellsum_rows;
+			cellsum_rows += cls_n[c];
+			split_cls.push_back(c);
+			uint64_t total = 0, acc = 0, chunk0 = 0;
+			for (int i = 0; i < cls_n[c]; i++) total += cls_cnt[cls_off[c] + i] + 1;
+			int i0 = 0, k = 1;
+			for (int i = 0; i < cls_n[c]; i++) {
+				acc += cls_cnt[cls_off[c] + i] + 1;
+				const bool last = i + 1 == cls_n[c];
+				if (last || acc * nseg >= total * k) {
+					uint64_t chunks = 0;
+					for (int j = i0; j <= i; j++) chunks += cls_cnt[cls_off[c] + j];
+					items.push_back({work[c] * (double)(chunks + 1) / (double)total, {c, i0, i + 1, (int)chunk0}});
+					chunk0 += chunks;
+					i0 = i + 1;
+					while (k < nseg && acc * nseg >= total * k) k++;
+				}
+			}
+		}
+		std::stable_sort(whole.begin(), whole.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+		for (const auto &it : whole) item_whole.insert(item_whole.end(), it.second.begin(), it.second.end());
+		std::stable_sort(items.begin(), items.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+		for (const auto &it : items) item.insert(item.end(), it.second.begin(), it.second.end());
+	}
+
 	// block streams of the matrix-core engine
 	std::vector<uint32_t> blk_stream, blk_tile((size_t)std::max(C, 1) * n_tile * 2 + 2, 0);
 	// Two layouts per classifier: per tile (pass 2: a wavefront walks one tile's blocks) and
@@ -502,6 +557,15 @@ int finalize_model(hibag_hip_model *m)
 		uint32_t whole[2];
 		build_block_stream(raw[c], nwp[c], mfma_nkb[c], spare, all_p0, all_n, blk_stream, whole, cls_nblk[c]);
 		raw[c] = RawRecords();
+	}
+	if (getenv("HIBAG_DEBUG_MODEL")) {
+		long long b1 = 0, b2 = 0, b2_tiles = 0;
+		for (int c = 0; c < C; c++) {
+			b1 += cls_nblk[c];
+			for (int t = 0; t < n_tile; t++) { b2 += blk_tile[((size_t)c * n_tile + t) * 2 + 1]; b2_tiles += blk_tile[((size_t)c * n_tile + t) * 2 + 1] > 0; }
+		}
+		fprintf(stderr, "[hibag model] %d classifiers, %d tiles, pairs %lld; blocks of 32: pass 1 %lld, pass 2 %lld in %lld (classifier, tile) segments\n",
+			C, n_tile, (long long)m->pair_evals, b1, b2, b2_tiles);
 	}
 	blk_stream.insert(blk_stream.end(), 2 * HIBAG_BLOCK_DWORDS(3), 0);   // look-ahead slack of the block walker
 	// per (classifier, tile) record of pass 2 (one s_load_dwordx8)
@@ -528,7 +592,8 @@ int finalize_model(hibag_hip_model *m)
 	};
 	const size_t o_nsnp = put(n_snp_c), o_nwp = put(nwp), o_snpoff = put(snp_off), o_snpidx = put(snp_index),
 		o_snpw = put(snp_weight), o_mrow = put(mask_row), o_order = put(c_order), o_tp0 = put(tile_p0), o_tn = put(tile_n),
-		o_coff = put(cls_off), o_cn = put(cls_n), o_nkb = put(mfma_nkb), o_btrow = put(bt_row), o_nblk = put(cls_nblk), o_bik = put(mfma_bik);
+		o_coff = put(cls_off), o_cn = put(cls_n), o_nkb = put(mfma_nkb), o_btrow = put(bt_row), o_nblk = put(cls_nblk), o_bik = put(mfma_bik),
+		o_item = put(item), o_srow = put(split_row), o_scls = put(split_cls), o_itemw = put(item_whole);
 
 	if (int rc = m->d_int.reserve(arena.size() * sizeof(int))) return rc;
 	if (int rc = m->d_stream.reserve(stream.size() * sizeof(uint32_t))) return rc;
@@ -565,6 +630,11 @@ int finalize_model(hibag_hip_model *m)
 	V.cls_cell = (const uint32_t *)(tbase + tb_cell);
 	V.cls_off = base + o_coff; V.cls_n = base + o_cn;
 	V.mfma_nkb = base + o_nkb; V.bt_row = base + o_btrow; V.cls_nblk = base + o_nblk; V.mfma_bik = base + o_bik;
+	V.n_item_split = (int)item.size() / 4; V.n_item_whole = (int)item_whole.size() / 4; V.n_split = (int)split_cls.size();
+	V.item_split = base + o_item; V.item_whole = base + o_itemw; V.item = V.item_whole; V.n_item = V.n_item_whole;
+	V.split_row = base + o_srow; V.split_cls = base + o_scls;
+	V.split_heavy_ns = split_heavy_ns; V.split_rest_ns = split_rest_ns;
+	m->cellsum_rows = cellsum_rows;
 	V.blk_off = (const uint64_t *)(tbase + tb_boff);
 	V.blk_tile = (const uint32_t *)(tbase + tb_btile);
 	V.ctile = (const uint32_t *)(tbase + tb_ctile);
@@ -584,7 +654,7 @@ int finalize_model(hibag_hip_model *m)
 int batch_limit(const hibag_hip_model *m)
 {
 	const double per_sample = 8.0 * (m->view.n_cell + 3) + 24.0 * m->view.n_classifier +
-		4.0 * m->mask_rows + 4.0 * m->view.n_classifier + 16.0 * m->bt_rows + 8.0 * m->view.n_classifier;
+		4.0 * m->mask_rows + 4.0 * m->view.n_classifier + 16.0 * m->bt_rows + 8.0 * m->view.n_classifier + 8.0 * m->cellsum_rows;
 	int lim = (int)(1.5e9 / std::max(per_sample, 1.0));
 	lim = std::max(64, std::min(lim, 1 << 17));
 	return lim / 64 * 64;
@@ -602,6 +672,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	if (int rc = m->ws_codes.reserve((size_t)std::max(m->n_snp, 1) * n_pad)) return rc;
 	if (int rc = m->ws_bt.reserve((size_t)std::max(m->bt_rows, 1) * n_pad * sizeof(uint4))) return rc;
 	if (int rc = m->ws_bias.reserve(2 * C * n_pad * sizeof(int))) return rc;
+	if (int rc = m->ws_cellsum.reserve((size_t)std::max(m->cellsum_rows, 1) * n_pad * sizeof(double))) return rc;
 	if (need_best)
 		if (int rc = m->ws_best.reserve(C * n_pad * sizeof(int))) return rc;
 	B.n_samp = n_samp; B.n_pad = n_pad;
@@ -609,6 +680,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	B.cw = m->ws_cw.as<double>(); B.tot = m->ws_tot.as<double>(); B.inv = m->ws_inv.as<double>();
 	B.part = m->ws_part.as<double>();
 	B.bt = m->ws_bt.as<uint4>(); B.bias = m->ws_bias.as<int>();
+	B.cellsum = m->ws_cellsum.as<double>();
 	return 0;
 }
 

@@ -79,6 +79,17 @@ struct HibagModelView {
 	const uint32_t *cls_cell;    // same layout: posterior index of each non-empty cell
 	const int *cls_off;          // [C] offset of the classifier's list in cls_cnt / cls_cell
 	const int *cls_n;            // [C] number of non-empty cells
+	// pass-1 work items (heaviest first): {classifier, first cell, end cell, first chunk} in the classifier's
+	// non-empty cell list.  A VALU-engine classifier with far more work than the others is cut into
+	// several items that store their cell sums (split_row[c] = its first row in HibagBatchView::cellsum,
+	// -1 = not split); k_total_scan then adds them in order.
+	int n_item, n_split;
+	const int *item;             // [n_item][4]: the launcher points this at the split or the whole list
+	int n_item_whole, n_item_split;
+	const int *item_whole, *item_split;
+	double split_heavy_ns, split_rest_ns;   // cost model: split when heavy > rest * groups / resident wavefronts
+	const int *split_row;        // [C]
+	const int *split_cls;        // [n_split] the split classifiers
 	const uint64_t *stream_off;  // [C] dword offset of the classifier's stream
 	const uint32_t *stream;      // the pair streams
 	const double *tab;           // [257] exp(d*log(1e-5))
@@ -103,6 +114,7 @@ struct HibagBatchView {
 	double *cw;         // [C][n_pad]
 	double *tot;        // [C][n_pad]
 	double *inv;        // [C][n_pad]
+	double *cellsum;    // [rows of the split classifiers][n_pad] (pass 1 scratch)
 	double *part;       // [P+3][n_pad]
 	// matrix-core engine: per classifier and sample group the B operand tiles
 	// (int8 +1/-1/0 per packed bit, MFMA lane layout) and the distance offsets

@@ -568,18 +568,19 @@ __global__ void k_unpack_tgeno(HibagModelView M, HibagBatchView B,
 // wavefronts of a block owns one group of 64 samples.
 template <int NWP>
 __device__ __forceinline__ double classifier_total(const HibagModelView &M, const HibagBatchView &B,
-	int c, int s, const double *tab_s)
+	int c, int s, int i0, int i1, int chunk0, double *__restrict__ rows, const double *tab_s)
 {
 	LaneMask<NWP> L;
 	load_masks<NWP>(B, M.mask_row[c], s, L);
 	const uint32_t *__restrict__ cnt = M.cls_cnt + M.cls_off[c];
-	const uint32_t *__restrict__ cp = M.stream + M.stream_off[c];
-	const int ncell = M.cls_n[c];
+	const uint32_t *__restrict__ cp = M.stream + M.stream_off[c] + (size_t)chunk0 * HIBAG_CHUNK_DWORDS(NWP);
 	double total = 0;
-	uint32_t n = cnt[0];
-	for (int i = 0; i < ncell; i++) {
+	uint32_t n = cnt[i0];
+	for (int i = i0; i < i1; i++) {
 		const uint32_t n_next = cnt[i + 1];           // fetched while this cell is evaluated
-		total += cell_sum<NWP>(n, cp, L, tab_s);
+		const double cell = cell_sum<NWP>(n, cp, L, tab_s);
+		if (rows) rows[(size_t)i * B.n_pad + s] = cell;   // split classifier: k_total_scan adds the cells in order
+		else total += cell;
 		n = n_next;
 	}
 	return total;
@@ -592,7 +593,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, Hi
 	__shared__ uint2 exp_s[256];
 	stage_expand_table(exp_s);
 	stage_table(M, tab_s);
-	const int c = M.c_order[blockIdx.y];
+	const int *__restrict__ item = M.item + 4 * blockIdx.y;
+	const int c = item[0];
 	const int group = blockIdx.x * BLOCK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (group * HIBAG_WAVE >= B.n_pad) return;
 	const int s = group * HIBAG_WAVE + (threadIdx.x & 63);
@@ -601,6 +603,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, Hi
 	if (__ballot(active) == 0) return;                // nobody needs this classifier
 	double total = 0;
 	const int nkb = M.mfma_nkb[c];
+	const int srow = M.n_split > 0 ? M.split_row[c] : -1;
 	if (nkb > 0) {
 #define CALL(N, BIK) { LaneOperand<N> T; load_operand<N, BIK>(M, B, c, group, threadIdx.x & 63, T);               \
 		walk_blocks<N, BIK>(M.blk_stream + M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, T, tab_s, exp_s,        \
@@ -609,12 +612,28 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, Hi
 		HIBAG_DISPATCH_NKB(M.mfma_bik[c] ? nkb : 4, CALL)
 #undef CALL
 	} else {
-#define CALL(N) total = classifier_total<N>(M, B, c, s, tab_s)
+		double *rows = srow >= 0 ? B.cellsum + (size_t)srow * B.n_pad : nullptr;
+#define CALL(N) total = classifier_total<N>(M, B, c, s, item[1], item[2], item[3], rows, tab_s)
 		HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
 #undef CALL
+		if (rows) return;
 	}
 	B.tot[at] = total;
 	B.inv[at] = 1 / total;                            // src/LibHLA.cpp:1827 (inf when total == 0)
+}
+
+// k_total_scan: the in-order total of a split classifier from its stored cell sums; thread = sample.
+__global__ void k_total_scan(HibagModelView M, HibagBatchView B)
+{
+	const int c = M.split_cls[blockIdx.y];
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= B.n_pad) return;
+	const double *__restrict__ rows = B.cellsum + (size_t)M.split_row[c] * B.n_pad;
+	const int n = M.cls_n[c];
+	double total = 0;
+	for (int i = 0; i < n; i++) total += rows[(size_t)i * B.n_pad + s];
+	B.tot[(size_t)c * B.n_pad + s] = total;
+	B.inv[(size_t)c * B.n_pad + s] = 1 / total;
 }
 
 // ---------------------------------------------------------------------------
@@ -974,7 +993,17 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 	if (M.n_classifier == 0) return;
 	const unsigned gx = (unsigned)((B.n_pad / HIBAG_WAVE + BLOCK_WAVES - 1) / BLOCK_WAVES);
 	static const int dbg_lds = getenv("HIBAG_DEBUG_LDS") ? atoi(getenv("HIBAG_DEBUG_LDS")) : 0;   // occupancy experiments
-	hipLaunchKernelGGL(k_total, dim3(gx, M.n_classifier), dim3(BLOCK_THREADS), dbg_lds, st, M, B);
+	// A classifier far heavier than the rest (VALU engine, > 32 SNPs) is only worth cutting up when its
+	// single-wavefront walk would outlast the rest of the pass, i.e. for small batches.
+	HibagModelView V = M;
+	const double groups = (double)(B.n_pad / HIBAG_WAVE);
+	const bool split = M.n_split > 0 && M.split_heavy_ns > M.split_rest_ns * groups / 4096.0;
+	V.item = split ? M.item_split : M.item_whole;
+	V.n_item = split ? M.n_item_split : M.n_item_whole;
+	if (!split) V.n_split = 0;
+	hipLaunchKernelGGL(k_total, dim3(gx, V.n_item), dim3(BLOCK_THREADS), dbg_lds, st, V, B);
+	if (split)
+		hipLaunchKernelGGL(k_total_scan, dim3(B.n_pad / 64, V.n_split), dim3(64), 0, st, V, B);
 }
 
 void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStream_t st)
