@@ -734,9 +734,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 			uint64_t jpack = ((uint64_t)rec[7] << 32) | rec[6];
 			int j = (int)(jpack & 15);
 			double a = acc[j][lane];
+			// inactive lanes (weight 0) must keep their sums: with 1/total replaced by 0 their term is
+			// (cell * 0) * 0 = +0 and a + 0 == a, which spares a select per closed cell
+			const double inv_e = active ? inv : 0.0;
 			auto fin = [&](double cell) {
-				const double v = (cell * inv) * w;
-				acc[j][lane] = a + (active ? v : 0.0);
+				const double v = (cell * inv_e) * w;
+				acc[j][lane] = a + v;
 				jpack >>= 4;
 				j = (int)(jpack & 15);
 				a = acc[j][lane];
