@@ -170,3 +170,48 @@ def load_geno(path: str, name: Optional[str] = None) -> HlaSNPGeno:
     ws = rdata.load_rdata(path)
     obj = ws[name] if name else next(iter(ws.values()))
     return geno_from_robj(obj)
+
+
+def model_to_robj(obj: HlaAttrBagObj) -> "rdata.RList":
+    """:class:`HlaAttrBagObj` -> the R list ``hlaModelToObj()`` returns (``R/HIBAG.R:1040-1062``; classifier
+    records as built by ``HIBAG_GetClassifierList``, ``src/HIBAG.cpp:871-953``), ready for
+    :func:`hibag_amd.rdata.save_rdata` -- R's ``hlaModelFromObj(get(load(file)))`` reads it back."""
+    R = rdata
+
+    def strs(v):
+        return None if v is None else R.RStrings(list(v))
+
+    def nums(v, dt):
+        return None if v is None else R.RArray(np.asarray(v, dt))
+
+    cls = []
+    for c in obj.classifiers:
+        n = len(c.freq)
+        haplos = R.RList([R.RArray(np.asarray(c.freq, np.float64)), R.RStrings([obj.hla_allele[int(a)] for a in c.hla]),
+                          R.RStrings(list(c.haplo))],
+                         {"names": ["freq", "hla", "haplo"],
+                          "row.names": R.RArray(np.array([NA_INTEGER, -n], np.int32)),      # R's compact 1..n row names
+                          "class": ["data.frame"]})
+        samp = c.samp_num if c.samp_num is not None else np.ones(obj.n_samp, np.int32)
+        cls.append(R.RList([R.RArray(np.asarray(samp, np.int32)), haplos, R.RArray(np.asarray(c.snpidx, np.int32) + 1),
+                            R.RArray(np.array([c.outofbag_acc], np.float64))],
+                           {"names": ["samp.num", "haplos", "snpidx", "outofbag.acc"]}))
+    hla_freq = None
+    if obj.hla_freq is not None:           # prop.table(table(H)): a named 1-d table
+        hla_freq = R.RArray(np.asarray(obj.hla_freq, np.float64),
+                            {"class": ["table"], "dim": R.RArray(np.array([obj.n_hla], np.int32)),
+                             "dimnames": R.RList([R.RStrings(list(obj.hla_allele))], {"names": ["H"]})})
+    fields = [
+        ("n.samp", R.RArray(np.array([obj.n_samp], np.int32))), ("n.snp", R.RArray(np.array([obj.n_snp], np.int32))),
+        ("sample.id", strs(obj.sample_id)), ("snp.id", strs(obj.snp_id)),
+        ("snp.position", nums(obj.snp_position, np.float64)), ("snp.allele", strs(obj.snp_allele)),
+        ("snp.allele.freq", nums(obj.snp_allele_freq, np.float64)), ("hla.locus", R.RStrings([obj.hla_locus])),
+        ("hla.allele", strs(obj.hla_allele)), ("hla.freq", hla_freq), ("assembly", R.RStrings([obj.assembly])),
+        ("classifiers", R.RList(cls)), ("matching", nums(obj.matching, np.float64)),
+        ("appendix", obj.appendix if obj.appendix is not None else R.RList([]))]
+    return R.RList([v for _, v in fields], {"names": [k for k, _ in fields], "class": ["hlaAttrBagObj"]})
+
+
+def save_model(path: str, obj: HlaAttrBagObj, name: str = "mobj") -> None:
+    """``mobj <- hlaModelToObj(model); save(mobj, file=path)``."""
+    rdata.save_rdata(path, {name: model_to_robj(obj)})

@@ -306,3 +306,123 @@ def factor_to_strings(x) -> List[Optional[str]]:
     if levels is None:
         raise ValueError("not a factor")
     return [None if int(k) == NA_INTEGER else levels[int(k) - 1] for k in np.asarray(x)]
+
+
+# ---------------------------------------------------------------------------
+# writer: the inverse of the reader for the data objects HIBAG exchanges (vectors, character
+# vectors, generic vectors and their attributes).  Serialisation version 2 (readable by every
+# R >= 2.3.0), XDR, the layout of R's serialize.c: WriteItem / OutStringVec / attributes as a
+# tagged pairlist, symbols through the reference table.
+
+class _Writer:
+    def __init__(self):
+        self.out = bytearray()
+        self.sym: Dict[str, int] = {}
+
+    def i32(self, v: int) -> None:
+        self.out += struct.pack(">i", v)
+
+    def charsxp(self, s: Optional[str]) -> None:
+        if s is None:
+            self.i32(_CHARSXP)
+            self.i32(-1)
+            return
+        raw = s.encode("utf-8")
+        gp = 64 if raw.isascii() else 8            # ASCII_MASK / UTF8_MASK
+        self.i32(_CHARSXP | (gp << 12))
+        self.i32(len(raw))
+        self.out += raw
+
+    def symbol(self, name: str) -> None:
+        if name in self.sym:
+            self.i32((self.sym[name] << 8) | _REFSXP)
+            return
+        self.sym[name] = len(self.sym) + 1
+        self.i32(_SYMSXP)
+        self.charsxp(name)
+
+    def attributes(self, attrs: Dict[str, Any]) -> None:
+        for k, v in attrs.items():
+            self.i32(_LISTSXP | 0x400)
+            self.symbol(k)
+            self.item(v)
+        self.i32(_NILVALUE)
+
+    def item(self, x: Any) -> None:
+        attrs = dict(getattr(x, "attrs", None) or {})
+        flag = (0x200 if attrs else 0) | (0x100 if "class" in attrs else 0)
+        if x is None:
+            self.i32(_NILVALUE)
+            return
+        if isinstance(x, str):
+            x = RStrings([x])
+        if isinstance(x, (bool, np.bool_)):
+            x = np.array([int(x)], np.int32).view(np.int32)
+            self.i32(_LGLSXP); self.i32(1); self.out += x.astype(">i4").tobytes()
+            return
+        if isinstance(x, (int, np.integer)):
+            x = np.array([x], np.int32)
+        if isinstance(x, (float, np.floating)):
+            x = np.array([x], np.float64)
+        if isinstance(x, RList) or (isinstance(x, (list, tuple)) and not isinstance(x, RStrings)
+                                    and not all(isinstance(e, str) or e is None for e in x)):
+            self.i32(_VECSXP | flag)
+            self.i32(len(x))
+            for e in x:
+                self.item(e)
+        elif isinstance(x, (RStrings, list, tuple)):
+            self.i32(_STRSXP | flag)
+            self.i32(len(x))
+            for e in x:
+                self.charsxp(e)
+        elif isinstance(x, np.ndarray):
+            a = np.asarray(x)
+            if a.dtype == np.bool_:
+                self.i32(_LGLSXP | flag); self.i32(a.size); self.out += a.astype(">i4").tobytes()
+            elif a.dtype.kind in "iu" and a.dtype != np.uint8:
+                self.i32(_INTSXP | flag); self.i32(a.size); self.out += a.astype(">i4").tobytes()
+            elif a.dtype == np.uint8:
+                self.i32(_RAWSXP | flag); self.i32(a.size); self.out += a.tobytes()
+            elif a.dtype.kind == "f":
+                self.i32(_REALSXP | flag); self.i32(a.size); self.out += a.astype(">f8").tobytes()
+            else:
+                raise TypeError(f"cannot serialise an array of dtype {a.dtype}")
+        elif isinstance(x, dict):                  # a pairlist
+            for k, v in x.items():
+                self.i32(_LISTSXP | 0x400)
+                self.symbol(str(k))
+                self.item(v)
+            self.i32(_NILVALUE)
+            return
+        else:
+            raise TypeError(f"cannot serialise {type(x).__name__}")
+        if attrs:
+            self.attributes(attrs)
+
+
+def _header(w: _Writer) -> None:
+    w.out += b"X\n"
+    w.i32(2)                 # serialisation version
+    w.i32(0x00030500)        # written "by" R 3.5.0
+    w.i32(0x00020300)        # readable from R 2.3.0
+
+
+def save_rdata(path: str, objects: Dict[str, Any], compress: bool = True) -> None:
+    """``save(..., file=path)``: a workspace holding ``objects`` (name -> value)."""
+    w = _Writer()
+    w.out += b"RDX2\n"
+    _header(w)
+    w.item(dict(objects))
+    data = bytes(w.out)
+    with open(path, "wb") as f:
+        f.write(gzip.compress(data, 6) if compress else data)
+
+
+def save_rds(path: str, obj: Any, compress: bool = True) -> None:
+    """``saveRDS(obj, path)``."""
+    w = _Writer()
+    _header(w)
+    w.item(obj)
+    data = bytes(w.out)
+    with open(path, "wb") as f:
+        f.write(gzip.compress(data, 6) if compress else data)
