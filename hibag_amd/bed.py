@@ -42,22 +42,24 @@ def _hla_assembly(assembly: str = "auto") -> str:
 
 
 def hlaLociInfo(assembly: str = "auto") -> Optional[Dict[str, tuple]]:
-    """``hlaLociInfo`` (``R/DataUtilities.R:1051-1070``): gene -> (chrom, start, end),
-    ``None`` for NA coordinates, in table order (the first row is the MHC itself)."""
+    """``hlaLociInfo`` (``R/DataUtilities.R:1051-1070``): gene -> (chrom, start, end), ``None`` for NA
+    coordinates, in table order (the first row is the MHC itself).  The coordinates are the
+    reference's per-assembly gene tables (``inst/doc/GeneInfo_<assembly>.txt``), kept here as
+    ``data/hla_loci.json``."""
     assembly = _hla_assembly(assembly)
-    fn = os.path.join(_DATA, f"GeneInfo_{assembly}.txt")
-    if not os.path.exists(fn):
+    global _LOCI
+    if _LOCI is None:
+        import json
+        with open(os.path.join(_DATA, "hla_loci.json")) as f:
+            _LOCI = json.load(f)
+    if assembly not in _LOCI:
         if assembly != "unknown":
             raise ValueError("Unknown human genome reference in 'assembly'!")
         return None
-    info: Dict[str, tuple] = {}
-    with open(fn) as f:
-        rows = [ln.rstrip("\n").split("\t") for ln in f if ln.strip() and not ln.startswith("#")]
-    for name, chrom, start, end in rows[1:]:
-        def num(x):
-            return None if x == "NA" else int(x)
-        info[name] = (int(chrom), num(start), num(end))
-    return info
+    return {name: tuple(v) for name, v in _LOCI[assembly].items()}
+
+
+_LOCI = None
 
 
 def _plural(n: int) -> str:

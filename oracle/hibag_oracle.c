@@ -18,6 +18,13 @@
  *     (hlaPredict() output on the training samples, R/HIBAG.R:253-258).
  * tests/test_oracle_pin.py recomputes both from data/HapMap_CEU_Geno.rdata and
  * data/HLA_Type_Table.rdata (committed as fixtures under tests/golden/).
+ *   - Beyond single values: hibag_oracle_train.c re-runs the training calls that
+ *     produced those two files (set.seed(100); hlaAttrBagging(...)) and gets
+ *     all 200 stored classifiers back bit for bit -- thousands of _BestGuess /
+ *     _PostProb / _PrepHaploMatch evaluations per model feed every decision
+ *     (tests/test_oracle_train.py).
+ *   - oracle_conv_bed (below) decodes inst/extdata/HapMap_CEU.bed to the
+ *     genotypes of data/HapMap_CEU_Geno.rdata (tests/test_bed_host.py).
  *
  * Every function cites the reference lines it follows.  Data layout is this
  * repo's own (flat SoA arrays), not the reference's classes.
