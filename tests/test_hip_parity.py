@@ -105,6 +105,19 @@ def test_every_classifier_width(hib, oracle, vote):
     assert_same(got, want)
 
 
+def test_many_alleles(hib, oracle):
+    """A locus with 180 alleles (16,290 allele pairs; HLA-B 4-digit reference panels are of this
+    size) and 400 haplotypes per classifier: tiles, finish kernels and batching at a large P."""
+    from hibag_amd import synth
+    model, founders, af = synth.make_model("hla-b", seed=21, n_hla=180, n_haplo=400, n_classifier=4, n_snp=120)
+    G, _ = synth.make_samples(founders, af, 70, seed=22)
+    G[2, :] = hib.NA_INTEGER
+    for vote in (1, 2):
+        want = oracle.predict(oracle.flatten(model), G, vote_method=vote, avx2=True, n_threads=8)
+        got = hib.hlaModelFromObj(model).predict_raw(G, vote, want_dosage=True, want_prob=True)
+        assert_same(got, want)
+
+
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 130])
 def test_ragged_batch_sizes(hib, oracle, n):
     from hibag_amd import synth
