@@ -614,6 +614,8 @@ int finalize_model(hibag_hip_model *m)
 	HIP_TRY(hipMemcpy(tbase + tb_boff, blk_off.data(), blk_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_btile, blk_tile.data(), blk_tile.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_ctile, ctile.data(), ctile.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	if (blk_stream.size() * sizeof(uint32_t) >= ((size_t)1 << 31))
+		return fail(HIBAG_HIP_EINVAL, "the model's haplotype-pair stream exceeds 2 GB");
 	if (int rc = m->d_blk.reserve(blk_stream.size() * sizeof(uint32_t))) return rc;
 	HIP_TRY(hipMemcpy(m->d_blk.p, blk_stream.data(), blk_stream.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(m->d_tab.p, m->tab, sizeof(m->tab), hipMemcpyHostToDevice));
@@ -639,6 +641,7 @@ int finalize_model(hibag_hip_model *m)
 	V.blk_tile = (const uint32_t *)(tbase + tb_btile);
 	V.ctile = (const uint32_t *)(tbase + tb_ctile);
 	V.blk_stream = m->d_blk.as<uint32_t>();
+	V.blk_bytes = (uint32_t)(blk_stream.size() * sizeof(uint32_t));
 	m->bt_rows = bt_rows;
 	V.stream = m->d_stream.as<uint32_t>();
 	V.tab = m->d_tab.as<double>();

@@ -103,6 +103,7 @@ struct HibagModelView {
 	const int *cls_nblk;         // [C] blocks in that stream
 	const uint32_t *blk_tile;    // [C][n_tile][2] = {first block of the tile, blocks of the tile}
 	const uint32_t *blk_stream;  // blocks of 32 records: W[nkb][32], prod[32] (f64), end mask, pad
+	uint32_t blk_bytes;          // its size (< 2 GB: addressed as a raw buffer with 32-bit offsets)
 	const uint32_t *ctile;       // [C][n_tile][8]: everything pass 2 needs per (classifier, tile) in one s_load_dwordx8:
 	                             // {engine code (1..3 = nkb with the offset in K, 4 = nkb 3 with accumulator offset, 0 = VALU), bt_row, block stream dword offset lo/hi, #blocks, #non-empty cells, row list lo/hi}
 };

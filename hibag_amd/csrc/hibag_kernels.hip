@@ -280,21 +280,25 @@ __device__ __forceinline__ void block_accumulate(const double *stage, uint32_t e
 // wave-uniform (broadcast) LDS reads, which are in-order with the table look-ups.
 // The record words of the next block travel the same way (VMEM, one block ahead).
 // The stream is padded so that the look-ahead stays in bounds.
+// The stream is addressed as a raw buffer (base in four SGPRs, block offset in one SGPR, lane
+// offset in one VGPR that never changes): the look-ahead loads then need no per-lane 64-bit
+// pointer arithmetic, which was 12 vector instructions per block.
 template <int NKB, bool BIK, class Fin>
-__device__ __forceinline__ void walk_blocks(const uint32_t *__restrict__ blk, int nblk, int lane,
+__device__ __forceinline__ void walk_blocks(__amdgpu_buffer_rsrc_t rs, uint32_t soff, int nblk, int lane,
 	const LaneOperand<NKB> &T, const double *tab_s, const uint2 *exp_s, double *stage, Fin &&fin)
 {
 	double cell = 0;
-	const int sh = (lane >> 5) * 16, li = lane & 31;
-	const int ls = lane < 33 ? lane : 0;             // staging lane: 32 factors + the meta pair
+	const int sh = (lane >> 5) * 16;
+	const int vo_w = (lane & 31) * 4;                // this lane's record word inside a K block row
+	const int vo_p = (lane < 33 ? lane : 0) * 8;     // staging lane: 32 factors + the meta pair
 	uint32_t w[NKB];
 #pragma unroll
-	for (int kb = 0; kb < NKB; kb++) w[kb] = blk[kb * 32 + li];
-	double pf = reinterpret_cast<const double *>(blk + 32 * NKB)[ls];
+	for (int kb = 0; kb < NKB; kb++) w[kb] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo_w + kb * 128, soff, 0);
+	double pf = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, vo_p + 128 * NKB, soff, 0));
 	for (int b = 0; b < nblk; b++) {
 		double *buf = stage + (b & 1) * STAGE_DOUBLES;
 		if (lane < 33) buf[lane] = pf;
-		const uint32_t *__restrict__ nxt = blk + HIBAG_BLOCK_DWORDS(NKB);
+		const uint32_t nxt = soff + 4 * HIBAG_BLOCK_DWORDS(NKB);
 
 		v16i D0, D1;
 #ifdef HIBAG_ABL_NOMFMA
@@ -304,8 +308,8 @@ __device__ __forceinline__ void walk_blocks(const uint32_t *__restrict__ blk, in
 		block_mfma<NKB, BIK>(w, sh, T, exp_s, D0, D1);
 #endif
 #pragma unroll
-		for (int kb = 0; kb < NKB; kb++) w[kb] = nxt[kb * 32 + li];
-		pf = reinterpret_cast<const double *>(nxt + 32 * NKB)[ls];
+		for (int kb = 0; kb < NKB; kb++) w[kb] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo_w + kb * 128, nxt, 0);
+		pf = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, vo_p + 128 * NKB, nxt, 0));
 #ifndef HIBAG_ABL_NOMFMA
 		block_own_sample(D0, D1);
 #endif
@@ -313,8 +317,15 @@ __device__ __forceinline__ void walk_blocks(const uint32_t *__restrict__ blk, in
 		const uint32_t endmask = __builtin_amdgcn_readfirstlane(meta.x);
 		const int n_valid = __builtin_amdgcn_readfirstlane(meta.y);
 		block_accumulate(buf, endmask, n_valid, D0, D1, cell, tab_s, fin);
-		blk = nxt;
+		soff = nxt;
 	}
+}
+
+// raw-buffer descriptor of the block stream (gfx9 word 3: 32-bit data format, no swizzle; reads past
+// the end return 0)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stream_rsrc(const HibagModelView &M)
+{
+	return __builtin_amdgcn_make_buffer_rsrc((void *)M.blk_stream, 0, (int)M.blk_bytes, 0x00020000);
 }
 
 // engine code: 1..3 = K blocks with the distance offset in K, 4 = 3 K blocks, accumulator offset (k = 31, 32)
@@ -606,7 +617,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, Hi
 	const int srow = M.n_split > 0 ? M.split_row[c] : -1;
 	if (nkb > 0) {
 #define CALL(N, BIK) { LaneOperand<N> T; load_operand<N, BIK>(M, B, c, group, threadIdx.x & 63, T);               \
-		walk_blocks<N, BIK>(M.blk_stream + M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, T, tab_s, exp_s,        \
+		walk_blocks<N, BIK>(stream_rsrc(M), (uint32_t)M.blk_off[c] * 4u, M.cls_nblk[c], threadIdx.x & 63, T, tab_s, exp_s, \
 			stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)],                                             \
 			[&](double cell) { total += cell; asm("" : "+v"(total)); /* keeps the cell end a scalar branch */ }); }
 		HIBAG_DISPATCH_NKB(M.mfma_bik[c] ? nkb : 4, CALL)
@@ -710,6 +721,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 	// lane's weight and 1/total.  Without this every classifier starts with a chain of
 	// dependent scalar and vector loads (~3000 cycles per classifier, measured with stamps).
 	typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+	const __amdgpu_buffer_rsrc_t rs = stream_rsrc(M);
 	const u32x8 *__restrict__ ct = reinterpret_cast<const u32x8 *>(M.ctile) + tile;
 	u32x8 rec_n = ct[0];
 	double w_n = B.cw[s], inv_n = B.inv[s];
@@ -744,9 +756,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 				j = (int)(jpack & 15);
 				a = acc[j][lane];
 			};
-			const uint32_t *__restrict__ blk = M.blk_stream + (((uint64_t)rec[3] << 32) | rec[2]);
+			const uint32_t blk = rec[2] * 4u;               // byte offset of the tile's first block (rec[3] is 0: < 4 GB)
 #define CALL(N, BIK) { LaneOperand<N> T; load_operand_row<N, BIK>(B, (int)rec[1], c, group, lane, T);              \
-			walk_blocks<N, BIK>(blk, (int)rec[4], lane, T, tab_s, exp_s, stage_s[wave], fin); }
+			walk_blocks<N, BIK>(rs, blk, (int)rec[4], lane, T, tab_s, exp_s, stage_s[wave], fin); }
 			HIBAG_DISPATCH_NKB(nkb, CALL)
 #undef CALL
 			if (poison) {                                // empty cells: (0 * inv) * w is NaN where inv is not finite
