@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,7 +47,8 @@ struct BuildState {
 	// device
 	void *d_hb = nullptr, *d_hf = nullptr, *d_start = nullptr, *d_planes = nullptr, *d_true = nullptr,
 		*d_best = nullptr, *d_post = nullptr, *d_tab = nullptr, *d_match = nullptr, *d_batch = nullptr;
-	size_t cap_h = 0, cap_s = 0, cap_match = 0, cap_batch = 0;
+	void *h_stage = nullptr;                // pinned host staging of the batched evaluation
+	size_t cap_h = 0, cap_s = 0, cap_match = 0, cap_batch = 0, cap_stage = 0;
 };
 BuildState g;
 thread_local char g_msg[400];
@@ -239,12 +241,22 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_batch_scan(BatchView B)
 	const int want = B.true_cell[s];
 	double best = 0, total = 0, hit = 0;
 	int b1 = -2147483647 - 1, b2 = -2147483647 - 1;
-	for (int i = 0; i < n; i++) {
-		const int h1 = cl[i] >> 16, h2 = cl[i] & 0xFFFF;
-		const double cell = B.cellv[((size_t)c * B.max_cells + i) * B.n_pad + s];
-		if (best < cell) { best = cell; b1 = h1; b2 = h2; }
-		if (h2 + h1 * (2 * B.n_hla - h1 - 1) / 2 == want) hit = cell;
-		total += cell;
+	const double *__restrict__ col = B.cellv + (size_t)c * B.max_cells * B.n_pad + s;
+	for (int i0 = 0; i0 < n; i0 += 64) {
+		// 64 loads in flight, then the strictly ordered scan over them: one load per dependent
+		// iteration would make this kernel pure memory latency (hundreds of cells per candidate)
+		double v[64];
+#pragma unroll
+		for (int j = 0; j < 64; j++) v[j] = (i0 + j < n) ? col[(size_t)(i0 + j) * B.n_pad] : 0.0;
+#pragma unroll
+		for (int j = 0; j < 64; j++) {
+			if (i0 + j >= n) break;
+			const int h1 = cl[i0 + j] >> 16, h2 = cl[i0 + j] & 0xFFFF;
+			const double cell = v[j];
+			if (best < cell) { best = cell; b1 = h1; b2 = h2; }
+			if (h2 + h1 * (2 * B.n_hla - h1 - 1) / 2 == want) hit = cell;
+			total += cell;
+		}
 	}
 	B.best[((size_t)c * 2) * B.n_pad + s] = b1;
 	B.best[((size_t)c * 2 + 1) * B.n_pad + s] = b2;
@@ -441,7 +453,9 @@ void hibag_build_done()
 {
 	for (void **p : {&g.d_hb, &g.d_start, &g.d_planes, &g.d_true, &g.d_best, &g.d_post, &g.d_tab, &g.d_match, &g.d_batch}) dev_free(*p);
 	g.d_hf = nullptr;
-	g.cap_h = g.cap_s = g.cap_match = g.cap_batch = 0;
+	if (g.h_stage) (void)hipHostFree(g.h_stage);
+	g.h_stage = nullptr;
+	g.cap_h = g.cap_s = g.cap_match = g.cap_batch = g.cap_stage = 0;
 	g.active = false; g.evaluated = false;
 }
 
@@ -548,23 +562,26 @@ uint32_t *hibag_build_haplomatch(const PluginHaplotype haplo[], const size_t n_h
 // build_acc_ib calls returns for n_cand candidate SNPs that extend the same genotype list
 // (src/LibHLA.cpp:2018-2038), evaluated together.  base_geno holds the committed SNPs
 // (position n_snp-1 missing); cand[i].column is the raw genotype of candidate i per sample.
+double g_batch_prof[4] = {0, 0, 0, 0};     // host packing, copies + kernels, read-back, host reductions (s)
+static double batch_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
 void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const HibagBuildCandidate cand[], int n_cand,
 	int acc_oob[], double loss_ib[])
 {
+	const double t0 = batch_now();
 	if (!g.active) build_throw("build_eval_batch before build_init");
 	if (n_snp < 1 || n_snp > 128 || n_cand < 0) build_throw("build_eval_batch: invalid sizes");
 	if (n_cand == 0) return;
 	const int nh = g.n_hla, n = g.n_sample, np = g.n_pad;
 	const int nw = (n_snp + 31) / 32, word = (n_snp - 1) >> 5, bit = (n_snp - 1) & 31;
-	upload_geno(base_geno);
-
 	size_t H = 0;
 	for (int c = 0; c < n_cand; c++) H += (size_t)cand[c].n_haplo;
 	const size_t Hs = std::max<size_t>(H, 1);
 	std::vector<uint32_t> hb((size_t)nw * Hs, 0), cw((size_t)n_cand * 2 * np);
 	std::vector<double> hf(Hs, 0.0);
 	std::vector<int> start((size_t)n_cand * (nh + 1), 0), cells, seg;
-	const int n_seg = std::max(1, std::min(64, 2048 / std::max(1, (np / HIBAG_WAVE) * n_cand)));
+	static const int wave_target = getenv("HIBAG_BATCH_WAVES") ? atoi(getenv("HIBAG_BATCH_WAVES")) : 2048;
+	const int n_seg = std::max(1, std::min(64, wave_target / std::max(1, (np / HIBAG_WAVE) * n_cand)));
 	int max_cells = 1;
 	std::vector<std::vector<int>> cell_list(n_cand);
 	std::vector<std::vector<uint64_t>> cell_work(n_cand);
@@ -628,34 +645,65 @@ void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const H
 		while (k <= n_seg) sg[k++] = (int)cell_list[c].size();
 	}
 
-	// one device arena: ints first, then doubles
-	const size_t b_hb = hb.size() * 4, b_cw = cw.size() * 4, b_start = start.size() * 4, b_cells = cells.size() * 4,
-		b_seg = seg.size() * 4, b_best = (size_t)n_cand * 2 * np * 4;
+	// genotype planes and true pairs of the cohort (what upload_geno does, but into the same transfer)
+	std::vector<uint32_t> planes((size_t)2 * NW * np);
+	std::vector<int> true_cell(np, -1);
+	g.true1.assign(n, 0); g.true2.assign(n, 0);
+	for (int w = 0; w < NW; w++)
+		for (int s = 0; s < np; s++) {
+			planes[(size_t)w * np + s] = s < n ? (uint32_t)((uint64_t)base_geno[s].snp1[w >> 1] >> (32 * (w & 1))) : 0u;
+			planes[(size_t)(NW + w) * np + s] = s < n ? (uint32_t)((uint64_t)base_geno[s].snp2[w >> 1] >> (32 * (w & 1))) : 0xFFFFFFFFu;
+		}
+	for (int s = 0; s < n; s++) {
+		int a1 = base_geno[s].hla1, a2 = base_geno[s].hla2;
+		if (a1 > a2) std::swap(a1, a2);
+		if (a1 < 0 || a2 >= nh) build_throw("genotype with an invalid true HLA pair");
+		g.true1[s] = a1; g.true2[s] = a2;
+		true_cell[s] = a2 + a1 * (2 * nh - a1 - 1) / 2;
+	}
+
+	// One device arena = [inputs | outputs | scratch]; the inputs travel in ONE copy from a pinned
+	// staging buffer and the outputs come back in one: a growth step is a handful of small arrays,
+	// and a dozen separate pageable copies cost more than the kernels.
 	size_t o = 0;
 	auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
-	const size_t o_hb = take(b_hb), o_cw = take(b_cw), o_start = take(b_start), o_cells = take(b_cells), o_seg = take(b_seg),
-		o_best = take(b_best), o_hf = take(hf.size() * 8), o_post = take((size_t)n_cand * np * 8),
-		o_cellv = take((size_t)n_cand * max_cells * np * 8);
+	const size_t o_hb = take(hb.size() * 4), o_cw = take(cw.size() * 4), o_start = take(start.size() * 4),
+		o_cells = take(cells.size() * 4), o_seg = take(seg.size() * 4), o_planes = take(planes.size() * 4),
+		o_true = take(true_cell.size() * 4), o_hf = take(hf.size() * 8), in_end = o;
+	const size_t b_best = (size_t)n_cand * 2 * np * 4, b_post = (size_t)n_cand * np * 8;
+	const size_t o_best = take(b_best), o_post = take(b_post), out_end = o;
+	const size_t o_cellv = take((size_t)n_cand * max_cells * np * 8);
 	reserve(g.d_batch, g.cap_batch, o, "hipMalloc(batch)");
-	char *d = (char *)g.d_batch;
-	HIP_OK(hipMemcpyAsync(d + o_hb, hb.data(), b_hb, hipMemcpyHostToDevice, 0), "copy batch");
-	HIP_OK(hipMemcpyAsync(d + o_cw, cw.data(), b_cw, hipMemcpyHostToDevice, 0), "copy batch");
-	HIP_OK(hipMemcpyAsync(d + o_start, start.data(), b_start, hipMemcpyHostToDevice, 0), "copy batch");
-	HIP_OK(hipMemcpyAsync(d + o_cells, cells.data(), b_cells, hipMemcpyHostToDevice, 0), "copy batch");
-	HIP_OK(hipMemcpyAsync(d + o_seg, seg.data(), b_seg, hipMemcpyHostToDevice, 0), "copy batch");
-	HIP_OK(hipMemcpyAsync(d + o_hf, hf.data(), hf.size() * 8, hipMemcpyHostToDevice, 0), "copy batch");
+	if (out_end > g.cap_stage) {
+		if (g.h_stage) (void)hipHostFree(g.h_stage);
+		g.h_stage = nullptr; g.cap_stage = 0;
+		HIP_OK(hipHostMalloc(&g.h_stage, out_end * 2, hipHostMallocDefault), "hipHostMalloc(staging)");
+		g.cap_stage = out_end * 2;
+	}
+	char *d = (char *)g.d_batch, *h = (char *)g.h_stage;
+	memcpy(h + o_hb, hb.data(), hb.size() * 4);
+	memcpy(h + o_cw, cw.data(), cw.size() * 4);
+	memcpy(h + o_start, start.data(), start.size() * 4);
+	memcpy(h + o_cells, cells.data(), cells.size() * 4);
+	memcpy(h + o_seg, seg.data(), seg.size() * 4);
+	memcpy(h + o_planes, planes.data(), planes.size() * 4);
+	memcpy(h + o_true, true_cell.data(), true_cell.size() * 4);
+	memcpy(h + o_hf, hf.data(), hf.size() * 8);
+	const double t1 = batch_now();
+	HIP_OK(hipMemcpyAsync(d, h, in_end, hipMemcpyHostToDevice, 0), "copy batch");
 	BatchView B{nh, np, nw, n_cand, n_seg, word, (const uint32_t *)(d + o_hb), (const double *)(d + o_hf), (int)Hs,
-		(const int *)(d + o_start), (const uint32_t *)g.d_planes, (const uint32_t *)(d + o_cw), (const int *)(d + o_cells),
-		(const int *)(d + o_seg), max_cells, (const int *)g.d_true, (const double *)g.d_tab, (double *)(d + o_cellv),
+		(const int *)(d + o_start), (const uint32_t *)(d + o_planes), (const uint32_t *)(d + o_cw), (const int *)(d + o_cells),
+		(const int *)(d + o_seg), max_cells, (const int *)(d + o_true), (const double *)g.d_tab, (double *)(d + o_cellv),
 		(int *)(d + o_best), (double *)(d + o_post)};
 	hipLaunchKernelGGL(k_batch_cells, dim3(np / HIBAG_WAVE, n_seg, n_cand), dim3(HIBAG_WAVE), 0, 0, B);
 	hipLaunchKernelGGL(k_batch_scan, dim3(np / HIBAG_WAVE, n_cand), dim3(HIBAG_WAVE), 0, 0, B);
 	HIP_OK(hipGetLastError(), "k_batch");
-	std::vector<int> best((size_t)n_cand * 2 * np);
-	std::vector<double> post((size_t)n_cand * np);
-	HIP_OK(hipMemcpyAsync(best.data(), d + o_best, b_best, hipMemcpyDeviceToHost, 0), "read batch");
-	HIP_OK(hipMemcpyAsync(post.data(), d + o_post, post.size() * 8, hipMemcpyDeviceToHost, 0), "read batch");
+	const double t2 = batch_now();
+	HIP_OK(hipMemcpyAsync(h + o_best, d + o_best, out_end - o_best, hipMemcpyDeviceToHost, 0), "read batch");
 	HIP_OK(hipStreamSynchronize(0), "batch");
+	const int *best = (const int *)(h + o_best);
+	const double *post = (const double *)(h + o_post);
+	const double t3 = batch_now();
 	for (int c = 0; c < n_cand; c++) {
 		int correct = 0;                                               // build_acc_oob
 		for (int s : g.oob)
@@ -666,4 +714,5 @@ void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const H
 		loss_ib[c] = loglik * -2;
 	}
 	g.evaluated = false;
+	g_batch_prof[0] += t1 - t0; g_batch_prof[1] += t2 - t1; g_batch_prof[2] += t3 - t2; g_batch_prof[3] += batch_now() - t3;
 }

@@ -21,6 +21,9 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <thread>
 #include <cfloat>
 #include <cmath>
@@ -39,6 +42,7 @@
 #include "hibag_plugin.h"
 
 int hibag_fail(int code, const char *fmt, ...);       // hibag_api.hip: sets the thread's last error
+extern double g_batch_prof[4];                        // hibag_build.hip
 
 namespace {
 
@@ -148,6 +152,59 @@ struct Sampling {
 	}
 };
 
+// Persistent helper threads for the per-step fits: a growth step lasts about a millisecond, so
+// creating threads per step would cost as much as the work.
+class Pool {
+	std::vector<std::thread> th;
+	std::mutex m;
+	std::condition_variable wake, done;
+	std::function<void()> job;
+	unsigned long gen = 0;
+	int pending = 0;
+	bool stop = false;
+public:
+	explicit Pool(int n_helpers)
+	{
+		for (int i = 0; i < n_helpers; i++)
+			th.emplace_back([this] {
+				unsigned long seen = 0;
+				for (;;) {
+					std::function<void()> f;
+					{
+						std::unique_lock<std::mutex> lk(m);
+						wake.wait(lk, [&] { return stop || gen != seen; });
+						if (stop) return;
+						seen = gen;
+						f = job;
+					}
+					f();
+					{
+						std::lock_guard<std::mutex> lk(m);
+						if (--pending == 0) done.notify_one();
+					}
+				}
+			});
+	}
+	~Pool()
+	{
+		{ std::lock_guard<std::mutex> lk(m); stop = true; }
+		wake.notify_all();
+		for (std::thread &t : th) t.join();
+	}
+	// runs f on every helper and on the caller; returns when all are done
+	void run(const std::function<void()> &f)
+	{
+		{
+			std::lock_guard<std::mutex> lk(m);
+			job = f; gen++; pending = (int)th.size();
+		}
+		wake.notify_all();
+		f();
+		std::unique_lock<std::mutex> lk(m);
+		done.wait(lk, [&] { return pending == 0; });
+	}
+};
+
 } // namespace
 
 struct hibag_hip_trainer {
@@ -165,6 +222,7 @@ struct hibag_hip_trainer {
 	std::vector<int> inbag, outbag;
 	std::vector<PairList> pl;
 	int n_threads = 1;                          // host threads that fit candidate SNPs concurrently
+	std::unique_ptr<Pool> pool;                 // n_threads - 1 helpers, created by the first training call
 
 	double unif() { return unif_fn ? unif_fn(unif_ctx) : rng.unif(); }
 	int random_num(int n)                                               // :120-126
@@ -464,11 +522,7 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 					valid[i] = 1;
 				}
 			};
-			const int n_thr = std::max(1, std::min(m, t.n_threads));
-			std::vector<std::thread> pool;
-			for (int k = 1; k < n_thr; k++) pool.emplace_back(work);
-			work();
-			for (std::thread &th : pool) th.join();
+			if (t.pool) t.pool->run(work); else work();
 		}
 		std::vector<int> accv(m, 0);
 		std::vector<double> lossv(m, 0.0);
@@ -634,12 +688,15 @@ int hibag_hip_trainer_new_classifiers(hibag_hip_trainer *t, int nclassifier, int
 	std::lock_guard<std::mutex> g2(device_state);
 	const size_t before = t->out.size();
 	try {
+		if (!t->pool && t->n_threads > 1) t->pool.reset(new Pool(t->n_threads - 1));
 		g_prof = Profile();
+		for (double &v : g_batch_prof) v = 0;
 		const double t0 = Profile::now();
 		build_classifiers(*t, nclassifier, mtry, prune != 0, verbose != 0 || verbose_detail != 0, verbose_detail != 0);
 		if (getenv("HIBAG_TRAIN_PROFILE"))
-			fprintf(stderr, "[hibag train] total %.3f s: pair lists (device) %.3f, EM (host) %.3f, scoring (device) %.3f\n",
-				Profile::now() - t0, g_prof.t[0], g_prof.t[1], g_prof.t[2]);
+			fprintf(stderr, "[hibag train] total %.3f s: pair lists (device) %.3f, EM (host) %.3f, scoring (device) %.3f "
+				"[pack %.3f, copy+kernels %.3f, read-back %.3f, reductions %.3f]\n",
+				Profile::now() - t0, g_prof.t[0], g_prof.t[1], g_prof.t[2], g_batch_prof[0], g_batch_prof[1], g_batch_prof[2], g_batch_prof[3]);
 	} catch (const char *msg) {
 		t->out.resize(before);                         // a failed call adds nothing
 		return hibag_fail(hibag_hip_device_count() <= 0 ? HIBAG_HIP_ENODEV : HIBAG_HIP_EINVAL, "%s", msg);
