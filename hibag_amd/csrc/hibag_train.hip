@@ -107,7 +107,12 @@ struct HapList {
 };
 
 struct HapPair { int h1, h2; bool flag; double gfreq; };                // CAlg_EM::THaploPair
-struct PairList { int boot, samp; std::vector<HapPair> p; };           // CAlg_EM::THaploPairList
+// CAlg_EM::THaploPairList of every in-bag sample, flattened: sample i owns p[off[i] .. off[i+1])
+struct PairSet {
+	std::vector<HapPair> p;
+	std::vector<int> off, boot, samp;
+	size_t size() const { return boot.size(); }
+};
 
 struct OutClassifier {
 	std::vector<int32_t> snpidx, samp_num, hla;
@@ -220,7 +225,7 @@ struct hibag_hip_trainer {
 	std::vector<PluginGenotype> g;
 	int g_nsnp = 0;
 	std::vector<int> inbag, outbag;
-	std::vector<PairList> pl;
+	PairSet pl;
 	int n_threads = 1;                          // host threads that fit candidate SNPs concurrently
 	std::unique_ptr<Pool> pool;                 // n_threads - 1 helpers, created by the first training call
 
@@ -335,36 +340,49 @@ void prepare_haplotypes(T &t, const HapList &cur, HapList &next)
 		start[h] = st; st += (int)cur.len[h];
 	}
 	const size_t n_ib = t.inbag.size();
-	t.pl.assign(n_ib, PairList());
-	for (size_t i = 0; i < n_ib; i++) { t.pl[i].boot = t.g[t.inbag[i]].bootstrap_count; t.pl[i].samp = t.inbag[i]; }
+	PairSet &ps = t.pl;
+	ps.p.clear();
+	ps.boot.resize(n_ib); ps.samp.resize(n_ib);
+	ps.off.assign(n_ib + 1, 0);
+	for (size_t i = 0; i < n_ib; i++) { ps.boot[i] = t.g[t.inbag[i]].bootstrap_count; ps.samp[i] = t.inbag[i]; }
 
 	size_t n_buf = 0;
 	uint32_t *buf = hibag_build_haplomatch(cur.list.data(), cur.len.data(), cur.n_snp, t.g.data(), n_buf);
+	// the device lists the pairs sample by sample (ascending in-bag index)
+	size_t k_prev = 0;
+	bool first = true;
+	auto close_range = [&](size_t k) {                                   // [off[k], end) is complete: CPU-branch order
+		std::sort(ps.p.begin() + ps.off[k], ps.p.end(), [](const HapPair &x, const HapPair &y) {
+			return x.h1 != y.h1 ? x.h1 < y.h1 : x.h2 < y.h2; });
+	};
 	if (buf) {
 		uint32_t n = buf[0] >> 1;
 		for (const uint32_t *p = buf + 1; n > 0; n--, p += 2) {
 			const size_t k = p[0];
-			if (k >= n_ib) { free(buf); throw "build_haplomatch returned an invalid sample index"; }
+			if (k >= n_ib || (!first && k < k_prev)) { free(buf); throw "build_haplomatch returned an invalid sample index"; }
+			if (first || k != k_prev) {
+				if (!first) close_range(k_prev);
+				for (size_t i = first ? 0 : k_prev + 1; i <= k; i++) ps.off[i] = (int)ps.p.size();
+				k_prev = k; first = false;
+			}
 			const PluginGenotype &g = t.g[t.inbag[k]];
 			const int a = (int)(2 * (start[g.hla1] + (p[1] & 0xFFFF))), b = (int)(2 * (start[g.hla2] + (p[1] >> 16)));
-			std::vector<HapPair> &PL = t.pl[k].p;
-			PL.push_back(HapPair{a, b, false, 0.0});
-			PL.push_back(HapPair{a, b + 1, false, 0.0});
-			if (a + 1 <= b) PL.push_back(HapPair{a + 1, b, false, 0.0});
-			PL.push_back(HapPair{a + 1, b + 1, false, 0.0});
+			ps.p.push_back(HapPair{a, b, false, 0.0});
+			ps.p.push_back(HapPair{a, b + 1, false, 0.0});
+			if (a + 1 <= b) ps.p.push_back(HapPair{a + 1, b, false, 0.0});
+			ps.p.push_back(HapPair{a + 1, b + 1, false, 0.0});
 		}
 		free(buf);
 	}
-	for (PairList &pl : t.pl) {
-		if (pl.p.empty()) throw "PairList should not be empty in PrepareHaplotypes().";   // :1070-1071
-		std::sort(pl.p.begin(), pl.p.end(), [](const HapPair &x, const HapPair &y) {
-			return x.h1 != y.h1 ? x.h1 < y.h1 : x.h2 < y.h2; });
-	}
+	if (!first) close_range(k_prev);
+	for (size_t i = first ? 0 : k_prev + 1; i <= n_ib; i++) ps.off[i] = (int)ps.p.size();
+	for (size_t i = 0; i < n_ib; i++)
+		if (ps.off[i + 1] == ps.off[i]) throw "PairList should not be empty in PrepareHaplotypes().";   // :1070-1071
 }
 
 // PrepareNewSNP, :1127-1183.  `pl` / `next` are the caller's working copies: candidates of one
 // growth step are fitted concurrently, each on its own copy.
-bool prepare_new_snp(const T &t, int snp, const HapList &cur, HapList &next, std::vector<PairList> &pls)
+bool prepare_new_snp(const T &t, int snp, const HapList &cur, HapList &next, PairSet &pls)
 {
 	int allele_cnt = 0, valid_cnt = 0;
 	for (int i : t.inbag) {
@@ -379,16 +397,18 @@ bool prepare_new_snp(const T &t, int snp, const HapList &cur, HapList &next, std
 		next.list[2 * i + 1].freq = p1 * cur.list[i].freq + EM_INIT_VAL_FRAC;
 	}
 	const int idx_new = next.n_snp - 1;
-	for (PairList &pl : pls) {
-		const int geno = t.geno[(size_t)pl.samp * t.n_snp + snp];
-		for (HapPair &p : pl.p)
+	for (size_t i = 0; i < pls.size(); i++) {
+		const int geno = t.geno[(size_t)pls.samp[i] * t.n_snp + snp];
+		for (int j = pls.off[i]; j < pls.off[i + 1]; j++) {
+			HapPair &p = pls.p[j];
 			p.flag = (0 <= geno && geno <= 2) ?
 				(get_allele(next.list[p.h1], idx_new) + get_allele(next.list[p.h2], idx_new) == geno) : true;
+		}
 	}
 	return true;
 }
 
-void expectation_maximization(const T &t, HapList &next, std::vector<PairList> &pls, std::vector<double> &log_buf)   // :1185-1255
+void expectation_maximization(const T &t, HapList &next, PairSet &pls, std::vector<double> &log_buf)   // :1185-1255
 {
 	const int total = t.n_samp;
 	const double em_reltol = std::sqrt(DBL_EPSILON);                    // :102
@@ -398,24 +418,29 @@ void expectation_maximization(const T &t, HapList &next, std::vector<PairList> &
 	for (int iter = 0; iter <= EM_MAX_ITER; iter++) {
 		const double old_loglik = loglik;
 		for (size_t i = 0; i < next.list.size(); i++) { next.old_freq[i] = next.list[i].freq; next.list[i].freq = 0; }
+		HapPair *const P = pls.p.data();
 		for (size_t i = 0; i < num; i++) {
-			PairList &pl = pls[i];
+			const int j0 = pls.off[i], j1 = pls.off[i + 1];
 			double psum = 0;
-			for (HapPair &p : pl.p)
+			for (int j = j0; j < j1; j++) {
+				HapPair &p = P[j];
 				if (p.flag) {
 					p.gfreq = (p.h1 != p.h2) ? (2 * next.old_freq[p.h1] * next.old_freq[p.h2])
 					                         : (next.old_freq[p.h1] * next.old_freq[p.h2]);
 					psum += p.gfreq;
 				}
-			log_buf[i] = pl.boot * std::log(psum);
-			psum = pl.boot / psum;
-			for (HapPair &p : pl.p) if (p.flag) p.gfreq *= psum;
+			}
+			log_buf[i] = pls.boot[i] * std::log(psum);
+			psum = pls.boot[i] / psum;
+			for (int j = j0; j < j1; j++) if (P[j].flag) P[j].gfreq *= psum;
 		}
 		loglik = 0;
 		for (size_t i = 0; i < num; i++) {
 			loglik += log_buf[i];
-			for (const HapPair &p : pls[i].p)
+			for (int j = pls.off[i]; j < pls.off[i + 1]; j++) {
+				const HapPair &p = P[j];
 				if (p.flag) { next.list[p.h1].freq += p.gfreq; next.list[p.h2].freq += p.gfreq; }
+			}
 		}
 		const double scale = 0.5 / total;
 		for (PluginHaplotype &h : next.list) h.freq *= scale;
@@ -511,7 +536,7 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 			std::atomic<int> next_i(0);
 			auto work = [&]() {
 				HapList nx;
-				std::vector<PairList> pls;
+				PairSet pls;
 				std::vector<double> log_buf;
 				for (int i; (i = next_i.fetch_add(1)) < m;) {
 					nx = next; pls = t.pl;
