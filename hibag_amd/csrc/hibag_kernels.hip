@@ -463,6 +463,34 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 	const int row0 = M.mask_row[c];
 	const int nkb = M.mfma_nkb[c];
 	int num = 0, den = 0;
+	unsigned __int128 xs128 = 0, ms128 = 0;    // the packed strings, when built in registers (k <= 32)
+	bool in_regs = false;
+#ifndef HIBAG_PACK_SLOW
+	if (k <= 32 && nwp <= 3) {
+		// usual case: one pass over the classifier's k SNPs (independent byte loads, several in
+		// flight) builds three k-bit fields, and the 3k-bit strings are put together with shifts
+		uint32_t X = 0, Mv = 0, E = 0;         // bit j: g == 2, g in {0, 2}, g == 1 at SNP j
+#pragma unroll 8
+		for (int j = 0; j < k; j++) {
+			const int snp = idx[j];
+			const uint32_t g = codes[(size_t)snp * B.n_pad + s];
+			const int wt = M.snp_weight[snp];
+			den += wt;
+			if (g != 3) num += wt;
+			X |= (uint32_t)(g == 2) << j;
+			Mv |= (uint32_t)(g == 0 || g == 2) << j;
+			E |= (uint32_t)(g == 1) << j;
+		}
+		const unsigned __int128 xs = (unsigned __int128)X | ((unsigned __int128)X << k);
+		const unsigned __int128 ms = (unsigned __int128)Mv | ((unsigned __int128)Mv << k) | ((unsigned __int128)E << (2 * k));
+		for (int m = 0; m < nwp; m++) {
+			B.masks[(size_t)(row0 + m) * B.n_pad + s] = (uint32_t)(xs >> (32 * m));
+			B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s] = (uint32_t)(ms >> (32 * m));
+		}
+		xs128 = xs; ms128 = ms; in_regs = true;
+	} else
+#endif
+	{
 	int comp = 0, i = 0;                       // position 32*m+q = comp*k + i
 	for (int m = 0; m < nwp; m++) {
 		uint32_t xw = 0, mw = 0;
@@ -484,6 +512,7 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 		B.masks[(size_t)(row0 + m) * B.n_pad + s] = xw;
 		B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s] = mw;
 	}
+	}
 	if (nkb > 0) {
 		// matrix-core engine: this sample's column of the B operand, a_k = +1 / -1 / 0 as int8 scaled
 		// by 8 (+8 -> 0x08, -8 -> 0xF8: the MFMA then yields 8*d, the byte offset of TAB[d]), written
@@ -495,8 +524,8 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 #pragma unroll
 		for (int m = 0; m < 3; m++)
 			if (m < nkb && m < nwp) {
-				xs[m] = B.masks[(size_t)(row0 + m) * B.n_pad + s];
-				ms[m] = B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s];
+				xs[m] = in_regs ? (uint32_t)(xs128 >> (32 * m)) : B.masks[(size_t)(row0 + m) * B.n_pad + s];
+				ms[m] = in_regs ? (uint32_t)(ms128 >> (32 * m)) : B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s];
 				bias += __popc(xs[m] & ms[m]);
 			}
 		const bool bik = M.mfma_bik[c] != 0;
