@@ -15,10 +15,13 @@ from .bed import HlaBEDGeno, hlaBED2Geno, hlaLociInfo  # noqa: F401
 from .train import (RRandom, hlaAllele, hlaAttrBagging, hlaParallelAttrBagging, hlaUniqueAllele,  # noqa: F401
                     set_seed)
 from .merge import hlaAlleleDigit, hlaPredMerge  # noqa: F401
+from .evaluate import (hlaAlleleSubset, hlaCompareAllele, hlaFlankingSNP, hlaGenoSubset, hlaSplitAllele,  # noqa: F401
+                       r_sample)
 from ._lib import HibagHipError  # noqa: F401
 
 __all__ = ["NA_INTEGER", "Classifier", "HlaAttrBagObj", "HlaSNPGeno", "load_geno", "load_model", "model_to_robj", "save_model",
            "HlaAlleleClass", "HlaAttrBagClass", "hlaClose", "hlaModelFromObj", "hlaModelToObj",
            "hlaPredict", "hlaSetKernelTarget", "hlaGenoSwitchStrand", "hlaSNPID", "HibagHipError",
-           "HlaBEDGeno", "hlaBED2Geno", "hlaLociInfo", "RRandom", "hlaAllele", "hlaAttrBagging", "hlaParallelAttrBagging", "hlaUniqueAllele", "hlaAlleleDigit", "hlaPredMerge",
+           "HlaBEDGeno", "hlaBED2Geno", "hlaLociInfo", "RRandom", "hlaAllele", "hlaAttrBagging", "hlaParallelAttrBagging", "hlaUniqueAllele", "hlaAlleleDigit", "hlaPredMerge", "hlaAlleleSubset", "hlaCompareAllele", "hlaFlankingSNP", "hlaGenoSubset",
+           "hlaSplitAllele", "r_sample",
            "set_seed"]
