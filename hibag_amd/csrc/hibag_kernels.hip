@@ -310,7 +310,7 @@ __device__ __forceinline__ void walk_blocks(__amdgpu_buffer_rsrc_t rs, uint32_t 
 #pragma unroll
 		for (int kb = 0; kb < NKB; kb++) w[kb] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo_w + kb * 128, nxt, 0);
 		pf = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, vo_p + 128 * NKB, nxt, 0));
-#ifndef HIBAG_ABL_NOMFMA
+#if !defined(HIBAG_ABL_NOMFMA) && !defined(HIBAG_ABL_NOSWAP)
 		block_own_sample(D0, D1);
 #endif
 		const uint2 meta = *reinterpret_cast<const uint2 *>(buf + 32);
