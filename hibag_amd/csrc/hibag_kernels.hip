@@ -833,9 +833,12 @@ __device__ __forceinline__ int classifier_best(const HibagModelView &M, const Hi
 	return best_p;
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS, 8) void k_vote_best(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
+__global__ __launch_bounds__(BLOCK_THREADS, 4) void k_vote_best(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
+	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
+	__shared__ uint2 exp_s[256];
+	stage_expand_table(exp_s);
 	stage_table(M, tab_s);
 	const int c = M.c_order[blockIdx.y];
 	const int group = blockIdx.x * BLOCK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -846,9 +849,28 @@ __global__ __launch_bounds__(BLOCK_THREADS, 8) void k_vote_best(HibagModelView M
 	if (__ballot(active) == 0) { best_cell[at] = -1; return; }
 	const double inv = B.inv[at];
 	int bp;
-#define CALL(N) bp = classifier_best<N>(M, B, c, s, inv, tab_s)
-	HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
+	const int nkb = M.mfma_nkb[c];
+	if (nkb > 0) {
+		// matrix-core engine: the cells close in the order of the classifier's non-empty cell list,
+		// so the winner is remembered by its position in that list
+		double best = 0;
+		int best_i = -1, i = 0;
+		auto fin = [&](double cell) {
+			const double prob = cell * inv;
+			if (best < prob) { best = prob; best_i = i; }
+			i++;
+		};
+#define CALL(N, BIK) { LaneOperand<N> T; load_operand<N, BIK>(M, B, c, group, threadIdx.x & 63, T);               \
+		walk_blocks<N, BIK>(stream_rsrc(M), (uint32_t)M.blk_off[c] * 4u, M.cls_nblk[c], threadIdx.x & 63, T, tab_s, exp_s, \
+			stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)], fin); }
+		HIBAG_DISPATCH_NKB(M.mfma_bik[c] ? nkb : 4, CALL)
 #undef CALL
+		bp = best_i < 0 ? -1 : (int)M.cls_cell[M.cls_off[c] + best_i];
+	} else {
+#define CALL(N) bp = classifier_best<N>(M, B, c, s, inv, tab_s)
+		HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
+#undef CALL
+	}
 	best_cell[at] = active ? bp : -1;
 }
 
