@@ -6,27 +6,27 @@
 // Mapping: LANE = SAMPLE.  A wavefront holds 64 samples and walks the model's
 // loop nest (classifier -> allele pair -> haplotype pair) in the reference's
 // order.  The nest depends only on the model, so the host flattens it into a
-// pair stream (hibag_device.h); control flow is wave-uniform, every model word
-// arrives through the scalar cache (s_load), and each lane reproduces the
+// pair stream (hibag_device.h); control flow is wave-uniform, and each lane reproduces the
 // reference's rounding sequence for its own sample: results are bit-identical
 // to the CPU kernels by construction, with no cross-lane reduction anywhere on
 // the numeric path.
 //
-// Per haplotype pair and wavefront the inner loop is
-//     d    = sum_w popc((W[w] ^ T'[w]) & M'[w])      v_bitop3_b32 + v_bcnt_u32_b32 per word
-//     cell += prod * TAB[d]                          ds_read_b64, v_mul_f64, v_add_f64
-// (W, prod uniform in SGPRs, fetched one chunk ahead; T', M' the lane's
-// genotype masks; TAB in LDS).
+// Two engines compute the distance d of a pair (bit-identical results):
+//   VALU engine   d = sum_w popc((W[w] ^ T'[w]) & M'[w]): v_bitop3_b32 + v_bcnt_u32_b32 per 32-bit
+//                 word of the 3k-bit pair string (W uniform in SGPRs, T'/M' the lane's genotype
+//                 masks); used for classifiers with more than 32 SNPs.
+//   matrix engine d = W . a with a in {-1, 0, +1}^3k per sample: an int8 GEMM of 32 records x 64
+//                 samples per block on v_mfma_i32_32x32x32_i8 (+ 16 v_permlane32_swap to give every
+//                 lane its own sample's column); the default.
+// In both, what the contract fixes stays on the vector ALU, per lane and in the reference's order:
+//     cell += prod * TAB[d]          ds_read_b64 (table in LDS), v_mul_f64, v_add_f64
 //
 // The normalisation 1/sum of a classifier's posterior needs all of its cells,
 // and 64 samples x P cells do not fit on chip, so the pair loop runs twice:
 // pass 1 (k_total) produces the in-order total per (sample, classifier), pass 2
-// (k_accum) recomputes each cell, scales it and adds it to the ensemble sum held
-// in VGPRs.  Recomputing is cheaper than moving 8*P bytes per (sample,
-// classifier) through HBM (DESIGN.md "Why two passes").
-//
-// No MFMA: the pair weight 1e-5^d(i,j) does not factor over (i,j) at
-// heterozygous SNPs, so there is no contraction to feed a matrix core.
+// (k_accum) recomputes each cell, scales it and adds it to the ensemble sum of its
+// tile of cells, held in LDS.  Recomputing is cheaper than moving 8*P bytes per
+// (sample, classifier) through HBM (DESIGN.md "Why two passes").
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no FMA fusion: the
 // reference multiplies and adds with separate roundings).
