@@ -721,8 +721,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 	// give all tiles of one sample group the same (blockIdx % 8): the group's
 	// masks / weights / totals are then fetched into one XCD's L2 only.
 	const int n_group = B.n_pad / HIBAG_WAVE;
-	const int n_quad = (M.n_tile + BLOCK_WAVES - 1) / BLOCK_WAVES;   // blocks per sample group
-	const int b = blockIdx.x;
+	const int n_quad = (M.n_tile + BLOCK_WAVES - 1) / BLOCK_WAVES;   // work items per sample group
+	// Grid-stride over the work items: the launcher may start fewer workgroups than items (a whole
+	// number of resident rounds), the first few then take a second item -- see hibag_launch_accum.
+	for (int b = blockIdx.x; b < n_group * n_quad; b += gridDim.x) {
 	int group, quad;
 	{
 		const int groups_full = n_group & ~7;          // groups covered by the swizzle
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 	}
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int tile = quad * BLOCK_WAVES + wave;
-	if (tile >= M.n_tile) return;
+	if (tile >= M.n_tile) continue;
 	const int lane = threadIdx.x & 63;
 	const int s = group * HIBAG_WAVE + lane;
 	const int ncell = M.tile_n[tile];
@@ -806,6 +808,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 
 	const int p0 = M.tile_p0[tile];
 	for (int j = 0; j < ncell; j++) B.part[(size_t)(p0 + j) * B.n_pad + s] = acc[j][lane];
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -1081,7 +1084,25 @@ void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStr
 		(void)hipMemsetAsync(B.part, 0, (size_t)M.n_cell * B.n_pad * sizeof(double), st);
 		return;
 	}
-	hipLaunchKernelGGL(k_accum, dim3(n), dim3(BLOCK_THREADS), 0, st, M, B);
+	// Wavefronts of this pass all take about the same time, so the launch proceeds in rounds of as many
+	// workgroups as fit on the chip, and a small remainder would occupy a whole extra round almost
+	// alone (10k samples: 3,140 items on 1,024 slots = 3.07 rounds).  In that case launch a whole
+	// number of rounds and let the first workgroups take a second item each.
+	static int slots = 0;
+	if (slots == 0) {
+		int per_cu = 0, cus = 0, dev = 0;
+		(void)hipGetDevice(&dev);
+		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_accum, BLOCK_THREADS, 0) != hipSuccess) per_cu = 0;
+		slots = per_cu > 0 && cus > 0 ? per_cu * cus : -1;
+		if (getenv("HIBAG_ROUNDS") && atoi(getenv("HIBAG_ROUNDS")) == 0) slots = -1;
+	}
+	unsigned grid = n;
+	if (slots > 0 && n > (unsigned)slots) {
+		const unsigned rem = n % (unsigned)slots;
+		if (rem > 0 && rem <= (unsigned)slots / 4) grid = n - rem;
+	}
+	hipLaunchKernelGGL(k_accum, dim3(grid), dim3(BLOCK_THREADS), 0, st, M, B);
 }
 
 void hibag_launch_vote(const HibagModelView &M, const HibagBatchView &B, int *d_best_cell, hipStream_t st)
