@@ -382,6 +382,11 @@ void build_tiles(int P, const std::vector<uint64_t> &cell_work, std::vector<int>
 	for (int p = 0; p < P; p++) total += cell_work[p] + 1;
 	const int min_tiles = (P + HIBAG_TILE - 1) / HIBAG_TILE;
 	const uint64_t target = std::max<uint64_t>(1, total / (uint64_t)std::max(min_tiles, 1));
+	// A tile is a wavefront of pass 2, and four tiles make a workgroup: every tile beyond the minimum
+	// is another wavefront per sample group (and possibly another, mostly empty, workgroup).  A tile is
+	// therefore closed early for balance only while the cells it leaves unused still fit into the
+	// minimum number of tiles.
+	int slack = min_tiles * HIBAG_TILE - P;
 	tile_p0.clear(); tile_n.clear();
 	int p = 0;
 	while (p < P) {
@@ -389,9 +394,10 @@ void build_tiles(int P, const std::vector<uint64_t> &cell_work, std::vector<int>
 		uint64_t w = 0;
 		while (p + n < P && n < HIBAG_TILE) {
 			const uint64_t cw = cell_work[p + n] + 1;
-			if (n > 0 && w + cw > target + target / 4) break;
+			if (n > 0 && w + cw > target + target / 4 && HIBAG_TILE - n <= slack) break;
 			w += cw; n++;
 		}
+		if (p + n < P) slack -= HIBAG_TILE - n;
 		tile_p0.push_back(p); tile_n.push_back(n);
 		p += n;
 	}
