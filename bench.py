@@ -47,8 +47,8 @@ MFMA_NS = 16.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--samples", type=int, default=SAMPLES_PER_GPU, help="samples per GPU per step")
     ap.add_argument("--shape", default=SHAPE)
     ap.add_argument("--prob", action="store_true", help="also return the full posterior matrix (type='response+prob')")

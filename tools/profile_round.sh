@@ -5,7 +5,7 @@
 # summaries into profiles/.
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/prof; rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $R/bench.py --no-cpu-baseline > $out/stats.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/write.log 2>&1
 cd $R
