@@ -54,6 +54,10 @@ def main():
     ap.add_argument("--prob", action="store_true", help="also return the full posterior matrix (type='response+prob')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-wide", action="store_true", help="diagnostic: drop the one 100-SNP classifier of the synthetic model")
+    ap.add_argument("--shard", choices=("samples", "classifiers"), default="samples",
+                    help="multi-GPU decomposition: every rank its own samples (default, no collective), or every rank a "
+                         "slice of the classifiers on the SAME samples, merged by one RCCL all-reduce of the partial "
+                         "posterior sums per step (BASELINE config 3's 'RCCL posterior merge'; strong scaling)")
     args = ap.parse_args()
 
     import numpy as np
@@ -83,8 +87,14 @@ def main():
     target = hibag_amd.hlaSetKernelTarget("hip")[0]
     model_obj, founders, afreq = synth.make_model(args.shape, wide_classifier=not args.no_wide)
     n = args.samples
-    geno, truth = synth.make_samples(founders, afreq, n, seed=synth.DEFAULT_SEED + 1 + rank)
-    model = hibag_amd.hlaModelFromObj(model_obj, device=local_rank)
+    by_classifier = args.shard == "classifiers"
+    geno, truth = synth.make_samples(founders, afreq, n, seed=synth.DEFAULT_SEED + 1 + (0 if by_classifier else rank))
+    if by_classifier:
+        from hibag_amd import dist as hdist
+        sub, sw = hdist.classifier_shard(model_obj, world, rank)
+        model = hibag_amd.HlaAttrBagClass(sub, device=local_rank, snp_weight=sw)
+    else:
+        model = hibag_amd.hlaModelFromObj(model_obj, device=local_rank)
 
     n_hla, P, S = model_obj.n_hla, model_obj.n_cell, model_obj.n_snp
     d_geno = torch.from_numpy(geno).to(dev)
@@ -96,7 +106,18 @@ def main():
     d_pp = torch.empty((n, P), dtype=torch.float64, device=dev) if args.prob else None
     stream = torch.cuda.current_stream(dev)
 
+    n_pad = (n + 63) // 64 * 64
+    d_part = torch.zeros((P + 3, n_pad), dtype=torch.float64, device=dev) if by_classifier else None
+
     def step():
+        if by_classifier:
+            # partial ensemble sums of this rank's classifiers -> ONE all-reduce -> arg-max / dosage on every rank
+            model.predict_partial_device(d_geno.data_ptr(), n, d_part.data_ptr(), stream=stream.cuda_stream)
+            if world > 1:
+                dist.all_reduce(d_part, op=dist.ReduceOp.SUM)
+            model.finish_device(d_part.data_ptr(), n, d_h1.data_ptr(), d_h2.data_ptr(), d_prob.data_ptr(), d_match.data_ptr(),
+                                d_dos.data_ptr(), None if d_pp is None else d_pp.data_ptr(), stream=stream.cuda_stream)
+            return
         model.predict_device(d_geno.data_ptr(), n, 1, d_h1.data_ptr(), d_h2.data_ptr(), d_prob.data_ptr(),
                              d_match.data_ptr(), d_dos.data_ptr(), None if d_pp is None else d_pp.data_ptr(),
                              stream=stream.cuda_stream)
@@ -129,9 +150,10 @@ def main():
     h1 = d_h1.cpu().numpy(); h2 = d_h2.cpu().numpy()
     call_acc = float(np.mean((h1 == truth[:, 0]) & (h2 == truth[:, 1])))
 
-    total_samples = n * world * args.steps
+    total_samples = n * (1 if by_classifier else world) * args.steps
     value = total_samples / dt
     pair_evals = model_obj.pair_evals_per_sample()
+    pe_rank = sub.pair_evals_per_sample() if by_classifier else pair_evals      # what one rank's kernels evaluate
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream) ----
     dom = max(("total", "accum"), key=lambda k: timing[k][0])
@@ -147,13 +169,13 @@ def main():
             traffic = json.load(open(tf)).get(f"k_{dom}", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    pairs_per_s_kernel = pair_evals * n / (avg_ms * 1e-3)
+    pairs_per_s_kernel = pe_rank * n / (avg_ms * 1e-3)
     # SIMD time per wavefront-pair (64 samples x one haplotype pair) against the issue floor:
     # two FP64 ops per pair, plus the int8 MFMAs of the distance dot product (2 per 32-record
     # block and 32-wide K block; K = 3k bit positions + 4 offset positions) on the matrix engine
-    ns_per_wave_pair = N_SIMD * avg_ms * 1e6 / (pair_evals * n / 64.0)
+    ns_per_wave_pair = N_SIMD * avg_ms * 1e6 / (pe_rank * n / 64.0)
     mfma_ns, w = 0.0, 0
-    for c in model_obj.classifiers:
+    for c in (sub if by_classifier else model_obj).classifiers:
         k, h = len(c.snpidx), len(c.freq)
         nkb = -(-(3 * k + 4) // 32) if 3 * k + 4 <= 96 else (-(-3 * k // 32) if 3 * k <= 96 else 0)
         mfma_ns += h * (h + 1) // 2 * (2 * nkb * MFMA_NS / 32.0)
@@ -177,12 +199,14 @@ def main():
     out = {
         "metric": "hlaPredict() samples/sec, 10k samples x 100-classifier HLA-B",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if by_classifier else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"synthetic {args.shape} model ({n_hla} alleles, {len(model_obj.classifiers)} classifiers, "
                                f"{S} SNPs, {pair_evals} haplotype-pair evaluations/sample), {n} samples per GPU per step, "
                                f"type={'response+prob' if args.prob else 'response+dosage'}, vote=prob",
-                   "samples_per_gpu": n, "parallelism": f"sample-sharded x{world} (no collective)",
+                   "samples_per_gpu": n,
+                   "parallelism": (f"classifier-sharded x{world} (one all-reduce of {P + 3} x {n_pad} doubles per step)"
+                                   if by_classifier else f"sample-sharded x{world} (no collective)"),
                    "kernel_target": target,
                    "engine": os.environ.get("HIBAG_ENGINE", "mfma") + " (int8 MFMA distances + FP64 VALU accumulation in reference order)"},
         "pair_evals_per_s": value * pair_evals,
