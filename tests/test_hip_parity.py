@@ -320,3 +320,38 @@ def test_more_samples_than_one_batch(hib, oracle):
     want = oracle.predict(oracle.flatten(model), G[sub], want_prob=False, avx2=True, n_threads=8)
     for k in want:
         assert np.array_equal(out[k][sub], want[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_models(hib, oracle, seed):
+    """Randomised structure: 1-12 alleles (some without haplotypes), 1-6 classifiers of 1-40 SNPs and 1-60
+    haplotypes (duplicates allowed), frequencies over 300 orders of magnitude, genotypes uniform over
+    {0, 1, 2, NA, -1, 3} -- mostly underflowing posteriors, NA calls and NaN propagation."""
+    rng = np.random.default_rng(1000 + seed)
+    n_hla = int(rng.integers(1, 13))
+    n_snp = int(rng.integers(1, 60))
+    classifiers = []
+    for _ in range(int(rng.integers(1, 7))):
+        k = int(rng.integers(1, min(n_snp, 40) + 1))
+        H = int(rng.integers(1, 61))
+        hla = np.sort(rng.integers(0, n_hla, H)).astype(np.int32)
+        freq = 10.0 ** rng.uniform(-300 if seed % 3 == 0 else -6, 0, H)
+        haplo = ["".join(rng.choice(["0", "1"], k)) for _ in range(H)]
+        classifiers.append(hib.Classifier(snpidx=rng.choice(n_snp, k, replace=False), freq=freq, hla=hla, haplo=haplo))
+    model = hib.HlaAttrBagObj(n_samp=0, n_snp=n_snp, hla_allele=[f"{i:02d}" for i in range(n_hla)], classifiers=classifiers)
+    n = int(rng.integers(1, 131))
+    if seed % 2:
+        G = rng.choice(np.array([0, 1, 2, hib.NA_INTEGER, -1, 3], np.int64), size=(n, n_snp), p=[.3, .3, .3, .04, .03, .03]).astype(np.int32)
+    else:                                   # genotypes compatible with the haplotypes of the first classifier
+        c0 = classifiers[0]
+        G = np.full((n, n_snp), hib.NA_INTEGER, np.int32)
+        for i in range(n):
+            a, b = rng.integers(0, len(c0.haplo), 2)
+            G[i, c0.snpidx] = np.array([int(x) + int(y) for x, y in zip(c0.haplo[a], c0.haplo[b])])
+        G[rng.random(G.shape) < 0.02] = hib.NA_INTEGER
+    m = hib.hlaModelFromObj(model)
+    for vote in (1, 2):
+        want = oracle.predict(oracle.flatten(model), G, vote_method=vote)
+        got = m.predict_raw(G, vote, want_dosage=True, want_prob=True)
+        assert_same(got, want)
+

@@ -129,3 +129,31 @@ def test_parallel_entry_single_rank(hib, oracle):
     for i, (g, w) in enumerate(zip(mod.obj.classifiers, want)):
         assert np.array_equal(g.snpidx, w["snpidx"]) and np.array_equal(g.freq, w["freq"]) and g.haplo == w["haplo"], i
     del remap
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_training_problems(hib, oracle, seed):
+    """Randomised cohorts (size, alleles, missingness, mtry, prune): the device-scored driver and the
+    oracle's CPU restatement must grow identical classifiers from the same stream."""
+    from hibag_amd import train
+    rng = np.random.default_rng(500 + seed)
+    n_hla = int(rng.integers(2, 11))
+    n_snp = int(rng.integers(8, 61))
+    n_samp = int(rng.integers(20, 121))
+    founders = (rng.random((n_hla, n_snp)) < rng.uniform(0.1, 0.9, n_snp)).astype(np.int32)
+    a = rng.integers(0, n_hla, (n_samp, 2))
+    G = (founders[a[:, 0]] + founders[a[:, 1]]).astype(np.int32)
+    G = np.where(rng.random(G.shape) < 0.03, (G + 1) % 3, G).astype(np.int32)
+    G[rng.random(G.shape) < rng.uniform(0, 0.15)] = hib.NA_INTEGER
+    mtry = int(rng.integers(1, n_snp + 1))
+    prune = bool(rng.integers(0, 2))
+    want = oracle.train(G, a[:, 0], a[:, 1], n_hla, nclassifier=3, mtry=mtry, prune=prune, seed=7 + seed)
+    tr = train._Trainer(G, a[:, 0], a[:, 1], n_hla)
+    tr.set_seed(7 + seed)
+    tr.new_classifiers(3, mtry, prune, False, False)
+    got = tr.classifiers()
+    tr.close()
+    for i, (g, w) in enumerate(zip(got, want)):
+        c = hib.Classifier(snpidx=w["snpidx"], freq=w["freq"], hla=w["hla"], haplo=w["haplo"], samp_num=w["samp_num"],
+                           outofbag_acc=w["acc"])
+        assert_same_classifier(_as_dict(g), c, i)
