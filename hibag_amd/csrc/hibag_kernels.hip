@@ -901,14 +901,28 @@ __global__ void k_scalars(HibagModelView M, HibagBatchView B, const int *__restr
 	const int s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= B.n_pad) return;
 	double sum_w = 0, sum_m = 0, num_m = 0;
-	for (int c = 0; c < M.n_classifier; c++) {
-		const size_t at = (size_t)c * B.n_pad + s;
-		const double w = B.cw[at];
-		if (!(w > 0)) continue;
-		sum_m += B.tot[at] * w;
-		num_m += w;
-		if (best_cell) { if (best_cell[at] >= 0) sum_w += 1.0; }
-		else sum_w += w;
+	for (int c0 = 0; c0 < M.n_classifier; c0 += 8) {
+		// eight classifiers' loads in flight, then the sums in classifier order (one thread per sample:
+		// with dependent loads this kernel would be pure memory latency)
+		double wv[8], tv[8];
+		int bv[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const bool in = c0 + j < M.n_classifier;
+			const size_t at = (size_t)(in ? c0 + j : c0) * B.n_pad + s;
+			wv[j] = in ? B.cw[at] : 0.0;
+			tv[j] = B.tot[at];
+			bv[j] = best_cell ? best_cell[at] : 0;
+		}
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const double w = wv[j];
+			if (!(w > 0)) continue;
+			sum_m += tv[j] * w;
+			num_m += w;
+			if (best_cell) { if (bv[j] >= 0) sum_w += 1.0; }
+			else sum_w += w;
+		}
 	}
 	const size_t P = (size_t)M.n_cell;
 	B.part[(P + 0) * B.n_pad + s] = sum_w;
