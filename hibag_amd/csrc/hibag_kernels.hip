@@ -452,11 +452,14 @@ __global__ __launch_bounds__(256) void k_bed_geno(const uint8_t *__restrict__ be
 // (missing SNPs have m = 0 everywhere), plus the classifier weight from
 // missingness (src/LibHLA.cpp:2418-2431).  grid (n_pad/64, C), block 64,
 // lane = sample: every code load is one coalesced 64-byte row segment.
-__global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatchView B,
+#define PACK_WAVES 4        // classifiers per workgroup (one wavefront each)
+__global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatchView B,
 	const uint8_t *__restrict__ codes)
 {
-	const int c = blockIdx.y;
-	const int s = blockIdx.x * HIBAG_WAVE + threadIdx.x;
+	const int c = blockIdx.y * PACK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	if (c >= M.n_classifier) return;
+	const int lane = threadIdx.x & 63;
+	const int s = blockIdx.x * HIBAG_WAVE + lane;
 	const int k = M.n_snp_c[c];
 	const int nwp = M.nwp[c];
 	const int *__restrict__ idx = M.snp_index + M.snp_off[c];
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 				bias += __popc(xs[m] & ms[m]);
 			}
 		const bool bik = M.mfma_bik[c] != 0;
-		const int n = threadIdx.x >> 5;
+		const int n = lane >> 5;
 #pragma unroll
 		for (int m = 0; m < 3; m++) {
 			if (m >= nkb) break;
@@ -552,12 +555,12 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatc
 						}
 					}
 				}
-				B.bt[((size_t)(M.bt_row[c] + n * nkb + m) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (threadIdx.x & 31)] =
+				B.bt[((size_t)(M.bt_row[c] + n * nkb + m) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (lane & 31)] =
 					uint4{a[0], a[1], a[2], a[3]};
 			}
 		}
 		if (!bik) {
-			const size_t at = ((size_t)(2 * c + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + (threadIdx.x & 31);
+			const size_t at = ((size_t)(2 * c + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + (lane & 31);
 			B.bias[at] = 8 * bias;
 			B.bias[at + 32] = 8 * bias;
 		}
@@ -1042,7 +1045,7 @@ void hibag_launch_pack(const HibagModelView &M, const HibagBatchView &B, const i
 {
 	if (M.n_classifier == 0 || M.n_snp == 0) return;
 	hipLaunchKernelGGL(k_codes, dim3(B.n_pad / 64, (M.n_snp + 63) / 64), dim3(256), 0, st, M, B, d_geno, d_codes);
-	hipLaunchKernelGGL(k_pack, dim3(B.n_pad / HIBAG_WAVE, M.n_classifier), dim3(HIBAG_WAVE), 0, st, M, B,
+	hipLaunchKernelGGL(k_pack, dim3(B.n_pad / HIBAG_WAVE, (M.n_classifier + PACK_WAVES - 1) / PACK_WAVES), dim3(PACK_WAVES * HIBAG_WAVE), 0, st, M, B,
 		(const uint8_t *)d_codes);
 }
 
@@ -1052,7 +1055,7 @@ void hibag_launch_pack_bed(const HibagModelView &M, const HibagBatchView &B, con
 	if (M.n_classifier == 0 || M.n_snp == 0) return;
 	hipLaunchKernelGGL(k_bed_codes, dim3(B.n_pad / 64, (M.n_snp + 3) / 4), dim3(256), 0, st, M, B, d_bed, mode, stride,
 		samp0, d_snp_row, d_flip, d_codes);
-	hipLaunchKernelGGL(k_pack, dim3(B.n_pad / HIBAG_WAVE, M.n_classifier), dim3(HIBAG_WAVE), 0, st, M, B,
+	hipLaunchKernelGGL(k_pack, dim3(B.n_pad / HIBAG_WAVE, (M.n_classifier + PACK_WAVES - 1) / PACK_WAVES), dim3(PACK_WAVES * HIBAG_WAVE), 0, st, M, B,
 		(const uint8_t *)d_codes);
 }
 
