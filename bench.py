@@ -42,6 +42,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 N_SIMD = 256 * 4
 FP64_OP_NS = 2.29
 MFMA_NS = 16.0
+UBENCH_FILE = os.path.join(ROOT, "profiles", "ubench_constants.json")   # parsed from the raw tools/ubench_* logs next to it
+
+
+def issue_constants():
+    """FP64 / MFMA issue costs (ns per wave-instruction per SIMD) from the committed micro-benchmark
+    logs (profiles/ubench_constants.json, written by tools/parse_ubench.py from the raw outputs of
+    tools/ubench_mfma and tools/ubench_valu); the built-in values are the round-1 measurements."""
+    c = {"fp64_op_ns": FP64_OP_NS, "mfma_i8_32x32x32_ns": MFMA_NS, "mfma_fp64_overlap": None, "source": "built-in (round 1)"}
+    try:
+        d = json.load(open(UBENCH_FILE))
+        c.update({k: d[k] for k in ("fp64_op_ns", "mfma_i8_32x32x32_ns", "mfma_fp64_overlap") if k in d})
+        c["source"] = "profiles/ubench_constants.json (" + d.get("tag", "?") + ")"
+    except (OSError, ValueError, KeyError):
+        pass
+    return c
 
 
 def main():
@@ -58,7 +73,14 @@ def main():
                     help="multi-GPU decomposition: every rank its own samples (default, no collective), or every rank a "
                          "slice of the classifiers on the SAME samples, merged by one RCCL all-reduce of the partial "
                          "posterior sums per step (BASELINE config 3's 'RCCL posterior merge'; strong scaling)")
+    ap.add_argument("--no-extras", action="store_true", help="skip host_inclusive / other_configs (profiling runs)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` starts its own ranks: one child process per GPU through
+        # torch.distributed.run (a CHILD, never an exec: nothing here has touched the GPU yet, but the
+        # rule of the pool is to spawn).  Rank 0's JSON line and the exit code are relayed.
+        sys.exit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -68,17 +90,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: hibag_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        probe = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(probe, op=dist.ReduceOp.SUM)     # a real collective over RCCL: every rank contributes 1
+        rccl_ranks = int(round(float(probe.item())))
+        assert rccl_ranks == dist.get_world_size() == world
 
     import hibag_amd
     from hibag_amd import synth
@@ -162,39 +186,55 @@ def main():
     bytes_per_sample = 4 * S + 24 + 8 * n_hla + (8 * P if args.prob else 0)
     alg_bytes = bytes_per_sample * n                                           # one launch covers the batch
     achieved_gbs = alg_bytes / (avg_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tf):
+    if os.path.exists(tf) and n == SAMPLES_PER_GPU and args.shape == SHAPE and not by_classifier:
         try:
-            traffic = json.load(open(tf)).get(f"k_{dom}", {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tf))
+            traffic = tj.get(f"k_{dom}", {}).get("hbm_bytes_per_launch")
+            traffic_source = ("not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, "
+                              "summary committed as profiles/pmc_traffic.json (" + str(tj.get("_source", {}).get("tag")) + ")")
         except Exception:
             traffic = None
+    K = issue_constants()
+    floor_ns, ns_per_wave_pair = issue_floor((sub if by_classifier else model_obj), avg_ms, n, K)
     pairs_per_s_kernel = pe_rank * n / (avg_ms * 1e-3)
-    # SIMD time per wavefront-pair (64 samples x one haplotype pair) against the issue floor:
-    # two FP64 ops per pair, plus the int8 MFMAs of the distance dot product (2 per 32-record
-    # block and 32-wide K block; K = 3k bit positions + 4 offset positions) on the matrix engine
-    ns_per_wave_pair = N_SIMD * avg_ms * 1e6 / (pe_rank * n / 64.0)
-    mfma_ns, w = 0.0, 0
-    for c in (sub if by_classifier else model_obj).classifiers:
-        k, h = len(c.snpidx), len(c.freq)
-        nkb = -(-(3 * k + 4) // 32) if 3 * k + 4 <= 96 else (-(-3 * k // 32) if 3 * k <= 96 else 0)
-        mfma_ns += h * (h + 1) // 2 * (2 * nkb * MFMA_NS / 32.0)
-        w += h * (h + 1) // 2
-    floor_ns = 2 * FP64_OP_NS + (mfma_ns / max(w, 1) if os.environ.get("HIBAG_ENGINE", "mfma") == "mfma" else 0.0)
     roofline = {
         "kernel": f"k_{dom}", "bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+        "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
         "avg_launch_ms": round(avg_ms, 4), "launches": int(dom_launches),
         "algorithmic_bytes_per_launch": int(alg_bytes),
         "issue": {"pair_evals_per_s": pairs_per_s_kernel,
                   "simd_ns_per_wave_pair": round(ns_per_wave_pair, 2),
                   "floor_ns_per_wave_pair": round(floor_ns, 2),
                   "frac": round(floor_ns / ns_per_wave_pair, 4),
+                  "constants": K,
                   "note": "the binding ceiling is SIMD issue, not HBM: per pair one FP64 mul + one FP64 add in the "
-                          "reference's order (2 x 2.29 ns) plus its share of the int8 MFMAs (16 ns each), which "
-                          "serialise on a SIMD (tools/ubench_mfma.hip, DESIGN.md section 5)"},
+                          "reference's order plus its share of the int8 MFMAs, which serialise with FP64 on a SIMD "
+                          "(constants: raw tools/ubench_* logs under profiles/, DESIGN.md section 5)"},
         "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in timing.items()},
     }
+
+    # classifier-sharded mode: how far the merged posterior is from the unsharded (= sample-sharded) result
+    shard_check = None
+    if by_classifier:
+        full = hibag_amd.hlaModelFromObj(model_obj, device=local_rank)
+        ref = full.predict_raw(geno, 1, want_dosage=False, want_prob=True)
+        if d_pp is None:
+            d_pp2 = torch.empty((n, P), dtype=torch.float64, device=dev)
+            model.finish_device(d_part.data_ptr(), n, d_h1.data_ptr(), d_h2.data_ptr(), d_prob.data_ptr(), d_match.data_ptr(),
+                                d_dos.data_ptr(), d_pp2.data_ptr(), stream=stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+        else:
+            d_pp2 = d_pp
+        got_pp = d_pp2.cpu().numpy()
+        denom = np.maximum(np.abs(ref["postprob"]), 1e-300)
+        live = ref["postprob"] > 1e-200            # below that both sides are sums of denormals
+        rel = float(np.max(np.abs(got_pp - ref["postprob"])[live] / denom[live])) if live.any() else 0.0
+        shard_check = {"max_rel_dev_posterior_vs_unsharded": rel,
+                       "calls_identical_to_unsharded": bool(np.array_equal(ref["h1"], h1) and np.array_equal(ref["h2"], h2)),
+                       "tolerance": 1e-10}
+        full.close()
 
     out = {
         "metric": "hlaPredict() samples/sec, 10k samples x 100-classifier HLA-B",
@@ -211,8 +251,18 @@ def main():
                    "engine": os.environ.get("HIBAG_ENGINE", "mfma") + " (int8 MFMA distances + FP64 VALU accumulation in reference order)"},
         "pair_evals_per_s": value * pair_evals,
         "call_accuracy_vs_truth": call_acc,
+        "rccl_ranks": rccl_ranks,
         "roofline": roofline,
     }
+    if shard_check is not None:
+        out["classifier_shard_check"] = shard_check
+
+    if rank == 0 and world == 1 and not args.no_extras and not by_classifier:
+        # SURVEY.md 8(d) protocol column: H2D of the genotypes + D2H of the requested outputs included
+        out["host_inclusive"] = host_inclusive(model, geno, n)
+        if args.shape == SHAPE and n == SAMPLES_PER_GPU:
+            model.close()
+            out["other_configs"] = other_configs(K)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model_obj, geno, h1, h2)
@@ -223,6 +273,124 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def issue_floor(obj, avg_ms, n, K):
+    """(floor, achieved) SIMD time in ns per wavefront-pair (64 samples x one haplotype pair) for a kernel that
+    took avg_ms over n samples: two FP64 ops per pair plus the pair's share of the int8 MFMAs of the distance
+    dot product (2 per 32-record block and 32-wide K block)."""
+    from hibag_amd import engine_nkb
+    mfma_ns, w = 0.0, 0
+    for c in obj.classifiers:
+        k, h = len(c.snpidx), len(c.freq)
+        mfma_ns += h * (h + 1) // 2 * (2 * engine_nkb(k) * K["mfma_i8_32x32x32_ns"] / 32.0)
+        w += h * (h + 1) // 2
+    floor = 2 * K["fp64_op_ns"] + (mfma_ns / max(w, 1) if os.environ.get("HIBAG_ENGINE", "mfma") == "mfma" else 0.0)
+    achieved = N_SIMD * avg_ms * 1e6 / (w * n / 64.0)
+    return floor, achieved
+
+
+def host_inclusive(model, geno, n, reps=5):
+    """hibag_hip_predict with host pointers: pageable int32 genotypes up, calls / prob / matching / dosage down."""
+    for _ in range(2):
+        model.predict_raw(geno, 1, want_dosage=True)
+    t = time.perf_counter()
+    for _ in range(reps):
+        model.predict_raw(geno, 1, want_dosage=True)
+    dt = (time.perf_counter() - t) / reps
+    return {"value": n / dt, "unit": "samples/s", "ms_per_step": dt * 1e3,
+            "what": "hibag_hip_predict: H2D of the int32 genotype matrix + kernels + D2H of H1, H2, prob, matching, dosage "
+                    "(pageable host memory); never `value`"}
+
+
+def other_configs(K):
+    """BASELINE configs 4 and 5 at reduced repetition (the metric's config is the main line): cfg4 = the
+    HLA-DRB1 shape (500 haplotypes per classifier), cfg5 = hlaAttrBagging() at 1,000 samples x 300 SNPs."""
+    import numpy as np
+    import torch
+    import hibag_amd
+    from hibag_amd import synth, train
+    res = {}
+    try:
+        obj, founders, af = synth.make_model("hla-drb1")
+        n4 = 4096
+        G, truth = synth.make_samples(founders, af, n4)
+        t = time.perf_counter()
+        m = hibag_amd.hlaModelFromObj(obj)
+        t_fin = time.perf_counter() - t
+        dev = torch.device("cuda", torch.cuda.current_device())
+        dg = torch.from_numpy(G).to(dev)
+        h1 = torch.empty(n4, dtype=torch.int32, device=dev); h2 = torch.empty_like(h1)
+        pr = torch.empty(n4, dtype=torch.float64, device=dev); mt = torch.empty_like(pr)
+        ds = torch.empty((n4, obj.n_hla), dtype=torch.float64, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        run = lambda: m.predict_device(dg.data_ptr(), n4, 1, h1.data_ptr(), h2.data_ptr(), pr.data_ptr(), mt.data_ptr(),
+                                       ds.data_ptr(), None, stream=st)
+        run(); torch.cuda.synchronize(dev)
+        m.set_timing(True); m.reset_timing()
+        steps = 3
+        t = time.perf_counter()
+        for _ in range(steps):
+            run()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t) / steps
+        tm = m.get_timing(); m.set_timing(False)
+        acc_ms = tm["accum"][0] / max(tm["accum"][1], 1)
+        floor, ach = issue_floor(obj, acc_ms, n4, K)
+        acc = float(np.mean((h1.cpu().numpy() == truth[:, 0]) & (h2.cpu().numpy() == truth[:, 1])))
+        res["cfg4_hla_drb1"] = {"samples_per_s": n4 / dt, "samples": n4, "ms_per_step": dt * 1e3,
+                                "pair_evals_per_sample": obj.pair_evals_per_sample(),
+                                "pair_evals_per_s": n4 / dt * obj.pair_evals_per_sample(),
+                                "kernels_ms_per_step": {k: round(v[0] / steps, 3) for k, v in tm.items()},
+                                "k_accum_issue_frac": round(floor / ach, 4), "model_finalize_s": round(t_fin, 2),
+                                "call_accuracy_vs_truth": acc}
+        m.close()
+    except Exception as e:                       # an extra must not take the metric line down
+        res["cfg4_hla_drb1"] = {"error": repr(e)}
+    try:
+        mdl, founders, af = synth.make_model("hla-b", seed=9, n_snp=300, n_classifier=1, wide_classifier=False)
+        G, truth = synth.make_samples(founders, af, 1000, seed=10)
+        mtry = int(np.ceil(np.sqrt(300)))
+        tr = train._Trainer(G, truth[:, 0], truth[:, 1], mdl.n_hla)
+        tr.set_seed(100)
+        tr.new_classifiers(1, mtry, True, False, False)           # warm-up (allocations, first launches)
+        ncl = 4
+        t = time.perf_counter()
+        tr.new_classifiers(ncl, mtry, True, False, False)
+        dt = (time.perf_counter() - t) / ncl
+        cls = tr.classifiers()
+        tr.close()
+        res["cfg5_training"] = {"s_per_classifier": dt, "classifiers_per_s": 1.0 / dt, "n_samp": 1000, "n_snp": 300,
+                                "n_hla": mdl.n_hla, "mtry": mtry, "classifiers_timed": ncl,
+                                "mean_snps": float(np.mean([len(c.snpidx) for c in cls])),
+                                "mean_haplo": float(np.mean([len(c.freq) for c in cls]))}
+    except Exception as e:
+        res["cfg5_training"] = {"error": repr(e)}
+    return res
+
+
+def spawn_ranks(n_gpus):
+    """Start `n_gpus` ranks of this script with torch.distributed.run as a child process and relay rank 0's line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    return p.returncode if (p.returncode != 0 or line is not None) else 1
 
 
 def usable_cores():

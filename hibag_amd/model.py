@@ -75,6 +75,18 @@ class HlaAttrBagObj:
         return int(sum(len(c.freq) * (len(c.freq) + 1) // 2 for c in self.classifiers))
 
 
+def engine_nkb(n_snp_c: int) -> int:
+    """32-wide K blocks of the int8 distance dot product the library's matrix engine uses for a
+    classifier with ``n_snp_c`` SNPs (``finalize_model`` in csrc/hibag_api.hip: the 3k bit positions
+    plus 4 offset positions when they fit in three blocks); 0 = VALU engine (more than 32 SNPs)."""
+    k = int(n_snp_c)
+    if 3 * k + 4 <= 96:
+        return max(1, -(-(3 * k + 4) // 32))
+    if 3 * k <= 96:
+        return max(1, -(-3 * k // 32))
+    return 0
+
+
 @dataclass
 class HlaSNPGeno:
     """``hlaSNPGenoClass``: ``genotype`` is [n_snp, n_samp] like the R matrix
