@@ -224,6 +224,7 @@ def model_to_robj(obj: HlaAttrBagObj) -> "rdata.RList":
     return R.RList([v for _, v in fields], {"names": [k for k, _ in fields], "class": ["hlaAttrBagObj"]})
 
 
-def save_model(path: str, obj: HlaAttrBagObj, name: str = "mobj") -> None:
-    """``mobj <- hlaModelToObj(model); save(mobj, file=path)``."""
-    rdata.save_rdata(path, {name: model_to_robj(obj)})
+def save_model(path: str, obj: HlaAttrBagObj, name: str = "mobj", compress=True, version: int = 2,
+               altrep: bool = False) -> None:
+    """``mobj <- hlaModelToObj(model); save(mobj, file=path, compress=, version=)``."""
+    rdata.save_rdata(path, {name: model_to_robj(obj)}, compress=compress, version=version, altrep=altrep)

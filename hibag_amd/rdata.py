@@ -37,6 +37,7 @@ _DOTSXP, _VECSXP, _EXPRSXP, _RAWSXP = 17, 19, 20, 24
 _ALTREP, _ATTRLISTSXP, _ATTRLANGSXP = 238, 239, 240
 _BASEENV, _EMPTYENV, _GLOBALENV, _UNBOUND, _MISSINGARG, _BASENAMESPACE = 241, 242, 253, 252, 251, 247
 _NAMESPACESXP, _PACKAGESXP, _PERSISTSXP, _REFSXP, _NILVALUE = 249, 250, 248, 255, 254
+_CDR = "\x00cdr"      # key of a dotted pair's non-list tail in a decoded pairlist
 
 
 class RArray(np.ndarray):
@@ -119,8 +120,9 @@ class _Reader:
         self.p += n
         return v
 
-    def item(self) -> Any:
-        flags = self.i32()
+    def item(self, flags: Optional[int] = None) -> Any:
+        if flags is None:
+            flags = self.i32()
         ty = flags & 0xFF
         has_attr = bool(flags & 0x200)
         has_tag = bool(flags & 0x400)
@@ -161,7 +163,10 @@ class _Reader:
                 if ty in (_NILVALUE, _NILSXP):
                     break
                 if ty not in (_LISTSXP, _LANGSXP, _ATTRLISTSXP, _ATTRLANGSXP):
-                    raise ValueError(f"unsupported pairlist tail type {ty}")
+                    # a dotted pair: the CDR is not a list (the serialised state of ALTREP wrappers and
+                    # deferred strings is CONS(payload, <integer metadata>), altclasses.c)
+                    out[_CDR] = self.item(flags)
+                    break
             return out
         if ty == _CHARSXP:
             n = self.i32()
@@ -172,10 +177,14 @@ class _Reader:
                 return raw.decode("latin-1")
             return raw.decode("utf-8", errors="replace")
         if ty == _ALTREP:
+            # serialize.c WriteItem: flags, ALTREP_SERIALIZED_CLASS, ALTREP_SERIALIZED_STATE, ATTRIB
             info = self.item()
             state = self.item()
-            self.item()  # attributes
-            return self._altrep(info, state)
+            attrs = self.item()
+            obj = self._altrep(info, state)
+            if isinstance(attrs, dict) and attrs and hasattr(obj, "attrs"):
+                obj.attrs = {k: _plain_attr(v) for k, v in attrs.items()}
+            return obj
 
         if ty in (_LGLSXP, _INTSXP):
             n = self.length()
@@ -232,8 +241,13 @@ class _Reader:
         if cls == "compact_realseq":
             n, start, step = (float(x) for x in np.asarray(state)[:3])
             return RArray(start + step * np.arange(int(n), dtype=np.float64))
-        if cls in ("wrap_integer", "wrap_real", "wrap_string", "wrap_logical", "wrap_list", "wrap_raw"):
-            return state[0] if isinstance(state, (list, dict)) and not hasattr(state, "dtype") else state
+        if cls in ("wrap_integer", "wrap_real", "wrap_string", "wrap_logical", "wrap_list", "wrap_raw", "wrap_complex"):
+            # state = CONS(wrapped vector, metadata {sortedness, no-NA}); the wrapper's own attributes follow
+            # as the ALTREP's ATTRIB, the wrapped vector's are dropped (wrapper_Unserialize -> make_wrapper)
+            inner = state.get(0) if isinstance(state, dict) else state[0]
+            if hasattr(inner, "attrs"):
+                inner.attrs = {}
+            return inner
         if cls == "deferred_string":
             src = state.get(0) if isinstance(state, dict) else state
             return RStrings([_num_to_rstring(x) for x in np.asarray(src)])
@@ -310,14 +324,39 @@ def factor_to_strings(x) -> List[Optional[str]]:
 
 # ---------------------------------------------------------------------------
 # writer: the inverse of the reader for the data objects HIBAG exchanges (vectors, character
-# vectors, generic vectors and their attributes).  Serialisation version 2 (readable by every
-# R >= 2.3.0), XDR, the layout of R's serialize.c: WriteItem / OutStringVec / attributes as a
-# tagged pairlist, symbols through the reference table.
+# vectors, generic vectors and their attributes).  XDR, the layout of R's serialize.c: WriteItem /
+# OutStringVec / attributes as a tagged pairlist, symbols through the reference table.
+# Serialisation version 2 (the default: readable by every R >= 2.3.0, and what the reference's own
+# fixtures use) or version 3 (R >= 3.5.0: native-encoding header, ALTREP items).  With version 3 and
+# ``altrep=True`` integer vectors that are arithmetic sequences with step +-1 go out the way R writes
+# ``a:b`` (ALTREP class compact_intseq), and :class:`Wrapped` / :class:`DeferredString` values as the
+# wrap_* / deferred_string ALTREP classes of altclasses.c.
+
+class Wrapped:
+    """A vector inside an ALTREP wrapper (what ``sort(x)`` returns in R >= 3.5: class wrap_real,
+    wrap_integer, wrap_string ... with {sortedness, no-NA} metadata).  Version-3 writer only."""
+
+    def __init__(self, inner, is_sorted: int = 1, no_na: int = 1):
+        self.inner, self.is_sorted, self.no_na = inner, int(is_sorted), int(no_na)
+        self.attrs = dict(getattr(inner, "attrs", None) or {})
+
+
+class DeferredString:
+    """``as.character(<integer or real vector>)`` before it is expanded (ALTREP class deferred_string)."""
+
+    def __init__(self, numbers):
+        self.numbers = np.asarray(numbers)
+        self.attrs: Dict[str, Any] = {}
+
 
 class _Writer:
-    def __init__(self):
+    def __init__(self, version: int = 2, altrep: bool = False):
+        if version not in (2, 3):
+            raise ValueError("serialisation version must be 2 or 3")
         self.out = bytearray()
         self.sym: Dict[str, int] = {}
+        self.version = version
+        self.altrep = altrep and version == 3
 
     def i32(self, v: int) -> None:
         self.out += struct.pack(">i", v)
@@ -348,11 +387,48 @@ class _Writer:
             self.item(v)
         self.i32(_NILVALUE)
 
+    def altrep_item(self, cls: str, pkg: str, rtype: int, state_writer, attrs: Dict[str, Any]) -> None:
+        """serialize.c WriteItem, ALTREP branch: flags, info = (class sym, package sym, type), state, ATTRIB."""
+        self.i32(_ALTREP | (0x100 if "class" in attrs else 0))
+        self.i32(_LISTSXP); self.symbol(cls)
+        self.i32(_LISTSXP); self.symbol(pkg)
+        self.i32(_LISTSXP); self.i32(_INTSXP); self.i32(1); self.i32(rtype)
+        self.i32(_NILVALUE)
+        state_writer()
+        if attrs:
+            self.attributes(attrs)
+        else:
+            self.i32(_NILVALUE)
+
     def item(self, x: Any) -> None:
         attrs = dict(getattr(x, "attrs", None) or {})
         flag = (0x200 if attrs else 0) | (0x100 if "class" in attrs else 0)
         if x is None:
             self.i32(_NILVALUE)
+            return
+        if isinstance(x, Wrapped):
+            if self.version < 3:
+                raise ValueError("ALTREP wrappers need serialisation version 3")
+            inner = x.inner
+            kind = ("string", _STRSXP) if isinstance(inner, (RStrings, list)) else \
+                   (("integer", _INTSXP) if np.asarray(inner).dtype.kind in "iu" else ("real", _REALSXP))
+
+            def state():                     # CONS(wrapped, metadata): a dotted pair
+                self.i32(_LISTSXP)
+                bare = RStrings(list(inner)) if kind[1] == _STRSXP else RArray(np.asarray(inner))
+                self.item(bare)
+                self.i32(_INTSXP); self.i32(2); self.i32(x.is_sorted); self.i32(x.no_na)
+            self.altrep_item("wrap_" + kind[0], "base", kind[1], state, attrs)
+            return
+        if isinstance(x, DeferredString):
+            if self.version < 3:
+                raise ValueError("deferred strings need serialisation version 3")
+
+            def state():                     # CONS(source vector, scipen)
+                self.i32(_LISTSXP)
+                self.item(RArray(x.numbers))
+                self.i32(_INTSXP); self.i32(1); self.i32(0)
+            self.altrep_item("deferred_string", "base", _STRSXP, state, attrs)
             return
         if isinstance(x, str):
             x = RStrings([x])
@@ -380,6 +456,13 @@ class _Writer:
             if a.dtype == np.bool_:
                 self.i32(_LGLSXP | flag); self.i32(a.size); self.out += a.astype(">i4").tobytes()
             elif a.dtype.kind in "iu" and a.dtype != np.uint8:
+                if self.altrep and a.ndim == 1 and a.size >= 2 and abs(int(a[1]) - int(a[0])) == 1 and \
+                        np.all(np.diff(a.astype(np.int64)) == int(a[1]) - int(a[0])) and not np.any(a == NA_INTEGER):
+                    def state():             # REALSXP {length, first, increment} (R_compact_intrange)
+                        self.i32(_REALSXP); self.i32(3)
+                        self.out += np.array([a.size, int(a[0]), int(a[1]) - int(a[0])], ">f8").tobytes()
+                    self.altrep_item("compact_intseq", "base", _INTSXP, state, attrs)
+                    return
                 self.i32(_INTSXP | flag); self.i32(a.size); self.out += a.astype(">i4").tobytes()
             elif a.dtype == np.uint8:
                 self.i32(_RAWSXP | flag); self.i32(a.size); self.out += a.tobytes()
@@ -402,27 +485,45 @@ class _Writer:
 
 def _header(w: _Writer) -> None:
     w.out += b"X\n"
-    w.i32(2)                 # serialisation version
-    w.i32(0x00030500)        # written "by" R 3.5.0
-    w.i32(0x00020300)        # readable from R 2.3.0
+    w.i32(w.version)         # serialisation version
+    if w.version == 2:
+        w.i32(0x00030500)    # written "by" R 3.5.0
+        w.i32(0x00020300)    # readable from R 2.3.0
+    else:
+        w.i32(0x00040201)    # written "by" R 4.2.1
+        w.i32(0x00030500)    # version-3 streams need R >= 3.5.0
+        enc = b"UTF-8"       # native encoding of the writing session
+        w.i32(len(enc))
+        w.out += enc
 
 
-def save_rdata(path: str, objects: Dict[str, Any], compress: bool = True) -> None:
-    """``save(..., file=path)``: a workspace holding ``objects`` (name -> value)."""
-    w = _Writer()
-    w.out += b"RDX2\n"
+def _compress(data: bytes, compress) -> bytes:
+    """``save(compress=)``: True / "gzip", "bzip2", "xz", or False / None."""
+    if compress in (True, "gzip"):
+        return gzip.compress(data, 6)
+    if compress == "bzip2":
+        return bz2.compress(data, 9)
+    if compress == "xz":
+        return lzma.compress(data, format=lzma.FORMAT_XZ, preset=6)
+    if compress in (False, None):
+        return data
+    raise ValueError("compress must be TRUE/FALSE or one of \"gzip\", \"bzip2\", \"xz\"")
+
+
+def save_rdata(path: str, objects: Dict[str, Any], compress=True, version: int = 2, altrep: bool = False) -> None:
+    """``save(..., file=path, compress=, version=)``: a workspace holding ``objects`` (name -> value)."""
+    w = _Writer(version, altrep)
+    w.out += b"RDX2\n" if version == 2 else b"RDX3\n"
     _header(w)
     w.item(dict(objects))
-    data = bytes(w.out)
     with open(path, "wb") as f:
-        f.write(gzip.compress(data, 6) if compress else data)
+        f.write(_compress(bytes(w.out), compress))
 
 
-def save_rds(path: str, obj: Any, compress: bool = True) -> None:
+def save_rds(path: str, obj: Any, compress=True, version: int = 2, altrep: bool = False) -> None:
     """``saveRDS(obj, path)``."""
-    w = _Writer()
+    w = _Writer(version, altrep)
     _header(w)
     w.item(obj)
-    data = bytes(w.out)
     with open(path, "wb") as f:
-        f.write(gzip.compress(data, 6) if compress else data)
+        f.write(_compress(bytes(w.out), compress))

@@ -1,0 +1,108 @@
+"""BASELINE.json's configs 3, 4 and 5 at their named shapes, on the GPU, through the C ABI.
+
+cfg3  "Same HLA-B model, 100k synthetic samples sharded across 8 MI355X, RCCL posterior merge":
+      the full 100-classifier HLA-B model, 100,000 samples through the host-pointer entry (crosses
+      the library's batch cut), and the classifier-sharded entry points with EIGHT shards emulated on
+      one device, their partial sums added in rank order like the all-reduce would
+      (src/LibHLA.cpp:2448-2476 is the sum being split; R/HIBAG.R:764-808 the reference's cluster branch).
+cfg4  "HLA-DRB1 4-digit model (~500 haplotypes/classifier)": full 100-classifier model against the oracle.
+cfg5  "hlaAttrBagging() training, 1k samples x 300 SNPs": the device-scored driver against the oracle's
+      CPU restatement, every field of every classifier equal (src/LibHLA.cpp:2268-2305).
+"""
+
+import numpy as np
+import pytest
+
+from test_oracle_train import assert_same_classifier
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hib():
+    import hibag_amd
+    hibag_amd.hlaSetKernelTarget("hip")
+    return hibag_amd
+
+
+def test_cfg3_100k_samples_eight_classifier_shards(hib, oracle):
+    import torch
+    from hibag_amd import dist as hd, synth
+    model, founders, af = synth.make_model("hla-b")
+    n = 100_000
+    G, truth = synth.make_samples(founders, af, n)
+    G[7, :] = hib.NA_INTEGER                              # one sample with every SNP missing -> NA call
+    dev_model = hib.hlaModelFromObj(model)
+    full = dev_model.predict_raw(G, 1, want_dosage=True, want_prob=True)     # more than one batch inside the library
+    dev_model.close()
+    ok = np.ones(n, bool); ok[7] = False
+    assert np.mean((full["h1"][ok] == truth[ok, 0]) & (full["h2"][ok] == truth[ok, 1])) > 0.9
+    assert full["h1"][7] == hib.NA_INTEGER and full["prob"][7] == 0.0
+
+    # a 200-sample subset against the CPU oracle: every output bit-identical
+    rng = np.random.default_rng(3)
+    sub = np.sort(np.concatenate([[0, 7, n - 1], rng.choice(n, 197, replace=False)]))
+    want = oracle.predict(oracle.flatten(model), G[sub], vote_method=1)
+    for k in ("h1", "h2", "prob", "matching", "dosage", "postprob"):
+        assert np.array_equal(full[k][sub], want[k], equal_nan=True), k
+
+    # eight classifier shards (13,13,13,13,12,12,12,12 classifiers) on the same samples; the partial entry
+    # takes one batch at a time, so the cohort goes through in slices
+    world = 8
+    shards = [hd.hip_classifier_sharded_fns(model, 0, world, r) for r in range(world)]
+    worst = 0.0
+    for lo in range(0, n, 25_000):
+        g = G[lo:lo + 25_000]
+        merged = None
+        for pf, ff, m in shards:                           # rank order, as a ring all-reduce(SUM) would add them
+            part = pf(g)
+            merged = part if merged is None else merged + part
+        got = shards[0][1](merged)
+        torch.cuda.synchronize()
+        sl = slice(lo, lo + len(g))
+        assert np.array_equal(got["h1"], full["h1"][sl]) and np.array_equal(got["h2"], full["h2"][sl])
+        fin = np.isfinite(full["postprob"][sl]).all(axis=1)
+        for k in ("prob", "matching", "dosage", "postprob"):
+            a, b = got[k][fin], full[k][sl][fin]
+            np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-300, err_msg=k)
+        live = full["postprob"][sl][fin] > 1e-200
+        worst = max(worst, float(np.max(np.abs(got["postprob"][fin] - full["postprob"][sl][fin])[live] /
+                                        full["postprob"][sl][fin][live])))
+    assert worst <= 1e-10
+    for _, _, m in shards:
+        m.close()
+
+
+def test_cfg4_hla_drb1_full_model_against_oracle(hib, oracle):
+    """The DRB1 shape at full size: 100 classifiers x 500 haplotypes (12.5 M haplotype pairs per sample)."""
+    from hibag_amd import synth
+    model, founders, af = synth.make_model("hla-drb1")
+    G, truth = synth.make_samples(founders, af, 2048)
+    m = hib.hlaModelFromObj(model)
+    got = m.predict_raw(G, 1, want_dosage=True, want_prob=True)
+    m.close()
+    assert np.mean((got["h1"] == truth[:, 0]) & (got["h2"] == truth[:, 1])) > 0.9
+    sub = np.arange(0, 2048, 86)[:24]                      # the oracle needs ~0.1 s per sample at this size
+    want = oracle.predict(oracle.flatten(model), G[sub], vote_method=1, avx2=True, n_threads=8)
+    for k in ("h1", "h2", "prob", "matching", "dosage", "postprob"):
+        assert np.array_equal(got[k][sub], want[k], equal_nan=True), k
+
+
+def test_cfg5_training_1k_samples_300_snps(hib, oracle):
+    from hibag_amd import synth, train
+    model, founders, af = synth.make_model("hla-b", seed=9, n_snp=300, n_classifier=1, wide_classifier=False)
+    G, truth = synth.make_samples(founders, af, 1000, seed=10)
+    mtry = int(np.ceil(np.sqrt(300)))
+    tr = train._Trainer(G, truth[:, 0], truth[:, 1], model.n_hla)
+    tr.set_seed(100)
+    tr.new_classifiers(3, mtry, True, False, False)
+    got = tr.classifiers()
+    tr.close()
+    want = oracle.train(G, truth[:, 0], truth[:, 1], model.n_hla, 3, mtry, True, 100)
+    assert len(got) == 3
+    for i, (g, w) in enumerate(zip(got, want)):
+        c = hib.Classifier(snpidx=w["snpidx"], freq=w["freq"], hla=w["hla"], haplo=w["haplo"], samp_num=w["samp_num"],
+                           outofbag_acc=w["acc"])
+        assert_same_classifier(dict(samp_num=g.samp_num, snpidx=g.snpidx, haplo=g.haplo, hla=g.hla, freq=g.freq,
+                                    acc=g.outofbag_acc), c, i)
+        assert len(g.snpidx) >= 5 and len(g.freq) >= 20
