@@ -123,7 +123,9 @@ struct KernelTimer {
 
 } // namespace
 
-// for the other translation units of the library (hibag_train.hip)
+// for the other translation units of the library (hibag_train.hip, hibag_build.hip)
+int hibag_selected_device() { return g_device; }        // the calling thread's hibag_hip_set_device() choice
+
 int hibag_fail(int code, const char *fmt, ...)
 {
 	char buf[512];

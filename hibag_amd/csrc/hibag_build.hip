@@ -27,6 +27,8 @@
 #include <vector>
 
 #include "hibag_device.h"
+
+int hibag_selected_device();      // hibag_api.hip
 #include "hibag_plugin.h"
 
 namespace {
@@ -429,6 +431,9 @@ void hibag_build_init(int n_hla, int n_sample)
 {
 	hibag_build_done();
 	if (n_hla <= 0 || n_sample < 0) build_throw("build_init: invalid dimensions");
+	// every allocation and launch of the build entries goes to the device the calling thread selected
+	// with hibag_hip_set_device (one process per GPU: LOCAL_RANK), not to whatever HIP's current device is
+	HIP_OK(hipSetDevice(hibag_selected_device()), "hipSetDevice");
 	g.n_hla = n_hla; g.n_sample = n_sample;
 	g.n_pad = (std::max(n_sample, 1) + HIBAG_WAVE - 1) / HIBAG_WAVE * HIBAG_WAVE;
 	g.boot.assign(n_sample, 1);

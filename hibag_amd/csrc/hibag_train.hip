@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <thread>
@@ -42,6 +43,7 @@
 #include "hibag_plugin.h"
 
 int hibag_fail(int code, const char *fmt, ...);       // hibag_api.hip: sets the thread's last error
+int hibag_selected_device();                          // hibag_api.hip: the thread's hibag_hip_set_device() choice
 extern double g_batch_prof[4];                        // hibag_build.hip
 
 namespace {
@@ -167,6 +169,12 @@ class Pool {
 	unsigned long gen = 0;
 	int pending = 0;
 	bool stop = false;
+	std::exception_ptr failed;                  // first exception of a job, rethrown by run() on the caller
+	void note_failure()
+	{
+		std::lock_guard<std::mutex> lk(m);
+		if (!failed) failed = std::current_exception();
+	}
 public:
 	explicit Pool(int n_helpers)
 	{
@@ -182,7 +190,7 @@ public:
 						seen = gen;
 						f = job;
 					}
-					f();
+					try { f(); } catch (...) { note_failure(); }     // never let an exception leave the thread
 					{
 						std::lock_guard<std::mutex> lk(m);
 						if (--pending == 0) done.notify_one();
@@ -204,15 +212,23 @@ public:
 			job = f; gen++; pending = (int)th.size();
 		}
 		wake.notify_all();
-		f();
+		try { f(); } catch (...) { note_failure(); }
+		// always wait for the helpers: they use objects on the caller's stack
 		std::unique_lock<std::mutex> lk(m);
 		done.wait(lk, [&] { return pending == 0; });
+		if (failed) {
+			std::exception_ptr e = failed;
+			failed = nullptr;
+			lk.unlock();
+			std::rethrow_exception(e);
+		}
 	}
 };
 
 } // namespace
 
 struct hibag_hip_trainer {
+	int device = 0;                             // HIP device of this trainer (hibag_hip_set_device at creation)
 	int n_snp = 0, n_samp = 0, n_hla = 0;
 	std::vector<int32_t> geno, h1, h2;          // geno [n_samp][n_snp]
 	RMersenne rng;
@@ -678,6 +694,7 @@ hibag_hip_trainer *hibag_hip_trainer_new(int n_snp, int n_samp, const int32_t *s
 	}
 	hibag_hip_trainer *t = new (std::nothrow) hibag_hip_trainer;
 	if (!t) { hibag_fail(HIBAG_HIP_ENOMEM, "out of host memory"); return nullptr; }
+	t->device = hibag_selected_device();
 	t->n_snp = n_snp; t->n_samp = n_samp; t->n_hla = n_hla;
 	t->geno.assign(snp_geno, snp_geno + (size_t)n_samp * n_snp);
 	t->h1.assign(H1, H1 + n_samp); t->h2.assign(H2, H2 + n_samp);
@@ -712,6 +729,8 @@ int hibag_hip_trainer_new_classifiers(hibag_hip_trainer *t, int nclassifier, int
 	static std::mutex device_state;                    // the build entries keep one device state per process
 	std::lock_guard<std::mutex> g2(device_state);
 	const size_t before = t->out.size();
+	if (hibag_hip_set_device(t->device)) return HIBAG_HIP_ENODEV;     // the build entries allocate on the selected device
+	if (hipSetDevice(t->device) != hipSuccess) return hibag_fail(HIBAG_HIP_ENODEV, "hipSetDevice(%d) failed", t->device);
 	try {
 		if (!t->pool && t->n_threads > 1) t->pool.reset(new Pool(t->n_threads - 1));
 		g_prof = Profile();

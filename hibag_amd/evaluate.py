@@ -112,10 +112,12 @@ def hlaCompareAllele(TrueHLA: HlaAlleleClass, PredHLA: HlaAlleleClass, allele_li
     ``call_threshold``."""
     pred = {s: i for i, s in enumerate(PredHLA.sample_id)}
     rows = [(i, pred[s]) for i, s in enumerate(TrueHLA.sample_id) if s in pred]
+    # R/DataUtilities.R:1376-1380: samples with an NA in the true OR the predicted pair are left out first
+    rows = [(i, j) for i, j in rows if TrueHLA.allele1[i] is not None and TrueHLA.allele2[i] is not None
+            and PredHLA.allele1[j] is not None and PredHLA.allele2[j] is not None]
     if allele_limit is not None:
         allowed = set(getattr(allele_limit, "hla_allele", allele_limit))
         rows = [(i, j) for i, j in rows if TrueHLA.allele1[i] in allowed and TrueHLA.allele2[i] in allowed]
-    rows = [(i, j) for i, j in rows if TrueHLA.allele1[i] is not None and TrueHLA.allele2[i] is not None]
     n = len(rows)
     cnt_ind = cnt_haplo = cnt_call = 0
     for i, j in rows:

@@ -249,8 +249,11 @@ def plan_snps_for_predict(obj: HlaAttrBagObj, snp, afreq_of_rows: Callable[[np.n
         sel = np.array([-1 if j is None else j for j in picked], np.int64)
         alleles = []
         for i, j in enumerate(picked):
-            a = None if j is None or j >= len(snp.snp_allele) else snp.snp_allele[j]
-            alleles.append(obj.snp_allele[i] if a is None else a)
+            if j is None:                          # unmatched: takes the model's alleles (R/HIBAG.R:641-646)
+                alleles.append(obj.snp_allele[i])
+            else:                                  # matched with an NA allele string: "" -> "mismatched alleles" rule
+                a = snp.snp_allele[j] if j < len(snp.snp_allele) else None
+                alleles.append("" if a is None else a)
 
     flip = np.zeros(len(obj_id), bool)
     if allele_check:

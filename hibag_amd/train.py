@@ -207,11 +207,15 @@ def _row_mean_half(g: np.ndarray) -> np.ndarray:
 def hlaAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,
                    mtry: Union[str, float, int] = "sqrt", prune: bool = True, na_rm: bool = True,
                    mono_rm: bool = True, maf: float = float("nan"), nthread: int = 1, verbose: bool = True,
-                   verbose_detail: bool = False, rng: Optional[RRandom] = None, grow=None) -> HlaAttrBagClass:
+                   verbose_detail: bool = False, rng: Optional[RRandom] = None, grow=None,
+                   device: Optional[int] = None) -> HlaAttrBagClass:
     """``hlaAttrBagging`` (``R/HIBAG.R:48-275``).  ``nthread`` is accepted for signature
     compatibility (the scoring runs on the device).  ``rng`` defaults to the module's
     R-compatible stream (see :func:`set_seed`).  ``grow`` (internal) replaces the single-device
-    call of the native driver, see :func:`hlaParallelAttrBagging`."""
+    call of the native driver, see :func:`hlaParallelAttrBagging`.  ``device`` (extension): the HIP
+    device that trains and holds the returned model (default: the thread's current selection)."""
+    if device is not None:
+        _lib.check(_lib.lib().hibag_hip_set_device(int(device)))
     if not isinstance(hla, HlaAlleleClass):
         raise TypeError("inherits(hla, \"hlaAlleleClass\") is not TRUE")
     if not isinstance(snp, HlaSNPGeno):
@@ -306,7 +310,7 @@ def hlaAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,
         sample_id=samp_id, snp_id=snp_id, snp_position=snp_pos, snp_allele=snp_allele,
         snp_allele_freq=_row_mean_half(geno), hla_freq=counts / counts.sum(),
         assembly=snp.assembly or "unknown", matching=None, appendix=None)
-    mod = HlaAttrBagClass(obj)
+    mod = HlaAttrBagClass(obj, device=device)
     if with_matching:
         if verbose:
             print("Calculating matching proportion:")
@@ -342,17 +346,22 @@ def grow_classifier_sharded(grow_fn, nclassifier: int, group=None) -> List[Class
 def hlaParallelAttrBagging(cl, hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,
                            mtry: Union[str, float, int] = "sqrt", prune: bool = True, na_rm: bool = True,
                            mono_rm: bool = True, maf: float = float("nan"), verbose: bool = True,
-                           verbose_detail: bool = False, seed: Optional[int] = None, group=None) -> HlaAttrBagClass:
+                           verbose_detail: bool = False, seed: Optional[int] = None, group=None,
+                           device: Optional[int] = None) -> HlaAttrBagClass:
     """``hlaParallelAttrBagging`` (``R/HIBAG.R:293-440``) for one process per GPU: ``cl`` is
     accepted for signature compatibility; the "cluster" is the initialised
     ``torch.distributed`` process group (RCCL on a GPU box).  Like the reference's workers
     (``clusterSetRNGStream``) every rank draws from its own stream: R's Mersenne-Twister seeded
     with ``seed + rank`` -- so the model differs from a serial run with the same seed, as it
-    does in the reference.  Every rank returns the complete model."""
+    does in the reference.  Every rank returns the complete model.  Each rank trains and keeps its model
+    on its own GPU: ``device`` defaults to ``LOCAL_RANK`` when a process group is live."""
+    import os
     import torch.distributed as dist
     live = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank(group) if live else 0
     base = 0 if seed is None else int(seed)
+    if device is None and live and _lib.lib().hibag_hip_device_count() > 1:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
 
     def grow(genomat, h1, h2, n_hla, n, m, pr):
         def grow_fn(count, r):
@@ -368,5 +377,5 @@ def hlaParallelAttrBagging(cl, hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier
         return grow_classifier_sharded(grow_fn, n, group)
 
     return hlaAttrBagging(hla, snp, nclassifier=nclassifier, mtry=mtry, prune=prune, na_rm=na_rm, mono_rm=mono_rm,
-                          maf=maf, verbose=verbose and rank == 0, verbose_detail=verbose_detail, grow=grow)
+                          maf=maf, verbose=verbose and rank == 0, verbose_detail=verbose_detail, grow=grow, device=device)
 

@@ -20,6 +20,23 @@ def _free_port():
     return p
 
 
+def _result(q, procs, timeout=180):
+    """First item a worker puts on `q`; fails (instead of hanging) when a worker dies or nothing arrives."""
+    import queue
+    import time
+    end = time.time() + timeout
+    while time.time() < end:
+        try:
+            return q.get(timeout=1.0)
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead:
+                raise AssertionError(f"a worker exited with code {dead[0]} before producing a result")
+    for p in procs:
+        p.terminate()
+    raise AssertionError("no result from the workers within the time limit")
+
+
 def _oracle_partial(O, fm_full, model, lo, hi, G):
     """[P+3, n] partial sums of classifiers lo..hi-1, as the HIP partial entry defines them."""
     P = fm_full.n_hla * (fm_full.n_hla + 1) // 2
@@ -90,12 +107,12 @@ def test_two_rank_gloo_orchestration(oracle):
     import torch.multiprocessing as mp
     from hibag_amd import synth
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, got2 = q.get()
+    got, got2 = _result(q, procs)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -182,12 +199,12 @@ def test_two_rank_gloo_training_shards(oracle):
     import torch.multiprocessing as mp
     from hibag_amd import synth
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get()
+    got = _result(q, procs)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0

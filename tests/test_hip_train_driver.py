@@ -157,3 +157,31 @@ def test_random_training_problems(hib, oracle, seed):
         c = hib.Classifier(snpidx=w["snpidx"], freq=w["freq"], hla=w["hla"], haplo=w["haplo"], samp_num=w["samp_num"],
                            outofbag_acc=w["acc"])
         assert_same_classifier(_as_dict(g), c, i)
+
+
+def test_training_runs_on_the_selected_device(hib, oracle):
+    """One process per GPU: the trainer and the model it returns live on the device chosen with
+    hibag_hip_set_device / device= (LOCAL_RANK under torchrun), not on device 0.  Needs two GPUs to see
+    a difference; on a one-GPU box it checks the selection plumbing and the error for a missing device."""
+    import torch
+    from hibag_amd import _lib, synth
+    L = _lib.lib()
+    n_dev = L.hibag_hip_device_count()
+    assert L.hibag_hip_set_device(n_dev) != 0 and b"not available" in L.hibag_hip_last_error()
+    model, founders, af = synth.make_model("hla-a-small", seed=5, n_snp=40)
+    G, truth = synth.make_samples(founders, af, 80, seed=6)
+    ids = [f"S{i}" for i in range(80)]
+    hla = hib.hlaAllele(ids, [model.hla_allele[a] for a in truth[:, 0]], [model.hla_allele[a] for a in truth[:, 1]], locus="A",
+                        assembly="hg19")
+    snp = hib.HlaSNPGeno(genotype=np.ascontiguousarray(G.T), sample_id=ids, snp_id=list(model.snp_id),
+                         snp_position=model.snp_position, snp_allele=list(model.snp_allele), assembly="hg19")
+    dev = n_dev - 1
+    free_other = torch.cuda.mem_get_info(0)[0] if n_dev > 1 else None
+    free_before = torch.cuda.mem_get_info(dev)[0]
+    hib.set_seed(11)
+    mod = hib.hlaAttrBagging(hla, snp, nclassifier=2, mtry=6, mono_rm=False, verbose=False, device=dev)
+    assert len(mod.obj.classifiers) == 2
+    assert torch.cuda.mem_get_info(dev)[0] < free_before          # the model (and the build state) sit on `dev`
+    if n_dev > 1:
+        assert abs(torch.cuda.mem_get_info(0)[0] - free_other) < (8 << 20)      # nothing landed on device 0
+    assert L.hibag_hip_set_device(0) == 0
