@@ -27,7 +27,7 @@ EXPORTS = [
     "hibag_hip_model_pair_evals", "hibag_hip_model_mutation_table", "hibag_hip_predict",
     "hibag_hip_predict_device", "hibag_hip_model_set_snp_weights", "hibag_hip_predict_partial_device",
     "hibag_hip_finish_device", "hibag_hip_set_timing", "hibag_hip_get_timing", "hibag_hip_reset_timing",
-    "hibag_hip_gpu_ext_proc", "hibag_hip_bed_flag", "hibag_hip_conv_bed", "hibag_hip_predict_bed",
+    "hibag_hip_gpu_ext_proc", "hibag_hip_bed_flag", "hibag_hip_conv_bed", "hibag_hip_predict_bed", "hibag_hip_predict_mapped", "hibag_hip_predict_mapped_device",
     "hibag_hip_trainer_new", "hibag_hip_trainer_free", "hibag_hip_trainer_set_rng", "hibag_hip_trainer_set_seed",
     "hibag_hip_trainer_new_classifiers", "hibag_hip_trainer_n_classifier", "hibag_hip_trainer_classifier_dims",
     "hibag_hip_trainer_classifier_get",
@@ -101,6 +101,8 @@ def lib() -> C.CDLL:
     L.hibag_hip_bed_flag.argtypes = [C.c_char_p]
     L.hibag_hip_conv_bed.argtypes = [C.c_char_p, i32, i32, i32, vp, vp]
     L.hibag_hip_predict_bed.argtypes = [vp, C.c_char_p, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.hibag_hip_predict_mapped.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.hibag_hip_predict_mapped_device.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 

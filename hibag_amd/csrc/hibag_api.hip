@@ -732,7 +732,9 @@ int check_predict_args(hibag_hip_model *m, const void *geno, int n_samp, int vot
 
 // Where a batch's genotypes come from: the int32 matrix, or a PLINK BED payload.
 struct PackSource {
-	const int32_t *d_geno = nullptr;       // [n_samp][n_snp]
+	const int32_t *d_geno = nullptr;       // [n_samp][row_len]
+	int row_len = 0;                       // SNPs per sample in d_geno (0: the model's n_snp, model order)
+	const int32_t *d_col = nullptr;        // [n_snp] column of each model SNP in d_geno (-1 = absent), nullptr = identity
 	const uint8_t *d_bed = nullptr;        // payload rows (see k_bed_codes)
 	int mode = 0;
 	size_t stride = 0;
@@ -756,7 +758,8 @@ int predict_device_locked(hibag_hip_model *m, const PackSource &src, int n_samp,
 			hibag_launch_pack_bed(m->view, B, src.d_bed, src.mode, src.stride, src.samp0 + s0, src.d_row, src.d_flip,
 				m->ws_codes.as<uint8_t>(), st);
 		else
-			hibag_launch_pack(m->view, B, src.d_geno + (size_t)s0 * m->n_snp, m->ws_codes.as<uint8_t>(), st);
+			hibag_launch_pack(m->view, B, src.d_geno + (size_t)s0 * (src.d_col ? src.row_len : m->n_snp), src.row_len,
+				src.d_col, src.d_flip, m->ws_codes.as<uint8_t>(), st);
 		m->timer.end(st);
 		run_core(m, B, vote_method, m->ws_part.as<double>(), st);
 		m->timer.begin(HIBAG_HIP_K_FINISH, st);
@@ -775,9 +778,11 @@ int predict_device_locked(hibag_hip_model *m, const PackSource &src, int n_samp,
 // needs more than a slice on the device; genotypes come from the host int32
 // matrix (uploaded slice by slice) or from a BED payload already on the device.
 int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSource *bed, int n_samp, int vote_method,
-	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob)
+	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob,
+	const PackSource *map = nullptr)
 {
-	const size_t P = (size_t)m->view.n_cell, nh = (size_t)m->n_hla, S = (size_t)m->n_snp;
+	// `map`: geno is the cohort's own matrix (map->row_len SNPs per sample); map->d_col / d_flip sit on the device
+	const size_t P = (size_t)m->view.n_cell, nh = (size_t)m->n_hla, S = map ? (size_t)map->row_len : (size_t)m->n_snp;
 	const int slice = batch_limit(m);
 	const size_t geno_bytes = (size_t)slice * std::max<size_t>(S, 1) * sizeof(int32_t);
 	const size_t o_h1 = 0, o_h2 = o_h1 + (size_t)slice * 4, o_mp = (o_h2 + (size_t)slice * 4 + 7) / 8 * 8,
@@ -1034,6 +1039,48 @@ int hibag_hip_predict(hibag_hip_model *m, const int32_t *geno, int n_samp, int v
 	return predict_staged_locked(m, geno, nullptr, n_samp, vote_method, H1, H2, max_prob, matching, dosage, postprob);
 }
 
+int hibag_hip_predict_mapped(hibag_hip_model *m, const int32_t *geno, int n_samp, int n_geno_snp,
+	const int32_t *snp_col, const int32_t *flip, int vote_method,
+	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob)
+{
+	if (int rc = check_predict_args(m, geno, n_samp, vote_method, H1, H2)) return rc;
+	if (n_geno_snp <= 0) return fail(HIBAG_HIP_EINVAL, "n_geno_snp must be positive");
+	if (!snp_col && m->n_snp > 0) return fail(HIBAG_HIP_EINVAL, "snp_col is NULL");
+	for (int k = 0; k < m->n_snp; k++)
+		if (snp_col[k] >= n_geno_snp) return fail(HIBAG_HIP_EINVAL, "snp_col[%d] = %d outside the %d SNPs of the genotype matrix", k, snp_col[k], n_geno_snp);
+	if (n_samp == 0) return 0;
+	std::lock_guard<std::mutex> g(m->lock);
+	HIP_TRY(hipSetDevice(m->device));
+	const size_t S = (size_t)std::max(m->n_snp, 1);
+	std::vector<int32_t> idx(2 * S, 0);
+	for (int k = 0; k < m->n_snp; k++) {
+		idx[k] = snp_col[k] < 0 ? -1 : snp_col[k];
+		idx[S + k] = flip ? (flip[k] != 0) : 0;
+	}
+	if (int rc = m->ws_bedidx.reserve(idx.size() * sizeof(int32_t))) return rc;
+	HIP_TRY(hipMemcpyAsync(m->ws_bedidx.p, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, 0));
+	HIP_TRY(hipStreamSynchronize(0));            // `idx` is pageable host memory about to go out of scope
+	PackSource map;
+	map.row_len = n_geno_snp;
+	map.d_col = m->ws_bedidx.as<int32_t>();
+	map.d_flip = m->ws_bedidx.as<int32_t>() + S;
+	return predict_staged_locked(m, geno, nullptr, n_samp, vote_method, H1, H2, max_prob, matching, dosage, postprob, &map);
+}
+
+int hibag_hip_predict_mapped_device(hibag_hip_model *m, const int32_t *d_geno, int n_samp, int n_geno_snp,
+	const int32_t *d_snp_col, const int32_t *d_flip, int vote_method,
+	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching, double *d_dosage,
+	double *d_postprob, void *stream)
+{
+	if (int rc = check_predict_args(m, d_geno, n_samp, vote_method, d_H1, d_H2)) return rc;
+	if (n_geno_snp <= 0 || !d_snp_col) return fail(HIBAG_HIP_EINVAL, "n_geno_snp must be positive and d_snp_col given");
+	std::lock_guard<std::mutex> g(m->lock);
+	PackSource src;
+	src.d_geno = d_geno; src.row_len = n_geno_snp; src.d_col = d_snp_col; src.d_flip = d_flip;
+	return predict_device_locked(m, src, n_samp, vote_method, d_H1, d_H2, d_max_prob, d_matching,
+		d_dosage, d_postprob, (hipStream_t)stream);
+}
+
 // ---- PLINK BED ------------------------------------------------------------
 
 int hibag_hip_bed_flag(const char *bed_fn)
@@ -1122,7 +1169,7 @@ int hibag_hip_predict_partial_device(hibag_hip_model *m, const int32_t *d_geno, 
 	HibagBatchView B;
 	if (int rc = make_batch(m, n_samp, false, B)) return rc;
 	m->timer.begin(HIBAG_HIP_K_PACK, st);
-	hibag_launch_pack(m->view, B, d_geno, m->ws_codes.as<uint8_t>(), st);
+	hibag_launch_pack(m->view, B, d_geno, 0, nullptr, nullptr, m->ws_codes.as<uint8_t>(), st);
 	m->timer.end(st);
 	run_core(m, B, 1, d_partial, st);
 	HIP_TRY(hipGetLastError());

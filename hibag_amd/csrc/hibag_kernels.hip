@@ -357,27 +357,41 @@ __device__ __forceinline__ void stage_table(const HibagModelView &M, double *tab
 }
 
 // ---------------------------------------------------------------------------
-// k_codes: the raw genotype matrix int32 [n_samp][n_snp] (sample-major, the
+// k_codes: the raw genotype matrix int32 [n_samp][row_len] (sample-major, the
 // memory of R's SNP x sample matrix) -> byte codes [n_snp][n_pad] with the
 // sample index fastest: 0/1/2 = genotype, 3 = missing (anything outside 0..2,
 // incl. NA_integer_, src/LibHLA.cpp:662-665).  64x64 transpose through LDS:
 // reads are coalesced along SNPs, writes along samples.
+// With `col` the matrix is the cohort's own (row_len SNPs in the cohort's order):
+// model SNP k is read from column col[k] (-1 = the cohort lacks it -> missing) and
+// flip[k] != 0 reverses its allele count, g -> 2 - g: the SNP selection and strand /
+// allele-order fix-up of hlaPredict (R/HIBAG.R:640-676) done while packing instead
+// of on the host.  col == nullptr: the matrix already is in model order (row_len = n_snp).
 __global__ __launch_bounds__(256) void k_codes(HibagModelView M, HibagBatchView B,
-	const int32_t *__restrict__ geno, uint8_t *__restrict__ codes)
+	const int32_t *__restrict__ geno, int row_len, const int32_t *__restrict__ col, const int32_t *__restrict__ flip,
+	uint8_t *__restrict__ codes)
 {
 	__shared__ uint8_t tile[64][65];
 	const int s0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	const int k = k0 + tx;
+	int c = -1, f = 0;
+	if (k < M.n_snp) {
+		c = col ? col[k] : k;
+		f = (col && flip) ? flip[k] : 0;
+	}
 	for (int r = ty; r < 64; r += 4) {
-		const int s = s0 + r, k = k0 + tx;
+		const int s = s0 + r;
 		int g = -1;
-		if (s < B.n_samp && k < M.n_snp) g = geno[(size_t)s * M.n_snp + k];
-		tile[r][tx] = (g >= 0 && g <= 2) ? (uint8_t)g : (uint8_t)3;
+		if (s < B.n_samp && c >= 0) g = geno[(size_t)s * row_len + c];
+		uint8_t v = (g >= 0 && g <= 2) ? (uint8_t)g : (uint8_t)3;
+		if (f && v != 3) v = (uint8_t)(2 - v);
+		tile[r][tx] = v;
 	}
 	__syncthreads();
 	for (int r = ty; r < 64; r += 4) {
-		const int k = k0 + r;
-		if (k < M.n_snp) codes[(size_t)k * B.n_pad + s0 + tx] = tile[tx][r];
+		const int kk = k0 + r;
+		if (kk < M.n_snp) codes[(size_t)kk * B.n_pad + s0 + tx] = tile[tx][r];
 	}
 }
 
@@ -1040,11 +1054,12 @@ __global__ __launch_bounds__(256) void k_finish_prob(HibagModelView M, HibagBatc
 
 static inline dim3 grid1(int n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
-void hibag_launch_pack(const HibagModelView &M, const HibagBatchView &B, const int32_t *d_geno, uint8_t *d_codes,
-	hipStream_t st)
+void hibag_launch_pack(const HibagModelView &M, const HibagBatchView &B, const int32_t *d_geno, int row_len,
+	const int32_t *d_col, const int32_t *d_flip, uint8_t *d_codes, hipStream_t st)
 {
 	if (M.n_classifier == 0 || M.n_snp == 0) return;
-	hipLaunchKernelGGL(k_codes, dim3(B.n_pad / 64, (M.n_snp + 63) / 64), dim3(256), 0, st, M, B, d_geno, d_codes);
+	hipLaunchKernelGGL(k_codes, dim3(B.n_pad / 64, (M.n_snp + 63) / 64), dim3(256), 0, st, M, B, d_geno,
+		d_col ? row_len : M.n_snp, d_col, d_flip, d_codes);
 	hipLaunchKernelGGL(k_pack, dim3(B.n_pad / HIBAG_WAVE, (M.n_classifier + PACK_WAVES - 1) / PACK_WAVES), dim3(PACK_WAVES * HIBAG_WAVE), 0, st, M, B,
 		(const uint8_t *)d_codes);
 }

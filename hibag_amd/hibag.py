@@ -173,6 +173,31 @@ class HlaAttrBagClass:
             _as_ptr(out.get("dosage")), _as_ptr(out.get("postprob"))))
         return out
 
+    def predict_mapped(self, genomat: np.ndarray, snp_col: np.ndarray, flip: Optional[np.ndarray] = None,
+                       vote_method: int = 1, want_dosage: bool = True, want_prob: bool = False) -> dict:
+        """``PredictHLA`` on the COHORT's own matrix ``genomat`` [n_samp, n_geno_snp] (``hibag_hip_predict_mapped``):
+        ``snp_col[k]`` = column of model SNP k (-1 = absent), ``flip[k]`` = reverse its allele count; the
+        selection and the flip happen on the device while the genotypes are packed."""
+        g = np.ascontiguousarray(genomat, np.int32)
+        if g.ndim != 2:
+            raise ValueError("genomat must be [n_samp, n_geno_snp]")
+        col = np.ascontiguousarray(snp_col, np.int32)
+        if col.shape != (self.obj.n_snp,):
+            raise ValueError("snp_col must have one entry per model SNP")
+        fl = None if flip is None else np.ascontiguousarray(np.asarray(flip) != 0, np.int32)
+        n = g.shape[0]
+        out = dict(h1=np.zeros(n, np.int32), h2=np.zeros(n, np.int32),
+                   prob=np.zeros(n, np.float64), matching=np.zeros(n, np.float64))
+        if want_dosage:
+            out["dosage"] = np.zeros((n, self.obj.n_hla), np.float64)
+        if want_prob:
+            out["postprob"] = np.zeros((n, self.obj.n_cell), np.float64)
+        _lib.check(_lib.lib().hibag_hip_predict_mapped(
+            self.handle, _as_ptr(g), n, g.shape[1], _as_ptr(col), _as_ptr(fl), int(vote_method),
+            _as_ptr(out["h1"]), _as_ptr(out["h2"]), _as_ptr(out["prob"]), _as_ptr(out["matching"]),
+            _as_ptr(out.get("dosage")), _as_ptr(out.get("postprob"))))
+        return out
+
     def predict_device(self, d_geno, n_samp: int, vote_method: int = 1, d_h1=None, d_h2=None, d_prob=None,
                        d_matching=None, d_dosage=None, d_postprob=None, stream=None):
         """Device-pointer form; arguments are ints (``tensor.data_ptr()``) or None."""
@@ -288,7 +313,7 @@ def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, HlaBEDGeno, np.nd
         print("Prediction:\n    " + ("based on the averaged posterior probabilities" if vote_method == 1
                                       else "by voting from all individual classifiers"), file=out)
 
-    bed_plan = None
+    bed_plan = map_plan = None
     if isinstance(snp, HlaBEDGeno):
         # extension: the genotypes stay in the PLINK BED file; the SNP matching / strand check
         # (R/HIBAG.R:550-686) runs on the annotation and the device decodes the file directly
@@ -310,15 +335,19 @@ def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, HlaBEDGeno, np.nd
         assembly = "auto-silent"
         mat = g
     else:
-        from .snpmatch import match_snps_for_predict
-        mat, assembly = match_snps_for_predict(obj, snp, match_type, allele_check, same_strand,
-                                               verbose, verbose_match)
+        # the SNP matching / strand check (R/HIBAG.R:550-686) decides on the annotation; the rows are
+        # picked and flipped on the device while the genotypes are packed (hibag_hip_predict_mapped)
+        from .snpmatch import _row_afreq, plan_snps_for_predict
+        map_plan = plan_snps_for_predict(obj, snp, lambda rows: _row_afreq(snp.genotype[rows]), match_type,
+                                         allele_check, same_strand, verbose, verbose_match)
+        assembly = map_plan.assembly
         geno_sampid = list(snp.sample_id)
+        mat = None
 
-    if bed_plan is None and mat.shape[0] != obj.n_snp:
+    if mat is not None and mat.shape[0] != obj.n_snp:
         raise ValueError("The number of SNPs is not valid, and it maybe due to duplicated 'snp.id' "
                          "or incorrect dimension of genotype matrix.")
-    n_samp = len(geno_sampid) if bed_plan is not None else mat.shape[1]
+    n_samp = len(geno_sampid) if mat is None else mat.shape[1]
     if verbose:
         print(f"# of samples: {n_samp}", file=out)
         print(f"Kernel target: {_kernel_info or 'hip'}", file=out)
@@ -329,6 +358,13 @@ def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, HlaBEDGeno, np.nd
         col = np.where(bed_plan.sel >= 0, snp.bed_index[np.maximum(bed_plan.sel, 0)], -1)
         rv = object.predict_bed(snp.bed_fn, snp.n_bed_samp, snp.n_bed_snp, col, bed_plan.flip, vote_method,
                                 want_dosage=want_dosage, want_prob=want_prob)
+    elif map_plan is not None:
+        g = np.asarray(snp.genotype)
+        if g.dtype.kind == "f":
+            g = np.where(np.isfinite(g), g, NA_INTEGER)
+        cohort = np.ascontiguousarray(g.astype(np.int64).T.astype(np.int32))      # [n_samp, cohort SNPs]: R's memory order
+        rv = object.predict_mapped(cohort, map_plan.sel, map_plan.flip, vote_method,
+                                   want_dosage=want_dosage, want_prob=want_prob)
     else:
         # as.integer(snp): R's NA -> NA_integer_ ; the C side treats anything outside 0..2 as missing
         if mat.dtype.kind == "f":

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIBAG_HIP_ABI_VERSION 2   /* 2: + PLINK BED entries, training driver */
+#define HIBAG_HIP_ABI_VERSION 3   /* 2: + PLINK BED entries, training driver; 3: + hibag_hip_predict_mapped[_device] */
 
 /* error codes */
 #define HIBAG_HIP_OK          0
@@ -126,6 +126,22 @@ int hibag_hip_predict(hibag_hip_model *m, const int32_t *geno, int n_samp,
 int hibag_hip_predict_device(hibag_hip_model *m, const int32_t *d_geno, int n_samp,
 	int vote_method, int32_t *d_H1, int32_t *d_H2, double *d_max_prob,
 	double *d_matching, double *d_dosage, double *d_postprob, void *stream);
+
+/* hlaPredict()'s SNP selection and strand / allele-order fix-up (R/HIBAG.R:640-676: the rows of the
+ * cohort's matrix picked by match(), absent SNPs as NA rows, hlaGenoSwitchStrand's g -> 2 - g) done on the
+ * device while the genotypes are packed, instead of building a second matrix on the host:
+ *   geno        int32 [n_samp][n_geno_snp]: the COHORT's matrix, its own SNPs in its own order
+ *   snp_col[model n_snp]  0-based column of each model SNP in geno, -1 = the cohort lacks it
+ *   flip[model n_snp]     NULL, or != 0 where the allele count must be reversed
+ * Otherwise as hibag_hip_predict / hibag_hip_predict_device (the _device form takes every pointer,
+ * snp_col and flip included, in device memory). */
+int hibag_hip_predict_mapped(hibag_hip_model *m, const int32_t *geno, int n_samp, int n_geno_snp,
+	const int32_t *snp_col, const int32_t *flip, int vote_method,
+	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob);
+int hibag_hip_predict_mapped_device(hibag_hip_model *m, const int32_t *d_geno, int n_samp, int n_geno_snp,
+	const int32_t *d_snp_col, const int32_t *d_flip, int vote_method,
+	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching, double *d_dosage,
+	double *d_postprob, void *stream);
 
 /* Classifier-sharded partial pass for multi-GPU runs: each rank owns a model
  * holding a subset of the classifiers but built with the FULL model's per-SNP

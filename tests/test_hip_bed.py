@@ -160,3 +160,58 @@ def test_predict_bed_full_size_equals_matrix_path(hib, tmp_path):
     b = m.predict_raw(G, 1, want_dosage=True, want_prob=True)
     for k in ("h1", "h2", "prob", "matching", "dosage", "postprob"):
         assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("n_samp", [333, 140_000])
+def test_int32_route_selects_and_flips_on_the_device(hib, oracle, n_samp):
+    """hlaPredict on an hlaSNPGenoClass whose SNP set differs from the model's (R/HIBAG.R:640-676): missing
+    model SNPs, extra cohort SNPs, shuffled order, reversed A/B alleles on a third of the SNPs.  The library
+    gets the cohort's own matrix plus the column map (hibag_hip_predict_mapped) and gathers / flips while
+    packing; the oracle gets the matrix the reference's host code would have built.  140,000 samples cross
+    the library's batch cut (the map must follow the slices)."""
+    from hibag_amd import synth
+    from hibag_amd.snpmatch import match_snps_for_predict
+    model, founders, af = synth.make_model("hla-a-small", seed=11)
+    G, _ = synth.make_samples(founders, af, n_samp, seed=12)          # [n_samp, S]
+    S = model.n_snp
+    rng = np.random.default_rng(13)
+    keep = rng.random(S) < 0.9
+    flip = rng.random(S) < 0.33
+    extra = 17
+    order = rng.permutation(int(keep.sum()) + extra)
+    rows, ids, pos, alle = [], [], [], []
+    for k in np.where(keep)[0]:
+        g = G[:, k].copy()
+        if flip[k]:
+            g = np.where(g == NA, NA, 2 - g)
+        rows.append(g); ids.append(model.snp_id[k]); pos.append(model.snp_position[k])
+        alle.append("G/A" if flip[k] else "A/G")
+    for e in range(extra):
+        rows.append(rng.integers(0, 3, G.shape[0]).astype(np.int32)); ids.append(f"x{e}"); pos.append(1000 + e); alle.append("C/T")
+    cohort = hib.HlaSNPGeno(genotype=np.array([rows[i] for i in order], np.int32), sample_id=[f"s{i}" for i in range(n_samp)],
+                            snp_id=[ids[i] for i in order], snp_position=np.array([pos[i] for i in order], np.float64),
+                            snp_allele=[alle[i] for i in order], assembly="hg19")
+    m = hib.hlaModelFromObj(model)
+    got = hib.hlaPredict(m, cohort, type="response+prob" if n_samp < 1000 else "response+dosage", verbose=False)
+    # what the reference's host code builds, then the oracle (a subset at the large size)
+    mat, _ = match_snps_for_predict(model, cohort, "Position", True, False, False, False)
+    sub = np.arange(n_samp) if n_samp < 1000 else np.unique(np.concatenate([[0, n_samp - 1], rng.choice(n_samp, 300, replace=False)]))
+    Gm = np.ascontiguousarray(mat.T[sub].astype(np.int32))
+    Gexp = G[sub].copy(); Gexp[:, ~keep] = NA
+    assert np.array_equal(Gm, Gexp)
+    want = oracle.predict(oracle.flatten(model), Gm, vote_method=1)
+    assert np.array_equal(got.h1[sub], want["h1"]) and np.array_equal(got.h2[sub], want["h2"])
+    assert np.array_equal(got.prob[sub], want["prob"], equal_nan=True)
+    assert np.array_equal(got.matching[sub], want["matching"], equal_nan=True)
+    assert np.array_equal(got.dosage.T[sub], want["dosage"], equal_nan=True)
+    if n_samp < 1000:
+        assert np.array_equal(got.postprob.T, want["postprob"], equal_nan=True)
+    # the mapped entry and the plain entry on the pre-built matrix agree bit for bit on every sample
+    plain = m.predict_raw(np.ascontiguousarray(mat.T.astype(np.int32)), 1, want_dosage=True)
+    assert np.array_equal(got.h1, plain["h1"]) and np.array_equal(got.prob, plain["prob"], equal_nan=True)
+    assert np.array_equal(got.dosage.T, plain["dosage"], equal_nan=True)
+    # argument errors
+    from hibag_amd import _lib
+    bad = np.full(model.n_snp, cohort.genotype.shape[0], np.int32)
+    with pytest.raises(_lib.HibagHipError, match="outside the"):
+        m.predict_mapped(np.zeros((2, cohort.genotype.shape[0]), np.int32), bad)
