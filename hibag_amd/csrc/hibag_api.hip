@@ -801,6 +801,7 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 		} else {
 			HIP_TRY(hipMemcpyAsync(m->ws_geno.p, geno + (size_t)s0 * S, (size_t)n * S * sizeof(int32_t),
 				hipMemcpyHostToDevice, 0));
+			if (map) src = *map;
 			src.d_geno = m->ws_geno.as<int32_t>();
 		}
 		if (int rc = predict_device_locked(m, src, n, vote_method,
