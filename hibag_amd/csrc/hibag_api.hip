@@ -155,7 +155,7 @@ struct hibag_hip_model {
 	size_t stream_bytes = 0;
 
 	// per-batch workspace (grow-only)
-	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias, ws_cellsum;
+	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_cellsum;
 	// plugin staging
 	DevBuf ws_tgeno, ws_weight;
 	// PLINK BED payload + SNP map of hibag_hip_predict_bed
@@ -168,7 +168,7 @@ struct hibag_hip_model {
 	{
 		(void)hipSetDevice(device);
 		timer.destroy();
-		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_cellsum, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
+		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_cellsum, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
 		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_tgeno, &ws_weight, &ws_bed, &ws_bedidx})
 			b->release();
 	}
@@ -248,15 +248,8 @@ void or_bits(uint32_t *dst, const uint64_t src[2], int nbits, int pos)
 // per cell in `cell_chunks[P]`.  The frequency factor is rounded exactly as the
 // reference does: f1*f1 for the leading diagonal term (:1786), (2*f1)*f2 else
 // (:1789-1793, :1808-1812); this file is compiled with -ffp-contract=off.
-// `raw` (optional) keeps every record un-chunked: raw->w (nwp words each), raw->p, raw->n[cell].
-struct RawRecords {
-	std::vector<uint32_t> w;
-	std::vector<double> p;
-	std::vector<uint32_t> n;
-};
-
 void build_pair_stream(const HostClassifier &k, int n_hla, int nwp, const int *st,
-	std::vector<uint32_t> &stream, std::vector<uint32_t> &cell_chunks, RawRecords *raw)
+	std::vector<uint32_t> &stream, std::vector<uint32_t> &cell_chunks)
 {
 	const int ks = k.n_snp;
 	const uint64_t lowmask[2] = {
@@ -276,11 +269,6 @@ void build_pair_stream(const HostClassifier &k, int n_hla, int nwp, const int *s
 	};
 	auto flush = [&]() -> uint32_t {
 		const size_t n = recp.size();
-		if (raw) {
-			raw->w.insert(raw->w.end(), recw.begin(), recw.end());
-			raw->p.insert(raw->p.end(), recp.begin(), recp.end());
-			raw->n.push_back((uint32_t)n);
-		}
 		const size_t nchunk = (n + HIBAG_CHUNK - 1) / HIBAG_CHUNK;
 		for (size_t ch = 0; ch < nchunk; ch++) {
 			const size_t base = stream.size();
@@ -318,61 +306,46 @@ void build_pair_stream(const HostClassifier &k, int n_hla, int nwp, const int *s
 	}
 }
 
-// Matrix-core engine: regroup one classifier's records per tile into blocks of
-// 32 (W[nkb][32], prod[32], end mask, pad).  Cells are padded to an even number
-// of records with {W = 0, prod = +0.0}; bit i of the end mask marks the record
-// that closes a cell.  Returns per tile {first block, #blocks} in `blk_tile`.
-// `spare_pos` >= 0: bits spare_pos..spare_pos+3 are set in EVERY record slot (padding included):
-// the K positions through which k_pack feeds the lane's distance offset into the dot product.
-void build_block_stream(const RawRecords &raw, int nwp, int nkb, int spare_pos, const std::vector<int> &tile_p0,
-	const std::vector<int> &tile_n, std::vector<uint32_t> &out, uint32_t *blk_tile, int &n_blocks)
+// Matrix-core engine: the pair list of a run of cells [p0, p0 + n) of one classifier, appended to `out`
+// as blocks of 32 slots (idx[32] = i1 | i2 << 16, end mask, valid count).  The visiting order inside a
+// cell is the reference's (src/LibHLA.cpp:1776-1821: i1 ascending, then i2; the leading diagonal pair
+// (i, i) first on the diagonal cells).  Cells are padded to an even slot count with the classifier's
+// all-zero haplotype `pad` (frequency 0: the slot adds +0.0); bit i of the end mask marks the slot that
+// closes a cell.  (h1, h2) of cell p0 are given; returns the number of blocks.
+int append_pair_blocks(const int *st, int n_hla, int h1, int h2, int n_cells, uint32_t pad, std::vector<uint32_t> &out)
 {
-	std::vector<uint32_t> spare((size_t)nkb, 0u);
-	if (spare_pos >= 0)
-		for (int j = 0; j < 4; j++) spare[(size_t)(spare_pos + j) >> 5] |= 1u << ((spare_pos + j) & 31);
-	std::vector<size_t> first(raw.n.size() + 1, 0);          // first record of each cell
-	for (size_t p = 0; p < raw.n.size(); p++) first[p + 1] = first[p] + raw.n[p];
-	n_blocks = 0;
-	const size_t BD = HIBAG_BLOCK_DWORDS(nkb);
-	for (size_t t = 0; t < tile_p0.size(); t++) {
-		std::vector<uint32_t> w;            // nkb words per slot
-		std::vector<double> pr;
-		std::vector<uint8_t> end;
-		for (int j = 0; j < tile_n[t]; j++) {
-			const size_t p = (size_t)tile_p0[t] + j;
-			const uint32_t n = raw.n[p];
-			if (!n) continue;
-			for (uint32_t i = 0; i < n; i++) {
-				for (int q = 0; q < nkb; q++) w.push_back(q < nwp ? raw.w[(first[p] + i) * nwp + q] : 0u);
-				pr.push_back(raw.p[first[p] + i]);
-				end.push_back(0);
-			}
-			if (n & 1) { w.insert(w.end(), (size_t)nkb, 0u); pr.push_back(0.0); end.push_back(0); }
-			end.back() = 1;
+	const uint32_t pad_idx = pad | (pad << 16);
+	size_t base = 0;
+	int fill = 32, n_blocks = 0;                 // slots used in the open block (32 = none open)
+	auto slot = [&](uint32_t idx, bool end) {
+		if (fill == 32) {
+			base = out.size();
+			out.resize(base + HIBAG_PLIST_DWORDS, 0u);
+			for (int i = 0; i < 32; i++) out[base + i] = pad_idx;
+			fill = 0; n_blocks++;
 		}
-		const size_t nb = (pr.size() + 31) / 32;
-		blk_tile[2 * t] = (uint32_t)n_blocks;
-		blk_tile[2 * t + 1] = (uint32_t)nb;
-		for (size_t b = 0; b < nb; b++) {
-			const size_t base = out.size();
-			out.resize(base + BD, 0);
-			uint32_t mask = 0;
-			for (int i = 0; i < 32; i++) {
-				const size_t r = b * 32 + i;
-				double prod = 0.0;
-				if (r < pr.size()) {
-					for (int q = 0; q < nkb; q++) out[base + (size_t)q * 32 + i] = w[r * nkb + q];
-					prod = pr[r];
-					if (end[r]) mask |= 1u << i;
-				}
-				for (int q = 0; q < nkb; q++) out[base + (size_t)q * 32 + i] |= spare[q];
-				memcpy(&out[base + 32 * (size_t)nkb + 2 * (size_t)i], &prod, sizeof(double));
+		out[base + fill] = idx;
+		if (end) out[base + 32] |= 1u << fill;
+		out[base + 33] = (uint32_t)++fill;
+	};
+	for (int c = 0; c < n_cells; c++) {
+		const int a0 = st[h1], a1 = st[h1 + 1], b0 = st[h2], b1 = st[h2 + 1];
+		const uint64_t n = h1 == h2 ? (uint64_t)(a1 - a0) * (a1 - a0 + 1) / 2 : (uint64_t)(a1 - a0) * (b1 - b0);
+		if (n) {
+			uint64_t i = 0;
+			const uint64_t total = n + (n & 1);
+			if (h1 == h2) {
+				for (int a = a0; a < a1; a++)
+					for (int b = a; b < a1; b++) { i++; slot((uint32_t)a | ((uint32_t)b << 16), i == total); }
+			} else {
+				for (int a = a0; a < a1; a++)
+					for (int b = b0; b < b1; b++) { i++; slot((uint32_t)a | ((uint32_t)b << 16), i == total); }
 			}
-			out[base + 32 * (size_t)nkb + 64] = mask;
-			out[base + 32 * (size_t)nkb + 65] = (uint32_t)std::min<size_t>(32, pr.size() - b * 32);
+			if (n & 1) slot(pad_idx, true);
 		}
-		n_blocks += (int)nb;
+		if (++h2 == n_hla) { h1++; h2 = h1; }
 	}
+	return n_blocks;
 }
 
 // Tiles for pass 2: consecutive posterior cells, at most HIBAG_TILE each, cut so
@@ -416,9 +389,11 @@ int finalize_model(hibag_hip_model *m)
 		snp_weight(std::max(S, 1), 0);
 	std::vector<uint64_t> stream_off(std::max(C, 1), 0), cell_work(P, 0);
 	std::vector<uint32_t> stream;
+	// per classifier: records (haplotype pairs) of every cell, and 4-record chunks of every cell
 	std::vector<std::vector<uint32_t>> cell_chunks(C);
-	std::vector<RawRecords> raw(C);
-	std::vector<int> mfma_nkb(std::max(C, 1), 0), mfma_bik(std::max(C, 1), 0), bt_row(std::max(C, 1), 0), cls_nblk(std::max(C, 1), 0);
+	std::vector<std::vector<int>> starts(C);
+	std::vector<int> mfma_nkb(std::max(C, 1), 0), bt_row(std::max(C, 1), 0), cls_nblk(std::max(C, 1), 0);
+	std::vector<uint32_t> hap, hap_off(std::max(C, 1), 0);
 	std::vector<int64_t> pairs(C);
 	int bt_rows = 0;
 	int rows = 0;
@@ -433,21 +408,37 @@ int finalize_model(hibag_hip_model *m)
 		if (k.snpidx.empty()) snp_index.insert(snp_index.end(), (size_t)k.n_snp, 0);
 		mask_row[c] = rows;
 		rows += 2 * nwp[c];
-		std::vector<int> st(nh + 1, 0);
+		std::vector<int> &st = starts[c];
+		st.assign(nh + 1, 0);
 		for (int i = 0; i < H; i++) st[k.hla[i] + 1]++;
 		for (int h = 0; h < nh; h++) st[h + 1] += st[h];
-		if (stream.size() & 1) stream.push_back(0);          // 8-byte alignment of the doubles inside
-		stream_off[c] = stream.size();
-		cell_chunks[c].assign(P, 0);
-		// matrix-core engine: K = the 3k bit positions + 4 spare positions that carry the distance
-		// offset (8*popc(x&m) <= 16k <= 4*120 as four int8 terms); k = 31, 32 have no room for them
-		// within 3 K blocks and start the accumulators at the offset instead
-		const int nkb_true = std::max(1, (3 * k.n_snp + 31) / 32), nkb_bik = (3 * k.n_snp + 4 + 31) / 32;
-		mfma_bik[c] = (m->use_mfma && nkb_bik <= 3) ? 1 : 0;
-		mfma_nkb[c] = mfma_bik[c] ? nkb_bik : ((m->use_mfma && nkb_true <= 3) ? nkb_true : 0);
+		// matrix-core engine: at most 32 SNPs, haplotype indices in 16 bits (one spare for the padding entry)
+		mfma_nkb[c] = (m->use_mfma && k.n_snp <= 32 && H < 65535) ? HIBAG_K_NKB(k.n_snp) : 0;
 		bt_row[c] = bt_rows;
 		bt_rows += 2 * mfma_nkb[c];
-		build_pair_stream(k, nh, nwp[c], st.data(), stream, cell_chunks[c], mfma_nkb[c] ? &raw[c] : nullptr);
+		cell_chunks[c].assign(P, 0);
+		if (mfma_nkb[c]) {
+			// no record stream: the kernels generate the records from the haplotype table
+			hap_off[c] = (uint32_t)(hap.size() / HIBAG_HAP_DWORDS);
+			for (int i = 0; i < H; i++) {
+				uint32_t f[2];
+				memcpy(f, &k.freq[i], sizeof(double));
+				hap.push_back((uint32_t)k.bits[2 * (size_t)i]); hap.push_back(f[0]); hap.push_back(f[1]);
+			}
+			hap.insert(hap.end(), HIBAG_HAP_DWORDS, 0u);          // the padding entry: no allele set, frequency +0.0
+			size_t p = 0;
+			for (int h1 = 0; h1 < nh; h1++)
+				for (int h2 = h1; h2 < nh; h2++) {
+					const uint64_t n1 = (uint64_t)(st[h1 + 1] - st[h1]), n2 = (uint64_t)(st[h2 + 1] - st[h2]);
+					const uint64_t n = h1 == h2 ? n1 * (n1 + 1) / 2 : n1 * n2;
+					if (n > 0xFFFFFFull * HIBAG_CHUNK) return fail(HIBAG_HIP_EINVAL, "an allele pair of classifier %d has too many haplotype pairs", c);
+					cell_chunks[c][p++] = (uint32_t)((n + HIBAG_CHUNK - 1) / HIBAG_CHUNK);
+				}
+		} else {
+			if (stream.size() & 1) stream.push_back(0);          // 8-byte alignment of the doubles inside
+			stream_off[c] = stream.size();
+			build_pair_stream(k, nh, nwp[c], st.data(), stream, cell_chunks[c]);
+		}
 		for (int p = 0; p < P; p++) cell_work[p] += (uint64_t)cell_chunks[c][p] * (nwp[c] + 2);
 		pairs[c] = (int64_t)H * (H + 1) / 2;
 		m->pair_evals += pairs[c];
@@ -458,10 +449,18 @@ int finalize_model(hibag_hip_model *m)
 	// the walker fetches one chunk ahead: keep a widest-record chunk of slack behind the last record
 	stream.insert(stream.end(), HIBAG_CHUNK_DWORDS(HIBAG_MAX_NWP), 0);
 	if (snp_index.empty()) snp_index.push_back(0);
+	if (hap.empty()) hap.insert(hap.end(), HIBAG_HAP_DWORDS, 0u);
 
 	std::vector<int> tile_p0, tile_n;
 	build_tiles(P, cell_work, tile_p0, tile_n);
 	const int n_tile = (int)tile_p0.size();
+	std::vector<int> tile_h1(n_tile, 0), tile_h2(n_tile, 0);      // (h1, h2) of every tile's first cell
+	{
+		int t = 0, p = 0;
+		for (int h1 = 0; h1 < nh && t < n_tile; h1++)
+			for (int h2 = h1; h2 < nh && t < n_tile; h2++, p++)
+				if (p == tile_p0[t]) { tile_h1[t] = h1; tile_h2[t] = h2; t++; }
+	}
 	// pass 1 lists (non-empty cells per classifier) and pass 2 tile entries
 	std::vector<uint32_t> cls_cnt, cls_cell, tile_meta((size_t)std::max(C, 1) * n_tile * HIBAG_TILE_META + 1, 0);
 	std::vector<int> cls_off(std::max(C, 1), 0), cls_n(std::max(C, 1), 0);
@@ -546,49 +545,45 @@ int finalize_model(hibag_hip_model *m)
 		for (const auto &it : items) item.insert(item.end(), it.second.begin(), it.second.end());
 	}
 
-	// block streams of the matrix-core engine
-	std::vector<uint32_t> blk_stream, blk_tile((size_t)std::max(C, 1) * n_tile * 2 + 2, 0);
-	// Two layouts per classifier: per tile (pass 2: a wavefront walks one tile's blocks) and
-	// all cells back to back (pass 1: no block is left half empty at a tile boundary).
-	std::vector<uint64_t> blk_off(std::max(C, 1), 0), blk_off_tiled(std::max(C, 1), 0);
-	const std::vector<int> all_p0(1, 0), all_n(1, P);
+	// pair lists of the matrix-core engine.  Pass 2 first, tile-major: the segments (tile t, classifier 0),
+	// (t, 1), ... follow each other, which is the order a pass-2 wavefront reads them in; then, per
+	// classifier, all cells back to back for pass 1 (no block left half empty at a tile boundary).
+	std::vector<uint32_t> plist;
+	std::vector<uint64_t> blk_off(std::max(C, 1), 0), seg_off((size_t)std::max(C, 1) * n_tile, 0);
+	std::vector<uint32_t> seg_nblk((size_t)std::max(C, 1) * n_tile, 0);
+	long long dbg_b1 = 0, dbg_b2 = 0, dbg_seg = 0;
+	for (int t = 0; t < n_tile; t++)
+		for (int c = 0; c < C; c++) {
+			if (!mfma_nkb[c]) continue;
+			seg_off[(size_t)c * n_tile + t] = plist.size();
+			const int nb = append_pair_blocks(starts[c].data(), nh, tile_h1[t], tile_h2[t], tile_n[t],
+				(uint32_t)m->cls[c].freq.size(), plist);
+			seg_nblk[(size_t)c * n_tile + t] = (uint32_t)nb;
+			dbg_b2 += nb; dbg_seg += nb > 0;
+		}
 	for (int c = 0; c < C; c++) {
 		if (!mfma_nkb[c]) continue;
-		const int spare = mfma_bik[c] ? 3 * n_snp_c[c] : -1;
-		if (blk_stream.size() & 1) blk_stream.push_back(0);
-		blk_off_tiled[c] = blk_stream.size();
-		int n_tiled = 0;
-		build_block_stream(raw[c], nwp[c], mfma_nkb[c], spare, tile_p0, tile_n, blk_stream,
-			&blk_tile[(size_t)c * n_tile * 2], n_tiled);
-		if (blk_stream.size() & 1) blk_stream.push_back(0);
-		blk_off[c] = blk_stream.size();
-		uint32_t whole[2];
-		build_block_stream(raw[c], nwp[c], mfma_nkb[c], spare, all_p0, all_n, blk_stream, whole, cls_nblk[c]);
-		raw[c] = RawRecords();
+		blk_off[c] = plist.size();
+		cls_nblk[c] = append_pair_blocks(starts[c].data(), nh, 0, 0, P, (uint32_t)m->cls[c].freq.size(), plist);
+		dbg_b1 += cls_nblk[c];
 	}
-	if (getenv("HIBAG_DEBUG_MODEL")) {
-		long long b1 = 0, b2 = 0, b2_tiles = 0;
-		for (int c = 0; c < C; c++) {
-			b1 += cls_nblk[c];
-			for (int t = 0; t < n_tile; t++) { b2 += blk_tile[((size_t)c * n_tile + t) * 2 + 1]; b2_tiles += blk_tile[((size_t)c * n_tile + t) * 2 + 1] > 0; }
-		}
-		fprintf(stderr, "[hibag model] %d classifiers, %d tiles, pairs %lld; blocks of 32: pass 1 %lld, pass 2 %lld in %lld (classifier, tile) segments\n",
-			C, n_tile, (long long)m->pair_evals, b1, b2, b2_tiles);
-	}
-	blk_stream.insert(blk_stream.end(), 2 * HIBAG_BLOCK_DWORDS(3), 0);   // look-ahead slack of the block walker
+	if (getenv("HIBAG_DEBUG_MODEL"))
+		fprintf(stderr, "[hibag model] %d classifiers, %d tiles, pairs %lld; blocks of 32: pass 1 %lld, pass 2 %lld in %lld (classifier, tile) segments; "
+			"pair lists %.1f MB, haplotype table %.1f KB, VALU-engine stream %.1f MB\n",
+			C, n_tile, (long long)m->pair_evals, dbg_b1, dbg_b2, dbg_seg, plist.size() * 4e-6, hap.size() * 4e-3, stream.size() * 4e-6);
+	plist.insert(plist.end(), 3 * HIBAG_PLIST_DWORDS, 0u);   // look-ahead slack of the block walker (two blocks)
 	// per (classifier, tile) record of pass 2 (one s_load_dwordx8)
 	std::vector<uint32_t> ctile((size_t)std::max(C, 1) * n_tile * 8 + 8, 0);
 	for (int c = 0; c < C; c++)
 		for (int t = 0; t < n_tile; t++) {
 			uint32_t *r = &ctile[((size_t)c * n_tile + t) * 8];
 			const uint32_t *me = &tile_meta[((size_t)c * n_tile + t) * HIBAG_TILE_META];
-			const uint64_t off = blk_off_tiled[c] + (uint64_t)blk_tile[((size_t)c * n_tile + t) * 2] * HIBAG_BLOCK_DWORDS(std::max(mfma_nkb[c], 1));
-			r[0] = (uint32_t)(mfma_nkb[c] == 0 ? 0 : (mfma_bik[c] ? mfma_nkb[c] : 4)); r[1] = (uint32_t)bt_row[c];
+			const uint64_t off = seg_off[(size_t)c * n_tile + t];
+			r[0] = (uint32_t)mfma_nkb[c]; r[1] = (uint32_t)bt_row[c];
 			r[2] = (uint32_t)off; r[3] = (uint32_t)(off >> 32);
-			r[4] = blk_tile[((size_t)c * n_tile + t) * 2 + 1];
+			r[4] = seg_nblk[(size_t)c * n_tile + t];
 			r[5] = me[0]; r[6] = me[2]; r[7] = me[3];
 		}
-
 
 	// one int arena
 	std::vector<int> arena;
@@ -598,18 +593,20 @@ int finalize_model(hibag_hip_model *m)
 		if (v.empty()) arena.push_back(0);
 		return off;
 	};
+	std::vector<int> hap_off_i(hap_off.begin(), hap_off.end());
 	const size_t o_nsnp = put(n_snp_c), o_nwp = put(nwp), o_snpoff = put(snp_off), o_snpidx = put(snp_index),
 		o_snpw = put(snp_weight), o_mrow = put(mask_row), o_order = put(c_order), o_tp0 = put(tile_p0), o_tn = put(tile_n),
-		o_coff = put(cls_off), o_cn = put(cls_n), o_nkb = put(mfma_nkb), o_btrow = put(bt_row), o_nblk = put(cls_nblk), o_bik = put(mfma_bik),
+		o_coff = put(cls_off), o_cn = put(cls_n), o_nkb = put(mfma_nkb), o_btrow = put(bt_row), o_nblk = put(cls_nblk), o_hapoff = put(hap_off_i),
 		o_item = put(item), o_srow = put(split_row), o_scls = put(split_cls), o_itemw = put(item_whole);
 
 	if (int rc = m->d_int.reserve(arena.size() * sizeof(int))) return rc;
 	if (int rc = m->d_stream.reserve(stream.size() * sizeof(uint32_t))) return rc;
 	const size_t tb_off = 0, tb_meta = stream_off.size() * sizeof(uint64_t), tb_cnt = tb_meta + tile_meta.size() * sizeof(uint32_t),
 		tb_cell = tb_cnt + cls_cnt.size() * sizeof(uint32_t),
-		tb_boff = (tb_cell + cls_cell.size() * sizeof(uint32_t) + 7) & ~(size_t)7, tb_btile = tb_boff + blk_off.size() * sizeof(uint64_t),
-		tb_ctile = (tb_btile + blk_tile.size() * sizeof(uint32_t) + 31) & ~(size_t)31,
-		tb_end = tb_ctile + ctile.size() * sizeof(uint32_t);
+		tb_boff = (tb_cell + cls_cell.size() * sizeof(uint32_t) + 7) & ~(size_t)7,
+		tb_ctile = (tb_boff + blk_off.size() * sizeof(uint64_t) + 31) & ~(size_t)31,
+		tb_hap = (tb_ctile + ctile.size() * sizeof(uint32_t) + 15) & ~(size_t)15,
+		tb_end = tb_hap + hap.size() * sizeof(uint32_t);
 	if (int rc = m->d_tile.reserve(tb_end)) return rc;
 	if (int rc = m->d_tab.reserve(sizeof(m->tab))) return rc;
 	HIP_TRY(hipMemcpy(m->d_int.p, arena.data(), arena.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -620,12 +617,10 @@ int finalize_model(hibag_hip_model *m)
 	HIP_TRY(hipMemcpy(tbase + tb_cnt, cls_cnt.data(), cls_cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_cell, cls_cell.data(), cls_cell.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_boff, blk_off.data(), blk_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(tbase + tb_btile, blk_tile.data(), blk_tile.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_ctile, ctile.data(), ctile.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	if (blk_stream.size() * sizeof(uint32_t) >= ((size_t)1 << 31))
-		return fail(HIBAG_HIP_EINVAL, "the model's haplotype-pair stream exceeds 2 GB");
-	if (int rc = m->d_blk.reserve(blk_stream.size() * sizeof(uint32_t))) return rc;
-	HIP_TRY(hipMemcpy(m->d_blk.p, blk_stream.data(), blk_stream.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(tbase + tb_hap, hap.data(), hap.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	if (int rc = m->d_blk.reserve(plist.size() * sizeof(uint32_t))) return rc;
+	HIP_TRY(hipMemcpy(m->d_blk.p, plist.data(), plist.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(m->d_tab.p, m->tab, sizeof(m->tab), hipMemcpyHostToDevice));
 
 	HibagModelView &V = m->view;
@@ -639,17 +634,19 @@ int finalize_model(hibag_hip_model *m)
 	V.cls_cnt = (const uint32_t *)(tbase + tb_cnt);
 	V.cls_cell = (const uint32_t *)(tbase + tb_cell);
 	V.cls_off = base + o_coff; V.cls_n = base + o_cn;
-	V.mfma_nkb = base + o_nkb; V.bt_row = base + o_btrow; V.cls_nblk = base + o_nblk; V.mfma_bik = base + o_bik;
+	V.mfma_nkb = base + o_nkb; V.bt_row = base + o_btrow; V.cls_nblk = base + o_nblk;
+	V.hap_off = (const uint32_t *)(base + o_hapoff);
 	V.n_item_split = (int)item.size() / 4; V.n_item_whole = (int)item_whole.size() / 4; V.n_split = (int)split_cls.size();
 	V.item_split = base + o_item; V.item_whole = base + o_itemw; V.item = V.item_whole; V.n_item = V.n_item_whole;
 	V.split_row = base + o_srow; V.split_cls = base + o_scls;
 	V.split_heavy_ns = split_heavy_ns; V.split_rest_ns = split_rest_ns;
 	m->cellsum_rows = cellsum_rows;
 	V.blk_off = (const uint64_t *)(tbase + tb_boff);
-	V.blk_tile = (const uint32_t *)(tbase + tb_btile);
 	V.ctile = (const uint32_t *)(tbase + tb_ctile);
-	V.blk_stream = m->d_blk.as<uint32_t>();
-	V.blk_bytes = (uint32_t)(blk_stream.size() * sizeof(uint32_t));
+	V.hap = (const uint32_t *)(tbase + tb_hap);
+	V.hap_entries = (uint32_t)(hap.size() / HIBAG_HAP_DWORDS);
+	V.plist = m->d_blk.as<uint32_t>();
+	V.plist_dwords = plist.size();
 	m->bt_rows = bt_rows;
 	V.stream = m->d_stream.as<uint32_t>();
 	V.tab = m->d_tab.as<double>();
@@ -682,7 +679,6 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	if (int rc = m->ws_part.reserve((size_t)(m->view.n_cell + 3) * n_pad * sizeof(double))) return rc;
 	if (int rc = m->ws_codes.reserve((size_t)std::max(m->n_snp, 1) * n_pad)) return rc;
 	if (int rc = m->ws_bt.reserve((size_t)std::max(m->bt_rows, 1) * n_pad * sizeof(uint4))) return rc;
-	if (int rc = m->ws_bias.reserve(2 * C * n_pad * sizeof(int))) return rc;
 	if (int rc = m->ws_cellsum.reserve((size_t)std::max(m->cellsum_rows, 1) * n_pad * sizeof(double))) return rc;
 	if (need_best)
 		if (int rc = m->ws_best.reserve(C * n_pad * sizeof(int))) return rc;
@@ -690,7 +686,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	B.masks = m->ws_planes.as<uint32_t>();
 	B.cw = m->ws_cw.as<double>(); B.tot = m->ws_tot.as<double>(); B.inv = m->ws_inv.as<double>();
 	B.part = m->ws_part.as<double>();
-	B.bt = m->ws_bt.as<uint4>(); B.bias = m->ws_bias.as<int>();
+	B.bt = m->ws_bt.as<uint4>();
 	B.cellsum = m->ws_cellsum.as<double>();
 	return 0;
 }

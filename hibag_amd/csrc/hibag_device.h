@@ -22,9 +22,17 @@
 //    (2 dwords), then one entry (j << 24 | chunks) per cell of the tile: the
 //    non-empty ones in order, then the empty ones }.
 //
-//    The matrix-core engine reads the same records regrouped per (classifier,
-//    tile) into BLOCKS of 32 (blk_stream): W[nkb][32] then prod[32] then a mask
-//    of the records that close a cell; cells are padded to an even record count.
+//    The matrix-core engine (classifiers with at most 32 SNPs) does not read pair
+//    records at all: it GENERATES them from an O(H) haplotype table
+//        hap[hap_off[c] + i] = { bits (SNP s of the classifier = bit s), freq lo, freq hi }   12 bytes
+//    (one extra all-zero entry per classifier serves the padding slots) and a 4-byte
+//    index pair (i1 | i2 << 16) per record, in BLOCKS of 32 slots:
+//        idx[32], mask of the slots that close a cell, number of valid slots      34 dwords
+//    Each lane builds its record's int8 A-operand rows and the frequency factor
+//    (2*f1)*f2 with the reference's rounding (src/LibHLA.cpp:1786-1813) itself.  Cells are
+//    padded to an even slot count.  Two lists: all cells of a classifier back to back
+//    (pass 1), and per (tile, classifier) segments stored tile-major (pass 2: a wavefront
+//    walks one tile's segments classifier after classifier through contiguous memory).
 //
 //  BATCH ("lane = sample": consecutive samples are consecutive addresses, so
 //  every per-lane access is one coalesced row segment of a wavefront):
@@ -54,8 +62,19 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 
 // dwords of one chunk for a classifier with nwp words per record
 #define HIBAG_CHUNK_DWORDS(nwp) (HIBAG_CHUNK * ((nwp) + 2))
-// dwords of one 32-record block of the matrix-core engine
-#define HIBAG_BLOCK_DWORDS(nkb) (32 * (nkb) + 66)
+// dwords of one 32-slot block of a pair list (matrix-core engine): idx[32], end mask, valid count
+#define HIBAG_PLIST_DWORDS 34
+#define HIBAG_HAP_DWORDS 3       // haplotype table entry: bits, freq lo, freq hi
+// K layout of the distance dot product for a classifier with k SNPs (K positions = bytes of the int8 operands):
+//   [0, k)          h1_s + h2_s  (A: 0/1/2)   x  B: +8 (g=0), -8 (g=1,2), 0 (missing)
+//   [ao, ao + k)    h1_s & h2_s  (A: 0/1)     x  B: +16 (g=1), else 0
+//   bp              A: 8                      x  B: 2*#(g=2) + #(g=1)   (<= 64)
+// so that the dot product is 8*d for the distance d of src/LibHLA.cpp:747-819 (g=0: h1+h2, g=2: 2-h1-h2,
+// g=1: [h1==h2] = 1-h1-h2+2*h1*h2).  k <= 15: one 32-wide K block (ao = k, bp = 2k); k <= 31: two
+// (ao = 32, bp = 31); k = 32: three (ao = 32, bp = 64).
+#define HIBAG_K_NKB(k) ((k) <= 15 ? 1 : ((k) <= 31 ? 2 : 3))
+#define HIBAG_K_AO(k) ((k) <= 15 ? (k) : 32)
+#define HIBAG_K_BP(k) ((k) <= 15 ? 2 * (k) : ((k) <= 31 ? 31 : 64))
 
 struct HibagModelView {
 	int n_hla;
@@ -95,17 +114,17 @@ struct HibagModelView {
 	const double *tab;           // [257] exp(d*log(1e-5))
 
 	// matrix-core engine (classifiers with at most 32 SNPs; hibag_kernels.hip "MFMA engine")
-	const int *mfma_nkb;         // [C] 32-wide K blocks of the distance dot product, 0 = use the VALU engine
+	const int *mfma_nkb;         // [C] 32-wide K blocks of the distance dot product (1: k <= 15, 2: k <= 31, 3: k = 32), 0 = use the VALU engine
 	const int *bt_row;           // [C] first operand row of the classifier in HibagBatchView::bt
-	const int *mfma_bik;         // [C] 1: the lane's distance offset rides in 4 spare K positions (3k..3k+3) of the dot
-	                             //     product (W bits set by the host, B bytes by k_pack); 0: it initialises the accumulators
-	const uint64_t *blk_off;     // [C] dword offset of the classifier's pass-1 block stream (all cells back to back)
-	const int *cls_nblk;         // [C] blocks in that stream
-	const uint32_t *blk_tile;    // [C][n_tile][2] = {first block of the tile, blocks of the tile}
-	const uint32_t *blk_stream;  // blocks of 32 records: W[nkb][32], prod[32] (f64), end mask, pad
-	uint32_t blk_bytes;          // its size (< 2 GB: addressed as a raw buffer with 32-bit offsets)
+	const uint32_t *hap;         // haplotype table, 3 dwords per entry (see above)
+	const uint32_t *hap_off;     // [C] first entry of the classifier
+	uint32_t hap_entries;        // entries in the table
+	const uint64_t *blk_off;     // [C] dword offset of the classifier's pass-1 pair list (all cells back to back)
+	const int *cls_nblk;         // [C] blocks in that list
+	const uint32_t *plist;       // pair lists: blocks of HIBAG_PLIST_DWORDS dwords
+	uint64_t plist_dwords;       // total size (a raw buffer is rebased per classifier / tile segment: no 4 GB limit)
 	const uint32_t *ctile;       // [C][n_tile][8]: everything pass 2 needs per (classifier, tile) in one s_load_dwordx8:
-	                             // {engine code (1..3 = nkb with the offset in K, 4 = nkb 3 with accumulator offset, 0 = VALU), bt_row, block stream dword offset lo/hi, #blocks, #non-empty cells, row list lo/hi}
+	                             // {engine code = nkb (0 = VALU), bt_row, pair list dword offset lo/hi, #blocks, #non-empty cells, row list lo/hi}
 };
 
 struct HibagBatchView {
@@ -118,9 +137,8 @@ struct HibagBatchView {
 	double *cellsum;    // [rows of the split classifiers][n_pad] (pass 1 scratch)
 	double *part;       // [P+3][n_pad]
 	// matrix-core engine: per classifier and sample group the B operand tiles
-	// (int8 +1/-1/0 per packed bit, MFMA lane layout) and the distance offsets
+	// (int8, MFMA lane layout; K layout above)
 	uint4 *bt;          // [(bt_row[c] + n*nkb + kb)][n_pad/64][64]
-	int *bias;          // [(2c + n)][n_pad/64][64]
 };
 
 #endif

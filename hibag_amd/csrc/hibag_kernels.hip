@@ -114,30 +114,32 @@ __device__ __forceinline__ double cell_sum(uint32_t n, const uint32_t *__restric
 }
 
 // ---------------------------------------------------------------------------
-// MFMA engine.  The distance is an integer dot product,
-//     d = sum_k ((W_k ^ x_k) & m_k) = sum_k W_k * a_k + sum_k m_k x_k,   a_k = m_k (1 - 2 x_k) in {-1,0,+1}
-// (both sides are scaled by 8 in the operands, so the MFMA delivers the byte offset of TAB[d] directly),
-// over the 3k packed bit positions, i.e. D[record][sample] = W[record][:] . a[:][sample] + bias[sample]:
-// a small int8 GEMM with K = 32*nkb.  One v_mfma_i32_32x32x32_i8 gives the exact
-// distances of 32 records x 32 samples; two (sample halves) cover the wavefront's
-// 64 samples, and 16 v_permlane32_swap move every lane's own-sample column into
-// its registers.  This takes the bit logic and popcounts (the dominant VALU cost,
-// tools/ubench_valu.hip) off the vector ALU; the FP64 accumulation below is
-// unchanged -- per lane, in the reference's order -- so results stay bit-identical.
-// Used for classifiers with at most 32 SNPs (nkb <= 3); wider ones use the VALU
-// engine above.
+// MFMA engine.  The distance of src/LibHLA.cpp:747-819 is, SNP by SNP, |g - h1 - h2| for a
+// called genotype g and 0 for a missing one:
+//     g = 0: h1 + h2      g = 2: 2 - h1 - h2      g = 1: [h1 == h2] = 1 - h1 - h2 + 2 h1 h2
+// i.e. an integer dot product over 2k + 1 positions (K layout in hibag_device.h),
+//     8 d = sum_s (h1_s + h2_s) * 8 t_s  +  sum_s (h1_s & h2_s) * 16 [g_s == 1]  +  8 * (2 #[g == 2] + #[g == 1]),
+// t_s = +1 / -1 / -1 / 0 for g_s = 0 / 1 / 2 / missing: D[record][sample] = A[record][:] . B[:][sample] is a
+// small int8 GEMM with K = 32 * nkb (nkb = 2 for 16..31 SNPs).  One v_mfma_i32_32x32x32_i8 gives the exact
+// distances of 32 records x 32 samples (scaled by 8: the byte offset of TAB[d]); two (sample halves) cover
+// the wavefront's 64 samples, and 16 v_permlane32_swap move every lane's own-sample column into its
+// registers.  The A rows are not stored anywhere: lane l builds the row of record l % 32 (K half l / 32)
+// from the two haplotype words of its pair, fetched from the model's O(H) haplotype table through the
+// 4-byte index pair of the slot, and the frequency factor (2 f1) f2 with the reference's rounding
+// (src/LibHLA.cpp:1786-1813).  The FP64 accumulation below is per lane, in the reference's order, so
+// results stay bit-identical to the CPU kernels.
+// Used for classifiers with at most 32 SNPs; wider ones use the VALU engine above.
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef unsigned v3u __attribute__((ext_vector_type(3)));
 
 template <int NKB>
 struct LaneOperand {
 	v4i b[2][NKB];      // B operand of sample half n, K block kb (MFMA lane layout)
-	int bias[2];
 };
 
-// BIK ("bias in K"): the distance offset is part of the dot product, T.bias is not used.
-template <int NKB, bool BIK>
-__device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt_row, int c, int group,
+template <int NKB>
+__device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt_row, int group,
 	int lane, LaneOperand<NKB> &T)
 {
 	const size_t n_group = (size_t)(B.n_pad / HIBAG_WAVE);
@@ -148,15 +150,7 @@ __device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt
 			const uint4 v = B.bt[((size_t)(bt_row + n * NKB + kb) * n_group + group) * HIBAG_WAVE + lane];
 			T.b[n][kb] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
 		}
-		T.bias[n] = BIK ? 0 : B.bias[((size_t)(2 * c + n) * n_group + group) * HIBAG_WAVE + lane];
 	}
-}
-
-template <int NKB, bool BIK>
-__device__ __forceinline__ void load_operand(const HibagModelView &M, const HibagBatchView &B, int c, int group,
-	int lane, LaneOperand<NKB> &T)
-{
-	load_operand_row<NKB, BIK>(B, M.bt_row[c], c, group, lane, T);
 }
 
 // 16 bits -> 16 bytes (bit i -> byte i = 0/1): per nibble (n * 0x00204081) & 0x01010101
@@ -168,11 +162,8 @@ __device__ __forceinline__ v4i expand_bits16(uint32_t x)
 	return r;
 }
 
-// Issue the MFMAs of one block: acc_n[r] of lane l = distance of record
-// 8(r/4) + 4(l/32) + r%4 to sample (l%32) of sample half n.
-// w[kb] = word kb of record (lane % 32), already in a register.
 // 8 bits -> 8 bytes (bit i -> byte i = 0/1) for all 256 byte values: the A operand
-// is expanded with two 8-byte LDS look-ups per K block instead of ~13 VALU ops.
+// is expanded with 8-byte LDS look-ups instead of ~13 VALU ops per 16 positions.
 __device__ __forceinline__ void stage_expand_table(uint2 *exp_s)
 {
 	for (int v = threadIdx.x; v < 256; v += blockDim.x) {
@@ -183,42 +174,76 @@ __device__ __forceinline__ void stage_expand_table(uint2 *exp_s)
 	}
 }
 
-template <int NKB, bool BIK>
-__device__ __forceinline__ void block_mfma(const uint32_t (&w)[NKB], int sh, const LaneOperand<NKB> &T,
-	const uint2 *exp_s, v16i &acc0, v16i &acc1)
+// the 16 bits of x at bit position sh as 16 bytes
+__device__ __forceinline__ v4i expand16_lds(uint32_t x, int sh, const uint2 *exp_s)
 {
-	if (BIK) {
-		// the offset is one of the K terms: the accumulators start at the inline constant 0
+	const uint32_t y = x >> sh;
+	const uint2 lo = exp_s[y & 0xFFu], hi = exp_s[(y >> 8) & 0xFFu];
+	return v4i{(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+}
+
+// The lane's constant part of the A operand: the value 8 at K position bp (the distance offset term).
+// Lane l owns the K bytes 16 (l / 32) .. + 15 of every 32-wide K block.
+template <int NKB>
+__device__ __forceinline__ v4i offset_term(int k, int lane, int &kb_of)
+{
+	const int bp = HIBAG_K_BP(k);
+	kb_of = bp >> 5;
+	const int q = bp & 31;
+	v4i c = {0, 0, 0, 0};
+	if ((q >> 4) == (lane >> 5)) {
+		const int b = q & 15;
 #pragma unroll
-		for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
-	} else {
-		// The accumulators start at the lane's distance offset.  The empty asm makes the offsets
-		// opaque per block: otherwise the two 16-register splats are hoisted out of the block loop
-		// and cost 32 VGPRs for its whole duration (one wavefront per SIMD less).
-		int b0 = T.bias[0], b1 = T.bias[1];
-		asm("" : "+v"(b0), "+v"(b1));
-#pragma unroll
-		for (int r = 0; r < 16; r++) { acc0[r] = b0; acc1[r] = b1; }
+		for (int d = 0; d < 4; d++)
+			if ((b >> 2) == d) c[d] = 8 << (8 * (b & 3));
 	}
+	return c;
+}
+
+// Issue the MFMAs of one block: acc_n[r] of lane l = 8 x distance of record
+// 8(r/4) + 4(l/32) + r%4 to sample (l%32) of sample half n.
+// h1, h2 = the haplotype words of record (lane % 32); sh = 16 (lane / 32); cterm = offset_term().
+template <int NKB>
+__device__ __forceinline__ void block_mfma(uint32_t h1, uint32_t h2, int k, int sh, const v4i &cterm,
+	const LaneOperand<NKB> &T, const uint2 *exp_s, v16i &acc0, v16i &acc1)
+{
 #pragma unroll
-	for (int kb = 0; kb < NKB; kb++) {
-		// A operand: lane l holds record l%32, K bytes 16*(l/32)..+15 of this K block
-		const uint32_t x = w[kb] >> sh;
-		const uint2 lo = exp_s[x & 0xFFu], hi = exp_s[(x >> 8) & 0xFFu];
-		const v4i a = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
-		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, T.b[0][kb], acc0, 0, 0, 0);
-		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, T.b[1][kb], acc1, 0, 0, 0);
+	for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }      // folds into the MFMA's inline-constant C operand
+	const v4i e1 = expand16_lds(h1, sh, exp_s), e2 = expand16_lds(h2, sh, exp_s);
+	v4i a0 = e1 + e2;                                                // bytes 0/1/2: no carry between bytes
+	if (NKB == 1) {
+		// k <= 15: the h1 & h2 part sits at positions [k, 2k) of the same K block, the offset term at 2k
+		const v4i ea = expand16_lds((h1 & h2) << k, sh, exp_s);
+		a0 = (a0 + ea) | cterm;
+		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[0][0], acc0, 0, 0, 0);
+		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[1][0], acc1, 0, 0, 0);
+	} else {
+		const v4i a1 = expand16_lds(h1 & h2, sh, exp_s);
+		if (NKB == 2) a0 = a0 | cterm;                               // position 31
+		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[0][0], acc0, 0, 0, 0);
+		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[1][0], acc1, 0, 0, 0);
+		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, T.b[0][1], acc0, 0, 0, 0);
+		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, T.b[1][1], acc1, 0, 0, 0);
+		if (NKB == 3) {                                              // k = 32: a third K block carries the offset term only
+			acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cterm, T.b[0][NKB - 1], acc0, 0, 0, 0);
+			acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cterm, T.b[1][NKB - 1], acc1, 0, 0, 0);
+		}
 	}
 }
 
 // Swap the upper lanes of half 0 with the lower lanes of half 1: afterwards every
 // lane holds its OWN sample: record i = 8g + q  ->  q < 4 ? D0[4g + q] : D1[4g + q - 4].
-__device__ __forceinline__ void block_own_sample(v16i &D0, v16i &D1)    // in place: (acc0, acc1) -> (D0, D1)
+// Only the register groups that hold valid records are moved (a partly filled last block).
+__device__ __forceinline__ void block_own_sample(v16i &D0, v16i &D1, int n_valid)    // in place: (acc0, acc1) -> (D0, D1)
 {
 #pragma unroll
-	for (int r = 0; r < 16; r++) {
-		const auto sw = __builtin_amdgcn_permlane32_swap(D0[r], D1[r], false, false);
-		D0[r] = sw[0]; D1[r] = sw[1];
+	for (int g = 0; g < 4; g++) {
+		if (8 * g >= n_valid) break;
+#pragma unroll
+		for (int r = 4 * g; r < 4 * g + 4; r++) {
+			const auto sw = __builtin_amdgcn_permlane32_swap(D0[r], D1[r], false, false);
+			D0[r] = sw[0]; D1[r] = sw[1];
+		}
 	}
 }
 
@@ -263,78 +288,93 @@ __device__ __forceinline__ void block_accumulate(const double *stage, uint32_t e
 	}
 }
 
-// LDS staging area of one wavefront: two buffers of 32 factors + {end mask, count}
-#define STAGE_DOUBLES 34
+// LDS staging area of one wavefront: two buffers of 32 factors
+#define STAGE_DOUBLES 32
 #define STAGE_BYTES (2 * STAGE_DOUBLES * 8)
 
-// Walk `nblk` consecutive blocks (wave-uniform pointer).
+// One haplotype-table entry through a raw buffer: {bits, freq lo, freq hi}
+__device__ __forceinline__ v3u load_hap(__amdgpu_buffer_rsrc_t hp, uint32_t i)
+{
+	return __builtin_amdgcn_raw_buffer_load_b96(hp, (int)(i * (4u * HIBAG_HAP_DWORDS)), 0, 0);
+}
+
+// Walk `nblk` consecutive blocks of a pair list (raw buffer `pl`, byte offset `soff`).
 //
 // Latency plan.  Nothing in this loop goes through the scalar cache: scalar loads
 // share the lgkmcnt counter with the LDS table look-ups and return out of order,
-// so every wait for table values would also wait for the scalar load just issued
-// (~600 cycles on a miss; measured with s_memtime stamps, the accumulation phase
-// was 80 % of a block's time that way).  Instead lanes 0..32 fetch the NEXT
-// block's 32 frequency factors + {end mask, count} with one per-lane VMEM load
-// (264 contiguous bytes) while this block is evaluated, park them in the
-// wavefront's LDS staging buffer, and the accumulation reads them back with
-// wave-uniform (broadcast) LDS reads, which are in-order with the table look-ups.
-// The record words of the next block travel the same way (VMEM, one block ahead).
-// The stream is padded so that the look-ahead stays in bounds.
-// The stream is addressed as a raw buffer (base in four SGPRs, block offset in one SGPR, lane
-// offset in one VGPR that never changes): the look-ahead loads then need no per-lane 64-bit
-// pointer arithmetic, which was 12 vector instructions per block.
-template <int NKB, bool BIK, class Fin>
-__device__ __forceinline__ void walk_blocks(__amdgpu_buffer_rsrc_t rs, uint32_t soff, int nblk, int lane,
-	const LaneOperand<NKB> &T, const double *tab_s, const uint2 *exp_s, double *stage, Fin &&fin)
+// so every wait for table values would also wait for the scalar load just issued.
+// Everything travels as per-lane vector loads, software-pipelined over the blocks:
+//   while block b is evaluated   the haplotype entries of block b+1 are gathered (their index
+//                                pairs arrived during block b-1) and the index pairs + {end mask,
+//                                count} of block b+2 are requested.
+// Lane l (and l+32: the other K half of the same row) then turns its pair (i1, i2) into the A-operand
+// row and the factor (2 f1) f2 -- f1 f1 for the leading diagonal pair i1 == i2 -- with one FP64
+// multiply; lanes 0..31 park the 32 factors in the wavefront's LDS staging buffer, from where the
+// accumulation reads them back as wave-uniform (broadcast) 16-byte LDS reads, in order with the
+// table look-ups.  The list is padded so that the look-ahead stays in bounds.
+template <int NKB, class Fin>
+__device__ __forceinline__ void walk_blocks(__amdgpu_buffer_rsrc_t pl, uint32_t soff, int nblk, int lane,
+	__amdgpu_buffer_rsrc_t hp, int k, const LaneOperand<NKB> &T, const double *tab_s, const uint2 *exp_s,
+	double *stage, Fin &&fin)
 {
 	double cell = 0;
 	const int sh = (lane >> 5) * 16;
-	const int vo_w = (lane & 31) * 4;                // this lane's record word inside a K block row
-	const int vo_p = (lane < 33 ? lane : 0) * 8;     // staging lane: 32 factors + the meta pair
-	uint32_t w[NKB];
-#pragma unroll
-	for (int kb = 0; kb < NKB; kb++) w[kb] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo_w + kb * 128, soff, 0);
-	double pf = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, vo_p + 128 * NKB, soff, 0));
+	const int vo_i = (lane & 31) * 4;                // this lane's slot inside a block
+	int kb_of;
+	const v4i cterm = offset_term<NKB>(k, lane, kb_of);
+	(void)kb_of;
+	const uint32_t BB = 4 * HIBAG_PLIST_DWORDS;      // bytes per block
+	// prologue: index pairs of blocks 0 and 1, entries of block 0
+	uint32_t idx = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff, 0);
+	uint2 meta = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(pl, 128, soff, 0));
+	uint32_t idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + BB, 0);
+	uint2 meta_n = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(pl, 128, soff + BB, 0));
+	v3u r1 = load_hap(hp, idx & 0xFFFFu), r2 = load_hap(hp, idx >> 16);
 	for (int b = 0; b < nblk; b++) {
 		double *buf = stage + (b & 1) * STAGE_DOUBLES;
-		if (lane < 33) buf[lane] = pf;
-		const uint32_t nxt = soff + 4 * HIBAG_BLOCK_DWORDS(NKB);
-
-		v16i D0, D1;
-#ifdef HIBAG_ABL_NOMFMA
-#pragma unroll
-		for (int r = 0; r < 16; r++) { D0[r] = (int)((w[0] >> r) & 7u) * 8; D1[r] = (int)((w[NKB - 1] >> (r + 3)) & 7u) * 8; }
-#else
-		block_mfma<NKB, BIK>(w, sh, T, exp_s, D0, D1);
-#endif
-#pragma unroll
-		for (int kb = 0; kb < NKB; kb++) w[kb] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo_w + kb * 128, nxt, 0);
-		pf = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, vo_p + 128 * NKB, nxt, 0));
-#if !defined(HIBAG_ABL_NOMFMA) && !defined(HIBAG_ABL_NOSWAP)
-		block_own_sample(D0, D1);
-#endif
-		const uint2 meta = *reinterpret_cast<const uint2 *>(buf + 32);
+		// this block's records: factor and A rows
+		const double f1 = __hiloint2double((int)r1.z, (int)r1.y), f2 = __hiloint2double((int)r2.z, (int)r2.y);
+		const double m = ((idx & 0xFFFFu) == (idx >> 16)) ? f1 : f1 + f1;      // 2*f1 is exact
+		const double prod = m * f2;
+		if (lane < 32) buf[lane] = prod;
 		const uint32_t endmask = __builtin_amdgcn_readfirstlane(meta.x);
 		const int n_valid = __builtin_amdgcn_readfirstlane(meta.y);
+		v16i D0, D1;
+		block_mfma<NKB>(r1.x, r2.x, k, sh, cterm, T, exp_s, D0, D1);
+		// look-ahead
+		const uint32_t nxt2 = soff + 2 * BB;
+		idx = idx_n; meta = meta_n;
+		r1 = load_hap(hp, idx & 0xFFFFu); r2 = load_hap(hp, idx >> 16);
+		idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, nxt2, 0);
+		meta_n = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(pl, 128, nxt2, 0));
+		block_own_sample(D0, D1, n_valid);
 		block_accumulate(buf, endmask, n_valid, D0, D1, cell, tab_s, fin);
-		soff = nxt;
+		soff += BB;
 	}
 }
 
-// raw-buffer descriptor of the block stream (gfx9 word 3: 32-bit data format, no swizzle; reads past
-// the end return 0)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t stream_rsrc(const HibagModelView &M)
+// raw-buffer descriptors (gfx9 word 3: 32-bit data format, no swizzle; reads past the end return 0).
+// The pair list is rebased at the segment a walk starts from, so that 32-bit offsets inside the
+// descriptor never limit the model size.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plist_rsrc(const HibagModelView &M, uint64_t dword_off)
 {
-	return __builtin_amdgcn_make_buffer_rsrc((void *)M.blk_stream, 0, (int)M.blk_bytes, 0x00020000);
+	const uint64_t left = (M.plist_dwords - dword_off) * 4;
+	return __builtin_amdgcn_make_buffer_rsrc((void *)(M.plist + dword_off), 0, left > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left, 0x00020000);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t hap_rsrc(const HibagModelView &M, uint32_t first)
+{
+	// exact bound: the look-ahead of a walk runs into the next segment's index pairs, whose entries may lie
+	// past the end of the table (out-of-range raw-buffer reads return 0 instead of faulting)
+	const uint64_t left = (uint64_t)(M.hap_entries - first) * (4u * HIBAG_HAP_DWORDS);
+	return __builtin_amdgcn_make_buffer_rsrc((void *)(M.hap + (size_t)first * HIBAG_HAP_DWORDS), 0, left > 0x7FFFFFF0ull ? 0x7FFFFFF0 : (int)left, 0x00020000);
 }
 
-// engine code: 1..3 = K blocks with the distance offset in K, 4 = 3 K blocks, accumulator offset (k = 31, 32)
+// engine code = number of 32-wide K blocks
 #define HIBAG_DISPATCH_NKB(code, CALL)     \
 	switch (code) {                        \
-	case 1:  { CALL(1, true); } break;     \
-	case 2:  { CALL(2, true); } break;     \
-	case 3:  { CALL(3, true); } break;     \
-	default: { CALL(3, false); } break;    \
+	case 1:  { CALL(1); } break;           \
+	case 2:  { CALL(2); } break;           \
+	default: { CALL(3); } break;           \
 	}
 
 // Record widths the kernels are specialised for; the host rounds a classifier's
@@ -458,14 +498,19 @@ __global__ __launch_bounds__(256) void k_bed_geno(const uint8_t *__restrict__ be
 	}
 }
 
-// k_pack: TGenotype::IntToSNP (src/LibHLA.cpp:662-706) for every (sample,
-// classifier), emitted directly as the lane masks of the packed pair string
+// k_pack: TGenotype::IntToSNP (src/LibHLA.cpp:662-706) for every (sample, classifier), plus the
+// classifier weight from missingness (src/LibHLA.cpp:2418-2431).  grid (n_pad/64, C / 4), one
+// wavefront per classifier, lane = sample: every code load is one coalesced 64-byte row segment.
+// Matrix-engine classifiers (at most 32 SNPs) get the sample's column of the int8 B operand in the K
+// layout of hibag_device.h, written to the two lanes (K halves) that own it in the MFMA layout:
+//   [0, k)        +8 where g = 0, -8 (0xF8) where g = 1 or 2, 0 where missing
+//   [ao, ao + k)  16 where g = 1
+//   bp            2 #[g = 2] + #[g = 1]     (times the A operand's 8: the distance offset)
+// VALU-engine classifiers get the lane masks of the packed 3k-bit pair string
 //   bits [0,k)   first haplotype : x = [g==2], m = [g in {0,2}]
 //   bits [k,2k)  second haplotype: same
 //   bits [2k,3k) ~(H1^H2)        : x = 0,      m = [g==1]
-// (missing SNPs have m = 0 everywhere), plus the classifier weight from
-// missingness (src/LibHLA.cpp:2418-2431).  grid (n_pad/64, C), block 64,
-// lane = sample: every code load is one coalesced 64-byte row segment.
+// (missing SNPs have m = 0 everywhere).
 #define PACK_WAVES 4        // classifiers per workgroup (one wavefront each)
 __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatchView B,
 	const uint8_t *__restrict__ codes)
@@ -480,13 +525,9 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 	const int row0 = M.mask_row[c];
 	const int nkb = M.mfma_nkb[c];
 	int num = 0, den = 0;
-	unsigned __int128 xs128 = 0, ms128 = 0;    // the packed strings, when built in registers (k <= 32)
-	bool in_regs = false;
-#ifndef HIBAG_PACK_SLOW
-	if (k <= 32 && nwp <= 3) {
-		// usual case: one pass over the classifier's k SNPs (independent byte loads, several in
-		// flight) builds three k-bit fields, and the 3k-bit strings are put together with shifts
-		uint32_t X = 0, Mv = 0, E = 0;         // bit j: g == 2, g in {0, 2}, g == 1 at SNP j
+	if (nkb > 0) {
+		// one pass over the classifier's k <= 32 SNPs (independent byte loads, several in flight)
+		uint32_t X = 0, Z = 0, E = 0;          // bit j: g == 2, g == 0, g == 1 at SNP j
 #pragma unroll 8
 		for (int j = 0; j < k; j++) {
 			const int snp = idx[j];
@@ -495,88 +536,54 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 			den += wt;
 			if (g != 3) num += wt;
 			X |= (uint32_t)(g == 2) << j;
-			Mv |= (uint32_t)(g == 0 || g == 2) << j;
+			Z |= (uint32_t)(g == 0) << j;
 			E |= (uint32_t)(g == 1) << j;
 		}
-		const unsigned __int128 xs = (unsigned __int128)X | ((unsigned __int128)X << k);
-		const unsigned __int128 ms = (unsigned __int128)Mv | ((unsigned __int128)Mv << k) | ((unsigned __int128)E << (2 * k));
-		for (int m = 0; m < nwp; m++) {
-			B.masks[(size_t)(row0 + m) * B.n_pad + s] = (uint32_t)(xs >> (32 * m));
-			B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s] = (uint32_t)(ms >> (32 * m));
-		}
-		xs128 = xs; ms128 = ms; in_regs = true;
-	} else
-#endif
-	{
-	int comp = 0, i = 0;                       // position 32*m+q = comp*k + i
-	for (int m = 0; m < nwp; m++) {
-		uint32_t xw = 0, mw = 0;
-		for (int q = 0; q < 32 && comp < 3 && k > 0; q++) {
-			const int snp = idx[i];
-			const uint32_t g = codes[(size_t)snp * B.n_pad + s];
-			const uint32_t bit = 1u << q;
-			if (comp == 0) {
-				const int wt = M.snp_weight[snp];
-				den += wt;
-				if (g != 3) num += wt;
-			}
-			if (comp < 2) {
-				if (g == 0 || g == 2) mw |= bit;
-				if (g == 2) xw |= bit;
-			} else if (g == 1) mw |= bit;
-			if (++i == k) { i = 0; comp++; }
-		}
-		B.masks[(size_t)(row0 + m) * B.n_pad + s] = xw;
-		B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s] = mw;
-	}
-	}
-	if (nkb > 0) {
-		// matrix-core engine: this sample's column of the B operand, a_k = +1 / -1 / 0 as int8 scaled
-		// by 8 (+8 -> 0x08, -8 -> 0xF8: the MFMA then yields 8*d, the byte offset of TAB[d]), written
-		// to the two lanes (K halves) that own it in the MFMA layout.  The distance offset
-		// 8*popc(x & m) either rides in the spare K positions 3k..3k+3 (terms of at most 120) or
-		// goes to B.bias for the accumulator start.
-		uint32_t xs[3] = {0, 0, 0}, ms[3] = {0, 0, 0};
-		int bias = 0;
-#pragma unroll
-		for (int m = 0; m < 3; m++)
-			if (m < nkb && m < nwp) {
-				xs[m] = in_regs ? (uint32_t)(xs128 >> (32 * m)) : B.masks[(size_t)(row0 + m) * B.n_pad + s];
-				ms[m] = in_regs ? (uint32_t)(ms128 >> (32 * m)) : B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s];
-				bias += __popc(xs[m] & ms[m]);
-			}
-		const bool bik = M.mfma_bik[c] != 0;
+		const uint32_t offset = 2u * (uint32_t)__popc(X) + (uint32_t)__popc(E);     // <= 64
+		const int ao = HIBAG_K_AO(k), bp = HIBAG_K_BP(k);
+		const uint64_t pos64 = Z, neg64 = X | E, e64 = (uint64_t)E << ao;
 		const int n = lane >> 5;
 #pragma unroll
 		for (int m = 0; m < 3; m++) {
 			if (m >= nkb) break;
+			const uint32_t pw = (uint32_t)(pos64 >> (32 * m)), nw = (uint32_t)(neg64 >> (32 * m)), ew = (uint32_t)(e64 >> (32 * m));
 #pragma unroll
 			for (int h = 0; h < 2; h++) {
-				const uint32_t xh = (xs[m] >> (16 * h)) & 0xFFFFu, mh = (ms[m] >> (16 * h)) & 0xFFFFu;
-				const v4i pos = expand_bits16(mh & ~xh), neg = expand_bits16(mh & xh);
+				const v4i pos = expand_bits16((pw >> (16 * h)) & 0xFFFFu), neg = expand_bits16((nw >> (16 * h)) & 0xFFFFu),
+					one = expand_bits16((ew >> (16 * h)) & 0xFFFFu);
 				uint32_t a[4];
 #pragma unroll
-				for (int q = 0; q < 4; q++) a[q] = (uint32_t)pos[q] * 0x08u | (uint32_t)neg[q] * 0xF8u;
-				if (bik) {
+				for (int q = 0; q < 4; q++) a[q] = (uint32_t)pos[q] * 0x08u | (uint32_t)neg[q] * 0xF8u | (uint32_t)one[q] * 0x10u;
+				if ((bp >> 5) == m && ((bp >> 4) & 1) == h) {
 #pragma unroll
-					for (int j = 0; j < 4; j++) {
-						const int p = 3 * k + j;                       // spare K position j
-						const int term = min(max(8 * bias - 120 * j, 0), 120);
-						if ((p >> 5) == m && ((p >> 4) & 1) == h) {
-#pragma unroll
-							for (int q = 0; q < 4; q++)
-								if (((p & 15) >> 2) == q) a[q] |= (uint32_t)term << (8 * (p & 3));
-						}
-					}
+					for (int q = 0; q < 4; q++)
+						if (((bp & 15) >> 2) == q) a[q] |= offset << (8 * (bp & 3));
 				}
 				B.bt[((size_t)(M.bt_row[c] + n * nkb + m) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (lane & 31)] =
 					uint4{a[0], a[1], a[2], a[3]};
 			}
 		}
-		if (!bik) {
-			const size_t at = ((size_t)(2 * c + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + (lane & 31);
-			B.bias[at] = 8 * bias;
-			B.bias[at + 32] = 8 * bias;
+	} else {
+		int comp = 0, i = 0;                       // position 32*m+q = comp*k + i
+		for (int m = 0; m < nwp; m++) {
+			uint32_t xw = 0, mw = 0;
+			for (int q = 0; q < 32 && comp < 3 && k > 0; q++) {
+				const int snp = idx[i];
+				const uint32_t g = codes[(size_t)snp * B.n_pad + s];
+				const uint32_t bit = 1u << q;
+				if (comp == 0) {
+					const int wt = M.snp_weight[snp];
+					den += wt;
+					if (g != 3) num += wt;
+				}
+				if (comp < 2) {
+					if (g == 0 || g == 2) mw |= bit;
+					if (g == 2) xw |= bit;
+				} else if (g == 1) mw |= bit;
+				if (++i == k) { i = 0; comp++; }
+			}
+			B.masks[(size_t)(row0 + m) * B.n_pad + s] = xw;
+			B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s] = mw;
 		}
 	}
 	B.cw[(size_t)c * B.n_pad + s] = (s < B.n_samp && den > 0) ? ((double)num / den) : 0.0;
@@ -662,11 +669,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, Hi
 	const int nkb = M.mfma_nkb[c];
 	const int srow = M.n_split > 0 ? M.split_row[c] : -1;
 	if (nkb > 0) {
-#define CALL(N, BIK) { LaneOperand<N> T; load_operand<N, BIK>(M, B, c, group, threadIdx.x & 63, T);               \
-		walk_blocks<N, BIK>(stream_rsrc(M), (uint32_t)M.blk_off[c] * 4u, M.cls_nblk[c], threadIdx.x & 63, T, tab_s, exp_s, \
-			stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)],                                             \
+#define CALL(N) { LaneOperand<N> T; load_operand_row<N>(B, M.bt_row[c], group, threadIdx.x & 63, T);                          \
+		walk_blocks<N>(plist_rsrc(M, M.blk_off[c]), 0u, M.cls_nblk[c], threadIdx.x & 63, hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c], \
+			T, tab_s, exp_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)],                                \
 			[&](double cell) { total += cell; asm("" : "+v"(total)); /* keeps the cell end a scalar branch */ }); }
-		HIBAG_DISPATCH_NKB(M.mfma_bik[c] ? nkb : 4, CALL)
+		HIBAG_DISPATCH_NKB(nkb, CALL)
 #undef CALL
 	} else {
 		double *rows = srow >= 0 ? B.cellsum + (size_t)srow * B.n_pad : nullptr;
@@ -769,7 +776,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 	// lane's weight and 1/total.  Without this every classifier starts with a chain of
 	// dependent scalar and vector loads (~3000 cycles per classifier, measured with stamps).
 	typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-	const __amdgpu_buffer_rsrc_t rs = stream_rsrc(M);
 	const u32x8 *__restrict__ ct = reinterpret_cast<const u32x8 *>(M.ctile) + tile;
 	u32x8 rec_n = ct[0];
 	double w_n = B.cw[s], inv_n = B.inv[s];
@@ -804,9 +810,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 				j = (int)(jpack & 15);
 				a = acc[j][lane];
 			};
-			const uint32_t blk = rec[2] * 4u;               // byte offset of the tile's first block (rec[3] is 0: < 4 GB)
-#define CALL(N, BIK) { LaneOperand<N> T; load_operand_row<N, BIK>(B, (int)rec[1], c, group, lane, T);              \
-			walk_blocks<N, BIK>(rs, blk, (int)rec[4], lane, T, tab_s, exp_s, stage_s[wave], fin); }
+#define CALL(N) { LaneOperand<N> T; load_operand_row<N>(B, (int)rec[1], group, lane, T);                                \
+			walk_blocks<N>(plist_rsrc(M, ((uint64_t)rec[3] << 32) | rec[2]), 0u, (int)rec[4], lane, hap_rsrc(M, M.hap_off[c]), \
+				M.n_snp_c[c], T, tab_s, exp_s, stage_s[wave], fin); }
 			HIBAG_DISPATCH_NKB(nkb, CALL)
 #undef CALL
 			if (poison) {                                // empty cells: (0 * inv) * w is NaN where inv is not finite
@@ -880,10 +886,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_vote_best(HibagModelView M
 			if (best < prob) { best = prob; best_i = i; }
 			i++;
 		};
-#define CALL(N, BIK) { LaneOperand<N> T; load_operand<N, BIK>(M, B, c, group, threadIdx.x & 63, T);               \
-		walk_blocks<N, BIK>(stream_rsrc(M), (uint32_t)M.blk_off[c] * 4u, M.cls_nblk[c], threadIdx.x & 63, T, tab_s, exp_s, \
-			stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)], fin); }
-		HIBAG_DISPATCH_NKB(M.mfma_bik[c] ? nkb : 4, CALL)
+#define CALL(N) { LaneOperand<N> T; load_operand_row<N>(B, M.bt_row[c], group, threadIdx.x & 63, T);                          \
+		walk_blocks<N>(plist_rsrc(M, M.blk_off[c]), 0u, M.cls_nblk[c], threadIdx.x & 63, hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c], \
+			T, tab_s, exp_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)], fin); }
+		HIBAG_DISPATCH_NKB(nkb, CALL)
 #undef CALL
 		bp = best_i < 0 ? -1 : (int)M.cls_cell[M.cls_off[c] + best_i];
 	} else {

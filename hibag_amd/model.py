@@ -77,14 +77,13 @@ class HlaAttrBagObj:
 
 def engine_nkb(n_snp_c: int) -> int:
     """32-wide K blocks of the int8 distance dot product the library's matrix engine uses for a
-    classifier with ``n_snp_c`` SNPs (``finalize_model`` in csrc/hibag_api.hip: the 3k bit positions
-    plus 4 offset positions when they fit in three blocks); 0 = VALU engine (more than 32 SNPs)."""
+    classifier with ``n_snp_c`` SNPs (``HIBAG_K_NKB`` in csrc/hibag_device.h: 2k + 1 positions --
+    h1+h2 against the genotype signs, h1&h2 against [g == 1], one offset term); 0 = VALU engine
+    (more than 32 SNPs)."""
     k = int(n_snp_c)
-    if 3 * k + 4 <= 96:
-        return max(1, -(-(3 * k + 4) // 32))
-    if 3 * k <= 96:
-        return max(1, -(-3 * k // 32))
-    return 0
+    if k > 32:
+        return 0
+    return 1 if k <= 15 else (2 if k <= 31 else 3)
 
 
 @dataclass
