@@ -335,8 +335,10 @@ int append_pair_blocks(const int *st, int n_hla, int h1, int h2, int n_cells, ui
 			uint64_t i = 0;
 			const uint64_t total = n + (n & 1);
 			if (h1 == h2) {
-				for (int a = a0; a < a1; a++)
-					for (int b = a; b < a1; b++) { i++; slot((uint32_t)a | ((uint32_t)b << 16), i == total); }
+				for (int a = a0; a < a1; a++) {
+					i++; slot((pad + 1 + (uint32_t)a) | ((uint32_t)a << 16), i == total);      // (a, a): factor f * f
+					for (int b = a + 1; b < a1; b++) { i++; slot((uint32_t)a | ((uint32_t)b << 16), i == total); }
+				}
 			} else {
 				for (int a = a0; a < a1; a++)
 					for (int b = b0; b < b1; b++) { i++; slot((uint32_t)a | ((uint32_t)b << 16), i == total); }
@@ -412,20 +414,22 @@ int finalize_model(hibag_hip_model *m)
 		st.assign(nh + 1, 0);
 		for (int i = 0; i < H; i++) st[k.hla[i] + 1]++;
 		for (int h = 0; h < nh; h++) st[h + 1] += st[h];
-		// matrix-core engine: at most 32 SNPs, haplotype indices in 16 bits (one spare for the padding entry)
-		mfma_nkb[c] = (m->use_mfma && k.n_snp <= 32 && H < 65535) ? HIBAG_K_NKB(k.n_snp) : 0;
+		// matrix-core engine: at most 32 SNPs, table indices (2H + 1 entries) in 16 bits
+		mfma_nkb[c] = (m->use_mfma && k.n_snp <= 32 && 2 * H + 1 < 65536) ? HIBAG_K_NKB(k.n_snp) : 0;
 		bt_row[c] = bt_rows;
 		bt_rows += 2 * mfma_nkb[c];
 		cell_chunks[c].assign(P, 0);
 		if (mfma_nkb[c]) {
 			// no record stream: the kernels generate the records from the haplotype table
 			hap_off[c] = (uint32_t)(hap.size() / HIBAG_HAP_DWORDS);
-			for (int i = 0; i < H; i++) {
-				uint32_t f[2];
-				memcpy(f, &k.freq[i], sizeof(double));
-				hap.push_back((uint32_t)k.bits[2 * (size_t)i]); hap.push_back(f[0]); hap.push_back(f[1]);
-			}
-			hap.insert(hap.end(), HIBAG_HAP_DWORDS, 0u);          // the padding entry: no allele set, frequency +0.0
+			auto entry = [&](double ff, uint32_t bits, double f) {
+				uint32_t w[5];
+				memcpy(&w[0], &ff, sizeof(double)); w[2] = bits; memcpy(&w[3], &f, sizeof(double));
+				hap.insert(hap.end(), w, w + 5);
+			};
+			for (int i = 0; i < H; i++) entry(2 * k.freq[i], (uint32_t)k.bits[2 * (size_t)i], k.freq[i]);
+			entry(0.0, 0u, 0.0);                                   // H: the padding entry (frequency +0.0)
+			for (int i = 0; i < H; i++) entry(k.freq[i], (uint32_t)k.bits[2 * (size_t)i], k.freq[i]);   // H+1+i: first of a diagonal pair
 			size_t p = 0;
 			for (int h1 = 0; h1 < nh; h1++)
 				for (int h2 = h1; h2 < nh; h2++) {

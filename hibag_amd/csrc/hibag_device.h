@@ -24,12 +24,15 @@
 //
 //    The matrix-core engine (classifiers with at most 32 SNPs) does not read pair
 //    records at all: it GENERATES them from an O(H) haplotype table
-//        hap[hap_off[c] + i] = { bits (SNP s of the classifier = bit s), freq lo, freq hi }   12 bytes
-//    (one extra all-zero entry per classifier serves the padding slots) and a 4-byte
-//    index pair (i1 | i2 << 16) per record, in BLOCKS of 32 slots:
+//        hap[hap_off[c] + i] = { ff (double), bits (SNP s of the classifier = bit s), f (double) }   20 bytes
+//    where f is the haplotype's frequency and ff = 2 f the factor it contributes as the FIRST haplotype
+//    of a pair (the reference's `ff = 2 * f1`, then `ff * f2`).  Entries H+1 .. 2H repeat the haplotypes
+//    with ff = f: the leading diagonal pair (i, i) of a cell (h, h), whose factor is f * f, is listed as
+//    (H + 1 + i, i).  Entry H is all zero and serves the padding slots.  The records are 4-byte
+//    index pairs (i1 | i2 << 16), in BLOCKS of 32 slots:
 //        idx[32], mask of the slots that close a cell, number of valid slots      34 dwords
 //    Each lane builds its record's int8 A-operand rows and the frequency factor
-//    (2*f1)*f2 with the reference's rounding (src/LibHLA.cpp:1786-1813) itself.  Cells are
+//    ff[i1] * f[i2] -- one multiplication, rounded like the reference's (src/LibHLA.cpp:1786-1813) -- itself.  Cells are
 //    padded to an even slot count.  Two lists: all cells of a classifier back to back
 //    (pass 1), and per (tile, classifier) segments stored tile-major (pass 2: a wavefront
 //    walks one tile's segments classifier after classifier through contiguous memory).
@@ -64,7 +67,7 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 #define HIBAG_CHUNK_DWORDS(nwp) (HIBAG_CHUNK * ((nwp) + 2))
 // dwords of one 32-slot block of a pair list (matrix-core engine): idx[32], end mask, valid count
 #define HIBAG_PLIST_DWORDS 34
-#define HIBAG_HAP_DWORDS 3       // haplotype table entry: bits, freq lo, freq hi
+#define HIBAG_HAP_DWORDS 5       // haplotype table entry: ff lo, ff hi, bits, f lo, f hi
 // K layout of the distance dot product for a classifier with k SNPs (K positions = bytes of the int8 operands):
 //   [0, k)          h1_s + h2_s  (A: 0/1/2)   x  B: +8 (g=0), -8 (g=1,2), 0 (missing)
 //   [ao, ao + k)    h1_s & h2_s  (A: 0/1)     x  B: +16 (g=1), else 0

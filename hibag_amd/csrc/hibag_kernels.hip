@@ -219,7 +219,7 @@ __device__ __forceinline__ void block_mfma(uint32_t h1, uint32_t h2, int k, int 
 		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[1][0], acc1, 0, 0, 0);
 	} else {
 		const v4i a1 = expand16_lds(h1 & h2, sh, exp_s);
-		if (NKB == 2) a0 = a0 | cterm;                               // position 31
+		if (NKB == 2) a0[3] |= cterm[3];                             // position 31: byte 15 of the upper K half
 		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[0][0], acc0, 0, 0, 0);
 		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[1][0], acc1, 0, 0, 0);
 		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, T.b[0][1], acc0, 0, 0, 0);
@@ -292,13 +292,27 @@ __device__ __forceinline__ void block_accumulate(const double *stage, uint32_t e
 #define STAGE_DOUBLES 32
 #define STAGE_BYTES (2 * STAGE_DOUBLES * 8)
 
-// One haplotype-table entry through a raw buffer: {bits, freq lo, freq hi}
-__device__ __forceinline__ v3u load_hap(__amdgpu_buffer_rsrc_t hp, uint32_t i)
+// The parts of a haplotype-table entry {ff, bits, f} a pair needs, through a raw buffer:
+// first haplotype {ff lo, ff hi, bits}, second haplotype {bits, f lo, f hi}
+__device__ __forceinline__ v3u load_hap_first(__amdgpu_buffer_rsrc_t hp, uint32_t i)
 {
 	return __builtin_amdgcn_raw_buffer_load_b96(hp, (int)(i * (4u * HIBAG_HAP_DWORDS)), 0, 0);
 }
+__device__ __forceinline__ v3u load_hap_second(__amdgpu_buffer_rsrc_t hp, uint32_t i)
+{
+	return __builtin_amdgcn_raw_buffer_load_b96(hp, (int)(i * (4u * HIBAG_HAP_DWORDS)), 8, 0);
+}
 
-// Walk `nblk` consecutive blocks of a pair list (raw buffer `pl`, byte offset `soff`).
+// What a walk has already fetched of the list behind its last block: the index pairs and {end mask,
+// count} of the next two blocks.  Pass 2 reads one tile's segments classifier after classifier through
+// contiguous memory, so the look-ahead of one walk is the prologue of the next.
+struct ListCursor {
+	uint64_t at = ~(uint64_t)0;      // dword offset of the block `idx` / `meta` belong to (~0: nothing fetched)
+	uint32_t idx = 0, idx_n = 0;     // index pairs of that block and of the one behind it (this lane's slot)
+	uint2 meta = {0, 0}, meta_n = {0, 0};
+};
+
+// Walk `nblk` consecutive blocks of a pair list starting at dword offset `at`.
 //
 // Latency plan.  Nothing in this loop goes through the scalar cache: scalar loads
 // share the lgkmcnt counter with the LDS table look-ups and return out of order,
@@ -308,15 +322,16 @@ __device__ __forceinline__ v3u load_hap(__amdgpu_buffer_rsrc_t hp, uint32_t i)
 //                                pairs arrived during block b-1) and the index pairs + {end mask,
 //                                count} of block b+2 are requested.
 // Lane l (and l+32: the other K half of the same row) then turns its pair (i1, i2) into the A-operand
-// row and the factor (2 f1) f2 -- f1 f1 for the leading diagonal pair i1 == i2 -- with one FP64
-// multiply; lanes 0..31 park the 32 factors in the wavefront's LDS staging buffer, from where the
-// accumulation reads them back as wave-uniform (broadcast) 16-byte LDS reads, in order with the
-// table look-ups.  The list is padded so that the look-ahead stays in bounds.
+// row and the factor ff[i1] * f[i2] with one FP64 multiply; lanes 0..31 park the 32 factors in the
+// wavefront's LDS staging buffer, from where the accumulation reads them back as wave-uniform
+// (broadcast) 16-byte LDS reads, in order with the table look-ups.  The list is padded so that the
+// look-ahead stays in bounds.
 template <int NKB, class Fin>
-__device__ __forceinline__ void walk_blocks(__amdgpu_buffer_rsrc_t pl, uint32_t soff, int nblk, int lane,
+__device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at, int nblk, int lane, ListCursor &cur,
 	__amdgpu_buffer_rsrc_t hp, int k, const LaneOperand<NKB> &T, const double *tab_s, const uint2 *exp_s,
 	double *stage, Fin &&fin)
 {
+	if (nblk <= 0) return;
 	double cell = 0;
 	const int sh = (lane >> 5) * 16;
 	const int vo_i = (lane & 31) * 4;                // this lane's slot inside a block
@@ -324,43 +339,47 @@ __device__ __forceinline__ void walk_blocks(__amdgpu_buffer_rsrc_t pl, uint32_t 
 	const v4i cterm = offset_term<NKB>(k, lane, kb_of);
 	(void)kb_of;
 	const uint32_t BB = 4 * HIBAG_PLIST_DWORDS;      // bytes per block
-	// prologue: index pairs of blocks 0 and 1, entries of block 0
-	uint32_t idx = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff, 0);
-	uint2 meta = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(pl, 128, soff, 0));
-	uint32_t idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + BB, 0);
-	uint2 meta_n = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(pl, 128, soff + BB, 0));
-	v3u r1 = load_hap(hp, idx & 0xFFFFu), r2 = load_hap(hp, idx >> 16);
+	// The list is addressed as a raw buffer rebased at this segment, so that the 32-bit offsets inside
+	// the descriptor never limit the model size.
+	const uint64_t left = (M.plist_dwords - at) * 4;
+	const __amdgpu_buffer_rsrc_t pl = __builtin_amdgcn_make_buffer_rsrc((void *)(M.plist + at), 0,
+		left > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left, 0x00020000);
+	uint32_t soff = 0;
+	if (cur.at != at) {                              // nothing usable fetched: index pairs of blocks 0 and 1
+		cur.idx = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff, 0);
+		cur.meta = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(pl, 128, soff, 0));
+		cur.idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + BB, 0);
+		cur.meta_n = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(pl, 128, soff + BB, 0));
+	}
+	uint32_t idx_n = cur.idx_n;
+	uint2 meta = cur.meta, meta_n = cur.meta_n;
+	v3u r1 = load_hap_first(hp, cur.idx & 0xFFFFu), r2 = load_hap_second(hp, cur.idx >> 16);
+	uint32_t idx_c = cur.idx;
 	for (int b = 0; b < nblk; b++) {
 		double *buf = stage + (b & 1) * STAGE_DOUBLES;
-		// this block's records: factor and A rows
-		const double f1 = __hiloint2double((int)r1.z, (int)r1.y), f2 = __hiloint2double((int)r2.z, (int)r2.y);
-		const double m = ((idx & 0xFFFFu) == (idx >> 16)) ? f1 : f1 + f1;      // 2*f1 is exact
-		const double prod = m * f2;
+		// this block's records: factor ff[i1] * f[i2] and A rows
+		const double prod = __hiloint2double((int)r1.y, (int)r1.x) * __hiloint2double((int)r2.z, (int)r2.y);
 		if (lane < 32) buf[lane] = prod;
 		const uint32_t endmask = __builtin_amdgcn_readfirstlane(meta.x);
 		const int n_valid = __builtin_amdgcn_readfirstlane(meta.y);
 		v16i D0, D1;
-		block_mfma<NKB>(r1.x, r2.x, k, sh, cterm, T, exp_s, D0, D1);
+		block_mfma<NKB>(r1.z, r2.x, k, sh, cterm, T, exp_s, D0, D1);
 		// look-ahead
 		const uint32_t nxt2 = soff + 2 * BB;
-		idx = idx_n; meta = meta_n;
-		r1 = load_hap(hp, idx & 0xFFFFu); r2 = load_hap(hp, idx >> 16);
+		meta = meta_n; idx_c = idx_n;
+		r1 = load_hap_first(hp, idx_c & 0xFFFFu); r2 = load_hap_second(hp, idx_c >> 16);
 		idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, nxt2, 0);
 		meta_n = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(pl, 128, nxt2, 0));
 		block_own_sample(D0, D1, n_valid);
 		block_accumulate(buf, endmask, n_valid, D0, D1, cell, tab_s, fin);
 		soff += BB;
 	}
+	cur.at = at + (uint64_t)nblk * HIBAG_PLIST_DWORDS;
+	cur.idx = idx_c; cur.idx_n = idx_n; cur.meta = meta; cur.meta_n = meta_n;
 }
 
-// raw-buffer descriptors (gfx9 word 3: 32-bit data format, no swizzle; reads past the end return 0).
-// The pair list is rebased at the segment a walk starts from, so that 32-bit offsets inside the
-// descriptor never limit the model size.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t plist_rsrc(const HibagModelView &M, uint64_t dword_off)
-{
-	const uint64_t left = (M.plist_dwords - dword_off) * 4;
-	return __builtin_amdgcn_make_buffer_rsrc((void *)(M.plist + dword_off), 0, left > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left, 0x00020000);
-}
+// raw-buffer descriptor of a classifier's haplotype table (gfx9 word 3: 32-bit data format, no swizzle;
+// reads past the end return 0)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t hap_rsrc(const HibagModelView &M, uint32_t first)
 {
 	// exact bound: the look-ahead of a walk runs into the next segment's index pairs, whose entries may lie
@@ -546,7 +565,9 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 #pragma unroll
 		for (int m = 0; m < 3; m++) {
 			if (m >= nkb) break;
-			const uint32_t pw = (uint32_t)(pos64 >> (32 * m)), nw = (uint32_t)(neg64 >> (32 * m)), ew = (uint32_t)(e64 >> (32 * m));
+			// (K block 2 exists for k = 32 only and holds nothing but the offset term)
+			const uint32_t pw = m < 2 ? (uint32_t)(pos64 >> (32 * m)) : 0u, nw = m < 2 ? (uint32_t)(neg64 >> (32 * m)) : 0u,
+				ew = m < 2 ? (uint32_t)(e64 >> (32 * m)) : 0u;
 #pragma unroll
 			for (int h = 0; h < 2; h++) {
 				const v4i pos = expand_bits16((pw >> (16 * h)) & 0xFFFFu), neg = expand_bits16((nw >> (16 * h)) & 0xFFFFu),
@@ -670,7 +691,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, Hi
 	const int srow = M.n_split > 0 ? M.split_row[c] : -1;
 	if (nkb > 0) {
 #define CALL(N) { LaneOperand<N> T; load_operand_row<N>(B, M.bt_row[c], group, threadIdx.x & 63, T);                          \
-		walk_blocks<N>(plist_rsrc(M, M.blk_off[c]), 0u, M.cls_nblk[c], threadIdx.x & 63, hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c], \
+		ListCursor cur;                                                                                                \
+		walk_blocks<N>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c],       \
 			T, tab_s, exp_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)],                                \
 			[&](double cell) { total += cell; asm("" : "+v"(total)); /* keeps the cell end a scalar branch */ }); }
 		HIBAG_DISPATCH_NKB(nkb, CALL)
@@ -779,6 +801,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 	const u32x8 *__restrict__ ct = reinterpret_cast<const u32x8 *>(M.ctile) + tile;
 	u32x8 rec_n = ct[0];
 	double w_n = B.cw[s], inv_n = B.inv[s];
+	ListCursor cur;                                   // the list look-ahead carries over from classifier to classifier
 	for (int c = 0; c < M.n_classifier; c++) {
 		const u32x8 rec = rec_n;
 		const double w = w_n, inv = inv_n;
@@ -811,7 +834,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 				a = acc[j][lane];
 			};
 #define CALL(N) { LaneOperand<N> T; load_operand_row<N>(B, (int)rec[1], group, lane, T);                                \
-			walk_blocks<N>(plist_rsrc(M, ((uint64_t)rec[3] << 32) | rec[2]), 0u, (int)rec[4], lane, hap_rsrc(M, M.hap_off[c]), \
+			walk_blocks<N>(M, ((uint64_t)rec[3] << 32) | rec[2], (int)rec[4], lane, cur, hap_rsrc(M, M.hap_off[c]),      \
 				M.n_snp_c[c], T, tab_s, exp_s, stage_s[wave], fin); }
 			HIBAG_DISPATCH_NKB(nkb, CALL)
 #undef CALL
@@ -887,7 +910,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_vote_best(HibagModelView M
 			i++;
 		};
 #define CALL(N) { LaneOperand<N> T; load_operand_row<N>(B, M.bt_row[c], group, threadIdx.x & 63, T);                          \
-		walk_blocks<N>(plist_rsrc(M, M.blk_off[c]), 0u, M.cls_nblk[c], threadIdx.x & 63, hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c], \
+		ListCursor cur;                                                                                                \
+		walk_blocks<N>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c],       \
 			T, tab_s, exp_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)], fin); }
 		HIBAG_DISPATCH_NKB(nkb, CALL)
 #undef CALL
