@@ -307,11 +307,11 @@ void build_pair_stream(const HostClassifier &k, int n_hla, int nwp, const int *s
 }
 
 // Matrix-core engine: the pair list of a run of cells [p0, p0 + n) of one classifier, appended to `out`
-// as blocks of 32 slots (idx[32] = i1 | i2 << 16, end mask, valid count).  The visiting order inside a
+// as blocks of 32 slots (i1 | i2 << 16 | end << 31).  The visiting order inside a
 // cell is the reference's (src/LibHLA.cpp:1776-1821: i1 ascending, then i2; the leading diagonal pair
 // (i, i) first on the diagonal cells).  Cells are padded to an even slot count with the classifier's
-// all-zero haplotype `pad` (frequency 0: the slot adds +0.0); bit i of the end mask marks the slot that
-// closes a cell.  (h1, h2) of cell p0 are given; returns the number of blocks.
+// all-zero haplotype `pad` (frequency 0: the slot adds +0.0); the end flag marks the slot that closes
+// a cell; the unused slots behind the last cell point at `pad` too.  (h1, h2) of cell p0 are given; returns the number of blocks.
 int append_pair_blocks(const int *st, int n_hla, int h1, int h2, int n_cells, uint32_t pad, std::vector<uint32_t> &out)
 {
 	const uint32_t pad_idx = pad | (pad << 16);
@@ -320,13 +320,10 @@ int append_pair_blocks(const int *st, int n_hla, int h1, int h2, int n_cells, ui
 	auto slot = [&](uint32_t idx, bool end) {
 		if (fill == 32) {
 			base = out.size();
-			out.resize(base + HIBAG_PLIST_DWORDS, 0u);
-			for (int i = 0; i < 32; i++) out[base + i] = pad_idx;
+			out.resize(base + HIBAG_PLIST_DWORDS, pad_idx);
 			fill = 0; n_blocks++;
 		}
-		out[base + fill] = idx;
-		if (end) out[base + 32] |= 1u << fill;
-		out[base + 33] = (uint32_t)++fill;
+		out[base + fill++] = idx | (end ? HIBAG_PLIST_END : 0u);
 	};
 	for (int c = 0; c < n_cells; c++) {
 		const int a0 = st[h1], a1 = st[h1 + 1], b0 = st[h2], b1 = st[h2 + 1];
@@ -414,8 +411,8 @@ int finalize_model(hibag_hip_model *m)
 		st.assign(nh + 1, 0);
 		for (int i = 0; i < H; i++) st[k.hla[i] + 1]++;
 		for (int h = 0; h < nh; h++) st[h + 1] += st[h];
-		// matrix-core engine: at most 32 SNPs, table indices (2H + 1 entries) in 16 bits
-		mfma_nkb[c] = (m->use_mfma && k.n_snp <= 32 && 2 * H + 1 < 65536) ? HIBAG_K_NKB(k.n_snp) : 0;
+		// matrix-core engine: at most 32 SNPs; table indices: first haplotype < 2H + 1 in 16 bits, second < H + 1 in 15
+		mfma_nkb[c] = (m->use_mfma && k.n_snp <= 32 && H < 32768) ? HIBAG_K_NKB(k.n_snp) : 0;
 		bt_row[c] = bt_rows;
 		bt_rows += 2 * mfma_nkb[c];
 		cell_chunks[c].assign(P, 0);
@@ -575,7 +572,7 @@ int finalize_model(hibag_hip_model *m)
 		fprintf(stderr, "[hibag model] %d classifiers, %d tiles, pairs %lld; blocks of 32: pass 1 %lld, pass 2 %lld in %lld (classifier, tile) segments; "
 			"pair lists %.1f MB, haplotype table %.1f KB, VALU-engine stream %.1f MB\n",
 			C, n_tile, (long long)m->pair_evals, dbg_b1, dbg_b2, dbg_seg, plist.size() * 4e-6, hap.size() * 4e-3, stream.size() * 4e-6);
-	plist.insert(plist.end(), 3 * HIBAG_PLIST_DWORDS, 0u);   // look-ahead slack of the block walker (two blocks)
+	plist.insert(plist.end(), 4 * HIBAG_PLIST_DWORDS, 0u);   // look-ahead slack of the block walker
 	// per (classifier, tile) record of pass 2 (one s_load_dwordx8)
 	std::vector<uint32_t> ctile((size_t)std::max(C, 1) * n_tile * 8 + 8, 0);
 	for (int c = 0; c < C; c++)
@@ -583,10 +580,12 @@ int finalize_model(hibag_hip_model *m)
 			uint32_t *r = &ctile[((size_t)c * n_tile + t) * 8];
 			const uint32_t *me = &tile_meta[((size_t)c * n_tile + t) * HIBAG_TILE_META];
 			const uint64_t off = seg_off[(size_t)c * n_tile + t];
-			r[0] = (uint32_t)mfma_nkb[c]; r[1] = (uint32_t)bt_row[c];
+			if (bt_row[c] > 0xFFFF) return fail(HIBAG_HIP_EINVAL, "too many classifiers for the matrix engine's operand rows");
+			r[0] = (uint32_t)mfma_nkb[c] | ((uint32_t)n_snp_c[c] << 2 & 0xFCu) | (me[0] << 8) | ((uint32_t)bt_row[c] << 16);
+			r[1] = hap_off[c];
 			r[2] = (uint32_t)off; r[3] = (uint32_t)(off >> 32);
 			r[4] = seg_nblk[(size_t)c * n_tile + t];
-			r[5] = me[0]; r[6] = me[2]; r[7] = me[3];
+			r[5] = 0; r[6] = me[2]; r[7] = me[3];
 		}
 
 	// one int arena

@@ -29,8 +29,8 @@
 //    of a pair (the reference's `ff = 2 * f1`, then `ff * f2`).  Entries H+1 .. 2H repeat the haplotypes
 //    with ff = f: the leading diagonal pair (i, i) of a cell (h, h), whose factor is f * f, is listed as
 //    (H + 1 + i, i).  Entry H is all zero and serves the padding slots.  The records are 4-byte
-//    index pairs (i1 | i2 << 16), in BLOCKS of 32 slots:
-//        idx[32], mask of the slots that close a cell, number of valid slots      34 dwords
+//    words  i1 | i2 << 16 | end << 31  (end = this slot closes a cell; i2 < 2^15), in BLOCKS of 32 slots
+//    (128 bytes); unused trailing slots of a segment's last block point at the zero entry.
 //    Each lane builds its record's int8 A-operand rows and the frequency factor
 //    ff[i1] * f[i2] -- one multiplication, rounded like the reference's (src/LibHLA.cpp:1786-1813) -- itself.  Cells are
 //    padded to an even slot count.  Two lists: all cells of a classifier back to back
@@ -65,8 +65,9 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 
 // dwords of one chunk for a classifier with nwp words per record
 #define HIBAG_CHUNK_DWORDS(nwp) (HIBAG_CHUNK * ((nwp) + 2))
-// dwords of one 32-slot block of a pair list (matrix-core engine): idx[32], end mask, valid count
-#define HIBAG_PLIST_DWORDS 34
+// dwords of one 32-slot block of a pair list (matrix-core engine)
+#define HIBAG_PLIST_DWORDS 32
+#define HIBAG_PLIST_END 0x80000000u   // slot flag: closes a cell
 #define HIBAG_HAP_DWORDS 5       // haplotype table entry: ff lo, ff hi, bits, f lo, f hi
 // K layout of the distance dot product for a classifier with k SNPs (K positions = bytes of the int8 operands):
 //   [0, k)          h1_s + h2_s  (A: 0/1/2)   x  B: +8 (g=0), -8 (g=1,2), 0 (missing)
@@ -127,7 +128,8 @@ struct HibagModelView {
 	const uint32_t *plist;       // pair lists: blocks of HIBAG_PLIST_DWORDS dwords
 	uint64_t plist_dwords;       // total size (a raw buffer is rebased per classifier / tile segment: no 4 GB limit)
 	const uint32_t *ctile;       // [C][n_tile][8]: everything pass 2 needs per (classifier, tile) in one s_load_dwordx8:
-	                             // {engine code = nkb (0 = VALU), bt_row, pair list dword offset lo/hi, #blocks, #non-empty cells, row list lo/hi}
+	                             // {nkb (0 = VALU) | k << 2 | #non-empty cells << 8 | bt_row << 16, first haplotype-table entry,
+	                             //  pair list dword offset lo/hi, #blocks, 0, row list lo/hi}
 };
 
 struct HibagBatchView {

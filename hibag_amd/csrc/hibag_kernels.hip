@@ -178,6 +178,9 @@ __device__ __forceinline__ void stage_expand_table(uint2 *exp_s)
 __device__ __forceinline__ v4i expand16_lds(uint32_t x, int sh, const uint2 *exp_s)
 {
 	const uint32_t y = x >> sh;
+#ifdef HIBAG_ABL_NOEXP
+	return v4i{(int)(y & 0x01010101u), (int)((y >> 1) & 0x01010101u), (int)((y >> 2) & 0x01010101u), (int)((y >> 3) & 0x01010101u)};
+#endif
 	const uint2 lo = exp_s[y & 0xFFu], hi = exp_s[(y >> 8) & 0xFFu];
 	return v4i{(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
 }
@@ -296,20 +299,25 @@ __device__ __forceinline__ void block_accumulate(const double *stage, uint32_t e
 // first haplotype {ff lo, ff hi, bits}, second haplotype {bits, f lo, f hi}
 __device__ __forceinline__ v3u load_hap_first(__amdgpu_buffer_rsrc_t hp, uint32_t i)
 {
+#ifdef HIBAG_ABL_NOGATHER
+	return v3u{0u, 0x3fb00000u + i, 0u};
+#endif
 	return __builtin_amdgcn_raw_buffer_load_b96(hp, (int)(i * (4u * HIBAG_HAP_DWORDS)), 0, 0);
 }
 __device__ __forceinline__ v3u load_hap_second(__amdgpu_buffer_rsrc_t hp, uint32_t i)
 {
+#ifdef HIBAG_ABL_NOGATHER
+	return v3u{0u, 0u, 0x3fb00000u + i};
+#endif
 	return __builtin_amdgcn_raw_buffer_load_b96(hp, (int)(i * (4u * HIBAG_HAP_DWORDS)), 8, 0);
 }
 
-// What a walk has already fetched of the list behind its last block: the index pairs and {end mask,
-// count} of the next two blocks.  Pass 2 reads one tile's segments classifier after classifier through
-// contiguous memory, so the look-ahead of one walk is the prologue of the next.
+// What a walk has already fetched of the list behind its last block: the slot words of the next two
+// blocks.  Pass 2 reads one tile's segments classifier after classifier through contiguous memory, so the
+// look-ahead of one walk is the prologue of the next.
 struct ListCursor {
-	uint64_t at = ~(uint64_t)0;      // dword offset of the block `idx` / `meta` belong to (~0: nothing fetched)
-	uint32_t idx = 0, idx_n = 0;     // index pairs of that block and of the one behind it (this lane's slot)
-	uint2 meta = {0, 0}, meta_n = {0, 0};
+	uint64_t at = ~(uint64_t)0;      // dword offset of the block `idx` belongs to (~0: nothing fetched)
+	uint32_t idx = 0, idx_n = 0;     // this lane's slot word of that block and of the one behind it
 };
 
 // Walk `nblk` consecutive blocks of a pair list starting at dword offset `at`.
@@ -318,14 +326,15 @@ struct ListCursor {
 // share the lgkmcnt counter with the LDS table look-ups and return out of order,
 // so every wait for table values would also wait for the scalar load just issued.
 // Everything travels as per-lane vector loads, software-pipelined over the blocks:
-//   while block b is evaluated   the haplotype entries of block b+1 are gathered (their index
-//                                pairs arrived during block b-1) and the index pairs + {end mask,
-//                                count} of block b+2 are requested.
-// Lane l (and l+32: the other K half of the same row) then turns its pair (i1, i2) into the A-operand
-// row and the factor ff[i1] * f[i2] with one FP64 multiply; lanes 0..31 park the 32 factors in the
-// wavefront's LDS staging buffer, from where the accumulation reads them back as wave-uniform
-// (broadcast) 16-byte LDS reads, in order with the table look-ups.  The list is padded so that the
-// look-ahead stays in bounds.
+//   at the top of block b   the haplotype entries of block b+1 are gathered (their slot words
+//                           arrived during block b-1) and the slot words of block b+2 are requested,
+// so that a whole block's evaluation covers their latency.  Lane l (and l+32: the other K half of
+// the same row) turns its pair (i1, i2) into the A-operand row and the factor ff[i1] * f[i2] with one
+// FP64 multiply; lanes 0..31 park the 32 factors in the wavefront's LDS staging buffer, from where the
+// accumulation reads them back as wave-uniform (broadcast) 16-byte LDS reads, in order with the table
+// look-ups.  The end-of-cell mask is the ballot of the slots' end flags; the number of slots worth
+// evaluating follows from the last slot that closes a cell or has a non-zero factor (a zero factor adds
+// +0.0: skipping it is exact).  The list is padded so that the look-ahead stays in bounds.
 template <int NKB, class Fin>
 __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at, int nblk, int lane, ListCursor &cur,
 	__amdgpu_buffer_rsrc_t hp, int k, const LaneOperand<NKB> &T, const double *tab_s, const uint2 *exp_s,
@@ -345,37 +354,35 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 	const __amdgpu_buffer_rsrc_t pl = __builtin_amdgcn_make_buffer_rsrc((void *)(M.plist + at), 0,
 		left > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left, 0x00020000);
 	uint32_t soff = 0;
-	if (cur.at != at) {                              // nothing usable fetched: index pairs of blocks 0 and 1
+	if (cur.at != at) {                              // nothing usable fetched: slot words of blocks 0 and 1
 		cur.idx = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff, 0);
-		cur.meta = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(pl, 128, soff, 0));
 		cur.idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + BB, 0);
-		cur.meta_n = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(pl, 128, soff + BB, 0));
 	}
-	uint32_t idx_n = cur.idx_n;
-	uint2 meta = cur.meta, meta_n = cur.meta_n;
-	v3u r1 = load_hap_first(hp, cur.idx & 0xFFFFu), r2 = load_hap_second(hp, cur.idx >> 16);
-	uint32_t idx_c = cur.idx;
+	uint32_t idx_c = cur.idx, idx_n = cur.idx_n;
+	v3u r1 = load_hap_first(hp, idx_c & 0xFFFFu), r2 = load_hap_second(hp, (idx_c >> 16) & 0x7FFFu);
 	for (int b = 0; b < nblk; b++) {
 		double *buf = stage + (b & 1) * STAGE_DOUBLES;
-		// this block's records: factor ff[i1] * f[i2] and A rows
+		// this block's records: haplotype words and the factor ff[i1] * f[i2]
+		const uint32_t h1 = r1.z, h2 = r2.x;
 		const double prod = __hiloint2double((int)r1.y, (int)r1.x) * __hiloint2double((int)r2.z, (int)r2.y);
-		if (lane < 32) buf[lane] = prod;
-		const uint32_t endmask = __builtin_amdgcn_readfirstlane(meta.x);
-		const int n_valid = __builtin_amdgcn_readfirstlane(meta.y);
-		v16i D0, D1;
-		block_mfma<NKB>(r1.z, r2.x, k, sh, cterm, T, exp_s, D0, D1);
-		// look-ahead
-		const uint32_t nxt2 = soff + 2 * BB;
-		meta = meta_n; idx_c = idx_n;
-		r1 = load_hap_first(hp, idx_c & 0xFFFFu); r2 = load_hap_second(hp, idx_c >> 16);
-		idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, nxt2, 0);
-		meta_n = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(pl, 128, nxt2, 0));
-		block_own_sample(D0, D1, n_valid);
-		block_accumulate(buf, endmask, n_valid, D0, D1, cell, tab_s, fin);
+		const uint32_t endmask = (uint32_t)__ballot((idx_c & HIBAG_PLIST_END) != 0);          // lanes 32..63 mirror 0..31
+		const uint32_t live = endmask | (uint32_t)__ballot(prod != 0.0);
+		const int n_valid = 32 - __builtin_clz(live | 1u) - (live == 0u);
+		// look-ahead: entries of block b+1, slot words of block b+2
+		idx_c = idx_n;
+		r1 = load_hap_first(hp, idx_c & 0xFFFFu); r2 = load_hap_second(hp, (idx_c >> 16) & 0x7FFFu);
+		idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + 2 * BB, 0);
+		if (n_valid > 0) {
+			if (lane < 32) buf[lane] = prod;
+			v16i D0, D1;
+			block_mfma<NKB>(h1, h2, k, sh, cterm, T, exp_s, D0, D1);
+			block_own_sample(D0, D1, n_valid);
+			block_accumulate(buf, endmask, n_valid, D0, D1, cell, tab_s, fin);
+		}
 		soff += BB;
 	}
 	cur.at = at + (uint64_t)nblk * HIBAG_PLIST_DWORDS;
-	cur.idx = idx_c; cur.idx_n = idx_n; cur.meta = meta; cur.meta_n = meta_n;
+	cur.idx = idx_c; cur.idx_n = idx_n;
 }
 
 // raw-buffer descriptor of a classifier's haplotype table (gfx9 word 3: 32-bit data format, no swizzle;
@@ -815,7 +822,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 		const bool active = w > 0;
 		if (__ballot(active) == 0) continue;
 		const bool poison = __ballot(active && !(fabs(inv) <= 1.79769313486231570815e+308)) != 0;
-		const int nkb = (int)rec[0];
+		const int nkb = (int)(rec[0] & 3u);
 		if (nkb > 0) {
 			// Cells close in the order of the tile's non-empty entries; their row numbers j come
 			// packed 4 bits each in two SGPRs, so closing a cell needs no memory access, and the
@@ -833,14 +840,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 				j = (int)(jpack & 15);
 				a = acc[j][lane];
 			};
-#define CALL(N) { LaneOperand<N> T; load_operand_row<N>(B, (int)rec[1], group, lane, T);                                \
-			walk_blocks<N>(M, ((uint64_t)rec[3] << 32) | rec[2], (int)rec[4], lane, cur, hap_rsrc(M, M.hap_off[c]),      \
-				M.n_snp_c[c], T, tab_s, exp_s, stage_s[wave], fin); }
+#define CALL(N) { LaneOperand<N> T; load_operand_row<N>(B, (int)(rec[0] >> 16), group, lane, T);                       \
+			walk_blocks<N>(M, ((uint64_t)rec[3] << 32) | rec[2], (int)rec[4], lane, cur, hap_rsrc(M, rec[1]),           \
+				(int)((rec[0] >> 2) & 63u), T, tab_s, exp_s, stage_s[wave], fin); }
 			HIBAG_DISPATCH_NKB(nkb, CALL)
 #undef CALL
 			if (poison) {                                // empty cells: (0 * inv) * w is NaN where inv is not finite
 				const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + tile) * HIBAG_TILE_META;
-				for (int i = (int)rec[5]; i < ncell; i++) {
+				for (int i = (int)((rec[0] >> 8) & 31u); i < ncell; i++) {
 					const double v = (0.0 * inv) * w;
 					acc[meta[4 + i] >> 24][lane] += active ? v : 0.0;
 				}
