@@ -155,7 +155,7 @@ struct hibag_hip_model {
 	size_t stream_bytes = 0;
 
 	// per-batch workspace (grow-only)
-	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_cellsum;
+	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias, ws_cellsum;
 	// plugin staging
 	DevBuf ws_tgeno, ws_weight;
 	// PLINK BED payload + SNP map of hibag_hip_predict_bed
@@ -168,7 +168,7 @@ struct hibag_hip_model {
 	{
 		(void)hipSetDevice(device);
 		timer.destroy();
-		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_cellsum, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
+		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_cellsum, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
 		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_tgeno, &ws_weight, &ws_bed, &ws_bedidx})
 			b->release();
 	}
@@ -420,9 +420,10 @@ int finalize_model(hibag_hip_model *m)
 			// no record stream: the kernels generate the records from the haplotype table
 			hap_off[c] = (uint32_t)(hap.size() / HIBAG_HAP_DWORDS);
 			auto entry = [&](double ff, uint32_t bits, double f) {
-				uint32_t w[5];
-				memcpy(&w[0], &ff, sizeof(double)); w[2] = bits; memcpy(&w[3], &f, sizeof(double));
-				hap.insert(hap.end(), w, w + 5);
+				uint32_t w[HIBAG_HAP_DWORDS] = {0};
+				for (int sb = 0; sb < 32; sb++) w[sb >> 2] |= ((bits >> sb) & 1u) << (8 * (sb & 3));
+				memcpy(&w[8], &ff, sizeof(double)); memcpy(&w[10], &f, sizeof(double));
+				hap.insert(hap.end(), w, w + HIBAG_HAP_DWORDS);
 			};
 			for (int i = 0; i < H; i++) entry(2 * k.freq[i], (uint32_t)k.bits[2 * (size_t)i], k.freq[i]);
 			entry(0.0, 0u, 0.0);                                   // H: the padding entry (frequency +0.0)
@@ -682,6 +683,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	if (int rc = m->ws_part.reserve((size_t)(m->view.n_cell + 3) * n_pad * sizeof(double))) return rc;
 	if (int rc = m->ws_codes.reserve((size_t)std::max(m->n_snp, 1) * n_pad)) return rc;
 	if (int rc = m->ws_bt.reserve((size_t)std::max(m->bt_rows, 1) * n_pad * sizeof(uint4))) return rc;
+	if (int rc = m->ws_bias.reserve(2 * C * n_pad * sizeof(int))) return rc;
 	if (int rc = m->ws_cellsum.reserve((size_t)std::max(m->cellsum_rows, 1) * n_pad * sizeof(double))) return rc;
 	if (need_best)
 		if (int rc = m->ws_best.reserve(C * n_pad * sizeof(int))) return rc;
@@ -689,7 +691,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	B.masks = m->ws_planes.as<uint32_t>();
 	B.cw = m->ws_cw.as<double>(); B.tot = m->ws_tot.as<double>(); B.inv = m->ws_inv.as<double>();
 	B.part = m->ws_part.as<double>();
-	B.bt = m->ws_bt.as<uint4>();
+	B.bt = m->ws_bt.as<uint4>(); B.bias = m->ws_bias.as<int>();
 	B.cellsum = m->ws_cellsum.as<double>();
 	return 0;
 }

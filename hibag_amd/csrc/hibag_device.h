@@ -24,15 +24,16 @@
 //
 //    The matrix-core engine (classifiers with at most 32 SNPs) does not read pair
 //    records at all: it GENERATES them from an O(H) haplotype table
-//        hap[hap_off[c] + i] = { ff (double), bits (SNP s of the classifier = bit s), f (double) }   20 bytes
+//        hap[hap_off[c] + i] = { E[32] (byte s = bit s of the haplotype, 0/1), ff (double), f (double) }   48 bytes
 //    where f is the haplotype's frequency and ff = 2 f the factor it contributes as the FIRST haplotype
 //    of a pair (the reference's `ff = 2 * f1`, then `ff * f2`).  Entries H+1 .. 2H repeat the haplotypes
 //    with ff = f: the leading diagonal pair (i, i) of a cell (h, h), whose factor is f * f, is listed as
 //    (H + 1 + i, i).  Entry H is all zero and serves the padding slots.  The records are 4-byte
 //    words  i1 | i2 << 16 | end << 31  (end = this slot closes a cell; i2 < 2^15), in BLOCKS of 32 slots
 //    (128 bytes); unused trailing slots of a segment's last block point at the zero entry.
-//    Each lane builds its record's int8 A-operand rows and the frequency factor
-//    ff[i1] * f[i2] -- one multiplication, rounded like the reference's (src/LibHLA.cpp:1786-1813) -- itself.  Cells are
+//    Each lane builds its record's int8 A-operand rows from the two E images (byte-wise sum and AND)
+//    and the frequency factor ff[i1] * f[i2] -- one multiplication, rounded like the reference's
+//    (src/LibHLA.cpp:1786-1813) -- itself.  Cells are
 //    padded to an even slot count.  Two lists: all cells of a classifier back to back
 //    (pass 1), and per (tile, classifier) segments stored tile-major (pass 2: a wavefront
 //    walks one tile's segments classifier after classifier through contiguous memory).
@@ -68,17 +69,18 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 // dwords of one 32-slot block of a pair list (matrix-core engine)
 #define HIBAG_PLIST_DWORDS 32
 #define HIBAG_PLIST_END 0x80000000u   // slot flag: closes a cell
-#define HIBAG_HAP_DWORDS 5       // haplotype table entry: ff lo, ff hi, bits, f lo, f hi
+#define HIBAG_HAP_DWORDS 12      // haplotype table entry: E[32] bytes, ff, f
 // K layout of the distance dot product for a classifier with k SNPs (K positions = bytes of the int8 operands):
 //   [0, k)          h1_s + h2_s  (A: 0/1/2)   x  B: +8 (g=0), -8 (g=1,2), 0 (missing)
 //   [ao, ao + k)    h1_s & h2_s  (A: 0/1)     x  B: +16 (g=1), else 0
-//   bp              A: 8                      x  B: 2*#(g=2) + #(g=1)   (<= 64)
+//   31              A: 8                      x  B: 2*#(g=2) + #(g=1)   (<= 64)
 // so that the dot product is 8*d for the distance d of src/LibHLA.cpp:747-819 (g=0: h1+h2, g=2: 2-h1-h2,
-// g=1: [h1==h2] = 1-h1-h2+2*h1*h2).  k <= 15: one 32-wide K block (ao = k, bp = 2k); k <= 31: two
-// (ao = 32, bp = 31); k = 32: three (ao = 32, bp = 64).
-#define HIBAG_K_NKB(k) ((k) <= 15 ? 1 : ((k) <= 31 ? 2 : 3))
-#define HIBAG_K_AO(k) ((k) <= 15 ? (k) : 32)
-#define HIBAG_K_BP(k) ((k) <= 15 ? 2 * (k) : ((k) <= 31 ? 31 : 64))
+// g=1: [h1==h2] = 1-h1-h2+2*h1*h2).  k <= 15: one 32-wide K block, ao = 16 (the lower K half of the MFMA
+// operand holds the sums, the upper one the ANDs); k <= 32: two, ao = 32 -- with 32 SNPs position 31 is
+// taken, and the offset 8*(2*#(g=2) + #(g=1)) starts the accumulators instead (HibagBatchView::bias).
+#define HIBAG_K_NKB(k) ((k) <= 15 ? 1 : 2)
+#define HIBAG_K_AO(k) ((k) <= 15 ? 16 : 32)
+#define HIBAG_K_BP 31
 
 struct HibagModelView {
 	int n_hla;
@@ -118,9 +120,9 @@ struct HibagModelView {
 	const double *tab;           // [257] exp(d*log(1e-5))
 
 	// matrix-core engine (classifiers with at most 32 SNPs; hibag_kernels.hip "MFMA engine")
-	const int *mfma_nkb;         // [C] 32-wide K blocks of the distance dot product (1: k <= 15, 2: k <= 31, 3: k = 32), 0 = use the VALU engine
+	const int *mfma_nkb;         // [C] 32-wide K blocks of the distance dot product (1: k <= 15, 2: k <= 32), 0 = use the VALU engine
 	const int *bt_row;           // [C] first operand row of the classifier in HibagBatchView::bt
-	const uint32_t *hap;         // haplotype table, 3 dwords per entry (see above)
+	const uint32_t *hap;         // haplotype table, HIBAG_HAP_DWORDS per entry (see above)
 	const uint32_t *hap_off;     // [C] first entry of the classifier
 	uint32_t hap_entries;        // entries in the table
 	const uint64_t *blk_off;     // [C] dword offset of the classifier's pass-1 pair list (all cells back to back)
@@ -142,8 +144,9 @@ struct HibagBatchView {
 	double *cellsum;    // [rows of the split classifiers][n_pad] (pass 1 scratch)
 	double *part;       // [P+3][n_pad]
 	// matrix-core engine: per classifier and sample group the B operand tiles
-	// (int8, MFMA lane layout; K layout above)
+	// (int8, MFMA lane layout; K layout above) and, for classifiers with 32 SNPs, the distance offsets
 	uint4 *bt;          // [(bt_row[c] + n*nkb + kb)][n_pad/64][64]
+	int *bias;          // [(2c + n)][n_pad/64][64]  8 * (2*#(g=2) + #(g=1)), written for 32-SNP classifiers only
 };
 
 #endif

@@ -39,6 +39,9 @@
 
 #define NA_INTEGER (-2147483647 - 1)
 #define CH HIBAG_CHUNK
+#ifndef HIBAG_GATHER_DEPTH
+#define HIBAG_GATHER_DEPTH 1                // blocks of look-ahead of the haplotype-entry gathers
+#endif
 #ifndef BLOCK_WAVES
 #define BLOCK_WAVES 4                       // wavefronts per workgroup (each on its own work item)
 #endif
@@ -131,15 +134,17 @@ __device__ __forceinline__ double cell_sum(uint32_t n, const uint32_t *__restric
 // Used for classifiers with at most 32 SNPs; wider ones use the VALU engine above.
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
-typedef unsigned v3u __attribute__((ext_vector_type(3)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 template <int NKB>
 struct LaneOperand {
 	v4i b[2][NKB];      // B operand of sample half n, K block kb (MFMA lane layout)
+	int bias[2];        // 32 SNPs only: the lane's distance offset (times 8) for each sample half
 };
 
-template <int NKB>
-__device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt_row, int group,
+// SPLAT: the classifier has 32 SNPs: no K position is left for the offset term, it starts the accumulators
+template <int NKB, bool SPLAT>
+__device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt_row, int c, int group,
 	int lane, LaneOperand<NKB> &T)
 {
 	const size_t n_group = (size_t)(B.n_pad / HIBAG_WAVE);
@@ -150,6 +155,7 @@ __device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt
 			const uint4 v = B.bt[((size_t)(bt_row + n * NKB + kb) * n_group + group) * HIBAG_WAVE + lane];
 			T.b[n][kb] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
 		}
+		T.bias[n] = SPLAT ? B.bias[((size_t)(2 * c + n) * n_group + group) * HIBAG_WAVE + lane] : 0;
 	}
 }
 
@@ -162,75 +168,46 @@ __device__ __forceinline__ v4i expand_bits16(uint32_t x)
 	return r;
 }
 
-// 8 bits -> 8 bytes (bit i -> byte i = 0/1) for all 256 byte values: the A operand
-// is expanded with 8-byte LDS look-ups instead of ~13 VALU ops per 16 positions.
-__device__ __forceinline__ void stage_expand_table(uint2 *exp_s)
-{
-	for (int v = threadIdx.x; v < 256; v += blockDim.x) {
-		uint2 e;
-		e.x = (((uint32_t)v & 0xFu) * 0x00204081u) & 0x01010101u;
-		e.y = ((((uint32_t)v >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
-		exp_s[v] = e;
-	}
-}
-
-// the 16 bits of x at bit position sh as 16 bytes
-__device__ __forceinline__ v4i expand16_lds(uint32_t x, int sh, const uint2 *exp_s)
-{
-	const uint32_t y = x >> sh;
-#ifdef HIBAG_ABL_NOEXP
-	return v4i{(int)(y & 0x01010101u), (int)((y >> 1) & 0x01010101u), (int)((y >> 2) & 0x01010101u), (int)((y >> 3) & 0x01010101u)};
-#endif
-	const uint2 lo = exp_s[y & 0xFFu], hi = exp_s[(y >> 8) & 0xFFu];
-	return v4i{(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
-}
-
-// The lane's constant part of the A operand: the value 8 at K position bp (the distance offset term).
-// Lane l owns the K bytes 16 (l / 32) .. + 15 of every 32-wide K block.
-template <int NKB>
-__device__ __forceinline__ v4i offset_term(int k, int lane, int &kb_of)
-{
-	const int bp = HIBAG_K_BP(k);
-	kb_of = bp >> 5;
-	const int q = bp & 31;
-	v4i c = {0, 0, 0, 0};
-	if ((q >> 4) == (lane >> 5)) {
-		const int b = q & 15;
-#pragma unroll
-		for (int d = 0; d < 4; d++)
-			if ((b >> 2) == d) c[d] = 8 << (8 * (b & 3));
-	}
-	return c;
-}
-
 // Issue the MFMAs of one block: acc_n[r] of lane l = 8 x distance of record
 // 8(r/4) + 4(l/32) + r%4 to sample (l%32) of sample half n.
-// h1, h2 = the haplotype words of record (lane % 32); sh = 16 (lane / 32); cterm = offset_term().
-template <int NKB>
-__device__ __forceinline__ void block_mfma(uint32_t h1, uint32_t h2, int k, int sh, const v4i &cterm,
-	const LaneOperand<NKB> &T, const uint2 *exp_s, v16i &acc0, v16i &acc1)
+// e1, e2 = this lane's 16 bytes of the two haplotypes' E images of record (lane % 32):
+//   two K blocks (16..32 SNPs): bytes 16 (lane / 32) .. + 15; block 0 = e1 + e2, block 1 = e1 & e2
+//   one K block (<= 15 SNPs):   bytes 0 .. 15 for every lane; the lower K half (lanes 0..31) carries
+//                               e1 + e2, the upper one e1 & e2
+// and the value 8 at K position 31 (byte 15 of the upper K half of block 0) meets the sample's offset term.
+template <int NKB, bool SPLAT>
+__device__ __forceinline__ void block_mfma(const v4i &e1, const v4i &e2, int lane, const LaneOperand<NKB> &T,
+	v16i &acc0, v16i &acc1)
 {
+	if (SPLAT) {
+		// The empty asm makes the offsets opaque per block: otherwise the two 16-register splats are
+		// hoisted out of the block loop and cost 32 VGPRs for its whole duration.
+		int b0 = T.bias[0], b1 = T.bias[1];
+		asm("" : "+v"(b0), "+v"(b1));
 #pragma unroll
-	for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }      // folds into the MFMA's inline-constant C operand
-	const v4i e1 = expand16_lds(h1, sh, exp_s), e2 = expand16_lds(h2, sh, exp_s);
-	v4i a0 = e1 + e2;                                                // bytes 0/1/2: no carry between bytes
+		for (int r = 0; r < 16; r++) { acc0[r] = b0; acc1[r] = b1; }
+	} else {
+#pragma unroll
+		for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }      // folds into the MFMA's inline-constant C operand
+	}
+	const bool upper = lane >= 32;
+	const int off3 = (upper && !SPLAT) ? (8 << 24) : 0;                 // K position 31
+	const v4i sum = e1 + e2;                                            // bytes 0/1/2: no carry between bytes
+	const v4i both = e1 & e2;
 	if (NKB == 1) {
-		// k <= 15: the h1 & h2 part sits at positions [k, 2k) of the same K block, the offset term at 2k
-		const v4i ea = expand16_lds((h1 & h2) << k, sh, exp_s);
-		a0 = (a0 + ea) | cterm;
+		v4i a0;
+#pragma unroll
+		for (int d = 0; d < 4; d++) a0[d] = upper ? both[d] : sum[d];
+		a0[3] |= off3;
 		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[0][0], acc0, 0, 0, 0);
 		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[1][0], acc1, 0, 0, 0);
 	} else {
-		const v4i a1 = expand16_lds(h1 & h2, sh, exp_s);
-		if (NKB == 2) a0[3] |= cterm[3];                             // position 31: byte 15 of the upper K half
+		v4i a0 = sum;
+		a0[3] |= off3;
 		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[0][0], acc0, 0, 0, 0);
 		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[1][0], acc1, 0, 0, 0);
-		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, T.b[0][1], acc0, 0, 0, 0);
-		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, T.b[1][1], acc1, 0, 0, 0);
-		if (NKB == 3) {                                              // k = 32: a third K block carries the offset term only
-			acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cterm, T.b[0][NKB - 1], acc0, 0, 0, 0);
-			acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(cterm, T.b[1][NKB - 1], acc1, 0, 0, 0);
-		}
+		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(both, T.b[0][NKB - 1], acc0, 0, 0, 0);
+		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(both, T.b[1][NKB - 1], acc1, 0, 0, 0);
 	}
 }
 
@@ -295,21 +272,17 @@ __device__ __forceinline__ void block_accumulate(const double *stage, uint32_t e
 #define STAGE_DOUBLES 32
 #define STAGE_BYTES (2 * STAGE_DOUBLES * 8)
 
-// The parts of a haplotype-table entry {ff, bits, f} a pair needs, through a raw buffer:
-// first haplotype {ff lo, ff hi, bits}, second haplotype {bits, f lo, f hi}
-__device__ __forceinline__ v3u load_hap_first(__amdgpu_buffer_rsrc_t hp, uint32_t i)
+// The parts of a haplotype-table entry {E[32], ff, f} through a raw buffer; `vo` = 4 HIBAG_HAP_DWORDS i
+// (+ this lane's offset into E for the image loads).
+__device__ __forceinline__ v4i load_hap_image(__amdgpu_buffer_rsrc_t hp, uint32_t vo)
 {
-#ifdef HIBAG_ABL_NOGATHER
-	return v3u{0u, 0x3fb00000u + i, 0u};
-#endif
-	return __builtin_amdgcn_raw_buffer_load_b96(hp, (int)(i * (4u * HIBAG_HAP_DWORDS)), 0, 0);
+	const auto v = __builtin_amdgcn_raw_buffer_load_b128(hp, (int)vo, 0, 0);
+	return v4i{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
 }
-__device__ __forceinline__ v3u load_hap_second(__amdgpu_buffer_rsrc_t hp, uint32_t i)
+__device__ __forceinline__ double load_hap_factor(__amdgpu_buffer_rsrc_t hp, uint32_t vo, int second)
 {
-#ifdef HIBAG_ABL_NOGATHER
-	return v3u{0u, 0u, 0x3fb00000u + i};
-#endif
-	return __builtin_amdgcn_raw_buffer_load_b96(hp, (int)(i * (4u * HIBAG_HAP_DWORDS)), 8, 0);
+	return __builtin_bit_cast(double, second ? __builtin_amdgcn_raw_buffer_load_b64(hp, (int)vo, 40, 0)
+	                                         : __builtin_amdgcn_raw_buffer_load_b64(hp, (int)vo, 32, 0));
 }
 
 // What a walk has already fetched of the list behind its last block: the slot words of the next two
@@ -329,25 +302,23 @@ struct ListCursor {
 //   at the top of block b   the haplotype entries of block b+1 are gathered (their slot words
 //                           arrived during block b-1) and the slot words of block b+2 are requested,
 // so that a whole block's evaluation covers their latency.  Lane l (and l+32: the other K half of
-// the same row) turns its pair (i1, i2) into the A-operand row and the factor ff[i1] * f[i2] with one
-// FP64 multiply; lanes 0..31 park the 32 factors in the wavefront's LDS staging buffer, from where the
-// accumulation reads them back as wave-uniform (broadcast) 16-byte LDS reads, in order with the table
-// look-ups.  The end-of-cell mask is the ballot of the slots' end flags; the number of slots worth
-// evaluating follows from the last slot that closes a cell or has a non-zero factor (a zero factor adds
-// +0.0: skipping it is exact).  The list is padded so that the look-ahead stays in bounds.
-template <int NKB, class Fin>
+// the same row) turns its pair (i1, i2) into the A-operand row (byte-wise sum and AND of the two E
+// images) and the factor ff[i1] * f[i2] with one FP64 multiply; lanes 0..31 park the 32 factors in the
+// wavefront's LDS staging buffer, from where the accumulation reads them back as wave-uniform
+// (broadcast) 16-byte LDS reads, in order with the table look-ups.  The end-of-cell mask is the ballot
+// of the slots' end flags; the number of slots worth evaluating follows from the last slot that closes
+// a cell or has a non-zero factor (a zero factor adds +0.0: skipping it is exact).  The list is padded
+// so that the look-ahead stays in bounds.
+template <int NKB, bool SPLAT, class Fin>
 __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at, int nblk, int lane, ListCursor &cur,
-	__amdgpu_buffer_rsrc_t hp, int k, const LaneOperand<NKB> &T, const double *tab_s, const uint2 *exp_s,
-	double *stage, Fin &&fin)
+	__amdgpu_buffer_rsrc_t hp, const LaneOperand<NKB> &T, const double *tab_s, double *stage, Fin &&fin)
 {
 	if (nblk <= 0) return;
 	double cell = 0;
-	const int sh = (lane >> 5) * 16;
 	const int vo_i = (lane & 31) * 4;                // this lane's slot inside a block
-	int kb_of;
-	const v4i cterm = offset_term<NKB>(k, lane, kb_of);
-	(void)kb_of;
+	const uint32_t img = NKB == 1 ? 0u : (uint32_t)(lane >> 5) * 16u;      // this lane's 16 bytes of an E image
 	const uint32_t BB = 4 * HIBAG_PLIST_DWORDS;      // bytes per block
+	const uint32_t ES = 4 * HIBAG_HAP_DWORDS;        // bytes per table entry
 	// The list is addressed as a raw buffer rebased at this segment, so that the 32-bit offsets inside
 	// the descriptor never limit the model size.
 	const uint64_t left = (M.plist_dwords - at) * 4;
@@ -359,23 +330,27 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 		cur.idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + BB, 0);
 	}
 	uint32_t idx_c = cur.idx, idx_n = cur.idx_n;
-	v3u r1 = load_hap_first(hp, idx_c & 0xFFFFu), r2 = load_hap_second(hp, (idx_c >> 16) & 0x7FFFu);
+	uint32_t o1 = (idx_c & 0xFFFFu) * ES, o2 = ((idx_c >> 16) & 0x7FFFu) * ES;
+	v4i e1 = load_hap_image(hp, o1 + img), e2 = load_hap_image(hp, o2 + img);
+	double ff = load_hap_factor(hp, o1, 0), f2 = load_hap_factor(hp, o2, 1);
 	for (int b = 0; b < nblk; b++) {
 		double *buf = stage + (b & 1) * STAGE_DOUBLES;
-		// this block's records: haplotype words and the factor ff[i1] * f[i2]
-		const uint32_t h1 = r1.z, h2 = r2.x;
-		const double prod = __hiloint2double((int)r1.y, (int)r1.x) * __hiloint2double((int)r2.z, (int)r2.y);
+		// this block's records: E images and the factor ff[i1] * f[i2]
+		const v4i a1 = e1, a2 = e2;
+		const double prod = ff * f2;
 		const uint32_t endmask = (uint32_t)__ballot((idx_c & HIBAG_PLIST_END) != 0);          // lanes 32..63 mirror 0..31
 		const uint32_t live = endmask | (uint32_t)__ballot(prod != 0.0);
-		const int n_valid = 32 - __builtin_clz(live | 1u) - (live == 0u);
+		const int n_valid = live ? 32 - __builtin_clz(live) : 0;
 		// look-ahead: entries of block b+1, slot words of block b+2
 		idx_c = idx_n;
-		r1 = load_hap_first(hp, idx_c & 0xFFFFu); r2 = load_hap_second(hp, (idx_c >> 16) & 0x7FFFu);
+		o1 = (idx_c & 0xFFFFu) * ES; o2 = ((idx_c >> 16) & 0x7FFFu) * ES;
+		e1 = load_hap_image(hp, o1 + img); e2 = load_hap_image(hp, o2 + img);
+		ff = load_hap_factor(hp, o1, 0); f2 = load_hap_factor(hp, o2, 1);
 		idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + 2 * BB, 0);
 		if (n_valid > 0) {
 			if (lane < 32) buf[lane] = prod;
 			v16i D0, D1;
-			block_mfma<NKB>(h1, h2, k, sh, cterm, T, exp_s, D0, D1);
+			block_mfma<NKB, SPLAT>(a1, a2, lane, T, D0, D1);
 			block_own_sample(D0, D1, n_valid);
 			block_accumulate(buf, endmask, n_valid, D0, D1, cell, tab_s, fin);
 		}
@@ -395,12 +370,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t hap_rsrc(const HibagModelView 
 	return __builtin_amdgcn_make_buffer_rsrc((void *)(M.hap + (size_t)first * HIBAG_HAP_DWORDS), 0, left > 0x7FFFFFF0ull ? 0x7FFFFFF0 : (int)left, 0x00020000);
 }
 
-// engine code = number of 32-wide K blocks
+// engine code: 1 = one K block (<= 15 SNPs), 2 = two K blocks, 3 = two K blocks and 32 SNPs (offset in the accumulators)
 #define HIBAG_DISPATCH_NKB(code, CALL)     \
 	switch (code) {                        \
-	case 1:  { CALL(1); } break;           \
-	case 2:  { CALL(2); } break;           \
-	default: { CALL(3); } break;           \
+	case 1:  { CALL(1, false); } break;    \
+	case 2:  { CALL(2, false); } break;    \
+	default: { CALL(2, true); } break;     \
 	}
 
 // Record widths the kernels are specialised for; the host rounds a classifier's
@@ -531,7 +506,7 @@ __global__ __launch_bounds__(256) void k_bed_geno(const uint8_t *__restrict__ be
 // layout of hibag_device.h, written to the two lanes (K halves) that own it in the MFMA layout:
 //   [0, k)        +8 where g = 0, -8 (0xF8) where g = 1 or 2, 0 where missing
 //   [ao, ao + k)  16 where g = 1
-//   bp            2 #[g = 2] + #[g = 1]     (times the A operand's 8: the distance offset)
+//   31            2 #[g = 2] + #[g = 1]     (times the A operand's 8: the distance offset; 32 SNPs: B.bias)
 // VALU-engine classifiers get the lane masks of the packed 3k-bit pair string
 //   bits [0,k)   first haplotype : x = [g==2], m = [g in {0,2}]
 //   bits [k,2k)  second haplotype: same
@@ -566,15 +541,13 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 			E |= (uint32_t)(g == 1) << j;
 		}
 		const uint32_t offset = 2u * (uint32_t)__popc(X) + (uint32_t)__popc(E);     // <= 64
-		const int ao = HIBAG_K_AO(k), bp = HIBAG_K_BP(k);
+		const int ao = HIBAG_K_AO(k);
 		const uint64_t pos64 = Z, neg64 = X | E, e64 = (uint64_t)E << ao;
 		const int n = lane >> 5;
 #pragma unroll
-		for (int m = 0; m < 3; m++) {
+		for (int m = 0; m < 2; m++) {
 			if (m >= nkb) break;
-			// (K block 2 exists for k = 32 only and holds nothing but the offset term)
-			const uint32_t pw = m < 2 ? (uint32_t)(pos64 >> (32 * m)) : 0u, nw = m < 2 ? (uint32_t)(neg64 >> (32 * m)) : 0u,
-				ew = m < 2 ? (uint32_t)(e64 >> (32 * m)) : 0u;
+			const uint32_t pw = (uint32_t)(pos64 >> (32 * m)), nw = (uint32_t)(neg64 >> (32 * m)), ew = (uint32_t)(e64 >> (32 * m));
 #pragma unroll
 			for (int h = 0; h < 2; h++) {
 				const v4i pos = expand_bits16((pw >> (16 * h)) & 0xFFFFu), neg = expand_bits16((nw >> (16 * h)) & 0xFFFFu),
@@ -582,14 +555,15 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 				uint32_t a[4];
 #pragma unroll
 				for (int q = 0; q < 4; q++) a[q] = (uint32_t)pos[q] * 0x08u | (uint32_t)neg[q] * 0xF8u | (uint32_t)one[q] * 0x10u;
-				if ((bp >> 5) == m && ((bp >> 4) & 1) == h) {
-#pragma unroll
-					for (int q = 0; q < 4; q++)
-						if (((bp & 15) >> 2) == q) a[q] |= offset << (8 * (bp & 3));
-				}
+				if (m == 0 && h == 1 && k < 32) a[3] |= offset << 24;       // K position 31 meets the A operand's 8
 				B.bt[((size_t)(M.bt_row[c] + n * nkb + m) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (lane & 31)] =
 					uint4{a[0], a[1], a[2], a[3]};
 			}
+		}
+		if (k == 32) {                                                      // no K position left: the offset starts the accumulators
+			const size_t at = ((size_t)(2 * c + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + (lane & 31);
+			B.bias[at] = 8 * (int)offset;
+			B.bias[at + 32] = 8 * (int)offset;
 		}
 	} else {
 		int comp = 0, i = 0;                       // position 32*m+q = comp*k + i
@@ -682,8 +656,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, Hi
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
-	__shared__ uint2 exp_s[256];
-	stage_expand_table(exp_s);
 	stage_table(M, tab_s);
 	const int *__restrict__ item = M.item + 4 * blockIdx.y;
 	const int c = item[0];
@@ -697,12 +669,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, Hi
 	const int nkb = M.mfma_nkb[c];
 	const int srow = M.n_split > 0 ? M.split_row[c] : -1;
 	if (nkb > 0) {
-#define CALL(N) { LaneOperand<N> T; load_operand_row<N>(B, M.bt_row[c], group, threadIdx.x & 63, T);                          \
+#define CALL(N, SP) { LaneOperand<N> T; load_operand_row<N, SP>(B, M.bt_row[c], c, group, threadIdx.x & 63, T);             \
 		ListCursor cur;                                                                                                \
-		walk_blocks<N>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c],       \
-			T, tab_s, exp_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)],                                \
+		walk_blocks<N, SP>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]),                 \
+			T, tab_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)],                                       \
 			[&](double cell) { total += cell; asm("" : "+v"(total)); /* keeps the cell end a scalar branch */ }); }
-		HIBAG_DISPATCH_NKB(nkb, CALL)
+		HIBAG_DISPATCH_NKB(nkb + (M.n_snp_c[c] == 32), CALL)
 #undef CALL
 	} else {
 		double *rows = srow >= 0 ? B.cellsum + (size_t)srow * B.n_pad : nullptr;
@@ -766,8 +738,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double acc_s[BLOCK_WAVES][HIBAG_TILE][HIBAG_WAVE];
 	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
-	__shared__ uint2 exp_s[256];
-	stage_expand_table(exp_s);
 	stage_table(M, tab_s);
 
 	// XCD-aware decode: workgroups are dealt round-robin over the 8 XCDs, so
@@ -840,10 +810,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 				j = (int)(jpack & 15);
 				a = acc[j][lane];
 			};
-#define CALL(N) { LaneOperand<N> T; load_operand_row<N>(B, (int)(rec[0] >> 16), group, lane, T);                       \
-			walk_blocks<N>(M, ((uint64_t)rec[3] << 32) | rec[2], (int)rec[4], lane, cur, hap_rsrc(M, rec[1]),           \
-				(int)((rec[0] >> 2) & 63u), T, tab_s, exp_s, stage_s[wave], fin); }
-			HIBAG_DISPATCH_NKB(nkb, CALL)
+#define CALL(N, SP) { LaneOperand<N> T; load_operand_row<N, SP>(B, (int)(rec[0] >> 16), c, group, lane, T);            \
+			walk_blocks<N, SP>(M, ((uint64_t)rec[3] << 32) | rec[2], (int)rec[4], lane, cur, hap_rsrc(M, rec[1]),       \
+				T, tab_s, stage_s[wave], fin); }
+			HIBAG_DISPATCH_NKB(nkb + (((rec[0] >> 2) & 63u) == 32u), CALL)
 #undef CALL
 			if (poison) {                                // empty cells: (0 * inv) * w is NaN where inv is not finite
 				const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + tile) * HIBAG_TILE_META;
@@ -893,8 +863,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_vote_best(HibagModelView M
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
-	__shared__ uint2 exp_s[256];
-	stage_expand_table(exp_s);
 	stage_table(M, tab_s);
 	const int c = M.c_order[blockIdx.y];
 	const int group = blockIdx.x * BLOCK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -916,11 +884,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_vote_best(HibagModelView M
 			if (best < prob) { best = prob; best_i = i; }
 			i++;
 		};
-#define CALL(N) { LaneOperand<N> T; load_operand_row<N>(B, M.bt_row[c], group, threadIdx.x & 63, T);                          \
+#define CALL(N, SP) { LaneOperand<N> T; load_operand_row<N, SP>(B, M.bt_row[c], c, group, threadIdx.x & 63, T);             \
 		ListCursor cur;                                                                                                \
-		walk_blocks<N>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c],       \
-			T, tab_s, exp_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)], fin); }
-		HIBAG_DISPATCH_NKB(nkb, CALL)
+		walk_blocks<N, SP>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]),                 \
+			T, tab_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)], fin); }
+		HIBAG_DISPATCH_NKB(nkb + (M.n_snp_c[c] == 32), CALL)
 #undef CALL
 		bp = best_i < 0 ? -1 : (int)M.cls_cell[M.cls_off[c] + best_i];
 	} else {

@@ -78,12 +78,13 @@ class HlaAttrBagObj:
 def engine_nkb(n_snp_c: int) -> int:
     """32-wide K blocks of the int8 distance dot product the library's matrix engine uses for a
     classifier with ``n_snp_c`` SNPs (``HIBAG_K_NKB`` in csrc/hibag_device.h: 2k + 1 positions --
-    h1+h2 against the genotype signs, h1&h2 against [g == 1], one offset term); 0 = VALU engine
+    h1+h2 against the genotype signs, h1&h2 against [g == 1], one offset term: one block up to 15 SNPs,
+    two up to 32); 0 = VALU engine
     (more than 32 SNPs)."""
     k = int(n_snp_c)
     if k > 32:
         return 0
-    return 1 if k <= 15 else (2 if k <= 31 else 3)
+    return 1 if k <= 15 else 2
 
 
 @dataclass
