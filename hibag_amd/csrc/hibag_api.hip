@@ -500,8 +500,8 @@ int finalize_model(hibag_hip_model *m)
 	int cellsum_rows = 0;
 	double split_heavy_ns = 0, split_rest_ns = 0;
 	{
-		// rough wavefront-time per record: matrix engine 50 ns at full occupancy, VALU engine 12 ns per
-		// 32-bit word when few wavefronts share a SIMD (the situation in which a tail forms), 4x that otherwise
+		// rough wavefront-time per record: matrix engine 50 ns at full occupancy, VALU engine 18 ns per
+		// 32-bit word while other wavefronts share its SIMD (measured), 48 ns at full occupancy
 		std::vector<double> work(C, 0.0);
 		double typical = 0;
 		int n_typ = 0;
@@ -521,7 +521,7 @@ int finalize_model(hibag_hip_model *m)
 				items.push_back({work[c], {c, 0, cls_n[c], 0}});
 				continue;
 			}
-			split_heavy_ns = std::max(split_heavy_ns, (double)pairs[c] * 12.0 * nwp[c]);
+			split_heavy_ns = std::max(split_heavy_ns, (double)pairs[c] * 18.0 * nwp[c]);       // measured: 1.1 ms for 5,050 pairs x 12 words
 			split_row[c] = cellsum_rows;
 			cellsum_rows += cls_n[c];
 			split_cls.push_back(c);

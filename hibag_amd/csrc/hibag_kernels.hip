@@ -516,6 +516,7 @@ __global__ __launch_bounds__(256) void k_bed_geno(const uint8_t *__restrict__ be
 __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView M, HibagBatchView B,
 	const uint8_t *__restrict__ codes)
 {
+	__shared__ uint32_t pack_s[PACK_WAVES][3][4][HIBAG_WAVE];
 	const int c = blockIdx.y * PACK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (c >= M.n_classifier) return;
 	const int lane = threadIdx.x & 63;
@@ -566,24 +567,37 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 			B.bias[at + 32] = 8 * (int)offset;
 		}
 	} else {
-		int comp = 0, i = 0;                       // position 32*m+q = comp*k + i
-		for (int m = 0; m < nwp; m++) {
-			uint32_t xw = 0, mw = 0;
-			for (int q = 0; q < 32 && comp < 3 && k > 0; q++) {
-				const int snp = idx[i];
+		// VALU engine (more than 32 SNPs, or the plugin path): one pass over the k <= 128 SNPs builds the
+		// three k-bit fields [g == 2], [g in {0, 2}], [g == 1] in LDS (four words each per lane); the 3k-bit
+		// strings are then put together word by word with wave-uniform bit offsets.
+		uint32_t (*fld)[4][HIBAG_WAVE] = pack_s[threadIdx.x >> 6];          // [field][word][lane]
+#pragma unroll
+		for (int w = 0; w < 4; w++) {
+			uint32_t X = 0, Mv = 0, E = 0;
+			const int j0 = 32 * w, j1 = min(k, j0 + 32);
+#pragma unroll 8
+			for (int j = j0; j < j1; j++) {
+				const int snp = idx[j];
 				const uint32_t g = codes[(size_t)snp * B.n_pad + s];
-				const uint32_t bit = 1u << q;
-				if (comp == 0) {
-					const int wt = M.snp_weight[snp];
-					den += wt;
-					if (g != 3) num += wt;
-				}
-				if (comp < 2) {
-					if (g == 0 || g == 2) mw |= bit;
-					if (g == 2) xw |= bit;
-				} else if (g == 1) mw |= bit;
-				if (++i == k) { i = 0; comp++; }
+				const int wt = M.snp_weight[snp];
+				den += wt;
+				if (g != 3) num += wt;
+				X |= (uint32_t)(g == 2) << (j - j0);
+				Mv |= (uint32_t)(g == 0 || g == 2) << (j - j0);
+				E |= (uint32_t)(g == 1) << (j - j0);
 			}
+			fld[0][w][lane] = X; fld[1][w][lane] = Mv; fld[2][w][lane] = E;
+		}
+		// 32 bits of field f starting at bit `off` (bits outside [0, 128) are zero); off is wave-uniform
+		auto bits_at = [&](int f, int off) -> uint32_t {
+			const int w0 = off >> 5, sh = off & 31;
+			const uint32_t v0 = (w0 >= 0 && w0 < 4) ? fld[f][w0][lane] : 0u;
+			const uint32_t v1 = (w0 + 1 >= 0 && w0 + 1 < 4) ? fld[f][w0 + 1][lane] : 0u;
+			return sh ? (v0 >> sh) | (v1 << (32 - sh)) : v0;
+		};
+		for (int m = 0; m < nwp; m++) {
+			const uint32_t xw = bits_at(0, 32 * m) | bits_at(0, 32 * m - k);
+			const uint32_t mw = bits_at(1, 32 * m) | bits_at(1, 32 * m - k) | bits_at(2, 32 * m - 2 * k);
 			B.masks[(size_t)(row0 + m) * B.n_pad + s] = xw;
 			B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s] = mw;
 		}
@@ -1103,7 +1117,8 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 	// single-wavefront walk would outlast the rest of the pass, i.e. for small batches.
 	HibagModelView V = M;
 	const double groups = (double)(B.n_pad / HIBAG_WAVE);
-	const bool split = M.n_split > 0 && M.split_heavy_ns > M.split_rest_ns * groups / 4096.0;
+	// (the heavy walk starts with the pass, so it only matters once it lasts about as long as everything else)
+	const bool split = M.n_split > 0 && 1.25 * M.split_heavy_ns > M.split_rest_ns * groups / 4096.0;
 	V.item = split ? M.item_split : M.item_whole;
 	V.n_item = split ? M.n_item_split : M.n_item_whole;
 	if (!split) V.n_split = 0;
