@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--samples", type=int, default=SAMPLES_PER_GPU, help="samples per GPU per step")
     ap.add_argument("--shape", default=SHAPE)
     ap.add_argument("--prob", action="store_true", help="also return the full posterior matrix (type='response+prob')")
+    ap.add_argument("--vote", choices=("prob", "majority"), default="prob", help="hlaPredict(vote=): averaged posteriors (default) or majority vote")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-wide", action="store_true", help="diagnostic: drop the one 100-SNP classifier of the synthetic model")
     ap.add_argument("--shard", choices=("samples", "classifiers"), default="samples",
@@ -112,6 +113,7 @@ def main():
     model_obj, founders, afreq = synth.make_model(args.shape, wide_classifier=not args.no_wide)
     n = args.samples
     by_classifier = args.shard == "classifiers"
+    vote_method = 2 if args.vote == "majority" else 1
     geno, truth = synth.make_samples(founders, afreq, n, seed=synth.DEFAULT_SEED + 1 + (0 if by_classifier else rank))
     if by_classifier:
         from hibag_amd import dist as hdist
@@ -142,7 +144,7 @@ def main():
             model.finish_device(d_part.data_ptr(), n, d_h1.data_ptr(), d_h2.data_ptr(), d_prob.data_ptr(), d_match.data_ptr(),
                                 d_dos.data_ptr(), None if d_pp is None else d_pp.data_ptr(), stream=stream.cuda_stream)
             return
-        model.predict_device(d_geno.data_ptr(), n, 1, d_h1.data_ptr(), d_h2.data_ptr(), d_prob.data_ptr(),
+        model.predict_device(d_geno.data_ptr(), n, vote_method, d_h1.data_ptr(), d_h2.data_ptr(), d_prob.data_ptr(),
                              d_match.data_ptr(), d_dos.data_ptr(), None if d_pp is None else d_pp.data_ptr(),
                              stream=stream.cuda_stream)
 
@@ -243,7 +245,7 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"synthetic {args.shape} model ({n_hla} alleles, {len(model_obj.classifiers)} classifiers, "
                                f"{S} SNPs, {pair_evals} haplotype-pair evaluations/sample), {n} samples per GPU per step, "
-                               f"type={'response+prob' if args.prob else 'response+dosage'}, vote=prob",
+                               f"type={'response+prob' if args.prob else 'response+dosage'}, vote={args.vote}",
                    "samples_per_gpu": n,
                    "parallelism": (f"classifier-sharded x{world} (one all-reduce of {P + 3} x {n_pad} doubles per step)"
                                    if by_classifier else f"sample-sharded x{world} (no collective)"),
@@ -264,7 +266,7 @@ def main():
             model.close()
             out["other_configs"] = other_configs(K)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and vote_method == 1:
         out["cpu_baseline"] = cpu_baseline(model_obj, geno, h1, h2)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
 

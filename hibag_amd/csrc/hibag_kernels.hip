@@ -330,8 +330,10 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 		cur.idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + BB, 0);
 	}
 	uint32_t idx_c = cur.idx, idx_n = cur.idx_n;
-	uint32_t o1 = (idx_c & 0xFFFFu) * ES, o2 = ((idx_c >> 16) & 0x7FFFu) * ES;
-	v4i e1 = load_hap_image(hp, o1 + img), e2 = load_hap_image(hp, o2 + img);
+	// One address per haplotype: entry * 48 + this lane's offset into the E image.  The factors are read 32 /
+	// 40 bytes behind it, which is right for lanes 0..31 (image offset 0) -- the only ones whose factors are used.
+	uint32_t o1 = (idx_c & 0xFFFFu) * ES + img, o2 = ((idx_c >> 16) & 0x7FFFu) * ES + img;
+	v4i e1 = load_hap_image(hp, o1), e2 = load_hap_image(hp, o2);
 	double ff = load_hap_factor(hp, o1, 0), f2 = load_hap_factor(hp, o2, 1);
 	for (int b = 0; b < nblk; b++) {
 		double *buf = stage + (b & 1) * STAGE_DOUBLES;
@@ -339,12 +341,12 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 		const v4i a1 = e1, a2 = e2;
 		const double prod = ff * f2;
 		const uint32_t endmask = (uint32_t)__ballot((idx_c & HIBAG_PLIST_END) != 0);          // lanes 32..63 mirror 0..31
-		const uint32_t live = endmask | (uint32_t)__ballot(prod != 0.0);
+		const uint32_t live = endmask | (uint32_t)__ballot(prod != 0.0);                      // low half: lanes 0..31
 		const int n_valid = live ? 32 - __builtin_clz(live) : 0;
 		// look-ahead: entries of block b+1, slot words of block b+2
 		idx_c = idx_n;
-		o1 = (idx_c & 0xFFFFu) * ES; o2 = ((idx_c >> 16) & 0x7FFFu) * ES;
-		e1 = load_hap_image(hp, o1 + img); e2 = load_hap_image(hp, o2 + img);
+		o1 = (idx_c & 0xFFFFu) * ES + img; o2 = ((idx_c >> 16) & 0x7FFFu) * ES + img;
+		e1 = load_hap_image(hp, o1); e2 = load_hap_image(hp, o2);
 		ff = load_hap_factor(hp, o1, 0); f2 = load_hap_factor(hp, o2, 1);
 		idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + 2 * BB, 0);
 		if (n_valid > 0) {

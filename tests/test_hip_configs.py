@@ -106,3 +106,21 @@ def test_cfg5_training_1k_samples_300_snps(hib, oracle):
         assert_same_classifier(dict(samp_num=g.samp_num, snpidx=g.snpidx, haplo=g.haplo, hla=g.hla, freq=g.freq,
                                     acc=g.outofbag_acc), c, i)
         assert len(g.snpidx) >= 5 and len(g.freq) >= 20
+
+
+def test_large_model_1500_haplotypes_per_classifier(hib, oracle):
+    """100 classifiers x 1,500 haplotypes = 112.6 M haplotype pairs per sample: with 20-byte pair records the
+    round-1 library refused this model (2 GB stream cap); the matrix engine now keeps an O(H) haplotype table
+    and 4-byte index pairs (0.9 GB for both passes' lists).  Finalizes, predicts, equals the oracle bit for bit."""
+    from hibag_amd import synth
+    model, founders, af = synth.make_model("hla-drb1", n_haplo=1500, wide_classifier=False)
+    assert model.pair_evals_per_sample() == 100 * 1500 * 1501 // 2
+    G, truth = synth.make_samples(founders, af, 192)
+    m = hib.hlaModelFromObj(model)
+    got = m.predict_raw(G, 1, want_dosage=True, want_prob=True)
+    m.close()
+    assert np.mean((got["h1"] == truth[:, 0]) & (got["h2"] == truth[:, 1])) > 0.9
+    sub = np.array([0, 1, 63, 64, 100, 191])
+    want = oracle.predict(oracle.flatten(model), G[sub], vote_method=1, avx2=True, n_threads=8)
+    for k in ("h1", "h2", "prob", "matching", "dosage", "postprob"):
+        assert np.array_equal(got[k][sub], want[k], equal_nan=True), k
