@@ -704,6 +704,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, Hi
 }
 
 // k_total_scan: the in-order total of a split classifier from its stored cell sums; thread = sample.
+// Eight loads in flight, then the eight additions in cell order (with one dependent load per addition the
+// kernel would be pure memory latency: a few hundred cells, one wavefront per 64 samples).
 __global__ void k_total_scan(HibagModelView M, HibagBatchView B)
 {
 	const int c = M.split_cls[blockIdx.y];
@@ -712,7 +714,15 @@ __global__ void k_total_scan(HibagModelView M, HibagBatchView B)
 	const double *__restrict__ rows = B.cellsum + (size_t)M.split_row[c] * B.n_pad;
 	const int n = M.cls_n[c];
 	double total = 0;
-	for (int i = 0; i < n; i++) total += rows[(size_t)i * B.n_pad + s];
+	int i = 0;
+	for (; i + 8 <= n; i += 8) {
+		double v[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) v[j] = rows[(size_t)(i + j) * B.n_pad + s];
+#pragma unroll
+		for (int j = 0; j < 8; j++) total += v[j];
+	}
+	for (; i < n; i++) total += rows[(size_t)i * B.n_pad + s];
 	B.tot[(size_t)c * B.n_pad + s] = total;
 	B.inv[(size_t)c * B.n_pad + s] = 1 / total;
 }
