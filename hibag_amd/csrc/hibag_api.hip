@@ -230,7 +230,7 @@ void push_classifier(hibag_hip_model *m, int n_snp_c, const int32_t *snpidx, int
 // specialised for (HIBAG_DISPATCH_NWP in hibag_kernels.hip).
 int round_nwp(int n)
 {
-	for (int v : {1, 2, 3, 4, 6, 8, 12})
+	for (int v : {1, 2, 3, 4, 6, 8, 10, 12})
 		if (n <= v) return v;
 	return HIBAG_MAX_NWP;
 }

@@ -394,6 +394,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t hap_rsrc(const HibagModelView 
 	case 4:  { CALL(4); } break;           \
 	case 6:  { CALL(6); } break;           \
 	case 8:  { CALL(8); } break;           \
+	case 10: { CALL(10); } break;          \
 	default: { CALL(12); } break;          \
 	}
 
@@ -828,11 +829,20 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 			// packed 4 bits each in two SGPRs, so closing a cell needs no memory access, and the
 			// LDS row of the NEXT cell to close is read while that cell is still being summed.
 			uint64_t jpack = ((uint64_t)rec[7] << 32) | rec[6];
-			int j = (int)(jpack & 15);
-			double a = acc[j][lane];
 			// inactive lanes (weight 0) must keep their sums: with 1/total replaced by 0 their term is
 			// (cell * 0) * 0 = +0 and a + 0 == a, which spares a select per closed cell
 			const double inv_e = active ? inv : 0.0;
+#ifndef HIBAG_NO_LDS_ADD
+			// S[p] += v as one LDS floating-point add (ds_add_f64: the same IEEE addition, no register for the old
+			// sum, nothing to wait for)
+			auto fin = [&](double cell) {
+				const double v = (cell * inv_e) * w;
+				__hip_atomic_fetch_add(&acc[(int)(jpack & 15)][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				jpack >>= 4;
+			};
+#else
+			int j = (int)(jpack & 15);
+			double a = acc[j][lane];
 			auto fin = [&](double cell) {
 				const double v = (cell * inv_e) * w;
 				acc[j][lane] = a + v;
@@ -840,6 +850,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 				j = (int)(jpack & 15);
 				a = acc[j][lane];
 			};
+#endif
 #define CALL(N, SP) { LaneOperand<N> T; load_operand_row<N, SP>(B, (int)(rec[0] >> 16), c, group, lane, T);            \
 			walk_blocks<N, SP, 8>(M, ((uint64_t)rec[3] << 32) | rec[2], (int)rec[4], lane, cur, hap_rsrc(M, rec[1]),       \
 				T, tab_s, stage_s[wave], fin); }
