@@ -5,19 +5,21 @@
 //
 // Mapping: LANE = SAMPLE.  A wavefront holds 64 samples and walks the model's
 // loop nest (classifier -> allele pair -> haplotype pair) in the reference's
-// order.  The nest depends only on the model, so the host flattens it into a
-// pair stream (hibag_device.h); control flow is wave-uniform, and each lane reproduces the
+// order.  The nest depends only on the model, so control flow is wave-uniform, and each lane reproduces the
 // reference's rounding sequence for its own sample: results are bit-identical
 // to the CPU kernels by construction, with no cross-lane reduction anywhere on
 // the numeric path.
 //
 // Two engines compute the distance d of a pair (bit-identical results):
+//   matrix engine 8 d = A . B over 2k+1 int8 positions (h1+h2 against the genotype's signs, h1&h2 against
+//                 [g = 1], one offset term): an int8 GEMM of 32 records x 64 samples per block on
+//                 v_mfma_i32_32x32x32_i8 (+ 16 v_permlane32_swap to give every lane its own sample's
+//                 column).  The records are generated: each lane gathers its pair's two haplotype
+//                 entries (byte images + frequency factors) from an O(H) table through a 4-byte index
+//                 pair.  Classifiers with at most 32 SNPs, i.e. all real ones; the default.
 //   VALU engine   d = sum_w popc((W[w] ^ T'[w]) & M'[w]): v_bitop3_b32 + v_bcnt_u32_b32 per 32-bit
-//                 word of the 3k-bit pair string (W uniform in SGPRs, T'/M' the lane's genotype
-//                 masks); used for classifiers with more than 32 SNPs.
-//   matrix engine d = W . a with a in {-1, 0, +1}^3k per sample: an int8 GEMM of 32 records x 64
-//                 samples per block on v_mfma_i32_32x32x32_i8 (+ 16 v_permlane32_swap to give every
-//                 lane its own sample's column); the default.
+//                 word of the stored 3k-bit pair string (W uniform in SGPRs, T'/M' the lane's genotype
+//                 masks); classifiers with more than 32 SNPs and the per-sample plugin path.
 // In both, what the contract fixes stays on the vector ALU, per lane and in the reference's order:
 //     cell += prod * TAB[d]          ds_read_b64 (table in LDS), v_mul_f64, v_add_f64
 //
