@@ -773,28 +773,19 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
 	stage_table(M, tab_s);
 
-	// XCD-aware decode: workgroups are dealt round-robin over the 8 XCDs, so
-	// give all tiles of one sample group the same (blockIdx % 8): the group's
-	// masks / weights / totals are then fetched into one XCD's L2 only.
+	// Work item = (XCD, four sample groups, one tile); the four wavefronts of a workgroup take the four groups.
+	// They read the same pair-list segments and the same haplotype-table entries at about the same time, so those
+	// come from the CU's L1 for three of them.  Workgroups are dealt round-robin over the 8 XCDs, so sample
+	// group g goes to XCD g % 8 with all its tiles: its operands / weights / totals are fetched into one XCD's L2 only.
 	const int n_group = B.n_pad / HIBAG_WAVE;
-	const int n_quad = (M.n_tile + BLOCK_WAVES - 1) / BLOCK_WAVES;   // work items per sample group
+	const int n_gq = ((n_group + 7) / 8 + BLOCK_WAVES - 1) / BLOCK_WAVES;      // group quads per XCD
 	// Grid-stride over the work items: the launcher may start fewer workgroups than items (a whole
 	// number of resident rounds), the first few then take a second item -- see hibag_launch_accum.
-	for (int b = blockIdx.x; b < n_group * n_quad; b += gridDim.x) {
-	int group, quad;
-	{
-		const int groups_full = n_group & ~7;          // groups covered by the swizzle
-		if (b < groups_full * n_quad) {
-			const int xcd = b & 7, j = b >> 3, jg = j / n_quad;
-			group = jg * 8 + xcd; quad = j - jg * n_quad;
-		} else {                                       // tail (< 8 groups): plain order
-			const int r = b - groups_full * n_quad;
-			group = groups_full + r / n_quad; quad = r % n_quad;
-		}
-	}
+	for (int b = blockIdx.x; b < 8 * n_gq * M.n_tile; b += gridDim.x) {
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int tile = quad * BLOCK_WAVES + wave;
-	if (tile >= M.n_tile) continue;
+	const int xcd = b & 7, jq = (b >> 3) / M.n_tile, tile = (b >> 3) - jq * M.n_tile;
+	const int group = (jq * BLOCK_WAVES + wave) * 8 + xcd;
+	if (group >= n_group) continue;
 	const int lane = threadIdx.x & 63;
 	const int s = group * HIBAG_WAVE + lane;
 	const int ncell = M.tile_n[tile];
@@ -1158,8 +1149,8 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 
 void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStream_t st)
 {
-	const unsigned n_quad = (unsigned)((M.n_tile + BLOCK_WAVES - 1) / BLOCK_WAVES);
-	const unsigned n = (unsigned)(B.n_pad / HIBAG_WAVE) * n_quad;
+	const unsigned n_group = (unsigned)(B.n_pad / HIBAG_WAVE);
+	const unsigned n = 8u * (((n_group + 7) / 8 + BLOCK_WAVES - 1) / BLOCK_WAVES) * (unsigned)M.n_tile;   // work items, see k_accum
 	if (n == 0 || M.n_classifier == 0) {
 		// no classifier: the ensemble sums are all zero (src/LibHLA.cpp:1491-1495)
 		(void)hipMemsetAsync(B.part, 0, (size_t)M.n_cell * B.n_pad * sizeof(double), st);
@@ -1167,7 +1158,7 @@ void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStr
 	}
 	// Wavefronts of this pass all take about the same time, so the launch proceeds in rounds of as many
 	// workgroups as fit on the chip, and a small remainder would occupy a whole extra round almost
-	// alone (10k samples: 3,140 items on 1,024 slots = 3.07 rounds).  In that case launch a whole
+	// alone (10k samples: 3,200 items on 1,024 slots = 3.1 rounds).  In that case launch a whole
 	// number of rounds and let the first workgroups take a second item each.
 	static int slots = 0;
 	if (slots == 0) {
