@@ -48,6 +48,9 @@
 #define BLOCK_WAVES 4                       // wavefronts per workgroup (each on its own work item)
 #endif
 #define BLOCK_THREADS (BLOCK_WAVES * HIBAG_WAVE)
+#ifndef ACCUM_WAVES
+#define ACCUM_WAVES 4                       // wavefronts per workgroup of pass 2 (sample groups that share a tile's lists in L1)
+#endif
 
 // The lane's genotype for one classifier: XOR mask x (= T') and AND mask m (= M').
 template <int NWP>
@@ -766,11 +769,11 @@ __device__ __forceinline__ void accumulate_classifier(const HibagModelView &M, c
 	}
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, HibagBatchView B)
+__global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
-	__shared__ double acc_s[BLOCK_WAVES][HIBAG_TILE][HIBAG_WAVE];
-	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
+	__shared__ double acc_s[ACCUM_WAVES][HIBAG_TILE][HIBAG_WAVE];
+	__shared__ double stage_s[ACCUM_WAVES][2 * STAGE_DOUBLES];
 	stage_table(M, tab_s);
 
 	// Work item = (XCD, four sample groups, one tile); the four wavefronts of a workgroup take the four groups.
@@ -778,13 +781,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_accum(HibagModelView M, Hi
 	// come from the CU's L1 for three of them.  Workgroups are dealt round-robin over the 8 XCDs, so sample
 	// group g goes to XCD g % 8 with all its tiles: its operands / weights / totals are fetched into one XCD's L2 only.
 	const int n_group = B.n_pad / HIBAG_WAVE;
-	const int n_gq = ((n_group + 7) / 8 + BLOCK_WAVES - 1) / BLOCK_WAVES;      // group quads per XCD
+	const int n_gq = ((n_group + 7) / 8 + ACCUM_WAVES - 1) / ACCUM_WAVES;      // group quads per XCD
 	// Grid-stride over the work items: the launcher may start fewer workgroups than items (a whole
 	// number of resident rounds), the first few then take a second item -- see hibag_launch_accum.
 	for (int b = blockIdx.x; b < 8 * n_gq * M.n_tile; b += gridDim.x) {
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int xcd = b & 7, jq = (b >> 3) / M.n_tile, tile = (b >> 3) - jq * M.n_tile;
-	const int group = (jq * BLOCK_WAVES + wave) * 8 + xcd;
+	const int group = (jq * ACCUM_WAVES + wave) * 8 + xcd;
 	if (group >= n_group) continue;
 	const int lane = threadIdx.x & 63;
 	const int s = group * HIBAG_WAVE + lane;
@@ -1150,7 +1153,7 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStream_t st)
 {
 	const unsigned n_group = (unsigned)(B.n_pad / HIBAG_WAVE);
-	const unsigned n = 8u * (((n_group + 7) / 8 + BLOCK_WAVES - 1) / BLOCK_WAVES) * (unsigned)M.n_tile;   // work items, see k_accum
+	const unsigned n = 8u * (((n_group + 7) / 8 + ACCUM_WAVES - 1) / ACCUM_WAVES) * (unsigned)M.n_tile;   // work items, see k_accum
 	if (n == 0 || M.n_classifier == 0) {
 		// no classifier: the ensemble sums are all zero (src/LibHLA.cpp:1491-1495)
 		(void)hipMemsetAsync(B.part, 0, (size_t)M.n_cell * B.n_pad * sizeof(double), st);
@@ -1165,7 +1168,7 @@ void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStr
 		int per_cu = 0, cus = 0, dev = 0;
 		(void)hipGetDevice(&dev);
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_accum, BLOCK_THREADS, 0) != hipSuccess) per_cu = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_accum, ACCUM_WAVES * HIBAG_WAVE, 0) != hipSuccess) per_cu = 0;
 		slots = per_cu > 0 && cus > 0 ? per_cu * cus : -1;
 		if (getenv("HIBAG_ROUNDS") && atoi(getenv("HIBAG_ROUNDS")) == 0) slots = -1;
 	}
@@ -1174,7 +1177,7 @@ void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStr
 		const unsigned rem = n % (unsigned)slots;
 		if (rem > 0 && rem <= (unsigned)slots / 4) grid = n - rem;
 	}
-	hipLaunchKernelGGL(k_accum, dim3(grid), dim3(BLOCK_THREADS), 0, st, M, B);
+	hipLaunchKernelGGL(k_accum, dim3(grid), dim3(ACCUM_WAVES * HIBAG_WAVE), 0, st, M, B);
 }
 
 void hibag_launch_vote(const HibagModelView &M, const HibagBatchView &B, int *d_best_cell, hipStream_t st)

@@ -262,7 +262,12 @@ int hibag_hip_reset_timing(hibag_hip_model *m);
  * An R package hands it to hlaPredict() as attr(cl, "proc_ptr") (R/HIBAG.R:707) or
  * to HIBAG_NewClassifiers as its last argument (src/HIBAG.cpp:601-602); see
  * INTEGRATION.md.  Failures inside these void entries throw `const char *`, which
- * the host's CORE_CATCH turns into an R error (src/HIBAG.cpp:41-60). */
+ * the host's CORE_CATCH turns into an R error (src/HIBAG.cpp:41-60).
+ * The table serves ONE model and ONE training state per process at a time, on the device
+ * selected with hibag_hip_set_device by the calling thread: predict_init replaces the model of
+ * the previous predict_init, build_init the previous build state -- the same restriction as the
+ * reference's single staging buffer (gpu_geno_buf, src/LibHLA.h:680), which is why the host must
+ * call with nthread = 1. */
 const void *hibag_hip_gpu_ext_proc(void);
 
 #ifdef __cplusplus
