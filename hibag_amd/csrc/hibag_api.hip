@@ -349,7 +349,7 @@ int append_pair_blocks(const int *st, int n_hla, int h1, int h2, int n_cells, ui
 
 // Tiles for pass 2: consecutive posterior cells, at most HIBAG_TILE each, cut so
 // that the chunk counts (summed over classifiers, plus a per-cell constant) are
-// balanced.  Consecutive cells keep one pair stream valid for both passes.
+// balanced.
 void build_tiles(int P, const std::vector<uint64_t> &cell_work, std::vector<int> &tile_p0, std::vector<int> &tile_n)
 {
 	uint64_t total = 0;

@@ -3,11 +3,15 @@
 //
 // Data layout in HBM (DESIGN.md "Data layout"):
 //
-//  MODEL (read-only, wave-uniform -> fetched with scalar loads).
+//  MODEL (read-only).
 //    The loop nest of _PostProb2 (src/LibHLA.cpp:1776-1821) depends only on the
-//    model, so the host flattens it once per classifier into a PAIR STREAM in
-//    exactly the reference's visiting order (allele pair h1<=h2, then haplotype
-//    i1, then i2).  One record per haplotype pair:
+//    model: all 64 lanes (samples) of a wavefront walk it together, in exactly the
+//    reference's visiting order (allele pair h1<=h2, then haplotype i1, then i2).
+//    For pass 2 the posterior cells are grouped in TILES of up to HIBAG_TILE consecutive
+//    cells with about equal work.
+//
+//    VALU-engine classifiers (more than 32 SNPs; every classifier of the per-sample plugin path)
+//    get the nest flattened into a PAIR STREAM, one record per haplotype pair, fetched with scalar loads:
 //        W[nwp]  the 3k-bit string  H1 | H2 << k | ~(H1^H2) << 2k   (k = #SNPs)
 //        prod    the frequency factor, rounded as the reference rounds it:
 //                f1*f1 for the leading diagonal term, (2*f1)*f2 otherwise
@@ -16,8 +20,7 @@
 //    padded with {W=0, prod=+0.0} records (adding +0.0*TAB[d] is exact).
 //    Cells without haplotype pairs own no chunk.  cls_cnt lists, per classifier,
 //    the chunk counts of its non-empty cells in posterior order (pass 1 walks
-//    it).  For pass 2 cells are grouped in TILES of up to HIBAG_TILE consecutive
-//    cells with about equal work; tile_meta[c][t] = { #non-empty cells, first
+//    it); tile_meta[c][t] = { #non-empty cells, first
 //    chunk of the tile, the row numbers j of the non-empty cells packed 4 bits each
 //    (2 dwords), then one entry (j << 24 | chunks) per cell of the tile: the
 //    non-empty ones in order, then the empty ones }.
@@ -116,7 +119,7 @@ struct HibagModelView {
 	const int *split_row;        // [C]
 	const int *split_cls;        // [n_split] the split classifiers
 	const uint64_t *stream_off;  // [C] dword offset of the classifier's stream
-	const uint32_t *stream;      // the pair streams
+	const uint32_t *stream;      // the pair records of the VALU-engine classifiers
 	const double *tab;           // [257] exp(d*log(1e-5))
 
 	// matrix-core engine (classifiers with at most 32 SNPs; hibag_kernels.hip "MFMA engine")
