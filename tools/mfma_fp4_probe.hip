@@ -1,0 +1,81 @@
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// mode 0: correctness / layout, mode 1: timing
+__global__ void k(const uint32_t *A, const uint32_t *B, float *D, int sa, int sb)
+{
+	const int l = threadIdx.x;
+	v8i a = {0,0,0,0,0,0,0,0}, b = {0,0,0,0,0,0,0,0};
+	for (int i = 0; i < 4; i++) { a[i] = (int)A[l * 4 + i]; b[i] = (int)B[l * 4 + i]; }
+	v16f c = {};
+	c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, sa, 0, sb);
+	for (int r = 0; r < 16; r++) D[l * 16 + r] = c[r];
+}
+
+__global__ __launch_bounds__(256) void kt(int iters, float *out)
+{
+	v8i a = {(int)threadIdx.x, 2, 3, 4, 0, 0, 0, 0}, b = {5, 6, (int)threadIdx.x, 8, 0, 0, 0, 0};
+	v16f c0 = {}, c1 = {};
+	for (int i = 0; i < iters; i++) {
+		c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c0, 4, 4, 0, 127, 0, 127);
+		c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, c1, 4, 4, 0, 127, 0, 127);
+		c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c0, 4, 4, 0, 127, 0, 127);
+		c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, c1, 4, 4, 0, 127, 0, 127);
+	}
+	float s = 0;
+	for (int r = 0; r < 16; r++) s += c0[r] + c1[r];
+	out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+int main()
+{
+	// A[row][k]: fp4 code per element; lane l holds row l%32, K elements 32*(l/32) .. +31 (assumed), 8 nibbles per dword
+	uint32_t hA[64 * 4], hB[64 * 4];
+	float hD[64 * 16];
+	// values: A[row][kk] = 1.0 (code 2) if kk <= row else 0  -> row sums = row+1 ; B[kk][col] = 1.0 for kk < 64 except col-dependent: B = 2.0 (code 4) if kk == col else 1.0
+	for (int l = 0; l < 64; l++) {
+		const int row = l % 32, kh = l / 32;
+		for (int d = 0; d < 4; d++) {
+			uint32_t wa = 0, wb = 0;
+			for (int n = 0; n < 8; n++) {
+				const int kk = 32 * kh + 8 * d + n;
+				const uint32_t ca = kk <= row ? 2u : 0u;
+				const uint32_t cb = kk == row ? 4u : 2u;      // here `row` plays the column for B's lane
+				wa |= ca << (4 * n); wb |= cb << (4 * n);
+			}
+			hA[l * 4 + d] = wa; hB[l * 4 + d] = wb;
+		}
+	}
+	uint32_t *dA, *dB; float *dD;
+	hipMalloc(&dA, sizeof hA); hipMalloc(&dB, sizeof hB); hipMalloc(&dD, sizeof hD);
+	hipMemcpy(dA, hA, sizeof hA, hipMemcpyHostToDevice); hipMemcpy(dB, hB, sizeof hB, hipMemcpyHostToDevice);
+	for (int trial = 0; trial < 2; trial++) {
+		const int sa = trial ? 54 : 127, sb = trial ? 54 : 127;
+		hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, dA, dB, dD, sa, sb);
+		hipMemcpy(hD, dD, sizeof hD, hipMemcpyDeviceToHost);
+		// expected D[row][col] = sum_kk A[row][kk]*B[kk][col] = (row+1) + (col <= row ? 1 : 0)
+		int bad = 0;
+		for (int l = 0; l < 64; l++) for (int r = 0; r < 16; r++) {
+			const int col = l % 32, row = 8 * (r / 4) + 4 * (l / 32) + r % 4;
+			const double want = (row + 1) + (col <= row ? 1 : 0);
+			uint32_t bits; memcpy(&bits, &hD[l * 16 + r], 4);
+			const double got = trial ? (double)bits : hD[l * 16 + r];
+			if (got != want) { if (bad < 5) printf("  mismatch lane %d reg %d: got %g (bits %08x) want %g\n", l, r, got, bits, want); bad++; }
+		}
+		printf("trial %d (scales %d,%d): %s (%d mismatches)%s\n", trial, sa, sb, bad ? "MISMATCH" : "OK", bad, trial ? "  [denormal outputs read as integers]" : "");
+	}
+	float *dOut; hipMalloc(&dOut, 256 * 8 * 256 * 4);
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	hipLaunchKernelGGL(kt, dim3(256 * 8), dim3(256), 0, 0, 10, dOut); hipDeviceSynchronize();
+	hipEventRecord(e0);
+	const int iters = 4000;
+	hipLaunchKernelGGL(kt, dim3(256 * 8), dim3(256), 0, 0, iters, dOut);
+	hipEventRecord(e1); hipEventSynchronize(e1);
+	float ms; hipEventElapsedTime(&ms, e0, e1);
+	printf("fp4 32x32x64: %.3f ms -> %.1f ns per MFMA per SIMD (8 waves/SIMD)\n", ms, ms * 1e6 / (8.0 * iters * 4));
+	return 0;
+}
