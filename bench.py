@@ -49,10 +49,11 @@ def issue_constants():
     """FP64 / MFMA issue costs (ns per wave-instruction per SIMD) from the committed micro-benchmark
     logs (profiles/ubench_constants.json, written by tools/parse_ubench.py from the raw outputs of
     tools/ubench_mfma and tools/ubench_valu); the built-in values are the round-1 measurements."""
-    c = {"fp64_op_ns": FP64_OP_NS, "mfma_i8_32x32x32_ns": MFMA_NS, "mfma_fp64_overlap": None, "source": "built-in (round 1)"}
+    c = {"fp64_op_ns": FP64_OP_NS, "mfma_i8_32x32x32_ns": MFMA_NS, "mfma_fp4_32x32x64_ns": 18.3, "mfma_fp64_overlap": None,
+         "source": "built-in (round 1)"}
     try:
         d = json.load(open(UBENCH_FILE))
-        c.update({k: d[k] for k in ("fp64_op_ns", "mfma_i8_32x32x32_ns", "mfma_fp64_overlap") if k in d})
+        c.update({k: d[k] for k in ("fp64_op_ns", "mfma_i8_32x32x32_ns", "mfma_fp4_32x32x64_ns", "mfma_fp64_overlap") if k in d})
         c["source"] = "profiles/ubench_constants.json (" + d.get("tag", "?") + ")"
     except (OSError, ValueError, KeyError):
         pass
@@ -250,7 +251,7 @@ def main():
                    "parallelism": (f"classifier-sharded x{world} (one all-reduce of {P + 3} x {n_pad} doubles per step)"
                                    if by_classifier else f"sample-sharded x{world} (no collective)"),
                    "kernel_target": target,
-                   "engine": os.environ.get("HIBAG_ENGINE", "mfma") + " (int8 MFMA distances + FP64 VALU accumulation in reference order)"},
+                   "engine": os.environ.get("HIBAG_ENGINE", "mfma") + " (FP4 / int8 MFMA distances + FP64 VALU accumulation in reference order)"},
         "pair_evals_per_s": value * pair_evals,
         "call_accuracy_vs_truth": call_acc,
         "rccl_ranks": rccl_ranks,
@@ -280,14 +281,15 @@ def main():
 def issue_floor(obj, avg_ms, n, K):
     """(floor, achieved) SIMD time in ns per wavefront-pair (64 samples x one haplotype pair) for a kernel that
     took avg_ms over n samples: two FP64 ops per pair plus the pair's share of the int8 MFMAs of the distance
-    dot product (2 per 32-record block and 32-wide K block)."""
-    from hibag_amd import engine_nkb
+    dot product: per 32-record block two FP4 instructions (K = 64) up to 28 SNPs, four int8 ones (K = 32 each) for 29..32."""
+    from hibag_amd import engine_kind
+    per_block = {"valu": 0.0, "fp4": 2 * K["mfma_fp4_32x32x64_ns"], "i8": 4 * K["mfma_i8_32x32x32_ns"]}
     mfma_ns, w = 0.0, 0
     for c in obj.classifiers:
         k, h = len(c.snpidx), len(c.freq)
-        mfma_ns += h * (h + 1) // 2 * (2 * engine_nkb(k) * K["mfma_i8_32x32x32_ns"] / 32.0)
+        mfma_ns += h * (h + 1) // 2 * per_block[engine_kind(k)] / 32.0
         w += h * (h + 1) // 2
-    floor = 2 * K["fp64_op_ns"] + (mfma_ns / max(w, 1) if os.environ.get("HIBAG_ENGINE", "mfma") == "mfma" else 0.0)
+    floor = 2 * K["fp64_op_ns"] + mfma_ns / max(w, 1)
     achieved = N_SIMD * avg_ms * 1e6 / (w * n / 64.0)
     return floor, achieved
 

@@ -143,6 +143,7 @@ struct hibag_hip_model {
 	bool finalized = false;
 	bool have_snpidx = true;
 	bool use_mfma = true;                  // matrix-core engine for classifiers with <= 32 SNPs (HIBAG_ENGINE=valu disables)
+	bool use_fp4 = true;                   // its FP4 form for <= 28 SNPs (HIBAG_ENGINE=i8 keeps every classifier on the int8 form)
 	std::vector<HostClassifier> cls;
 	std::vector<int> snp_weight_override;   // classifier-sharded runs
 	int64_t pair_evals = 0;
@@ -391,7 +392,8 @@ int finalize_model(hibag_hip_model *m)
 	// per classifier: records (haplotype pairs) of every cell, and 4-record chunks of every cell
 	std::vector<std::vector<uint32_t>> cell_chunks(C);
 	std::vector<std::vector<int>> starts(C);
-	std::vector<int> mfma_nkb(std::max(C, 1), 0), bt_row(std::max(C, 1), 0), cls_nblk(std::max(C, 1), 0);
+	std::vector<int> engine(std::max(C, 1), 0), bt_row(std::max(C, 1), 0), cls_nblk(std::max(C, 1), 0);
+	std::vector<int> &mfma_nkb = engine;                 // (non-zero = a matrix engine)
 	std::vector<uint32_t> hap, hap_off(std::max(C, 1), 0);
 	std::vector<int64_t> pairs(C);
 	int bt_rows = 0;
@@ -411,19 +413,27 @@ int finalize_model(hibag_hip_model *m)
 		st.assign(nh + 1, 0);
 		for (int i = 0; i < H; i++) st[k.hla[i] + 1]++;
 		for (int h = 0; h < nh; h++) st[h + 1] += st[h];
-		// matrix-core engine: at most 32 SNPs; table indices: first haplotype < 2H + 1 in 16 bits, second < H + 1 in 15
-		mfma_nkb[c] = (m->use_mfma && k.n_snp <= 32 && H < 32768) ? HIBAG_K_NKB(k.n_snp) : 0;
+		// matrix-core engines: at most 32 SNPs; table indices: first haplotype < 2H + 1 in 16 bits, second < H + 1 in 15
+		engine[c] = (m->use_mfma && H < 32768) ? HIBAG_ENGINE_OF(k.n_snp, m->use_fp4) : HIBAG_ENGINE_VALU;
 		bt_row[c] = bt_rows;
-		bt_rows += 2 * mfma_nkb[c];
+		bt_rows += HIBAG_ENGINE_ROWS(engine[c]);
 		cell_chunks[c].assign(P, 0);
 		if (mfma_nkb[c]) {
 			// no record stream: the kernels generate the records from the haplotype table
-			hap_off[c] = (uint32_t)(hap.size() / HIBAG_HAP_DWORDS);
+			hap_off[c] = (uint32_t)hap.size();
+			const bool fp4 = engine[c] == HIBAG_ENGINE_FP4;
 			auto entry = [&](double ff, uint32_t bits, double f) {
-				uint32_t w[HIBAG_HAP_DWORDS] = {0};
-				for (int sb = 0; sb < 32; sb++) w[sb >> 2] |= ((bits >> sb) & 1u) << (8 * (sb & 3));
-				memcpy(&w[8], &ff, sizeof(double)); memcpy(&w[10], &f, sizeof(double));
-				hap.insert(hap.end(), w, w + HIBAG_HAP_DWORDS);
+				uint32_t w[12] = {0};
+				int n = 0;
+				if (fp4) {                     // nibble s = 2 (the e2m1 code of 1.0) where bit s is set
+					for (int sb = 0; sb < 32; sb++) w[sb >> 3] |= ((bits >> sb) & 1u) << (4 * (sb & 7) + 1);
+					n = 4;
+				} else {                       // byte s = 1 where bit s is set
+					for (int sb = 0; sb < 32; sb++) w[sb >> 2] |= ((bits >> sb) & 1u) << (8 * (sb & 3));
+					n = 8;
+				}
+				memcpy(&w[n], &ff, sizeof(double)); memcpy(&w[n + 2], &f, sizeof(double));
+				hap.insert(hap.end(), w, w + n + 4);
 			};
 			for (int i = 0; i < H; i++) entry(2 * k.freq[i], (uint32_t)k.bits[2 * (size_t)i], k.freq[i]);
 			entry(0.0, 0u, 0.0);                                   // H: the padding entry (frequency +0.0)
@@ -451,7 +461,7 @@ int finalize_model(hibag_hip_model *m)
 	// the walker fetches one chunk ahead: keep a widest-record chunk of slack behind the last record
 	stream.insert(stream.end(), HIBAG_CHUNK_DWORDS(HIBAG_MAX_NWP), 0);
 	if (snp_index.empty()) snp_index.push_back(0);
-	if (hap.empty()) hap.insert(hap.end(), HIBAG_HAP_DWORDS, 0u);
+	if (hap.empty()) hap.insert(hap.end(), 12, 0u);
 
 	std::vector<int> tile_p0, tile_n;
 	build_tiles(P, cell_work, tile_p0, tile_n);
@@ -638,7 +648,7 @@ int finalize_model(hibag_hip_model *m)
 	V.cls_cnt = (const uint32_t *)(tbase + tb_cnt);
 	V.cls_cell = (const uint32_t *)(tbase + tb_cell);
 	V.cls_off = base + o_coff; V.cls_n = base + o_cn;
-	V.mfma_nkb = base + o_nkb; V.bt_row = base + o_btrow; V.cls_nblk = base + o_nblk;
+	V.engine = base + o_nkb; V.bt_row = base + o_btrow; V.cls_nblk = base + o_nblk;
 	V.hap_off = (const uint32_t *)(base + o_hapoff);
 	V.n_item_split = (int)item.size() / 4; V.n_item_whole = (int)item_whole.size() / 4; V.n_split = (int)split_cls.size();
 	V.item_split = base + o_item; V.item_whole = base + o_itemw; V.item = V.item_whole; V.n_item = V.n_item_whole;
@@ -648,7 +658,7 @@ int finalize_model(hibag_hip_model *m)
 	V.blk_off = (const uint64_t *)(tbase + tb_boff);
 	V.ctile = (const uint32_t *)(tbase + tb_ctile);
 	V.hap = (const uint32_t *)(tbase + tb_hap);
-	V.hap_entries = (uint32_t)(hap.size() / HIBAG_HAP_DWORDS);
+	V.hap_dwords = (uint32_t)hap.size();
 	V.plist = m->d_blk.as<uint32_t>();
 	V.plist_dwords = plist.size();
 	m->bt_rows = bt_rows;
@@ -935,6 +945,7 @@ hibag_hip_model *hibag_hip_model_new(int n_hla, int n_snp)
 	m->device = g_device;
 	const char *engine = getenv("HIBAG_ENGINE");         // "valu": bit logic + popcount on the vector ALU for every classifier
 	m->use_mfma = !(engine && strcmp(engine, "valu") == 0);
+	m->use_fp4 = !(engine && strcmp(engine, "i8") == 0);
 	m->n_hla = n_hla;
 	m->n_snp = n_snp;
 	build_table(m->tab);

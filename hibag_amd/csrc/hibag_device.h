@@ -27,14 +27,14 @@
 //
 //    The matrix-core engine (classifiers with at most 32 SNPs) does not read pair
 //    records at all: it GENERATES them from an O(H) haplotype table
-//        hap[hap_off[c] + i] = { E[32] (byte s = bit s of the haplotype, 0/1), ff (double), f (double) }   48 bytes
+//        entry i of classifier c = { image of the haplotype's bits (bytes or nibbles, by engine), ff (double), f (double) }   48 / 32 bytes
 //    where f is the haplotype's frequency and ff = 2 f the factor it contributes as the FIRST haplotype
 //    of a pair (the reference's `ff = 2 * f1`, then `ff * f2`).  Entries H+1 .. 2H repeat the haplotypes
 //    with ff = f: the leading diagonal pair (i, i) of a cell (h, h), whose factor is f * f, is listed as
 //    (H + 1 + i, i).  Entry H is all zero and serves the padding slots.  The records are 4-byte
 //    words  i1 | i2 << 16 | end << 31  (end = this slot closes a cell; i2 < 2^15), in BLOCKS of 32 slots
 //    (128 bytes); unused trailing slots of a segment's last block point at the zero entry.
-//    Each lane builds its record's int8 A-operand rows from the two E images (byte-wise sum and AND)
+//    Each lane builds its record's A-operand rows from the two images (element-wise sum and AND)
 //    and the frequency factor ff[i1] * f[i2] -- one multiplication, rounded like the reference's
 //    (src/LibHLA.cpp:1786-1813) -- itself.  Cells are
 //    padded to an even slot count.  Two lists: all cells of a classifier back to back
@@ -72,18 +72,35 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 // dwords of one 32-slot block of a pair list (matrix-core engine)
 #define HIBAG_PLIST_DWORDS 32
 #define HIBAG_PLIST_END 0x80000000u   // slot flag: closes a cell
-#define HIBAG_HAP_DWORDS 12      // haplotype table entry: E[32] bytes, ff, f
-// K layout of the distance dot product for a classifier with k SNPs (K positions = bytes of the int8 operands):
-//   [0, k)          h1_s + h2_s  (A: 0/1/2)   x  B: +8 (g=0), -8 (g=1,2), 0 (missing)
-//   [ao, ao + k)    h1_s & h2_s  (A: 0/1)     x  B: +16 (g=1), else 0
-//   31              A: 8                      x  B: 2*#(g=2) + #(g=1)   (<= 64)
-// so that the dot product is 8*d for the distance d of src/LibHLA.cpp:747-819 (g=0: h1+h2, g=2: 2-h1-h2,
-// g=1: [h1==h2] = 1-h1-h2+2*h1*h2).  k <= 15: one 32-wide K block, ao = 16 (the lower K half of the MFMA
-// operand holds the sums, the upper one the ANDs); k <= 32: two, ao = 32 -- with 32 SNPs position 31 is
-// taken, and the offset 8*(2*#(g=2) + #(g=1)) starts the accumulators instead (HibagBatchView::bias).
-#define HIBAG_K_NKB(k) ((k) <= 15 ? 1 : 2)
-#define HIBAG_K_AO(k) ((k) <= 15 ? 16 : 32)
-#define HIBAG_K_BP 31
+// Matrix-engine variants (HibagModelView::engine[c]; 0 = VALU engine) and their haplotype-table entries:
+//   FP4  (up to 28 SNPs)  v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands: one instruction per sample half covers all
+//                         K = 64 positions.  Entry = { N[16] (nibble s = 2, the code of 1.0, where bit s is set), ff, f }: 8 dwords
+//   I8   (29..31 SNPs), I8S (32 SNPs)  v_mfma_i32_32x32x32_i8, two K blocks.  Entry = { E[32] (byte s = bit s), ff, f }: 12 dwords
+#define HIBAG_ENGINE_VALU 0
+#define HIBAG_ENGINE_FP4 1
+#define HIBAG_ENGINE_I8 2
+#define HIBAG_ENGINE_I8S 3
+#define HIBAG_ENGINE_OF(k, fp4) ((k) > 32 ? HIBAG_ENGINE_VALU : ((fp4) && (k) <= 28 ? HIBAG_ENGINE_FP4 : ((k) == 32 ? HIBAG_ENGINE_I8S : HIBAG_ENGINE_I8)))
+#define HIBAG_ENGINE_ROWS(e) ((e) == HIBAG_ENGINE_FP4 ? 2 : ((e) == HIBAG_ENGINE_VALU ? 0 : 4))   // B-operand rows (16 B per lane each)
+#define HIBAG_ENGINE_HAP_DWORDS(e) ((e) == HIBAG_ENGINE_FP4 ? 8 : 12)
+// K layout of the distance dot product for a classifier with k SNPs.  With the genotype g of the sample at SNP s:
+//   g = 0: h1 + h2      g = 2: 2 - h1 - h2      g = 1: [h1 == h2] = 1 - h1 - h2 + 2 h1 h2        (src/LibHLA.cpp:747-819)
+//   8 d = sum_s (h1_s + h2_s) * 8 t_s  +  sum_s (h1_s & h2_s) * 16 [g_s == 1]  +  8 * offset,
+//   t_s = +1 / -1 / -1 / 0 for g = 0 / 1 / 2 / missing,   offset = 2 #[g == 2] + #[g == 1]
+// I8 / I8S (K positions = bytes of the int8 operands):
+//   [0, k)          A: h1_s + h2_s (0/1/2)   B: +8 / -8 / -8 / 0
+//   [32, 32 + k)    A: h1_s & h2_s (0/1)     B: 16 [g == 1]
+//   31              A: 8                     B: offset            (32 SNPs: position 31 is taken, the offset
+//                                                                   starts the accumulators instead: HibagBatchView::bias)
+// FP4 (K positions = nibbles; the lower K half [0, 32) of B is scaled by 2^-73, the upper one by 2^-72, A by 2^-73, so
+// that the f32 result is the DENORMAL number 8 d * 2^-149, whose bit pattern is the integer 8 d):
+//   [0, k)          A: h1_s + h2_s           B: +1 / -1 / -1 / 0
+//   [32, 32 + k)    A: h1_s & h2_s           B: [g == 1]          (counts twice through the scale)
+//   k .. k + 3      A: 1, 1, 1, 4            B: offset bit 0 * 1, bit 1 * 2, bit 2 * 4, bit 3 * 2
+//   32 + k, + 1     A: 1, 1                  B: offset bit 4 * 1, bit 5 * 2        (offset <= 2 k <= 56)
+#define HIBAG_FP4_SCALE_A 54
+#define HIBAG_FP4_SCALE_B_LO 54
+#define HIBAG_FP4_SCALE_B_HI 55
 
 struct HibagModelView {
 	int n_hla;
@@ -123,17 +140,17 @@ struct HibagModelView {
 	const double *tab;           // [257] exp(d*log(1e-5))
 
 	// matrix-core engine (classifiers with at most 32 SNPs; hibag_kernels.hip "MFMA engine")
-	const int *mfma_nkb;         // [C] 32-wide K blocks of the distance dot product (1: k <= 15, 2: k <= 32), 0 = use the VALU engine
+	const int *engine;           // [C] HIBAG_ENGINE_*
 	const int *bt_row;           // [C] first operand row of the classifier in HibagBatchView::bt
-	const uint32_t *hap;         // haplotype table, HIBAG_HAP_DWORDS per entry (see above)
-	const uint32_t *hap_off;     // [C] first entry of the classifier
-	uint32_t hap_entries;        // entries in the table
+	const uint32_t *hap;         // haplotype table (entry size by engine, see below)
+	const uint32_t *hap_off;     // [C] dword offset of the classifier's first entry
+	uint32_t hap_dwords;         // size of the table
 	const uint64_t *blk_off;     // [C] dword offset of the classifier's pass-1 pair list (all cells back to back)
 	const int *cls_nblk;         // [C] blocks in that list
 	const uint32_t *plist;       // pair lists: blocks of HIBAG_PLIST_DWORDS dwords
 	uint64_t plist_dwords;       // total size (a raw buffer is rebased per classifier / tile segment: no 4 GB limit)
 	const uint32_t *ctile;       // [C][n_tile][8]: everything pass 2 needs per (classifier, tile) in one s_load_dwordx8:
-	                             // {nkb (0 = VALU) | k << 2 | #non-empty cells << 8 | bt_row << 16, first haplotype-table entry,
+	                             // {engine | k << 2 | #non-empty cells << 8 | bt_row << 16, dword offset of the first haplotype-table entry,
 	                             //  pair list dword offset lo/hi, #blocks, 0, row list lo/hi}
 };
 
@@ -148,7 +165,7 @@ struct HibagBatchView {
 	double *part;       // [P+3][n_pad]
 	// matrix-core engine: per classifier and sample group the B operand tiles
 	// (int8, MFMA lane layout; K layout above) and, for classifiers with 32 SNPs, the distance offsets
-	uint4 *bt;          // [(bt_row[c] + n*nkb + kb)][n_pad/64][64]
+	uint4 *bt;          // [(bt_row[c] + n * (rows / 2) + kb)][n_pad/64][64]
 	int *bias;          // [(2c + n)][n_pad/64][64]  8 * (2*#(g=2) + #(g=1)), written for 32-SNP classifiers only
 };
 

@@ -138,20 +138,22 @@ __device__ __forceinline__ double cell_sum(uint32_t n, const uint32_t *__restric
 // results stay bit-identical to the CPU kernels.
 // Used for classifiers with at most 32 SNPs; wider ones use the VALU engine above.
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
-template <int NKB>
 struct LaneOperand {
-	v4i b[2][NKB];      // B operand of sample half n, K block kb (MFMA lane layout)
-	int bias[2];        // 32 SNPs only: the lane's distance offset (times 8) for each sample half
+	v4i b[2][2];        // B operand of sample half n, K block kb (MFMA lane layout); the FP4 engine uses b[n][0] only
+	int bias[2];        // I8S (32 SNPs) only: the lane's distance offset (times 8) for each sample half
 };
 
-// SPLAT: the classifier has 32 SNPs: no K position is left for the offset term, it starts the accumulators
-template <int NKB, bool SPLAT>
+// ENG = HIBAG_ENGINE_FP4 / _I8 / _I8S
+template <int ENG>
 __device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt_row, int c, int group,
-	int lane, LaneOperand<NKB> &T)
+	int lane, LaneOperand &T)
 {
+	constexpr int NKB = ENG == HIBAG_ENGINE_FP4 ? 1 : 2;
 	const size_t n_group = (size_t)(B.n_pad / HIBAG_WAVE);
 #pragma unroll
 	for (int n = 0; n < 2; n++) {
@@ -160,7 +162,7 @@ __device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt
 			const uint4 v = B.bt[((size_t)(bt_row + n * NKB + kb) * n_group + group) * HIBAG_WAVE + lane];
 			T.b[n][kb] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
 		}
-		T.bias[n] = SPLAT ? B.bias[((size_t)(2 * c + n) * n_group + group) * HIBAG_WAVE + lane] : 0;
+		T.bias[n] = ENG == HIBAG_ENGINE_I8S ? B.bias[((size_t)(2 * c + n) * n_group + group) * HIBAG_WAVE + lane] : 0;
 	}
 }
 
@@ -173,18 +175,60 @@ __device__ __forceinline__ v4i expand_bits16(uint32_t x)
 	return r;
 }
 
+// 8 bits -> 8 nibbles (bit i -> nibble i = 0/1)
+__device__ __forceinline__ uint32_t expand_bits8_nibbles(uint32_t x)
+{
+	x = (x | (x << 12)) & 0x000F000Fu;
+	x = (x | (x << 6)) & 0x03030303u;
+	x = (x | (x << 3)) & 0x11111111u;
+	return x;
+}
+
+// The lane's constant part of an FP4 A row (K layout in hibag_device.h): lanes 0..31 own the K positions 0..31
+// (nibbles k .. k+3 = 1, 1, 1, 4 -> codes 2, 2, 2, 6), lanes 32..63 the positions 32..63 (nibbles k, k+1 = 1, 1).
+__device__ __forceinline__ v4i fp4_offset_term(int k, int lane)
+{
+	const unsigned __int128 c = (unsigned __int128)(lane < 32 ? 0x6222u : 0x22u) << (4 * k);
+	return v4i{(int)(uint32_t)c, (int)(uint32_t)(c >> 32), (int)(uint32_t)(c >> 64), (int)(uint32_t)(c >> 96)};
+}
+
 // Issue the MFMAs of one block: acc_n[r] of lane l = 8 x distance of record
 // 8(r/4) + 4(l/32) + r%4 to sample (l%32) of sample half n.
-// e1, e2 = this lane's 16 bytes of the two haplotypes' E images of record (lane % 32):
-//   two K blocks (16..32 SNPs): bytes 16 (lane / 32) .. + 15; block 0 = e1 + e2, block 1 = e1 & e2
-//   one K block (<= 15 SNPs):   bytes 0 .. 15 for every lane; the lower K half (lanes 0..31) carries
-//                               e1 + e2, the upper one e1 & e2
-// and the value 8 at K position 31 (byte 15 of the upper K half of block 0) meets the sample's offset term.
-template <int NKB, bool SPLAT>
-__device__ __forceinline__ void block_mfma(const v4i &e1, const v4i &e2, int lane, const LaneOperand<NKB> &T,
+// e1, e2 = this lane's 16 bytes of the two haplotypes' images of record (lane % 32):
+//   I8 / I8S  bytes 16 (lane / 32) .. + 15 of the byte images; K block 0 = e1 + e2, K block 1 = e1 & e2; the value 8
+//             at K position 31 (byte 15 of the upper K half of block 0) meets the sample's offset term
+//   FP4       the whole nibble image (32 nibbles of code 0 / 2); lanes 0..31 carry e1 + e2 (codes 0 / 2 / 4 = 0, 1, 2),
+//             lanes 32..63 e1 & e2, each plus its constant nibbles `cterm`; the f32 result is the denormal 8 d * 2^-149,
+//             i.e. its bits are the integer 8 d
+template <int ENG>
+__device__ __forceinline__ void block_mfma(const v4i &e1, const v4i &e2, int lane, const v4i &cterm, const LaneOperand &T,
 	v16i &acc0, v16i &acc1)
 {
-	if (SPLAT) {
+	const bool upper = lane >= 32;
+	if (ENG == HIBAG_ENGINE_FP4) {
+		v4i a;
+		if (upper) {
+#pragma unroll
+			for (int d = 0; d < 4; d++) a[d] = (e1[d] & e2[d]) | cterm[d];
+		} else {
+#pragma unroll
+			for (int d = 0; d < 4; d++) a[d] = e1[d] + e2[d] + cterm[d];       // nibbles 0 / 2 / 4 and the constants: no carry
+		}
+		const v8i a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+		const v8i b0 = {T.b[0][0][0], T.b[0][0][1], T.b[0][0][2], T.b[0][0][3], 0, 0, 0, 0};
+		const v8i b1 = {T.b[1][0][0], T.b[1][0][1], T.b[1][0][2], T.b[1][0][3], 0, 0, 0, 0};
+		const int sb = upper ? HIBAG_FP4_SCALE_B_HI : HIBAG_FP4_SCALE_B_LO;
+		v16f z;
+#pragma unroll
+		for (int r = 0; r < 16; r++) z[r] = 0.0f;
+		const v16f d0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, z, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sb);
+		const v16f d1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, z, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sb);
+		acc0 = __builtin_bit_cast(v16i, d0);
+		acc1 = __builtin_bit_cast(v16i, d1);
+		return;
+	}
+	if (ENG == HIBAG_ENGINE_I8S) {
+		// 32 SNPs: no K position is left for the offset term, it starts the accumulators.
 		// The empty asm makes the offsets opaque per block: otherwise the two 16-register splats are
 		// hoisted out of the block loop and cost 32 VGPRs for its whole duration.
 		int b0 = T.bias[0], b1 = T.bias[1];
@@ -195,25 +239,14 @@ __device__ __forceinline__ void block_mfma(const v4i &e1, const v4i &e2, int lan
 #pragma unroll
 		for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }      // folds into the MFMA's inline-constant C operand
 	}
-	const bool upper = lane >= 32;
-	const int off3 = (upper && !SPLAT) ? (8 << 24) : 0;                 // K position 31
-	const v4i sum = e1 + e2;                                            // bytes 0/1/2: no carry between bytes
+	const int off3 = (upper && ENG != HIBAG_ENGINE_I8S) ? (8 << 24) : 0;   // K position 31
+	v4i a0 = e1 + e2;                                                   // bytes 0/1/2: no carry between bytes
 	const v4i both = e1 & e2;
-	if (NKB == 1) {
-		v4i a0;
-#pragma unroll
-		for (int d = 0; d < 4; d++) a0[d] = upper ? both[d] : sum[d];
-		a0[3] |= off3;
-		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[0][0], acc0, 0, 0, 0);
-		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[1][0], acc1, 0, 0, 0);
-	} else {
-		v4i a0 = sum;
-		a0[3] |= off3;
-		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[0][0], acc0, 0, 0, 0);
-		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[1][0], acc1, 0, 0, 0);
-		acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(both, T.b[0][NKB - 1], acc0, 0, 0, 0);
-		acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(both, T.b[1][NKB - 1], acc1, 0, 0, 0);
-	}
+	a0[3] |= off3;
+	acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[0][0], acc0, 0, 0, 0);
+	acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, T.b[1][0], acc1, 0, 0, 0);
+	acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(both, T.b[0][1], acc0, 0, 0, 0);
+	acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(both, T.b[1][1], acc1, 0, 0, 0);
 }
 
 // Swap the upper lanes of half 0 with the lower lanes of half 1: afterwards every
@@ -281,17 +314,18 @@ __device__ __forceinline__ void block_accumulate(const double *stage, uint32_t e
 #define STAGE_DOUBLES 32
 #define STAGE_BYTES (2 * STAGE_DOUBLES * 8)
 
-// The parts of a haplotype-table entry {E[32], ff, f} through a raw buffer; `vo` = 4 HIBAG_HAP_DWORDS i
-// (+ this lane's offset into E for the image loads).
+// The parts of a haplotype-table entry {image, ff, f} through a raw buffer; `vo` = the entry's byte offset
+// (+ this lane's offset into the image for the image loads); FO = byte offset of ff inside an entry.
 __device__ __forceinline__ v4i load_hap_image(__amdgpu_buffer_rsrc_t hp, uint32_t vo)
 {
 	const auto v = __builtin_amdgcn_raw_buffer_load_b128(hp, (int)vo, 0, 0);
 	return v4i{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
 }
+template <int FO>
 __device__ __forceinline__ double load_hap_factor(__amdgpu_buffer_rsrc_t hp, uint32_t vo, int second)
 {
-	return __builtin_bit_cast(double, second ? __builtin_amdgcn_raw_buffer_load_b64(hp, (int)vo, 40, 0)
-	                                         : __builtin_amdgcn_raw_buffer_load_b64(hp, (int)vo, 32, 0));
+	return __builtin_bit_cast(double, second ? __builtin_amdgcn_raw_buffer_load_b64(hp, (int)vo, FO + 8, 0)
+	                                         : __builtin_amdgcn_raw_buffer_load_b64(hp, (int)vo, FO, 0));
 }
 
 // What a walk has already fetched of the list behind its last block: the slot words of the next two
@@ -318,16 +352,20 @@ struct ListCursor {
 // of the slots' end flags; the number of slots worth evaluating follows from the last slot that closes
 // a cell or has a non-zero factor (a zero factor adds +0.0: skipping it is exact).  The list is padded
 // so that the look-ahead stays in bounds.
-template <int NKB, bool SPLAT, int G, class Fin>
+template <int ENG, int G, class Fin>
 __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at, int nblk, int lane, ListCursor &cur,
-	__amdgpu_buffer_rsrc_t hp, const LaneOperand<NKB> &T, const double *tab_s, double *stage, Fin &&fin)
+	__amdgpu_buffer_rsrc_t hp, int k, const LaneOperand &T, const double *tab_s, double *stage, Fin &&fin)
 {
 	if (nblk <= 0) return;
+	constexpr bool FP4 = ENG == HIBAG_ENGINE_FP4;
+	constexpr uint32_t ES = 4 * HIBAG_ENGINE_HAP_DWORDS(ENG);                // bytes per table entry
+	constexpr int FO = FP4 ? 16 : 32;                                         // ff behind the image
 	double cell = 0;
 	const int vo_i = (lane & 31) * 4;                // this lane's slot inside a block
-	const uint32_t img = NKB == 1 ? 0u : (uint32_t)(lane >> 5) * 16u;      // this lane's 16 bytes of an E image
+	// this lane's 16 bytes of an image: the K half's bytes (int8), the whole nibble image (FP4)
+	const uint32_t img = FP4 ? 0u : (uint32_t)(lane >> 5) * 16u;
+	const v4i cterm = FP4 ? fp4_offset_term(k, lane) : v4i{0, 0, 0, 0};
 	const uint32_t BB = 4 * HIBAG_PLIST_DWORDS;      // bytes per block
-	const uint32_t ES = 4 * HIBAG_HAP_DWORDS;        // bytes per table entry
 	// The list is addressed as a raw buffer rebased at this segment, so that the 32-bit offsets inside
 	// the descriptor never limit the model size.
 	const uint64_t left = (M.plist_dwords - at) * 4;
@@ -339,14 +377,14 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 		cur.idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + BB, 0);
 	}
 	uint32_t idx_c = cur.idx, idx_n = cur.idx_n;
-	// One address per haplotype: entry * 48 + this lane's offset into the E image.  The factors are read 32 /
-	// 40 bytes behind it, which is right for lanes 0..31 (image offset 0) -- the only ones whose factors are used.
+	// One address per haplotype: entry * size + this lane's offset into the image.  The factors are read FO / FO + 8
+	// bytes behind it, which is right for lanes 0..31 (image offset 0) -- the only ones whose factors are used.
 	uint32_t o1 = (idx_c & 0xFFFFu) * ES + img, o2 = ((idx_c >> 16) & 0x7FFFu) * ES + img;
 	v4i e1 = load_hap_image(hp, o1), e2 = load_hap_image(hp, o2);
-	double ff = load_hap_factor(hp, o1, 0), f2 = load_hap_factor(hp, o2, 1);
+	double ff = load_hap_factor<FO>(hp, o1, 0), f2 = load_hap_factor<FO>(hp, o2, 1);
 	for (int b = 0; b < nblk; b++) {
 		double *buf = stage + (b & 1) * STAGE_DOUBLES;
-		// this block's records: E images and the factor ff[i1] * f[i2]
+		// this block's records: images and the factor ff[i1] * f[i2]
 		const v4i a1 = e1, a2 = e2;
 		const double prod = ff * f2;
 		const uint32_t endmask = (uint32_t)__ballot((idx_c & HIBAG_PLIST_END) != 0);          // lanes 32..63 mirror 0..31
@@ -356,12 +394,12 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 		idx_c = idx_n;
 		o1 = (idx_c & 0xFFFFu) * ES + img; o2 = ((idx_c >> 16) & 0x7FFFu) * ES + img;
 		e1 = load_hap_image(hp, o1); e2 = load_hap_image(hp, o2);
-		ff = load_hap_factor(hp, o1, 0); f2 = load_hap_factor(hp, o2, 1);
+		ff = load_hap_factor<FO>(hp, o1, 0); f2 = load_hap_factor<FO>(hp, o2, 1);
 		idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + 2 * BB, 0);
 		if (n_valid > 0) {
 			if (lane < 32) buf[lane] = prod;
 			v16i D0, D1;
-			block_mfma<NKB, SPLAT>(a1, a2, lane, T, D0, D1);
+			block_mfma<ENG>(a1, a2, lane, cterm, T, D0, D1);
 			block_own_sample(D0, D1, n_valid);
 			block_accumulate<G>(buf, endmask, n_valid, D0, D1, cell, tab_s, fin);
 		}
@@ -373,20 +411,20 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 
 // raw-buffer descriptor of a classifier's haplotype table (gfx9 word 3: 32-bit data format, no swizzle;
 // reads past the end return 0)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t hap_rsrc(const HibagModelView &M, uint32_t first)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t hap_rsrc(const HibagModelView &M, uint32_t first_dword)
 {
 	// exact bound: the look-ahead of a walk runs into the next segment's index pairs, whose entries may lie
 	// past the end of the table (out-of-range raw-buffer reads return 0 instead of faulting)
-	const uint64_t left = (uint64_t)(M.hap_entries - first) * (4u * HIBAG_HAP_DWORDS);
-	return __builtin_amdgcn_make_buffer_rsrc((void *)(M.hap + (size_t)first * HIBAG_HAP_DWORDS), 0, left > 0x7FFFFFF0ull ? 0x7FFFFFF0 : (int)left, 0x00020000);
+	const uint64_t left = (uint64_t)(M.hap_dwords - first_dword) * 4u;
+	return __builtin_amdgcn_make_buffer_rsrc((void *)(M.hap + first_dword), 0, left > 0x7FFFFFF0ull ? 0x7FFFFFF0 : (int)left, 0x00020000);
 }
 
-// engine code: 1 = one K block (<= 15 SNPs), 2 = two K blocks, 3 = two K blocks and 32 SNPs (offset in the accumulators)
-#define HIBAG_DISPATCH_NKB(code, CALL)     \
-	switch (code) {                        \
-	case 1:  { CALL(1, false); } break;    \
-	case 2:  { CALL(2, false); } break;    \
-	default: { CALL(2, true); } break;     \
+// matrix-engine variant of a classifier -> template instance
+#define HIBAG_DISPATCH_ENGINE(code, CALL)              \
+	switch (code) {                                    \
+	case HIBAG_ENGINE_FP4: { CALL(HIBAG_ENGINE_FP4); } break;  \
+	case HIBAG_ENGINE_I8:  { CALL(HIBAG_ENGINE_I8); } break;   \
+	default:               { CALL(HIBAG_ENGINE_I8S); } break;  \
 	}
 
 // Record widths the kernels are specialised for; the host rounds a classifier's
@@ -514,11 +552,8 @@ __global__ __launch_bounds__(256) void k_bed_geno(const uint8_t *__restrict__ be
 // k_pack: TGenotype::IntToSNP (src/LibHLA.cpp:662-706) for every (sample, classifier), plus the
 // classifier weight from missingness (src/LibHLA.cpp:2418-2431).  grid (n_pad/64, C / 4), one
 // wavefront per classifier, lane = sample: every code load is one coalesced 64-byte row segment.
-// Matrix-engine classifiers (at most 32 SNPs) get the sample's column of the int8 B operand in the K
-// layout of hibag_device.h, written to the two lanes (K halves) that own it in the MFMA layout:
-//   [0, k)        +8 where g = 0, -8 (0xF8) where g = 1 or 2, 0 where missing
-//   [ao, ao + k)  16 where g = 1
-//   31            2 #[g = 2] + #[g = 1]     (times the A operand's 8: the distance offset; 32 SNPs: B.bias)
+// Matrix-engine classifiers (at most 32 SNPs) get the sample's column of the B operand (int8 bytes or FP4 nibbles)
+// in the K layout of hibag_device.h, written to the two lanes (K halves) that own it in the MFMA layout.
 // VALU-engine classifiers get the lane masks of the packed 3k-bit pair string
 //   bits [0,k)   first haplotype : x = [g==2], m = [g in {0,2}]
 //   bits [k,2k)  second haplotype: same
@@ -537,7 +572,7 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 	const int nwp = M.nwp[c];
 	const int *__restrict__ idx = M.snp_index + M.snp_off[c];
 	const int row0 = M.mask_row[c];
-	const int nkb = M.mfma_nkb[c];
+	const int nkb = M.engine[c];                      // matrix-engine variant, 0 = VALU engine
 	int num = 0, den = 0;
 	if (nkb > 0) {
 		// one pass over the classifier's k <= 32 SNPs (independent byte loads, several in flight)
@@ -554,29 +589,52 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 			E |= (uint32_t)(g == 1) << j;
 		}
 		const uint32_t offset = 2u * (uint32_t)__popc(X) + (uint32_t)__popc(E);     // <= 64
-		const int ao = HIBAG_K_AO(k);
-		const uint64_t pos64 = Z, neg64 = X | E, e64 = (uint64_t)E << ao;
 		const int n = lane >> 5;
-#pragma unroll
-		for (int m = 0; m < 2; m++) {
-			if (m >= nkb) break;
-			const uint32_t pw = (uint32_t)(pos64 >> (32 * m)), nw = (uint32_t)(neg64 >> (32 * m)), ew = (uint32_t)(e64 >> (32 * m));
+		if (nkb == HIBAG_ENGINE_FP4) {
+			// e2m1 codes: +1 -> 0x2, -1 -> 0xA, 2 -> 0x4, 4 -> 0x6.  K half 0 (positions 0..31): the signs of the SNPs,
+			// then offset bits 0..3 at k..k+3; K half 1 (positions 32..63): [g == 1] of the SNPs, then offset bits 4, 5.
+			const uint32_t neg = X | E;
 #pragma unroll
 			for (int h = 0; h < 2; h++) {
-				const v4i pos = expand_bits16((pw >> (16 * h)) & 0xFFFFu), neg = expand_bits16((nw >> (16 * h)) & 0xFFFFu),
-					one = expand_bits16((ew >> (16 * h)) & 0xFFFFu);
 				uint32_t a[4];
 #pragma unroll
-				for (int q = 0; q < 4; q++) a[q] = (uint32_t)pos[q] * 0x08u | (uint32_t)neg[q] * 0xF8u | (uint32_t)one[q] * 0x10u;
-				if (m == 0 && h == 1 && k < 32) a[3] |= offset << 24;       // K position 31 meets the A operand's 8
-				B.bt[((size_t)(M.bt_row[c] + n * nkb + m) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (lane & 31)] =
+				for (int q = 0; q < 4; q++) {
+					const uint32_t z8 = (Z >> (8 * q)) & 0xFFu, n8 = (neg >> (8 * q)) & 0xFFu, e8 = (E >> (8 * q)) & 0xFFu;
+					a[q] = h == 0 ? (expand_bits8_nibbles(z8 | n8) << 1) | (expand_bits8_nibbles(n8) << 3)
+					              : expand_bits8_nibbles(e8) << 1;
+				}
+				// the offset's binary digits: codes 1 * b0, 2 * b1, 4 * b2, 2 * b3 (meets A = 4) | 1 * b4, 2 * b5
+				const uint32_t digits = h == 0 ? ((offset & 1u) * 0x2u) | (((offset >> 1) & 1u) * 0x40u) | (((offset >> 2) & 1u) * 0x600u) |
+				                                 (((offset >> 3) & 1u) * 0x4000u)
+				                               : (((offset >> 4) & 1u) * 0x2u) | (((offset >> 5) & 1u) * 0x40u);
+				const unsigned __int128 d128 = (unsigned __int128)digits << (4 * k);
+#pragma unroll
+				for (int q = 0; q < 4; q++) a[q] |= (uint32_t)(d128 >> (32 * q));
+				B.bt[((size_t)(M.bt_row[c] + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (lane & 31)] =
 					uint4{a[0], a[1], a[2], a[3]};
 			}
-		}
-		if (k == 32) {                                                      // no K position left: the offset starts the accumulators
-			const size_t at = ((size_t)(2 * c + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + (lane & 31);
-			B.bias[at] = 8 * (int)offset;
-			B.bias[at + 32] = 8 * (int)offset;
+		} else {
+			const uint64_t pos64 = Z, neg64 = X | E, e64 = (uint64_t)E << 32;
+#pragma unroll
+			for (int m = 0; m < 2; m++) {
+				const uint32_t pw = (uint32_t)(pos64 >> (32 * m)), nw = (uint32_t)(neg64 >> (32 * m)), ew = (uint32_t)(e64 >> (32 * m));
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					const v4i pos = expand_bits16((pw >> (16 * h)) & 0xFFFFu), neg = expand_bits16((nw >> (16 * h)) & 0xFFFFu),
+						one = expand_bits16((ew >> (16 * h)) & 0xFFFFu);
+					uint32_t a[4];
+#pragma unroll
+					for (int q = 0; q < 4; q++) a[q] = (uint32_t)pos[q] * 0x08u | (uint32_t)neg[q] * 0xF8u | (uint32_t)one[q] * 0x10u;
+					if (m == 0 && h == 1 && k < 32) a[3] |= offset << 24;       // K position 31 meets the A operand's 8
+					B.bt[((size_t)(M.bt_row[c] + n * 2 + m) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (lane & 31)] =
+						uint4{a[0], a[1], a[2], a[3]};
+				}
+			}
+			if (k == 32) {                                                      // no K position left: the offset starts the accumulators
+				const size_t at = ((size_t)(2 * c + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + (lane & 31);
+				B.bias[at] = 8 * (int)offset;
+				B.bias[at + 32] = 8 * (int)offset;
+			}
 		}
 	} else {
 		// VALU engine (more than 32 SNPs, or the plugin path): one pass over the k <= 128 SNPs builds the
@@ -692,15 +750,15 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, Hi
 	const bool active = B.cw[at] > 0;                 // src/LibHLA.cpp:2451
 	if (__ballot(active) == 0) return;                // nobody needs this classifier
 	double total = 0;
-	const int nkb = M.mfma_nkb[c];
+	const int nkb = M.engine[c];                      // matrix-engine variant, 0 = VALU engine
 	const int srow = M.n_split > 0 ? M.split_row[c] : -1;
 	if (nkb > 0) {
-#define CALL(N, SP) { LaneOperand<N> T; load_operand_row<N, SP>(B, M.bt_row[c], c, group, threadIdx.x & 63, T);             \
+#define CALL(E) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, threadIdx.x & 63, T);                           \
 		ListCursor cur;                                                                                                \
-		walk_blocks<N, SP, 4>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]),                 \
+		walk_blocks<E, 4>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c],    \
 			T, tab_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)],                                       \
 			[&](double cell) { total += cell; asm("" : "+v"(total)); /* keeps the cell end a scalar branch */ }); }
-		HIBAG_DISPATCH_NKB(nkb + (M.n_snp_c[c] == 32), CALL)
+		HIBAG_DISPATCH_ENGINE(nkb, CALL)
 #undef CALL
 	} else {
 		double *rows = srow >= 0 ? B.cellsum + (size_t)srow * B.n_pad : nullptr;
@@ -847,10 +905,10 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 				a = acc[j][lane];
 			};
 #endif
-#define CALL(N, SP) { LaneOperand<N> T; load_operand_row<N, SP>(B, (int)(rec[0] >> 16), c, group, lane, T);            \
-			walk_blocks<N, SP, 8>(M, ((uint64_t)rec[3] << 32) | rec[2], (int)rec[4], lane, cur, hap_rsrc(M, rec[1]),       \
-				T, tab_s, stage_s[wave], fin); }
-			HIBAG_DISPATCH_NKB(nkb + (((rec[0] >> 2) & 63u) == 32u), CALL)
+#define CALL(E) { LaneOperand T; load_operand_row<E>(B, (int)(rec[0] >> 16), c, group, lane, T);                          \
+			walk_blocks<E, 8>(M, ((uint64_t)rec[3] << 32) | rec[2], (int)rec[4], lane, cur, hap_rsrc(M, rec[1]),        \
+				(int)((rec[0] >> 2) & 63u), T, tab_s, stage_s[wave], fin); }
+			HIBAG_DISPATCH_ENGINE(nkb, CALL)
 #undef CALL
 			if (poison) {                                // empty cells: (0 * inv) * w is NaN where inv is not finite
 				const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + tile) * HIBAG_TILE_META;
@@ -910,7 +968,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_vote_best(HibagModelView M
 	if (__ballot(active) == 0) { best_cell[at] = -1; return; }
 	const double inv = B.inv[at];
 	int bp;
-	const int nkb = M.mfma_nkb[c];
+	const int nkb = M.engine[c];                      // matrix-engine variant, 0 = VALU engine
 	if (nkb > 0) {
 		// matrix-core engine: the cells close in the order of the classifier's non-empty cell list,
 		// so the winner is remembered by its position in that list
@@ -921,11 +979,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_vote_best(HibagModelView M
 			if (best < prob) { best = prob; best_i = i; }
 			i++;
 		};
-#define CALL(N, SP) { LaneOperand<N> T; load_operand_row<N, SP>(B, M.bt_row[c], c, group, threadIdx.x & 63, T);             \
+#define CALL(E) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, threadIdx.x & 63, T);                           \
 		ListCursor cur;                                                                                                \
-		walk_blocks<N, SP, 4>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]),                 \
+		walk_blocks<E, 4>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c],    \
 			T, tab_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)], fin); }
-		HIBAG_DISPATCH_NKB(nkb + (M.n_snp_c[c] == 32), CALL)
+		HIBAG_DISPATCH_ENGINE(nkb, CALL)
 #undef CALL
 		bp = best_i < 0 ? -1 : (int)M.cls_cell[M.cls_off[c] + best_i];
 	} else {

@@ -14,6 +14,8 @@ Index conventions are the C side's, not R's: ``Classifier.snpidx`` and
 
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass, field
 from typing import Any, List, Optional, Sequence
 
@@ -75,16 +77,21 @@ class HlaAttrBagObj:
         return int(sum(len(c.freq) * (len(c.freq) + 1) // 2 for c in self.classifiers))
 
 
-def engine_nkb(n_snp_c: int) -> int:
-    """32-wide K blocks of the int8 distance dot product the library's matrix engine uses for a
-    classifier with ``n_snp_c`` SNPs (``HIBAG_K_NKB`` in csrc/hibag_device.h: 2k + 1 positions --
-    h1+h2 against the genotype signs, h1&h2 against [g == 1], one offset term: one block up to 15 SNPs,
-    two up to 32); 0 = VALU engine
-    (more than 32 SNPs)."""
+def engine_kind(n_snp_c: int) -> str:
+    """The library's distance engine for a classifier with ``n_snp_c`` SNPs (``HIBAG_ENGINE_OF`` in
+    csrc/hibag_device.h): ``"fp4"`` (up to 28 SNPs: one v_mfma_scale_f32_32x32x64_f8f6f4 per sample half and
+    32-record block), ``"i8"`` (29..32 SNPs: two v_mfma_i32_32x32x32_i8), ``"valu"`` (more than 32 SNPs)."""
     k = int(n_snp_c)
     if k > 32:
-        return 0
-    return 1 if k <= 15 else 2
+        return "valu"
+    if os.environ.get("HIBAG_ENGINE") == "valu":
+        return "valu"
+    return "fp4" if k <= 28 and os.environ.get("HIBAG_ENGINE") != "i8" else "i8"
+
+
+def engine_nkb(n_snp_c: int) -> int:
+    """int8-equivalent K blocks (kept for callers of round 1's interface): 0 = VALU engine."""
+    return {"valu": 0, "fp4": 1, "i8": 2}[engine_kind(n_snp_c)]
 
 
 @dataclass

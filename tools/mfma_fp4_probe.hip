@@ -6,6 +6,17 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 // mode 0: correctness / layout, mode 1: timing
+__global__ void k2(const uint32_t *A, const uint32_t *B, float *D)
+{
+	const int l = threadIdx.x;
+	v8i a = {0,0,0,0,0,0,0,0}, b = {0,0,0,0,0,0,0,0};
+	for (int i = 0; i < 4; i++) { a[i] = (int)A[l * 4 + i]; b[i] = (int)B[l * 4 + i]; }
+	v16f c = {};
+	const int sb = l < 32 ? 54 : 55;      // per-lane scale: the upper K half of B counts twice
+	c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 54, 0, sb);
+	for (int r = 0; r < 16; r++) D[l * 16 + r] = c[r];
+}
+
 __global__ void k(const uint32_t *A, const uint32_t *B, float *D, int sa, int sb)
 {
 	const int l = threadIdx.x;
@@ -67,6 +78,34 @@ int main()
 			if (got != want) { if (bad < 5) printf("  mismatch lane %d reg %d: got %g (bits %08x) want %g\n", l, r, got, bits, want); bad++; }
 		}
 		printf("trial %d (scales %d,%d): %s (%d mismatches)%s\n", trial, sa, sb, bad ? "MISMATCH" : "OK", bad, trial ? "  [denormal outputs read as integers]" : "");
+	}
+	{
+		// trial 2: A[row][kk] in {0,1,2,4} codes {0,2,4,6}; B[kk][col] in {+1,-1,2,0} codes {2,0xA,4,0}; upper K half scaled x2
+		static const uint32_t acode[4] = {0, 2, 4, 6}; static const double aval[4] = {0, 1, 2, 4};
+		static const uint32_t bcode[4] = {2, 0xA, 4, 0}; static const double bval[4] = {1, -1, 2, 0};
+		auto ai = [](int row, int kk) { return (row * 7 + kk * 3 + (kk >> 2)) & 3; };
+		auto bi = [](int kk, int col) { return (col * 5 + kk + (kk >> 3)) & 3; };
+		for (int l = 0; l < 64; l++) for (int d = 0; d < 4; d++) {
+			uint32_t wa = 0, wb = 0;
+			for (int n = 0; n < 8; n++) {
+				const int kk = 32 * (l / 32) + 8 * d + n;
+				wa |= acode[ai(l % 32, kk)] << (4 * n); wb |= bcode[bi(kk, l % 32)] << (4 * n);
+			}
+			hA[l * 4 + d] = wa; hB[l * 4 + d] = wb;
+		}
+		hipMemcpy(dA, hA, sizeof hA, hipMemcpyHostToDevice); hipMemcpy(dB, hB, sizeof hB, hipMemcpyHostToDevice);
+		hipLaunchKernelGGL(k2, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+		hipMemcpy(hD, dD, sizeof hD, hipMemcpyDeviceToHost);
+		int bad = 0, neg = 0;
+		for (int l = 0; l < 64; l++) for (int r = 0; r < 16; r++) {
+			const int col = l % 32, row = 8 * (r / 4) + 4 * (l / 32) + r % 4;
+			double want = 0;
+			for (int kk = 0; kk < 64; kk++) want += aval[ai(row, kk)] * bval[bi(kk, col)] * (kk < 32 ? 1 : 2);
+			uint32_t bits; memcpy(&bits, &hD[l * 16 + r], 4);
+			if (want < 0) { neg++; if ((bits & 0x7FFFFFFFu) != (uint32_t)(-8 * want) || !(bits >> 31)) bad++; continue; }
+			if (bits != (uint32_t)(8 * want)) { if (bad < 5) printf("  mismatch lane %d reg %d: bits %08x want %g\n", l, r, bits, 8 * want); bad++; }
+		}
+		printf("trial 2 (per-lane B scale 54/55, signed operands): %s (%d mismatches, %d negative sums)\n", bad ? "MISMATCH" : "OK", bad, neg);
 	}
 	float *dOut; hipMalloc(&dOut, 256 * 8 * 256 * 4);
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
