@@ -97,7 +97,7 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 //   [0, k)          A: h1_s + h2_s           B: +1 / -1 / -1 / 0
 //   [32, 32 + k)    A: h1_s & h2_s           B: [g == 1]          (counts twice through the scale)
 //   k .. k + 3      A: 1, 1, 1, 4            B: offset bit 0 * 1, bit 1 * 2, bit 2 * 4, bit 3 * 2
-//   32 + k, + 1     A: 1, 1                  B: offset bit 4 * 1, bit 5 * 2        (offset <= 2 k <= 56)
+//   32 + k, + 1     A: 4, 4                  B: offset bit 4 * 2, bit 5 * 4        (count twice; offset <= 2 k <= 56)
 #define HIBAG_FP4_SCALE_A 54
 #define HIBAG_FP4_SCALE_B_LO 54
 #define HIBAG_FP4_SCALE_B_HI 55

@@ -185,10 +185,10 @@ __device__ __forceinline__ uint32_t expand_bits8_nibbles(uint32_t x)
 }
 
 // The lane's constant part of an FP4 A row (K layout in hibag_device.h): lanes 0..31 own the K positions 0..31
-// (nibbles k .. k+3 = 1, 1, 1, 4 -> codes 2, 2, 2, 6), lanes 32..63 the positions 32..63 (nibbles k, k+1 = 1, 1).
+// (nibbles k .. k+3 = 1, 1, 1, 4 -> codes 2, 2, 2, 6), lanes 32..63 the positions 32..63 (nibbles k, k+1 = 4, 4 -> 6, 6).
 __device__ __forceinline__ v4i fp4_offset_term(int k, int lane)
 {
-	const unsigned __int128 c = (unsigned __int128)(lane < 32 ? 0x6222u : 0x22u) << (4 * k);
+	const unsigned __int128 c = (unsigned __int128)(lane < 32 ? 0x6222u : 0x66u) << (4 * k);
 	return v4i{(int)(uint32_t)c, (int)(uint32_t)(c >> 32), (int)(uint32_t)(c >> 64), (int)(uint32_t)(c >> 96)};
 }
 
@@ -603,10 +603,10 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 					a[q] = h == 0 ? (expand_bits8_nibbles(z8 | n8) << 1) | (expand_bits8_nibbles(n8) << 3)
 					              : expand_bits8_nibbles(e8) << 1;
 				}
-				// the offset's binary digits: codes 1 * b0, 2 * b1, 4 * b2, 2 * b3 (meets A = 4) | 1 * b4, 2 * b5
+				// the offset's binary digits: codes 1 * b0, 2 * b1, 4 * b2, 2 * b3 (meets A = 4) | 2 * b4, 4 * b5 (meet A = 4, count twice)
 				const uint32_t digits = h == 0 ? ((offset & 1u) * 0x2u) | (((offset >> 1) & 1u) * 0x40u) | (((offset >> 2) & 1u) * 0x600u) |
 				                                 (((offset >> 3) & 1u) * 0x4000u)
-				                               : (((offset >> 4) & 1u) * 0x2u) | (((offset >> 5) & 1u) * 0x40u);
+				                               : (((offset >> 4) & 1u) * 0x4u) | (((offset >> 5) & 1u) * 0x60u);
 				const unsigned __int128 d128 = (unsigned __int128)digits << (4 * k);
 #pragma unroll
 				for (int q = 0; q < 4; q++) a[q] |= (uint32_t)(d128 >> (32 * q));
