@@ -11,11 +11,14 @@
 // the numeric path.
 //
 // Two engines compute the distance d of a pair (bit-identical results):
-//   matrix engine 8 d = A . B over 2k+1 int8 positions (h1+h2 against the genotype's signs, h1&h2 against
-//                 [g = 1], one offset term): an int8 GEMM of 32 records x 64 samples per block on
-//                 v_mfma_i32_32x32x32_i8 (+ 16 v_permlane32_swap to give every lane its own sample's
-//                 column).  The records are generated: each lane gathers its pair's two haplotype
-//                 entries (byte images + frequency factors) from an O(H) table through a 4-byte index
+//   matrix engine 8 d = A . B over 2k+1 positions (h1+h2 against the genotype's signs, h1&h2 against
+//                 [g = 1], an offset term): a small GEMM of 32 records x 64 samples per block --
+//                 up to 28 SNPs on the FP4 matrix path (v_mfma_scale_f32_32x32x64_f8f6f4, e2m1 operands: all 64 K
+//                 positions in one instruction per sample half; block scales of 2^-73 make the f32 result the
+//                 denormal 8 d * 2^-149, whose bit pattern IS the integer 8 d), 29..32 SNPs on
+//                 v_mfma_i32_32x32x32_i8 (two K blocks) -- plus 16 v_permlane32_swap to give every lane its own
+//                 sample's column.  The records are generated: each lane gathers its pair's two haplotype
+//                 entries (nibble / byte images + frequency factors) from an O(H) table through a 4-byte index
 //                 pair.  Classifiers with at most 32 SNPs, i.e. all real ones; the default.
 //   VALU engine   d = sum_w popc((W[w] ^ T'[w]) & M'[w]): v_bitop3_b32 + v_bcnt_u32_b32 per 32-bit
 //                 word of the stored 3k-bit pair string (W uniform in SGPRs, T'/M' the lane's genotype
