@@ -156,7 +156,9 @@ struct hibag_hip_model {
 	size_t stream_bytes = 0;
 
 	// per-batch workspace (grow-only)
-	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias, ws_cellsum;
+	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias, ws_cellsum, ws_sync;
+	uint32_t epoch = 0;                    // batch counter for the hand-over flags (HibagBatchView::epoch)
+	int *h_err = nullptr;                  // host-mapped error word of the hand-overs
 	// plugin staging
 	DevBuf ws_tgeno, ws_weight;
 	// PLINK BED payload + SNP map of hibag_hip_predict_bed
@@ -169,7 +171,8 @@ struct hibag_hip_model {
 	{
 		(void)hipSetDevice(device);
 		timer.destroy();
-		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_cellsum, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
+		if (h_err) (void)hipHostFree(h_err);
+		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_cellsum, &ws_sync, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
 		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_tgeno, &ws_weight, &ws_bed, &ws_bedidx})
 			b->release();
 	}
@@ -599,6 +602,27 @@ int finalize_model(hibag_hip_model *m)
 			r[5] = 0; r[6] = me[2]; r[7] = me[3];
 		}
 
+	// cost prefix sums of pass 2 (where the launcher cuts an item into chunks), in quarter-blocks: a matrix-engine visit costs its blocks
+	// plus a start-up; a VALU-engine visit 4 records x nwp words per chunk at ~48 ns per word-record against
+	// ~110 ns per quarter-block
+	std::vector<uint32_t> acc_cum((size_t)n_tile * (C + 1), 0);
+	for (int t = 0; t < n_tile; t++) {
+		uint64_t sum = 0;
+		for (int c = 0; c < C; c++) {
+			uint64_t cost = 3;
+			if (mfma_nkb[c]) cost += 4ull * seg_nblk[(size_t)c * n_tile + t];
+			else {
+				uint64_t chunks = 0;
+				for (int j = 0; j < tile_n[t]; j++) chunks += cell_chunks[c][tile_p0[t] + j];
+				cost += (chunks * (uint64_t)nwp[c] * 17 + 9) / 10;
+			}
+			acc_cum[(size_t)t * (C + 1) + c] = (uint32_t)sum;
+			sum += cost;
+			if (sum > 0xFFFFFFF0ull) return fail(HIBAG_HIP_EINVAL, "tile %d has too many haplotype pairs", t);
+		}
+		acc_cum[(size_t)t * (C + 1) + C] = (uint32_t)sum;
+	}
+
 	// one int arena
 	std::vector<int> arena;
 	auto put = [&](const std::vector<int> &v) {
@@ -620,7 +644,8 @@ int finalize_model(hibag_hip_model *m)
 		tb_boff = (tb_cell + cls_cell.size() * sizeof(uint32_t) + 7) & ~(size_t)7,
 		tb_ctile = (tb_boff + blk_off.size() * sizeof(uint64_t) + 31) & ~(size_t)31,
 		tb_hap = (tb_ctile + ctile.size() * sizeof(uint32_t) + 15) & ~(size_t)15,
-		tb_end = tb_hap + hap.size() * sizeof(uint32_t);
+		tb_acum = tb_hap + hap.size() * sizeof(uint32_t),
+		tb_end = tb_acum + acc_cum.size() * sizeof(uint32_t);
 	if (int rc = m->d_tile.reserve(tb_end)) return rc;
 	if (int rc = m->d_tab.reserve(sizeof(m->tab))) return rc;
 	HIP_TRY(hipMemcpy(m->d_int.p, arena.data(), arena.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -633,6 +658,8 @@ int finalize_model(hibag_hip_model *m)
 	HIP_TRY(hipMemcpy(tbase + tb_boff, blk_off.data(), blk_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_ctile, ctile.data(), ctile.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_hap, hap.data(), hap.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	if (!acc_cum.empty())
+		HIP_TRY(hipMemcpy(tbase + tb_acum, acc_cum.data(), acc_cum.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	if (int rc = m->d_blk.reserve(plist.size() * sizeof(uint32_t))) return rc;
 	HIP_TRY(hipMemcpy(m->d_blk.p, plist.data(), plist.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(m->d_tab.p, m->tab, sizeof(m->tab), hipMemcpyHostToDevice));
@@ -659,6 +686,7 @@ int finalize_model(hibag_hip_model *m)
 	V.ctile = (const uint32_t *)(tbase + tb_ctile);
 	V.hap = (const uint32_t *)(tbase + tb_hap);
 	V.hap_dwords = (uint32_t)hap.size();
+	V.acc_cum = (const uint32_t *)(tbase + tb_acum);
 	V.plist = m->d_blk.as<uint32_t>();
 	V.plist_dwords = plist.size();
 	m->bt_rows = bt_rows;
@@ -697,6 +725,23 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	if (int rc = m->ws_cellsum.reserve((size_t)std::max(m->cellsum_rows, 1) * n_pad * sizeof(double))) return rc;
 	if (need_best)
 		if (int rc = m->ws_best.reserve(C * n_pad * sizeof(int))) return rc;
+	{
+		// hand-over flags: one per pass-2 item (8 XCDs x group quads x tiles)
+		const size_t n_gq = ((size_t)(n_pad / HIBAG_WAVE + 7) / 8 + 3) / 4;
+		const size_t n_flag2 = 8 * n_gq * (size_t)std::max(m->view.n_tile, 1);
+		const size_t n_flag1 = (size_t)((n_pad / HIBAG_WAVE + 3) / 4) * (size_t)std::max(std::max(m->view.n_item_whole, m->view.n_item_split), 1);
+		const size_t n_flag = n_flag2 + n_flag1;
+		const size_t had = m->ws_sync.cap;
+		if (int rc = m->ws_sync.reserve(n_flag * sizeof(unsigned long long))) return rc;
+		if (m->ws_sync.cap != had) { HIP_TRY(hipMemset(m->ws_sync.p, 0, m->ws_sync.cap)); m->epoch = 0; }
+		if (!m->h_err) {
+			HIP_TRY(hipHostMalloc((void **)&m->h_err, sizeof(int), hipHostMallocMapped));
+			*m->h_err = 0;
+		}
+		if (++m->epoch == 0) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipMemset(m->ws_sync.p, 0, m->ws_sync.cap)); m->epoch = 1; }
+	}
+	B.sync = m->ws_sync.as<unsigned long long>(); B.epoch = m->epoch; B.err = m->h_err;
+	B.sync_total = B.sync + 8 * (((size_t)(n_pad / HIBAG_WAVE + 7) / 8 + 3) / 4) * (size_t)std::max(m->view.n_tile, 1);
 	B.n_samp = n_samp; B.n_pad = n_pad;
 	B.masks = m->ws_planes.as<uint32_t>();
 	B.cw = m->ws_cw.as<double>(); B.tot = m->ws_tot.as<double>(); B.inv = m->ws_inv.as<double>();
@@ -829,6 +874,7 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 		if (dosage) HIP_TRY(hipMemcpyAsync(dosage + (size_t)s0 * nh, o + o_ds, (size_t)n * nh * 8, hipMemcpyDeviceToHost, 0));
 		if (postprob) HIP_TRY(hipMemcpyAsync(postprob + (size_t)s0 * P, o + o_pp, (size_t)n * P * 8, hipMemcpyDeviceToHost, 0));
 		HIP_TRY(hipStreamSynchronize(0));
+		if (m->h_err && *m->h_err) { *m->h_err = 0; return fail(HIBAG_HIP_ESTATE, "a hand-over between workgroups never arrived"); }
 	}
 	return 0;
 }
@@ -1317,6 +1363,7 @@ int plugin_avg_prob(hibag_hip_model *m, const PluginGenotype geno[], const doubl
 	HIP_TRY(hipMemcpyAsync(out_prob, d_out, P * sizeof(double), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(out_match, d_out + P, sizeof(double), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
+	if (m->h_err && *m->h_err) { *m->h_err = 0; return fail(HIBAG_HIP_ESTATE, "a hand-over between workgroups never arrived"); }
 	return 0;
 }
 

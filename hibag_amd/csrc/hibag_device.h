@@ -152,6 +152,9 @@ struct HibagModelView {
 	const uint32_t *ctile;       // [C][n_tile][8]: everything pass 2 needs per (classifier, tile) in one s_load_dwordx8:
 	                             // {engine | k << 2 | #non-empty cells << 8 | bt_row << 16, dword offset of the first haplotype-table entry,
 	                             //  pair list dword offset lo/hi, #blocks, 0, row list lo/hi}
+
+	// chunked items (hibag_kernels.hip "hand-overs"): cost prefix sums in quarter-blocks of 32 records
+	const uint32_t *acc_cum;     // [n_tile][C + 1] pass 2: cost of the tile's classifiers 0 .. c-1
 };
 
 struct HibagBatchView {
@@ -167,6 +170,12 @@ struct HibagBatchView {
 	// (int8, MFMA lane layout; K layout above) and, for classifiers with 32 SNPs, the distance offsets
 	uint4 *bt;          // [(bt_row[c] + n * (rows / 2) + kb)][n_pad/64][64]
 	int *bias;          // [(2c + n)][n_pad/64][64]  8 * (2*#(g=2) + #(g=1)), written for 32-SNP classifiers only
+	// hand-over flags of chunked work items: (epoch << 32 | progress) per item; a new epoch per batch, so the
+	// flags are never cleared
+	unsigned long long *sync;         // pass 2: [8 XCDs][group quads][tiles]
+	unsigned long long *sync_total;   // pass 1: [items x group quads]
+	uint32_t epoch;
+	int *err;           // host-mapped: set when a hand-over never arrived (should not happen; the launch then gives wrong sums)
 };
 
 #endif

@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
 #include "hibag_device.h"
 #include "hibag_kernels.h"
 
@@ -339,7 +340,8 @@ struct ListCursor {
 	uint32_t idx = 0, idx_n = 0;     // this lane's slot word of that block and of the one behind it
 };
 
-// Walk `nblk` consecutive blocks of a pair list starting at dword offset `at`.
+// Walk `nblk` consecutive blocks of a pair list starting at dword offset `at`; `cell` = the sum of the cell the
+// first record belongs to so far (0 at a cell boundary), on return that of the cell the walk ended in.
 //
 // Latency plan.  Nothing in this loop goes through the scalar cache: scalar loads
 // share the lgkmcnt counter with the LDS table look-ups and return out of order,
@@ -357,13 +359,12 @@ struct ListCursor {
 // so that the look-ahead stays in bounds.
 template <int ENG, int G, class Fin>
 __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at, int nblk, int lane, ListCursor &cur,
-	__amdgpu_buffer_rsrc_t hp, int k, const LaneOperand &T, const double *tab_s, double *stage, Fin &&fin)
+	__amdgpu_buffer_rsrc_t hp, int k, const LaneOperand &T, const double *tab_s, double *stage, double &cell, Fin &&fin)
 {
 	if (nblk <= 0) return;
 	constexpr bool FP4 = ENG == HIBAG_ENGINE_FP4;
 	constexpr uint32_t ES = 4 * HIBAG_ENGINE_HAP_DWORDS(ENG);                // bytes per table entry
 	constexpr int FO = FP4 ? 16 : 32;                                         // ff behind the image
-	double cell = 0;
 	const int vo_i = (lane & 31) * 4;                // this lane's slot inside a block
 	// this lane's 16 bytes of an image: the K half's bytes (int8), the whole nibble image (FP4)
 	const uint32_t img = FP4 ? 0u : (uint32_t)(lane >> 5) * 16u;
@@ -739,39 +740,140 @@ __device__ __forceinline__ double classifier_total(const HibagModelView &M, cons
 	return total;
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total(HibagModelView M, HibagBatchView B)
+// ---- hand-overs -----------------------------------------------------------------------------------
+// A pass is a few thousand work items of similar length on ~1,000 resident workgroups, so its last round runs
+// mostly empty (10k samples: 3,200 items of pass 2 on 1,024 slots = 3.1 rounds, the chip idle for most of the
+// fourth).  The items of the last round or two are therefore cut into K chunks along their classifier sequence,
+// each chunk a workgroup of its own: the last round is then made of pieces a K-th as long.  A chunk continues the
+// sums of the one before it -- parked in the output rows and announced by a flag -- so the additions and their
+// order are those of the undivided item.  All first chunks are dispatched before all second chunks, and so on: a
+// workgroup only ever waits for one that was dispatched (a whole round of chunks) earlier, and no cycle can form.
+//
+// Visibility.  Chunks of one item run on one XCD (workgroups b and b + 8 share an XCD, and an item's chunks sit a
+// multiple of 8 apart), so the hand-over goes through that XCD's L2: the parked sums are plain stores, complete in L2
+// once the storing wavefront's vmcnt is 0 (the vector L1 writes through); the flag follows behind a workgroup barrier
+// as an L1-bypassing (sc1) store; the reader polls it with sc1 loads and fetches the sums with sc1 loads, which
+// bypass its CU's L1.  No cache is flushed or invalidated (agent-scope fences cost 2-7 us each here and
+// evict everybody's L1).  The dispatch order is observed behaviour, not a contract: every flag carries the XCD
+// number of its writer, and a reader on another XCD reports the launch as failed instead of using the sums.
+__device__ __forceinline__ unsigned xcc_id()
+{
+	unsigned x;
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+	return x & 15u;
+}
+
+__device__ __forceinline__ void handover_post(unsigned long long *flag, uint32_t epoch, uint32_t progress)
+{
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wavefront's parked sums have reached L2
+	__syncthreads();
+	if (threadIdx.x == 0)
+		__hip_atomic_store(flag, ((unsigned long long)epoch << 32) | (xcc_id() << 24) | progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void handover_wait(unsigned long long *flag, uint32_t epoch, uint32_t progress, int *err)
+{
+	if (threadIdx.x == 0) {
+		const unsigned long long want = ((unsigned long long)epoch << 32) | progress;
+		unsigned spins = 0;
+		for (;;) {
+			const unsigned long long v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if ((v & ~(15ull << 24)) == want) {
+				if (((unsigned)(v >> 24) & 15u) != xcc_id()) *err = 2;     // written on another XCD: not coherent through L2
+				break;
+			}
+			__builtin_amdgcn_s_sleep(16);
+			if (++spins > (1u << 19)) { *err = 1; break; }      // ~0.3 s: give up rather than hang the device
+		}
+	}
+	__syncthreads();
+}
+
+// a parked sum: read past the CU's L1
+__device__ __forceinline__ double load_parked(const double *p)
+{
+	return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// first classifier of a tile whose cost prefix reaches `target` (acc_cum row of the tile: C + 1 entries)
+__device__ __forceinline__ int chunk_bound(const uint32_t *__restrict__ cum, int C, uint64_t target)
+{
+	int a = 0, b = C;
+	while (a < b) {
+		const int mid = (a + b) >> 1;
+		if (cum[mid] >= target) b = mid; else a = mid + 1;
+	}
+	return a;
+}
+
+// Workgroup b < n_whole: item b (items run classifier-major: item = b / gx, group quad = b % gx).  Behind them the
+// other `rest` items in K chunks along their block lists, all first chunks, then all second chunks ... ("hand-overs"
+// above; `stride` = rest rounded up to a multiple of 8, so that the chunks of an item share an XCD).  Only
+// matrix-engine items are cut; a chunk hands over the lane's running total and the sum of the cell it stopped in,
+// parked in the classifier's tot / inv rows.
+__global__ __launch_bounds__(BLOCK_THREADS, 5) void k_total(HibagModelView M, HibagBatchView B, int gx, int n_whole, int rest, int stride, int K)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
-	stage_table(M, tab_s);
-	const int *__restrict__ item = M.item + 4 * blockIdx.y;
+	int li = blockIdx.x, k = 0;
+	if (li >= n_whole) {
+		const int jj = li - n_whole;
+		k = jj / stride;
+		if (jj - k * stride >= rest) return;
+		li = n_whole + jj - k * stride;
+	}
+	const int *__restrict__ item = M.item + 4 * (li / gx);
 	const int c = item[0];
-	const int group = blockIdx.x * BLOCK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	if (group * HIBAG_WAVE >= B.n_pad) return;
+	const int nkb = M.engine[c];                      // matrix-engine variant, 0 = VALU engine
+	// blocks [b0, b1) of the classifier's list
+	int b0 = 0, b1 = nkb > 0 ? M.cls_nblk[c] : 0;
+	const bool chunked = blockIdx.x >= n_whole && nkb > 0;
+	if (blockIdx.x >= n_whole) {
+		if (nkb > 0) {
+			const long long nb = b1;
+			b0 = (int)(nb * k / K); b1 = (int)(nb * (k + 1) / K);
+			if (b0 >= b1 && !(k == K - 1 && nb == 0)) return;      // (fewer blocks than chunks: an empty list still needs its total written)
+		} else if (k > 0) return;                                  // VALU-engine items are not cut
+	}
+	const bool first = b0 == 0, last = !chunked || k == K - 1;
+	stage_table(M, tab_s);
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int group = (li % gx) * BLOCK_WAVES + wave;
 	const int s = group * HIBAG_WAVE + (threadIdx.x & 63);
 	const size_t at = (size_t)c * B.n_pad + s;
-	const bool active = B.cw[at] > 0;                 // src/LibHLA.cpp:2451
-	if (__ballot(active) == 0) return;                // nobody needs this classifier
-	double total = 0;
-	const int nkb = M.engine[c];                      // matrix-engine variant, 0 = VALU engine
-	const int srow = M.n_split > 0 ? M.split_row[c] : -1;
-	if (nkb > 0) {
+	// a wavefront beyond the batch, or one none of whose samples uses the classifier (src/LibHLA.cpp:2451), has nothing
+	// to do in any chunk
+	bool live = group * HIBAG_WAVE < B.n_pad;
+	if (live) live = __ballot(B.cw[at] > 0) != 0;
+	unsigned long long *flag = B.sync_total + (li - n_whole);
+	if (!first) handover_wait(flag, B.epoch, (uint32_t)b0, B.err);
+	if (live) {
+		double total = 0;
+		const int srow = M.n_split > 0 ? M.split_row[c] : -1;
+		if (nkb > 0) {
+			double cell = 0;
+			if (!first) { total = load_parked(&B.tot[at]); cell = load_parked(&B.inv[at]); }
 #define CALL(E) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, threadIdx.x & 63, T);                           \
-		ListCursor cur;                                                                                                \
-		walk_blocks<E, 4>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c],    \
-			T, tab_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)],                                       \
-			[&](double cell) { total += cell; asm("" : "+v"(total)); /* keeps the cell end a scalar branch */ }); }
-		HIBAG_DISPATCH_ENGINE(nkb, CALL)
+			ListCursor cur;                                                                                                \
+			walk_blocks<E, 4>(M, M.blk_off[c] + (uint64_t)b0 * HIBAG_PLIST_DWORDS, b1 - b0, threadIdx.x & 63, cur,     \
+				hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c], T, tab_s, stage_s[wave], cell,                                    \
+				[&](double v) { total += v; asm("" : "+v"(total)); /* keeps the cell end a scalar branch */ }); }
+			HIBAG_DISPATCH_ENGINE(nkb, CALL)
 #undef CALL
-	} else {
-		double *rows = srow >= 0 ? B.cellsum + (size_t)srow * B.n_pad : nullptr;
+			if (!last) { B.tot[at] = total; B.inv[at] = cell; }
+		} else {
+			double *rows = srow >= 0 ? B.cellsum + (size_t)srow * B.n_pad : nullptr;
 #define CALL(N) total = classifier_total<N>(M, B, c, s, item[1], item[2], item[3], rows, tab_s)
-		HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
+			HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
 #undef CALL
-		if (rows) return;
+			if (rows) return;
+		}
+		if (last) {
+			B.tot[at] = total;
+			B.inv[at] = 1 / total;                        // src/LibHLA.cpp:1827 (inf when total == 0)
+		}
 	}
-	B.tot[at] = total;
-	B.inv[at] = 1 / total;                            // src/LibHLA.cpp:1827 (inf when total == 0)
+	if (!last) handover_post(flag, B.epoch, (uint32_t)b1);
 }
 
 // k_total_scan: the in-order total of a split classifier from its stored cell sums; thread = sample.
@@ -830,12 +932,13 @@ __device__ __forceinline__ void accumulate_classifier(const HibagModelView &M, c
 	}
 }
 
-__global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagModelView M, HibagBatchView B)
+// grid = 8 x (n_whole + K * (items per XCD - n_whole)): per XCD first the undivided items, then the others' first
+// chunks, second chunks, ...
+__global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagModelView M, HibagBatchView B, int n_whole, int K)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double acc_s[ACCUM_WAVES][HIBAG_TILE][HIBAG_WAVE];
 	__shared__ double stage_s[ACCUM_WAVES][2 * STAGE_DOUBLES];
-	stage_table(M, tab_s);
 
 	// Work item = (XCD, four sample groups, one tile); the four wavefronts of a workgroup take the four groups.
 	// They read the same pair-list segments and the same haplotype-table entries at about the same time, so those
@@ -843,20 +946,44 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 	// group g goes to XCD g % 8 with all its tiles: its operands / weights / totals are fetched into one XCD's L2 only.
 	const int n_group = B.n_pad / HIBAG_WAVE;
 	const int n_gq = ((n_group + 7) / 8 + ACCUM_WAVES - 1) / ACCUM_WAVES;      // group quads per XCD
-	// Grid-stride over the work items: the launcher may start fewer workgroups than items (a whole
-	// number of resident rounds), the first few then take a second item -- see hibag_launch_accum.
-	for (int b = blockIdx.x; b < 8 * n_gq * M.n_tile; b += gridDim.x) {
+	const int C = M.n_classifier;
+	const int n_item_x = n_gq * M.n_tile;             // items of one XCD: (group quad, tile), tile fastest
+	const int xcd = blockIdx.x & 7, wx = blockIdx.x >> 3;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int xcd = b & 7, jq = (b >> 3) / M.n_tile, tile = (b >> 3) - jq * M.n_tile;
-	const int group = (jq * ACCUM_WAVES + wave) * 8 + xcd;
-	if (group >= n_group) continue;
 	const int lane = threadIdx.x & 63;
-	const int s = group * HIBAG_WAVE + lane;
-	const int ncell = M.tile_n[tile];
 	double (*acc)[HIBAG_WAVE] = acc_s[wave];
 
+	// this workgroup's classifiers [cb, ce) of its item
+	int item = wx, cb = 0, ce = C;
+	if (wx >= n_whole) {
+		const int rest = n_item_x - n_whole, k = (wx - n_whole) / rest;
+		item = n_whole + (wx - n_whole) - k * rest;
+		const uint32_t *__restrict__ cum = M.acc_cum + (size_t)(item % M.n_tile) * (C + 1);
+		const uint64_t total = cum[C];
+		if (k > 0) cb = chunk_bound(cum, C, (total * (uint64_t)k + K - 1) / K);
+		if (k < K - 1) ce = chunk_bound(cum, C, (total * (uint64_t)(k + 1) + K - 1) / K);
+		if (cb >= ce) return;                         // (fewer classifiers than chunks)
+	}
+	stage_table(M, tab_s);
+	const int jq = item / M.n_tile, tile = item - jq * M.n_tile;
+	const int group = (jq * ACCUM_WAVES + wave) * 8 + xcd;
+	unsigned long long *flag = B.sync + (size_t)xcd * n_item_x + item;
+	if (cb > 0) handover_wait(flag, B.epoch, (uint32_t)cb, B.err);
+	if (group < n_group) {
+	const int s = group * HIBAG_WAVE + lane;
+	const int ncell = M.tile_n[tile];
+	const int p0 = M.tile_p0[tile];
+
+	if (cb > 0) {                                     // continue the parked sums (all loads in flight together)
+		double v[HIBAG_TILE];
 #pragma unroll
-	for (int j = 0; j < HIBAG_TILE; j++) acc[j][lane] = 0;
+		for (int j = 0; j < HIBAG_TILE; j++) v[j] = load_parked(&B.part[(size_t)(p0 + (j < ncell ? j : 0)) * B.n_pad + s]);
+#pragma unroll
+		for (int j = 0; j < HIBAG_TILE; j++) acc[j][lane] = v[j];
+	} else {
+#pragma unroll
+		for (int j = 0; j < HIBAG_TILE; j++) acc[j][lane] = 0;
+	}
 
 	// Everything classifier c+1 needs that does not cost many registers is requested while
 	// classifier c is evaluated: its (classifier, tile) record (one s_load_dwordx8) and the
@@ -864,14 +991,14 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 	// dependent scalar and vector loads (~3000 cycles per classifier, measured with stamps).
 	typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 	const u32x8 *__restrict__ ct = reinterpret_cast<const u32x8 *>(M.ctile) + tile;
-	u32x8 rec_n = ct[0];
-	double w_n = B.cw[s], inv_n = B.inv[s];
+	u32x8 rec_n = ct[(size_t)cb * M.n_tile];
+	double w_n = B.cw[(size_t)cb * B.n_pad + s], inv_n = B.inv[(size_t)cb * B.n_pad + s];
 	ListCursor cur;                                   // the list look-ahead carries over from classifier to classifier
-	for (int c = 0; c < M.n_classifier; c++) {
+	for (int c = cb; c < ce; c++) {
 		const u32x8 rec = rec_n;
 		const double w = w_n, inv = inv_n;
 		{
-			const int cn = (c + 1 < M.n_classifier) ? c + 1 : c;
+			const int cn = (c + 1 < C) ? c + 1 : c;
 			rec_n = ct[(size_t)cn * M.n_tile];
 			w_n = B.cw[(size_t)cn * B.n_pad + s];
 			inv_n = B.inv[(size_t)cn * B.n_pad + s];
@@ -883,13 +1010,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 		const int nkb = (int)(rec[0] & 3u);
 		if (nkb > 0) {
 			// Cells close in the order of the tile's non-empty entries; their row numbers j come
-			// packed 4 bits each in two SGPRs, so closing a cell needs no memory access, and the
-			// LDS row of the NEXT cell to close is read while that cell is still being summed.
+			// packed 4 bits each in two SGPRs, so closing a cell needs no memory access.
 			uint64_t jpack = ((uint64_t)rec[7] << 32) | rec[6];
 			// inactive lanes (weight 0) must keep their sums: with 1/total replaced by 0 their term is
 			// (cell * 0) * 0 = +0 and a + 0 == a, which spares a select per closed cell
 			const double inv_e = active ? inv : 0.0;
-#ifndef HIBAG_NO_LDS_ADD
 			// S[p] += v as one LDS floating-point add (ds_add_f64: the same IEEE addition, no register for the old
 			// sum, nothing to wait for)
 			auto fin = [&](double cell) {
@@ -897,20 +1022,10 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 				__hip_atomic_fetch_add(&acc[(int)(jpack & 15)][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				jpack >>= 4;
 			};
-#else
-			int j = (int)(jpack & 15);
-			double a = acc[j][lane];
-			auto fin = [&](double cell) {
-				const double v = (cell * inv_e) * w;
-				acc[j][lane] = a + v;
-				jpack >>= 4;
-				j = (int)(jpack & 15);
-				a = acc[j][lane];
-			};
-#endif
 #define CALL(E) { LaneOperand T; load_operand_row<E>(B, (int)(rec[0] >> 16), c, group, lane, T);                          \
+			double cell = 0;                                                                                            \
 			walk_blocks<E, 8>(M, ((uint64_t)rec[3] << 32) | rec[2], (int)rec[4], lane, cur, hap_rsrc(M, rec[1]),        \
-				(int)((rec[0] >> 2) & 63u), T, tab_s, stage_s[wave], fin); }
+				(int)((rec[0] >> 2) & 63u), T, tab_s, stage_s[wave], cell, fin); }
 			HIBAG_DISPATCH_ENGINE(nkb, CALL)
 #undef CALL
 			if (poison) {                                // empty cells: (0 * inv) * w is NaN where inv is not finite
@@ -927,9 +1042,10 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 		}
 	}
 
-	const int p0 = M.tile_p0[tile];
+	// the item's sums, or -- parked -- what the workgroup behind continues from
 	for (int j = 0; j < ncell; j++) B.part[(size_t)(p0 + j) * B.n_pad + s] = acc[j][lane];
 	}
+	if (ce < C) handover_post(flag, B.epoch, (uint32_t)ce);
 }
 
 // ---------------------------------------------------------------------------
@@ -984,8 +1100,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_vote_best(HibagModelView M
 		};
 #define CALL(E) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, threadIdx.x & 63, T);                           \
 		ListCursor cur;                                                                                                \
+		double cell = 0;                                                                                               \
 		walk_blocks<E, 4>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c],    \
-			T, tab_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)], fin); }
+			T, tab_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)], cell, fin); }
 		HIBAG_DISPATCH_ENGINE(nkb, CALL)
 #undef CALL
 		bp = best_i < 0 ? -1 : (int)M.cls_cell[M.cls_off[c] + best_i];
@@ -1192,11 +1309,28 @@ void hibag_launch_unpack_tgeno(const HibagModelView &M, const HibagBatchView &B,
 	hipLaunchKernelGGL(k_unpack_tgeno, dim3(M.n_classifier), dim3(HIBAG_WAVE), 0, st, M, B, d_tgeno, d_weight);
 }
 
+// resident workgroups of a kernel on the current device (0 = unknown)
+template <class F>
+static int resident_blocks(F kernel, int threads)
+{
+	int per_cu = 0, cus = 0, dev = 0;
+	(void)hipGetDevice(&dev);
+	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess) return 0;
+	return per_cu > 0 && cus > 0 ? per_cu * cus : 0;
+}
+
+// chunks per item of the last rounds of passes 1 and 2 ("hand-overs"; HIBAG_TAIL_K=1: undivided items only)
+static int tail_chunks()
+{
+	static const int k = getenv("HIBAG_TAIL_K") ? std::max(1, std::min(64, atoi(getenv("HIBAG_TAIL_K")))) : 4;
+	return k;
+}
+
 void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st)
 {
 	if (M.n_classifier == 0) return;
 	const unsigned gx = (unsigned)((B.n_pad / HIBAG_WAVE + BLOCK_WAVES - 1) / BLOCK_WAVES);
-	static const int dbg_lds = getenv("HIBAG_DEBUG_LDS") ? atoi(getenv("HIBAG_DEBUG_LDS")) : 0;   // occupancy experiments
 	// A classifier far heavier than the rest (VALU engine, > 32 SNPs) is only worth cutting up when its
 	// single-wavefront walk would outlast the rest of the pass, i.e. for small batches.
 	HibagModelView V = M;
@@ -1206,7 +1340,18 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 	V.item = split ? M.item_split : M.item_whole;
 	V.n_item = split ? M.n_item_split : M.n_item_whole;
 	if (!split) V.n_split = 0;
-	hipLaunchKernelGGL(k_total, dim3(gx, V.n_item), dim3(BLOCK_THREADS), dbg_lds, st, V, B);
+	// more items than resident workgroups: the last, incomplete round and the full round before it go in K chunks each
+	static const int slots = resident_blocks(k_total, BLOCK_THREADS);
+	const unsigned n = gx * (unsigned)V.n_item;
+	unsigned n_whole = n, rest = 0, stride = 8, K = 1;
+	if (tail_chunks() > 1 && slots > 0 && n > (unsigned)slots) {
+		K = (unsigned)tail_chunks();
+		rest = n % (unsigned)slots + (unsigned)slots;
+		n_whole = n - rest;
+		stride = (rest + 7) / 8 * 8;
+	}
+	hipLaunchKernelGGL(k_total, dim3(n_whole + (rest ? K * stride : 0)), dim3(BLOCK_THREADS), 0, st, V, B,
+		(int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
 	if (split)
 		hipLaunchKernelGGL(k_total_scan, dim3(B.n_pad / 64, V.n_split), dim3(64), 0, st, V, B);
 }
@@ -1220,25 +1365,15 @@ void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStr
 		(void)hipMemsetAsync(B.part, 0, (size_t)M.n_cell * B.n_pad * sizeof(double), st);
 		return;
 	}
-	// Wavefronts of this pass all take about the same time, so the launch proceeds in rounds of as many
-	// workgroups as fit on the chip, and a small remainder would occupy a whole extra round almost
-	// alone (10k samples: 3,200 items on 1,024 slots = 3.1 rounds).  In that case launch a whole
-	// number of rounds and let the first workgroups take a second item each.
-	static int slots = 0;
-	if (slots == 0) {
-		int per_cu = 0, cus = 0, dev = 0;
-		(void)hipGetDevice(&dev);
-		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_accum, ACCUM_WAVES * HIBAG_WAVE, 0) != hipSuccess) per_cu = 0;
-		slots = per_cu > 0 && cus > 0 ? per_cu * cus : -1;
-		if (getenv("HIBAG_ROUNDS") && atoi(getenv("HIBAG_ROUNDS")) == 0) slots = -1;
+	// more items than resident workgroups: the last, incomplete round and the full round before it go in K chunks each
+	static const int slots = resident_blocks(k_accum, ACCUM_WAVES * HIBAG_WAVE);
+	const unsigned nx = n / 8, sx = (unsigned)slots / 8;
+	unsigned n_whole = nx, K = 1;
+	if (tail_chunks() > 1 && sx > 0 && nx > sx) {
+		K = (unsigned)tail_chunks();
+		n_whole = nx - (nx % sx + sx);
 	}
-	unsigned grid = n;
-	if (slots > 0 && n > (unsigned)slots) {
-		const unsigned rem = n % (unsigned)slots;
-		if (rem > 0 && rem <= (unsigned)slots / 4) grid = n - rem;
-	}
-	hipLaunchKernelGGL(k_accum, dim3(grid), dim3(ACCUM_WAVES * HIBAG_WAVE), 0, st, M, B);
+	hipLaunchKernelGGL(k_accum, dim3(8 * (n_whole + K * (nx - n_whole))), dim3(ACCUM_WAVES * HIBAG_WAVE), 0, st, M, B, (int)n_whole, (int)K);
 }
 
 void hibag_launch_vote(const HibagModelView &M, const HibagBatchView &B, int *d_best_cell, hipStream_t st)

@@ -73,6 +73,27 @@ def test_cfg3_100k_samples_eight_classifier_shards(hib, oracle):
         m.close()
 
 
+def test_chunked_work_items_equal_the_oracle(hib, oracle):
+    """3,400 samples of the HLA-B model: more work items than resident workgroups in both passes, so the last rounds'
+    items run as chunks that continue each other's sums through the output rows (hibag_kernels.hip "hand-overs").
+    Every output of every sample bit-equal to the oracle, samples without genotypes and unused classifiers included."""
+    from hibag_amd import synth
+    model, founders, af = synth.make_model("hla-b")
+    n = 3400
+    G, truth = synth.make_samples(founders, af, n, seed=77)
+    G[5, :] = hib.NA_INTEGER
+    G[64:128, :] = hib.NA_INTEGER                         # a whole wavefront without any genotype
+    G[200:264, ::2] = hib.NA_INTEGER
+    m = hib.hlaModelFromObj(model)
+    got = m.predict_raw(G, 1, want_dosage=True, want_prob=True)
+    again = m.predict_raw(G, 1, want_dosage=True, want_prob=True)     # next batch: a new epoch of hand-over flags
+    m.close()
+    want = oracle.predict(oracle.flatten(model), G, vote_method=1, avx2=True, n_threads=8)
+    for k in ("h1", "h2", "prob", "matching", "dosage", "postprob"):
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+        assert np.array_equal(again[k], want[k], equal_nan=True), k
+
+
 def test_cfg4_hla_drb1_full_model_against_oracle(hib, oracle):
     """The DRB1 shape at full size: 100 classifiers x 500 haplotypes (12.5 M haplotype pairs per sample)."""
     from hibag_amd import synth
