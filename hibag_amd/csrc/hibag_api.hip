@@ -152,11 +152,12 @@ struct hibag_hip_model {
 	// device model
 	DevBuf d_int, d_stream, d_tile, d_tab, d_blk;
 	HibagModelView view{};
-	int mask_rows = 0, bt_rows = 0, cellsum_rows = 0;
+	int mask_rows = 0, bt_rows = 0, cell_rows = 0;
 	size_t stream_bytes = 0;
 
 	// per-batch workspace (grow-only)
-	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias, ws_cellsum, ws_sync;
+	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias, ws_cells, ws_sync;
+	bool store_cells = false;              // pass 2 reads back the cell sums pass 1 stored (HibagModelView::store_cells)
 	uint32_t epoch = 0;                    // batch counter for the hand-over flags (HibagBatchView::epoch)
 	int *h_err = nullptr;                  // host-mapped error word of the hand-overs
 	// plugin staging
@@ -172,7 +173,7 @@ struct hibag_hip_model {
 		(void)hipSetDevice(device);
 		timer.destroy();
 		if (h_err) (void)hipHostFree(h_err);
-		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_cellsum, &ws_sync, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
+		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_cells, &ws_sync, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
 		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_tgeno, &ws_weight, &ws_bed, &ws_bedidx})
 			b->release();
 	}
@@ -479,6 +480,7 @@ int finalize_model(hibag_hip_model *m)
 	// pass 1 lists (non-empty cells per classifier) and pass 2 tile entries
 	std::vector<uint32_t> cls_cnt, cls_cell, tile_meta((size_t)std::max(C, 1) * n_tile * HIBAG_TILE_META + 1, 0);
 	std::vector<int> cls_off(std::max(C, 1), 0), cls_n(std::max(C, 1), 0);
+	std::vector<uint32_t> tile_k0((size_t)std::max(C, 1) * n_tile, 0);
 	for (int c = 0; c < C; c++) {
 		cls_off[c] = (int)cls_cnt.size();
 		for (int p = 0; p < P; p++)
@@ -486,8 +488,10 @@ int finalize_model(hibag_hip_model *m)
 		cls_n[c] = (int)cls_cnt.size() - cls_off[c];
 		cls_cnt.push_back(0); cls_cell.push_back(0);        // the walker reads one count ahead
 		uint64_t off = 0;
+		int k_first = 0;                                    // non-empty cells of the classifier in earlier tiles
 		for (int t = 0; t < n_tile; t++) {
 			uint32_t *me = &tile_meta[((size_t)c * n_tile + t) * HIBAG_TILE_META];
+			tile_k0[(size_t)c * n_tile + t] = (uint32_t)k_first;
 			if (off > 0xFFFFFFFFull) return fail(HIBAG_HIP_EINVAL, "classifier %d has too many haplotype pairs", c);
 			me[1] = (uint32_t)off;
 			int k = 0;
@@ -498,6 +502,7 @@ int finalize_model(hibag_hip_model *m)
 				if (n) { jpack |= (uint64_t)j << (4 * k); me[4 + k++] = ((uint32_t)j << 24) | n; off += n; }
 			}
 			me[0] = (uint32_t)k;
+			k_first += k;
 			me[2] = (uint32_t)jpack; me[3] = (uint32_t)(jpack >> 32);
 			for (int j = 0; j < tile_n[t]; j++)
 				if (!cell_chunks[c][tile_p0[t] + j]) me[4 + k++] = (uint32_t)j << 24;
@@ -563,11 +568,24 @@ int finalize_model(hibag_hip_model *m)
 	// pair lists of the matrix-core engine.  Pass 2 first, tile-major: the segments (tile t, classifier 0),
 	// (t, 1), ... follow each other, which is the order a pass-2 wavefront reads them in; then, per
 	// classifier, all cells back to back for pass 1 (no block left half empty at a tile boundary).
+	// Pass 2 either evaluates every haplotype pair a second time (from tile-major copies of the pair lists) or reads
+	// back the cell sums pass 1 stored, 8 bytes per sample, classifier and non-empty cell.  Measured on MI355X: a pair
+	// costs ~0.25 ps per sample, a stored cell ~2.6 ps (written in pass 1, read in pass 2, both HBM-bound), so storing pays
+	// from about a dozen pairs per cell (the HLA-B benchmark model: 10.9; the DRB1 shape: 80).  HIBAG_PASS2 overrides.
+	{
+		long long n_cells = 0;
+		for (int c = 0; c < C; c++) n_cells += cls_n[c];
+		m->store_cells = C > 0 && (double)m->pair_evals >= 14.0 * (double)std::max<long long>(n_cells, 1);
+		if (const char *e = getenv("HIBAG_PASS2")) {
+			if (!strcmp(e, "stream")) m->store_cells = C > 0;
+			else if (!strcmp(e, "recompute")) m->store_cells = false;
+		}
+	}
 	std::vector<uint32_t> plist;
 	std::vector<uint64_t> blk_off(std::max(C, 1), 0), seg_off((size_t)std::max(C, 1) * n_tile, 0);
 	std::vector<uint32_t> seg_nblk((size_t)std::max(C, 1) * n_tile, 0);
 	long long dbg_b1 = 0, dbg_b2 = 0, dbg_seg = 0;
-	for (int t = 0; t < n_tile; t++)
+	for (int t = 0; t < n_tile && !m->store_cells; t++)
 		for (int c = 0; c < C; c++) {
 			if (!mfma_nkb[c]) continue;
 			seg_off[(size_t)c * n_tile + t] = plist.size();
@@ -576,12 +594,22 @@ int finalize_model(hibag_hip_model *m)
 			seg_nblk[(size_t)c * n_tile + t] = (uint32_t)nb;
 			dbg_b2 += nb; dbg_seg += nb > 0;
 		}
+	const uint64_t p1_base = plist.size();
+	std::vector<uint32_t> blk_close;
 	for (int c = 0; c < C; c++) {
 		if (!mfma_nkb[c]) continue;
 		blk_off[c] = plist.size();
 		cls_nblk[c] = append_pair_blocks(starts[c].data(), nh, 0, 0, P, (uint32_t)m->cls[c].freq.size(), plist);
 		dbg_b1 += cls_nblk[c];
+		uint32_t closed = 0;
+		for (int b = 0; b < cls_nblk[c] && m->store_cells; b++) {
+			blk_close.push_back(closed);
+			for (int i = 0; i < HIBAG_PLIST_DWORDS; i++) closed += plist[blk_off[c] + (size_t)b * HIBAG_PLIST_DWORDS + i] >> 31;
+		}
 	}
+	if (blk_close.empty()) blk_close.push_back(0);
+	std::vector<int> cell_row((size_t)C + 1, 0);
+	for (int c = 0; c < C; c++) cell_row[c + 1] = cell_row[c] + (m->store_cells || split_row[c] >= 0 ? cls_n[c] : 0);
 	if (getenv("HIBAG_DEBUG_MODEL"))
 		fprintf(stderr, "[hibag model] %d classifiers, %d tiles, pairs %lld; blocks of 32: pass 1 %lld, pass 2 %lld in %lld (classifier, tile) segments; "
 			"pair lists %.1f MB, haplotype table %.1f KB, VALU-engine stream %.1f MB\n",
@@ -599,7 +627,7 @@ int finalize_model(hibag_hip_model *m)
 			r[1] = hap_off[c];
 			r[2] = (uint32_t)off; r[3] = (uint32_t)(off >> 32);
 			r[4] = seg_nblk[(size_t)c * n_tile + t];
-			r[5] = 0; r[6] = me[2]; r[7] = me[3];
+			r[5] = tile_k0[(size_t)c * n_tile + t]; r[6] = me[2]; r[7] = me[3];
 		}
 
 	// cost prefix sums of pass 2 (where the launcher cuts an item into chunks), in quarter-blocks: a matrix-engine visit costs its blocks
@@ -635,7 +663,7 @@ int finalize_model(hibag_hip_model *m)
 	const size_t o_nsnp = put(n_snp_c), o_nwp = put(nwp), o_snpoff = put(snp_off), o_snpidx = put(snp_index),
 		o_snpw = put(snp_weight), o_mrow = put(mask_row), o_order = put(c_order), o_tp0 = put(tile_p0), o_tn = put(tile_n),
 		o_coff = put(cls_off), o_cn = put(cls_n), o_nkb = put(mfma_nkb), o_btrow = put(bt_row), o_nblk = put(cls_nblk), o_hapoff = put(hap_off_i),
-		o_item = put(item), o_srow = put(split_row), o_scls = put(split_cls), o_itemw = put(item_whole);
+		o_item = put(item), o_srow = put(split_row), o_scls = put(split_cls), o_itemw = put(item_whole), o_crow = put(cell_row);
 
 	if (int rc = m->d_int.reserve(arena.size() * sizeof(int))) return rc;
 	if (int rc = m->d_stream.reserve(stream.size() * sizeof(uint32_t))) return rc;
@@ -645,7 +673,8 @@ int finalize_model(hibag_hip_model *m)
 		tb_ctile = (tb_boff + blk_off.size() * sizeof(uint64_t) + 31) & ~(size_t)31,
 		tb_hap = (tb_ctile + ctile.size() * sizeof(uint32_t) + 15) & ~(size_t)15,
 		tb_acum = tb_hap + hap.size() * sizeof(uint32_t),
-		tb_end = tb_acum + acc_cum.size() * sizeof(uint32_t);
+		tb_close = tb_acum + acc_cum.size() * sizeof(uint32_t),
+		tb_end = tb_close + blk_close.size() * sizeof(uint32_t);
 	if (int rc = m->d_tile.reserve(tb_end)) return rc;
 	if (int rc = m->d_tab.reserve(sizeof(m->tab))) return rc;
 	HIP_TRY(hipMemcpy(m->d_int.p, arena.data(), arena.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -660,6 +689,7 @@ int finalize_model(hibag_hip_model *m)
 	HIP_TRY(hipMemcpy(tbase + tb_hap, hap.data(), hap.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	if (!acc_cum.empty())
 		HIP_TRY(hipMemcpy(tbase + tb_acum, acc_cum.data(), acc_cum.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(tbase + tb_close, blk_close.data(), blk_close.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	if (int rc = m->d_blk.reserve(plist.size() * sizeof(uint32_t))) return rc;
 	HIP_TRY(hipMemcpy(m->d_blk.p, plist.data(), plist.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(m->d_tab.p, m->tab, sizeof(m->tab), hipMemcpyHostToDevice));
@@ -681,12 +711,16 @@ int finalize_model(hibag_hip_model *m)
 	V.item_split = base + o_item; V.item_whole = base + o_itemw; V.item = V.item_whole; V.n_item = V.n_item_whole;
 	V.split_row = base + o_srow; V.split_cls = base + o_scls;
 	V.split_heavy_ns = split_heavy_ns; V.split_rest_ns = split_rest_ns;
-	m->cellsum_rows = cellsum_rows;
 	V.blk_off = (const uint64_t *)(tbase + tb_boff);
 	V.ctile = (const uint32_t *)(tbase + tb_ctile);
 	V.hap = (const uint32_t *)(tbase + tb_hap);
 	V.hap_dwords = (uint32_t)hap.size();
 	V.acc_cum = (const uint32_t *)(tbase + tb_acum);
+	V.blk_close = (const uint32_t *)(tbase + tb_close);
+	V.p1_base = p1_base;
+	V.cell_row = base + o_crow;
+	V.store_cells = m->store_cells ? 1 : 0;
+	m->cell_rows = cell_row[C];
 	V.plist = m->d_blk.as<uint32_t>();
 	V.plist_dwords = plist.size();
 	m->bt_rows = bt_rows;
@@ -698,14 +732,14 @@ int finalize_model(hibag_hip_model *m)
 	return 0;
 }
 
-// Samples per batch: bounds the workspace (the [P+3][n_pad] partial sums
-// dominate) to roughly 1.5 GB while keeping batches large enough to fill the
-// 256 CUs many times over.
+// Samples per batch: bounds the workspace (the stored cell sums of pass 1 dominate: 8 bytes per
+// classifier and non-empty cell) to roughly 16 GB of the 288 while keeping batches large enough to
+// fill the 256 CUs many times over.
 int batch_limit(const hibag_hip_model *m)
 {
 	const double per_sample = 8.0 * (m->view.n_cell + 3) + 24.0 * m->view.n_classifier +
-		4.0 * m->mask_rows + 4.0 * m->view.n_classifier + 16.0 * m->bt_rows + 8.0 * m->view.n_classifier + 8.0 * m->cellsum_rows;
-	int lim = (int)(1.5e9 / std::max(per_sample, 1.0));
+		4.0 * m->mask_rows + 4.0 * m->view.n_classifier + 16.0 * m->bt_rows + 8.0 * m->view.n_classifier + 8.0 * m->cell_rows;
+	int lim = (int)(16e9 / std::max(per_sample, 1.0));
 	lim = std::max(64, std::min(lim, 1 << 17));
 	return lim / 64 * 64;
 }
@@ -722,7 +756,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	if (int rc = m->ws_codes.reserve((size_t)std::max(m->n_snp, 1) * n_pad)) return rc;
 	if (int rc = m->ws_bt.reserve((size_t)std::max(m->bt_rows, 1) * n_pad * sizeof(uint4))) return rc;
 	if (int rc = m->ws_bias.reserve(2 * C * n_pad * sizeof(int))) return rc;
-	if (int rc = m->ws_cellsum.reserve((size_t)std::max(m->cellsum_rows, 1) * n_pad * sizeof(double))) return rc;
+	if (int rc = m->ws_cells.reserve((size_t)std::max(m->cell_rows, 1) * n_pad * sizeof(double))) return rc;
 	if (need_best)
 		if (int rc = m->ws_best.reserve(C * n_pad * sizeof(int))) return rc;
 	{
@@ -747,7 +781,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	B.cw = m->ws_cw.as<double>(); B.tot = m->ws_tot.as<double>(); B.inv = m->ws_inv.as<double>();
 	B.part = m->ws_part.as<double>();
 	B.bt = m->ws_bt.as<uint4>(); B.bias = m->ws_bias.as<int>();
-	B.cellsum = m->ws_cellsum.as<double>();
+	B.cells = m->ws_cells.as<double>();
 	return 0;
 }
 
@@ -1067,6 +1101,11 @@ int64_t hibag_hip_model_pair_evals(const hibag_hip_model *m)
 	int64_t n = 0;
 	for (const auto &c : m->cls) n += (int64_t)c.freq.size() * ((int64_t)c.freq.size() + 1) / 2;
 	return n;
+}
+
+int64_t hibag_hip_model_stored_cells(const hibag_hip_model *m)
+{
+	return m && m->finalized && m->store_cells ? (int64_t)m->cell_rows : 0;
 }
 
 int hibag_hip_model_mutation_table(const hibag_hip_model *m, double *out)

@@ -126,7 +126,7 @@ struct HibagModelView {
 	const int *cls_n;            // [C] number of non-empty cells
 	// pass-1 work items (heaviest first): {classifier, first cell, end cell, first chunk} in the classifier's
 	// non-empty cell list.  A VALU-engine classifier with far more work than the others is cut into
-	// several items that store their cell sums (split_row[c] = its first row in HibagBatchView::cellsum,
+	// several items that store their cell sums (split_row[c] >= 0: the classifier is split,
 	// -1 = not split); k_total_scan then adds them in order.
 	int n_item, n_split;
 	const int *item;             // [n_item][4]: the launcher points this at the split or the whole list
@@ -153,6 +153,14 @@ struct HibagModelView {
 	                             // {engine | k << 2 | #non-empty cells << 8 | bt_row << 16, dword offset of the first haplotype-table entry,
 	                             //  pair list dword offset lo/hi, #blocks, 0, row list lo/hi}
 
+	// stored cells: rows of HibagBatchView::cells.  store_cells = 1: pass 1 writes every cell sum and pass 2 reads
+	// them back (models with many haplotype pairs per cell, where that is cheaper than evaluating every pair again);
+	// 0: only a split classifier has rows (for k_total_scan), pass 2 evaluates the pairs again from its tile-major lists
+	int store_cells;
+	const int *cell_row;         // [C + 1] first row of the classifier (one row per non-empty cell, in cls_cell order)
+	const uint32_t *blk_close;   // per pass-1 block: cells closed in the classifier's earlier blocks (where a chunk resumes)
+	uint64_t p1_base;            // dword offset of the first pass-1 list in plist (block number = (offset - p1_base) / 32)
+
 	// chunked items (hibag_kernels.hip "hand-overs"): cost prefix sums in quarter-blocks of 32 records
 	const uint32_t *acc_cum;     // [n_tile][C + 1] pass 2: cost of the tile's classifiers 0 .. c-1
 };
@@ -164,7 +172,7 @@ struct HibagBatchView {
 	double *cw;         // [C][n_pad]
 	double *tot;        // [C][n_pad]
 	double *inv;        // [C][n_pad]
-	double *cellsum;    // [rows of the split classifiers][n_pad] (pass 1 scratch)
+	double *cells;      // [cell_row[C]][n_pad] every (classifier, non-empty cell) sum of pass 1
 	double *part;       // [P+3][n_pad]
 	// matrix-core engine: per classifier and sample group the B operand tiles
 	// (int8, MFMA lane layout; K layout above) and, for classifiers with 32 SNPs, the distance offsets

@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include "hibag_device.h"
 #include "hibag_kernels.h"
@@ -720,6 +721,15 @@ __global__ void k_unpack_tgeno(HibagModelView M, HibagBatchView B,
 // (src/LibHLA.cpp:1776-1826).  Empty cells add +0.0 and are skipped.
 // grid (ceil(groups/4), C) with the heaviest classifiers first; each of the 4
 // wavefronts of a block owns one group of 64 samples.
+// The cell sums pass 1 stores for pass 2: per classifier and 64-sample group one row of 64 doubles per non-empty cell
+// (cls_cell order), the rows of a group back to back -- a wavefront writes its classifier's cells as one
+// sequential stream, and pass 2 reads a tile's cells of a classifier as one contiguous piece.
+__device__ __forceinline__ double *cell_rows(const HibagModelView &M, const HibagBatchView &B, int c, int group)
+{
+	const size_t n_group = (size_t)(B.n_pad / HIBAG_WAVE), n = (size_t)(M.cell_row[c + 1] - M.cell_row[c]);
+	return B.cells + ((size_t)M.cell_row[c] * n_group + (size_t)group * n) * HIBAG_WAVE;
+}
+
 template <int NWP>
 __device__ __forceinline__ double classifier_total(const HibagModelView &M, const HibagBatchView &B,
 	int c, int s, int i0, int i1, int chunk0, double *__restrict__ rows, const double *tab_s)
@@ -733,8 +743,8 @@ __device__ __forceinline__ double classifier_total(const HibagModelView &M, cons
 	for (int i = i0; i < i1; i++) {
 		const uint32_t n_next = cnt[i + 1];           // fetched while this cell is evaluated
 		const double cell = cell_sum<NWP>(n, cp, L, tab_s);
-		if (rows) rows[(size_t)i * B.n_pad + s] = cell;   // split classifier: k_total_scan adds the cells in order
-		else total += cell;
+		if (rows) __builtin_nontemporal_store(cell, &rows[(size_t)i * HIBAG_WAVE + (s & 63)]);   // pass 2 reads the cells back (or k_total_scan, for a split classifier)
+		total += cell;
 		n = n_next;
 	}
 	return total;
@@ -811,6 +821,9 @@ __device__ __forceinline__ int chunk_bound(const uint32_t *__restrict__ cum, int
 // above; `stride` = rest rounded up to a multiple of 8, so that the chunks of an item share an XCD).  Only
 // matrix-engine items are cut; a chunk hands over the lane's running total and the sum of the cell it stopped in,
 // parked in the classifier's tot / inv rows.
+// STORE: every cell sum goes to HibagBatchView::cells for pass 2 to read back (models whose pass 2 streams, see
+// k_accum_cells); otherwise only a split VALU-engine classifier stores its cells (for k_total_scan).
+template <bool STORE>
 __global__ __launch_bounds__(BLOCK_THREADS, 5) void k_total(HibagModelView M, HibagBatchView B, int gx, int n_whole, int rest, int stride, int K)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
@@ -849,24 +862,33 @@ __global__ __launch_bounds__(BLOCK_THREADS, 5) void k_total(HibagModelView M, Hi
 	if (!first) handover_wait(flag, B.epoch, (uint32_t)b0, B.err);
 	if (live) {
 		double total = 0;
-		const int srow = M.n_split > 0 ? M.split_row[c] : -1;
+		const bool split = M.n_split > 0 && M.split_row[c] >= 0;    // a split classifier: k_total_scan adds its cells in order
+		double *__restrict__ rows = STORE || split ? cell_rows(M, B, c, group) : nullptr;   // this classifier's cell sums, one row each
 		if (nkb > 0) {
 			double cell = 0;
 			if (!first) { total = load_parked(&B.tot[at]); cell = load_parked(&B.inv[at]); }
-#define CALL(E) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, threadIdx.x & 63, T);                           \
+			// cells closed by earlier chunks = the row this one starts at
+			int row = !STORE || first ? 0 : (int)M.blk_close[(M.blk_off[c] - M.p1_base) / HIBAG_PLIST_DWORDS + (uint64_t)b0];
+			const int lane = threadIdx.x & 63;
+			// (a store issued where the cell closes; parking the sums in LDS and sending them a block later, so that
+			// the vmcnt waits of the look-ahead gathers never include a young store, measured 10 % slower)
+			auto fin = [&](double v) {
+				if (STORE) { __builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++; }
+				total += v;
+				asm("" : "+v"(total));                    // keeps the cell end a scalar branch
+			};
+#define CALL(E) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, lane, T);                                       \
 			ListCursor cur;                                                                                                \
-			walk_blocks<E, 4>(M, M.blk_off[c] + (uint64_t)b0 * HIBAG_PLIST_DWORDS, b1 - b0, threadIdx.x & 63, cur,     \
-				hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c], T, tab_s, stage_s[wave], cell,                                    \
-				[&](double v) { total += v; asm("" : "+v"(total)); /* keeps the cell end a scalar branch */ }); }
+			walk_blocks<E, 4>(M, M.blk_off[c] + (uint64_t)b0 * HIBAG_PLIST_DWORDS, b1 - b0, lane, cur,                 \
+				hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c], T, tab_s, stage_s[wave], cell, fin); }
 			HIBAG_DISPATCH_ENGINE(nkb, CALL)
 #undef CALL
 			if (!last) { B.tot[at] = total; B.inv[at] = cell; }
 		} else {
-			double *rows = srow >= 0 ? B.cellsum + (size_t)srow * B.n_pad : nullptr;
 #define CALL(N) total = classifier_total<N>(M, B, c, s, item[1], item[2], item[3], rows, tab_s)
 			HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
 #undef CALL
-			if (rows) return;
+			if (split) return;
 		}
 		if (last) {
 			B.tot[at] = total;
@@ -884,18 +906,18 @@ __global__ void k_total_scan(HibagModelView M, HibagBatchView B)
 	const int c = M.split_cls[blockIdx.y];
 	const int s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= B.n_pad) return;
-	const double *__restrict__ rows = B.cellsum + (size_t)M.split_row[c] * B.n_pad;
+	const double *__restrict__ rows = cell_rows(M, B, c, s >> 6) + (s & 63);
 	const int n = M.cls_n[c];
 	double total = 0;
 	int i = 0;
 	for (; i + 8 <= n; i += 8) {
 		double v[8];
 #pragma unroll
-		for (int j = 0; j < 8; j++) v[j] = rows[(size_t)(i + j) * B.n_pad + s];
+		for (int j = 0; j < 8; j++) v[j] = rows[(size_t)(i + j) * HIBAG_WAVE];
 #pragma unroll
 		for (int j = 0; j < 8; j++) total += v[j];
 	}
-	for (; i < n; i++) total += rows[(size_t)i * B.n_pad + s];
+	for (; i < n; i++) total += rows[(size_t)i * HIBAG_WAVE];
 	B.tot[(size_t)c * B.n_pad + s] = total;
 	B.inv[(size_t)c * B.n_pad + s] = 1 / total;
 }
@@ -1046,6 +1068,98 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 	for (int j = 0; j < ncell; j++) B.part[(size_t)(p0 + j) * B.n_pad + s] = acc[j][lane];
 	}
 	if (ce < C) handover_post(flag, B.epoch, (uint32_t)ce);
+}
+
+// ---------------------------------------------------------------------------
+// k_accum_cells (pass 2, cells read back): S[p] += (cell * (1/total)) * w over the classifiers in order
+// (src/LibHLA.cpp:1828 then :1497-1507) with the cell sums pass 1 stored -- 8 bytes per sample, classifier and
+// non-empty cell instead of a second evaluation of every haplotype pair; bound by HBM reads.
+// Wavefront = (tile of up to 16 cells, 64 samples), the tile's sums in registers; the four wavefronts of a
+// workgroup take four tiles of one sample group (its weights and 1/totals then come from L1 for three of them), and a
+// group's workgroups all go to XCD group % 8, so those rows stay in one L2.
+#define CELLS_WAVES 4
+__global__ __launch_bounds__(CELLS_WAVES * HIBAG_WAVE, 4) void k_accum_cells(HibagModelView M, HibagBatchView B)
+{
+	__shared__ double acc_s[CELLS_WAVES][HIBAG_TILE][HIBAG_WAVE];
+	const int n_group = B.n_pad / HIBAG_WAVE;
+	const int tq = (M.n_tile + CELLS_WAVES - 1) / CELLS_WAVES;
+	const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	const int group = (jb / tq) * 8 + xcd, tile = (jb % tq) * CELLS_WAVES + wave;
+	if (group >= n_group || tile >= M.n_tile) return;
+	const int s = group * HIBAG_WAVE + lane;
+	const int C = M.n_classifier;
+	const int ncell = M.tile_n[tile];
+	double (*acc)[HIBAG_WAVE] = acc_s[wave];
+#pragma unroll
+	for (int q = 0; q < HIBAG_TILE; q++) acc[q][lane] = 0;
+
+	typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+	const u32x8 *__restrict__ ct = reinterpret_cast<const u32x8 *>(M.ctile) + tile;
+	const size_t n_group_z = (size_t)n_group;
+	struct Visit { u32x8 rec; int row0, row1; double w, inv; };
+	// what classifier c contributes to the tile: its record (one s_load_dwordx8), where its cells start, the lane's
+	// weight and 1/total.  Requested two classifiers ahead, so that nothing below waits for a load it has just issued.
+	auto visit = [&](int c) {
+		Visit x;
+		x.rec = ct[(size_t)c * M.n_tile];
+		x.row0 = M.cell_row[c]; x.row1 = M.cell_row[c + 1];
+		x.w = B.cw[(size_t)c * B.n_pad + s];
+		x.inv = B.inv[(size_t)c * B.n_pad + s];
+		return x;
+	};
+	// request the tile's n non-empty cells of the classifier (rows k0 .. k0 + n - 1 of the group's cells), four at a time.
+	// (Also where pass 1 skipped the classifier because no sample of the group uses it: the rows then hold stale
+	// numbers, which `add` never looks at.)
+	auto fetch = [&](const Visit &x, double (&v)[HIBAG_TILE]) {
+		const int n = (int)((x.rec[0] >> 8) & 31u);
+		const double *__restrict__ rows = B.cells + ((size_t)x.row0 * n_group_z + (size_t)group * (size_t)(x.row1 - x.row0) + x.rec[5]) * HIBAG_WAVE + lane;
+#pragma unroll
+		for (int g = 0; g < HIBAG_TILE; g += 4) {
+			if (g >= n) break;
+#pragma unroll
+			for (int i = g; i < g + 4; i++) v[i] = __builtin_nontemporal_load(rows + (size_t)(i < n ? i : n - 1) * HIBAG_WAVE);
+		}
+	};
+	// S[p] += (cell * (1/total)) * w for those cells, rows in the order of the tile's non-empty list
+	auto add = [&](int c, const Visit &x, const double (&v)[HIBAG_TILE]) {
+		const bool active = x.w > 0;
+		if (__ballot(active) == 0) return;           // nobody in the group uses the classifier (src/LibHLA.cpp:2451)
+		const bool poison = __ballot(active && !(fabs(x.inv) <= 1.79769313486231570815e+308)) != 0;
+		const double inv_e = active ? x.inv : 0.0;   // inactive lanes keep their sums: (cell * 0) * 0 = +0
+		const int n = (int)((x.rec[0] >> 8) & 31u);
+		uint64_t jp = ((uint64_t)x.rec[7] << 32) | x.rec[6];
+#pragma unroll
+		for (int i = 0; i < HIBAG_TILE; i++) {
+			if (i >= n) break;
+			__hip_atomic_fetch_add(&acc[(int)(jp & 15)][lane], (v[i] * inv_e) * x.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			jp >>= 4;
+		}
+		if (poison) {                                // empty cells: (0 * inv) * w is NaN where inv is not finite
+			const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + tile) * HIBAG_TILE_META;
+			for (int i = n; i < ncell; i++) {
+				const double t = (0.0 * x.inv) * x.w;
+				acc[meta[4 + i] >> 24][lane] += active ? t : 0.0;
+			}
+		}
+	};
+
+	// two classifiers per turn: while classifier c is added, the cells of c + 1 and the records of c + 2 are in flight
+	double va[HIBAG_TILE], vb[HIBAG_TILE];
+	Visit x0 = visit(0), x1 = visit(C > 1 ? 1 : 0);
+	fetch(x0, va);
+	for (int c = 0; c < C; c += 2) {
+		const Visit x2 = visit(c + 2 < C ? c + 2 : C - 1);
+		if (c + 1 < C) fetch(x1, vb);
+		add(c, x0, va);
+		const Visit x3 = visit(c + 3 < C ? c + 3 : C - 1);
+		if (c + 2 < C) fetch(x2, va);
+		if (c + 1 < C) add(c + 1, x1, vb);
+		x0 = x2; x1 = x3;
+	}
+	const int p0 = M.tile_p0[tile];
+	for (int q = 0; q < ncell; q++) B.part[(size_t)(p0 + q) * B.n_pad + s] = acc[q][lane];
 }
 
 // ---------------------------------------------------------------------------
@@ -1341,7 +1455,7 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 	V.n_item = split ? M.n_item_split : M.n_item_whole;
 	if (!split) V.n_split = 0;
 	// more items than resident workgroups: the last, incomplete round and the full round before it go in K chunks each
-	static const int slots = resident_blocks(k_total, BLOCK_THREADS);
+	static const int slots = resident_blocks(k_total<false>, BLOCK_THREADS);
 	const unsigned n = gx * (unsigned)V.n_item;
 	unsigned n_whole = n, rest = 0, stride = 8, K = 1;
 	if (tail_chunks() > 1 && slots > 0 && n > (unsigned)slots) {
@@ -1350,14 +1464,22 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 		n_whole = n - rest;
 		stride = (rest + 7) / 8 * 8;
 	}
-	hipLaunchKernelGGL(k_total, dim3(n_whole + (rest ? K * stride : 0)), dim3(BLOCK_THREADS), 0, st, V, B,
-		(int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
+	const dim3 grid(n_whole + (rest ? K * stride : 0));
+	if (M.store_cells)
+		hipLaunchKernelGGL(k_total<true>, grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
+	else
+		hipLaunchKernelGGL(k_total<false>, grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
 	if (split)
 		hipLaunchKernelGGL(k_total_scan, dim3(B.n_pad / 64, V.n_split), dim3(64), 0, st, V, B);
 }
 
 void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStream_t st)
 {
+	if (M.store_cells && M.n_classifier > 0) {         // pass 1 stored the cells: read them back
+		const unsigned groups_x = (unsigned)((B.n_pad / HIBAG_WAVE + 7) / 8), tq = (unsigned)((M.n_tile + CELLS_WAVES - 1) / CELLS_WAVES);
+		hipLaunchKernelGGL(k_accum_cells, dim3(8 * groups_x * tq), dim3(CELLS_WAVES * HIBAG_WAVE), 0, st, M, B);
+		return;
+	}
 	const unsigned n_group = (unsigned)(B.n_pad / HIBAG_WAVE);
 	const unsigned n = 8u * (((n_group + 7) / 8 + ACCUM_WAVES - 1) / ACCUM_WAVES) * (unsigned)M.n_tile;   // work items, see k_accum
 	if (n == 0 || M.n_classifier == 0) {

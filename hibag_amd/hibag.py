@@ -112,6 +112,10 @@ class HlaAttrBagClass:
     def pair_evals(self) -> int:
         return int(_lib.lib().hibag_hip_model_pair_evals(self.handle))
 
+    def stored_cells(self) -> int:
+        """Cell sums per sample that pass 1 stores for pass 2 to read back (0: pass 2 evaluates every pair again)."""
+        return int(_lib.lib().hibag_hip_model_stored_cells(self.handle))
+
     def mutation_table(self) -> np.ndarray:
         t = np.empty(257, np.float64)
         _lib.check(_lib.lib().hibag_hip_model_mutation_table(self.handle, _as_ptr(t)))

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIBAG_HIP_ABI_VERSION 3   /* 2: + PLINK BED entries, training driver; 3: + hibag_hip_predict_mapped[_device] */
+#define HIBAG_HIP_ABI_VERSION 4   /* 2: + PLINK BED entries, training driver; 3: + hibag_hip_predict_mapped[_device]; 4: + hibag_hip_model_stored_cells */
 
 /* error codes */
 #define HIBAG_HIP_OK          0
@@ -97,6 +97,10 @@ int hibag_hip_model_n_snp(const hibag_hip_model *m);
 int hibag_hip_model_n_classifier(const hibag_hip_model *m);
 /* sum over classifiers of H_c(H_c+1)/2: haplotype-pair evaluations per sample */
 int64_t hibag_hip_model_pair_evals(const hibag_hip_model *m);
+/* How a finalized model runs its second pass: > 0 = pass 1 stores that many cell sums per sample (8 bytes each: one
+ * per classifier and allele pair with at least one haplotype pair) and pass 2 reads them back; 0 = pass 2 evaluates
+ * every haplotype pair a second time.  Chosen at finalize from pairs per cell. */
+int64_t hibag_hip_model_stored_cells(const hibag_hip_model *m);
 /* the 257-entry mutation/error table the device uses, exp(d*log(1e-5))
  * (src/LibHLA.cpp:166-183); out[257] */
 int hibag_hip_model_mutation_table(const hibag_hip_model *m, double *out);

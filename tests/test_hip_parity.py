@@ -303,6 +303,41 @@ def test_both_engines_give_the_same_bits(hib, oracle, monkeypatch):
     assert_same({k: v[:96] for k, v in a.items()}, oracle.predict(oracle.flatten(model), G[:96], avx2=True, n_threads=8))
 
 
+@pytest.mark.parametrize("mode", ["stream", "recompute"])
+def test_both_forms_of_pass_two(hib, oracle, monkeypatch, mode):
+    """Pass 2 either reads back the cell sums pass 1 stored or evaluates every haplotype pair again; the model picks
+    by pairs per cell (hibag_hip_model_stored_cells).  Both forms forced on models of every engine and width, on
+    underflowing totals (NaN propagation through empty cells) and on unused classifiers: the same bits as the oracle."""
+    from hibag_amd import synth
+    from hibag_amd.model import Classifier, HlaAttrBagObj
+    monkeypatch.setenv("HIBAG_PASS2", mode)
+    ks = list(range(1, 41)) + [63, 64, 65, 66, 96, 127, 128]
+    model, founders, af = synth.make_model("hla-a-small", seed=77, n_classifier=len(ks), n_snp=160,
+                                           snp_counts=ks, wide_classifier=False)
+    G, _ = synth.make_samples(founders, af, 200, seed=78, miss=0.05)
+    G[3, :] = hib.NA_INTEGER
+    G[64:128, :] = hib.NA_INTEGER                        # a whole wavefront that uses no classifier
+    m = hib.hlaModelFromObj(model)
+    assert (m.stored_cells() > 0) == (mode == "stream")
+    assert_same(m.predict_raw(G, 1, want_dosage=True, want_prob=True),
+                oracle.predict(oracle.flatten(model), G, avx2=True, n_threads=8))
+    # the benchmark shape incl. its 100-SNP classifier, more work items than resident workgroups (chunked items)
+    model, founders, af = synth.make_model("hla-b")
+    G, _ = synth.make_samples(founders, af, 3400, seed=5)
+    G[7, ::3] = hib.NA_INTEGER
+    assert_same(hib.hlaModelFromObj(model).predict_raw(G, 1, want_dosage=True, want_prob=True),
+                oracle.predict(oracle.flatten(model), G, avx2=True, n_threads=8))
+    # total == 0 -> 1/total = inf -> NaN through the empty cells as well
+    k = 100
+    far = Classifier(np.arange(k), [0.5, 0.5], [0, 1], ["1" * k, "1" * k])
+    near = Classifier(np.arange(4), [0.3, 0.3, 0.4], [0, 1, 2], ["0000", "0101", "1111"])
+    model = HlaAttrBagObj(0, k, ["a", "b", "c"], [near, far])
+    G = np.zeros((3, k), np.int32)
+    G[1, 40:] = hib.NA_INTEGER
+    G[2, :] = hib.NA_INTEGER
+    assert_same(hib.hlaModelFromObj(model).predict_raw(G, 1, want_dosage=True, want_prob=True), oracle.predict(oracle.flatten(model), G))
+
+
 def test_more_samples_than_one_batch(hib, oracle):
     """The driver cuts the cohort into batches (<= 131,072 samples); results must not depend on
     where the cuts fall."""
