@@ -570,8 +570,8 @@ int finalize_model(hibag_hip_model *m)
 	// classifier, all cells back to back for pass 1 (no block left half empty at a tile boundary).
 	// Pass 2 either evaluates every haplotype pair a second time (from tile-major copies of the pair lists) or reads
 	// back the cell sums pass 1 stored, 8 bytes per sample, classifier and non-empty cell.  Measured on MI355X: a pair
-	// costs ~0.25 ps per sample, a stored cell ~2.6 ps (written in pass 1, read in pass 2, both HBM-bound), so storing pays
-	// from about a dozen pairs per cell (the HLA-B benchmark model: 10.9; the DRB1 shape: 80).  HIBAG_PASS2 overrides.
+	// costs ~0.25 ps per sample, a stored cell ~2.2 ps (written in pass 1, read in pass 2, both HBM-bound), so storing pays
+	// from about nine pairs per cell (the HLA-B benchmark model: 8.5, measured break-even; the DRB1 shape: 73).  HIBAG_PASS2 overrides.
 	{
 		long long n_cells = 0;
 		for (int c = 0; c < C; c++) n_cells += cls_n[c];
