@@ -24,7 +24,7 @@ EXPORTS = [
     "hibag_hip_set_kernel_target", "hibag_hip_model_new", "hibag_hip_model_add_classifier",
     "hibag_hip_model_add_classifier_packed", "hibag_hip_model_finalize", "hibag_hip_model_free",
     "hibag_hip_model_n_hla", "hibag_hip_model_n_snp", "hibag_hip_model_n_classifier",
-    "hibag_hip_model_pair_evals", "hibag_hip_model_stored_cells", "hibag_hip_model_mutation_table", "hibag_hip_predict",
+    "hibag_hip_model_pair_evals", "hibag_hip_model_stored_cells", "hibag_hip_model_second_pass_pairs", "hibag_hip_model_mutation_table", "hibag_hip_predict",
     "hibag_hip_predict_device", "hibag_hip_model_set_snp_weights", "hibag_hip_predict_partial_device",
     "hibag_hip_finish_device", "hibag_hip_set_timing", "hibag_hip_get_timing", "hibag_hip_reset_timing",
     "hibag_hip_gpu_ext_proc", "hibag_hip_bed_flag", "hibag_hip_conv_bed", "hibag_hip_predict_bed", "hibag_hip_predict_mapped", "hibag_hip_predict_mapped_device",
@@ -81,6 +81,8 @@ def lib() -> C.CDLL:
     L.hibag_hip_model_pair_evals.restype = i64
     L.hibag_hip_model_stored_cells.argtypes = [vp]
     L.hibag_hip_model_stored_cells.restype = i64
+    L.hibag_hip_model_second_pass_pairs.argtypes = [vp]
+    L.hibag_hip_model_second_pass_pairs.restype = i64
     L.hibag_hip_model_mutation_table.argtypes = [vp, vp]
     L.hibag_hip_predict.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.hibag_hip_predict_device.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]

@@ -157,7 +157,8 @@ struct hibag_hip_model {
 
 	// per-batch workspace (grow-only)
 	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias, ws_cells, ws_sync;
-	bool store_cells = false;              // pass 2 reads back the cell sums pass 1 stored (HibagModelView::store_cells)
+	int store_mode = 0;                    // which cell sums pass 1 stores for pass 2 (HibagModelView::store_cells)
+	int64_t second_pass_pairs = 0;         // haplotype pairs per sample pass 2 evaluates again
 	uint32_t epoch = 0;                    // batch counter for the hand-over flags (HibagBatchView::epoch)
 	int *h_err = nullptr;                  // host-mapped error word of the hand-overs
 	// plugin staging
@@ -317,23 +318,28 @@ void build_pair_stream(const HostClassifier &k, int n_hla, int nwp, const int *s
 // (i, i) first on the diagonal cells).  Cells are padded to an even slot count with the classifier's
 // all-zero haplotype `pad` (frequency 0: the slot adds +0.0); the end flag marks the slot that closes
 // a cell; the unused slots behind the last cell point at `pad` too.  (h1, h2) of cell p0 are given; returns the number of blocks.
-int append_pair_blocks(const int *st, int n_hla, int h1, int h2, int n_cells, uint32_t pad, std::vector<uint32_t> &out)
+int append_pair_blocks(const int *st, int n_hla, int h1, int h2, int n_cells, uint32_t pad, std::vector<uint32_t> &out,
+	uint64_t store_above, uint64_t skip_above)
 {
+	// store_above: cells with more pairs carry the STORE flag on their closing slot; skip_above: cells with more
+	// pairs are left out (pass-2 lists: their sums come from memory)
 	const uint32_t pad_idx = pad | (pad << 16);
 	size_t base = 0;
 	int fill = 32, n_blocks = 0;                 // slots used in the open block (32 = none open)
+	uint32_t end_flags = HIBAG_PLIST_END;
 	auto slot = [&](uint32_t idx, bool end) {
 		if (fill == 32) {
 			base = out.size();
 			out.resize(base + HIBAG_PLIST_DWORDS, pad_idx);
 			fill = 0; n_blocks++;
 		}
-		out[base + fill++] = idx | (end ? HIBAG_PLIST_END : 0u);
+		out[base + fill++] = idx | (end ? end_flags : 0u);
 	};
 	for (int c = 0; c < n_cells; c++) {
 		const int a0 = st[h1], a1 = st[h1 + 1], b0 = st[h2], b1 = st[h2 + 1];
 		const uint64_t n = h1 == h2 ? (uint64_t)(a1 - a0) * (a1 - a0 + 1) / 2 : (uint64_t)(a1 - a0) * (b1 - b0);
-		if (n) {
+		if (n && n <= skip_above) {
+			end_flags = HIBAG_PLIST_END | (n > store_above ? HIBAG_PLIST_STORE : 0u);
 			uint64_t i = 0;
 			const uint64_t total = n + (n & 1);
 			if (h1 == h2) {
@@ -394,7 +400,7 @@ int finalize_model(hibag_hip_model *m)
 	std::vector<uint64_t> stream_off(std::max(C, 1), 0), cell_work(P, 0);
 	std::vector<uint32_t> stream;
 	// per classifier: records (haplotype pairs) of every cell, and 4-record chunks of every cell
-	std::vector<std::vector<uint32_t>> cell_chunks(C);
+	std::vector<std::vector<uint32_t>> cell_chunks(C), cell_pairs(C);
 	std::vector<std::vector<int>> starts(C);
 	std::vector<int> engine(std::max(C, 1), 0), bt_row(std::max(C, 1), 0), cls_nblk(std::max(C, 1), 0);
 	std::vector<int> &mfma_nkb = engine;                 // (non-zero = a matrix engine)
@@ -403,6 +409,7 @@ int finalize_model(hibag_hip_model *m)
 	int bt_rows = 0;
 	int rows = 0;
 	m->pair_evals = 0;
+	int64_t valu_pairs = 0;
 	for (int c = 0; c < C; c++) {
 		const HostClassifier &k = m->cls[c];
 		const int H = (int)k.freq.size();
@@ -417,11 +424,12 @@ int finalize_model(hibag_hip_model *m)
 		st.assign(nh + 1, 0);
 		for (int i = 0; i < H; i++) st[k.hla[i] + 1]++;
 		for (int h = 0; h < nh; h++) st[h + 1] += st[h];
-		// matrix-core engines: at most 32 SNPs; table indices: first haplotype < 2H + 1 in 16 bits, second < H + 1 in 15
-		engine[c] = (m->use_mfma && H < 32768) ? HIBAG_ENGINE_OF(k.n_snp, m->use_fp4) : HIBAG_ENGINE_VALU;
+		// matrix-core engines: at most 32 SNPs; table indices: first haplotype < 2H + 1 in 16 bits, second < H + 1 in 14
+		engine[c] = (m->use_mfma && H < 16384) ? HIBAG_ENGINE_OF(k.n_snp, m->use_fp4) : HIBAG_ENGINE_VALU;
 		bt_row[c] = bt_rows;
 		bt_rows += HIBAG_ENGINE_ROWS(engine[c]);
 		cell_chunks[c].assign(P, 0);
+		cell_pairs[c].assign(P, 0);
 		if (mfma_nkb[c]) {
 			// no record stream: the kernels generate the records from the haplotype table
 			hap_off[c] = (uint32_t)hap.size();
@@ -448,6 +456,7 @@ int finalize_model(hibag_hip_model *m)
 					const uint64_t n1 = (uint64_t)(st[h1 + 1] - st[h1]), n2 = (uint64_t)(st[h2 + 1] - st[h2]);
 					const uint64_t n = h1 == h2 ? n1 * (n1 + 1) / 2 : n1 * n2;
 					if (n > 0xFFFFFFull * HIBAG_CHUNK) return fail(HIBAG_HIP_EINVAL, "an allele pair of classifier %d has too many haplotype pairs", c);
+					cell_pairs[c][p] = (uint32_t)n;
 					cell_chunks[c][p++] = (uint32_t)((n + HIBAG_CHUNK - 1) / HIBAG_CHUNK);
 				}
 		} else {
@@ -458,6 +467,7 @@ int finalize_model(hibag_hip_model *m)
 		for (int p = 0; p < P; p++) cell_work[p] += (uint64_t)cell_chunks[c][p] * (nwp[c] + 2);
 		pairs[c] = (int64_t)H * (H + 1) / 2;
 		m->pair_evals += pairs[c];
+		if (!mfma_nkb[c]) valu_pairs += pairs[c];
 		c_order[c] = c;
 	}
 	if (!m->snp_weight_override.empty()) snp_weight = m->snp_weight_override;
@@ -477,10 +487,41 @@ int finalize_model(hibag_hip_model *m)
 			for (int h2 = h1; h2 < nh && t < n_tile; h2++, p++)
 				if (p == tile_p0[t]) { tile_h1[t] = h1; tile_h2[t] = h2; t++; }
 	}
+	// Which cell sums pass 1 stores for pass 2 (HibagModelView::store_cells).  Measured on MI355X: evaluating a haplotype
+	// pair again costs ~0.25 ps per sample, a stored cell ~2.2 ps (written in pass 1, read in pass 2, both at HBM speed).
+	// A model with many pairs per non-empty cell (the DRB1 shape: 73) stores every cell and pass 2 only reads; otherwise
+	// (the HLA-B benchmark model: 8.5) the cells with more than `store_above` pairs of the matrix-engine classifiers are
+	// stored -- 15 % of its cells hold 62 % of its pairs -- and pass 2 evaluates the rest (thresholds 8 .. 16 measure the same;
+	// below, the stores slow pass 1 down more than pass 2 gains).  HIBAG_PASS2 = stream |
+	// hybrid | recompute and HIBAG_STORE_PAIRS override.
+	uint64_t store_above = 12;
+	if (const char *e = getenv("HIBAG_STORE_PAIRS")) store_above = (uint64_t)std::max(0, atoi(e));
+	{
+		long long n_cells = 0, n_big = 0;
+		for (int c = 0; c < C; c++)
+			for (int p = 0; p < P; p++) {
+				n_cells += cell_chunks[c][p] != 0;
+				n_big += mfma_nkb[c] && cell_pairs[c][p] > store_above;
+			}
+		m->store_mode = C == 0 ? 0 : (double)m->pair_evals >= 14.0 * (double)std::max<long long>(n_cells, 1) ? 1 : n_big ? 2 : 0;
+		if (const char *e = getenv("HIBAG_PASS2")) {
+			if (!strcmp(e, "stream")) m->store_mode = C > 0;
+			else if (!strcmp(e, "recompute")) m->store_mode = 0;
+			else if (!strcmp(e, "hybrid")) m->store_mode = n_big ? 2 : 0;
+		}
+	}
+	const int store_mode = m->store_mode;
+	// a cell of a matrix-engine classifier whose sum pass 2 reads instead of evaluating its pairs (mode 2)
+	auto stored_big = [&](int c, int p) { return store_mode == 2 && mfma_nkb[c] && cell_pairs[c][p] > store_above; };
+
 	// pass 1 lists (non-empty cells per classifier) and pass 2 tile entries
 	std::vector<uint32_t> cls_cnt, cls_cell, tile_meta((size_t)std::max(C, 1) * n_tile * HIBAG_TILE_META + 1, 0);
 	std::vector<int> cls_off(std::max(C, 1), 0), cls_n(std::max(C, 1), 0);
-	std::vector<uint32_t> tile_k0((size_t)std::max(C, 1) * n_tile, 0);
+	std::vector<uint32_t> tile_k0((size_t)std::max(C, 1) * n_tile, 0), tile_nlist((size_t)std::max(C, 1) * n_tile, 0),
+		tile_nstored((size_t)std::max(C, 1) * n_tile, 0);
+	std::vector<uint64_t> tile_jpack((size_t)std::max(C, 1) * n_tile, 0);
+	std::vector<int> n_stored_c(std::max(C, 1), 0);        // cells of the classifier pass 1 stores in mode 2
+	m->second_pass_pairs = 0;
 	for (int c = 0; c < C; c++) {
 		cls_off[c] = (int)cls_cnt.size();
 		for (int p = 0; p < P; p++)
@@ -502,8 +543,25 @@ int finalize_model(hibag_hip_model *m)
 				if (n) { jpack |= (uint64_t)j << (4 * k); me[4 + k++] = ((uint32_t)j << 24) | n; off += n; }
 			}
 			me[0] = (uint32_t)k;
-			k_first += k;
 			me[2] = (uint32_t)jpack; me[3] = (uint32_t)(jpack >> 32);
+			{
+				// what pass 2 gets per (classifier, tile): the cells it evaluates (in closing order), then those it reads
+				uint64_t jp = 0;
+				int nl = 0, ns = 0;
+				for (int j = 0; j < tile_n[t]; j++)
+					if (cell_chunks[c][tile_p0[t] + j] && !stored_big(c, tile_p0[t] + j)) {
+						jp |= (uint64_t)j << (4 * nl++);
+						if (store_mode != 1) m->second_pass_pairs += mfma_nkb[c] ? cell_pairs[c][tile_p0[t] + j] : 0;
+					}
+				for (int j = 0; j < tile_n[t]; j++)
+					if (stored_big(c, tile_p0[t] + j)) jp |= (uint64_t)j << (4 * (nl + ns++));
+				tile_jpack[(size_t)c * n_tile + t] = jp;
+				tile_nlist[(size_t)c * n_tile + t] = (uint32_t)nl;
+				tile_nstored[(size_t)c * n_tile + t] = (uint32_t)ns;
+				if (store_mode == 2) tile_k0[(size_t)c * n_tile + t] = (uint32_t)n_stored_c[c];   // first stored row of the tile
+				n_stored_c[c] += ns;
+			}
+			k_first += k;
 			for (int j = 0; j < tile_n[t]; j++)
 				if (!cell_chunks[c][tile_p0[t] + j]) me[4 + k++] = (uint32_t)j << 24;
 		}
@@ -568,29 +626,16 @@ int finalize_model(hibag_hip_model *m)
 	// pair lists of the matrix-core engine.  Pass 2 first, tile-major: the segments (tile t, classifier 0),
 	// (t, 1), ... follow each other, which is the order a pass-2 wavefront reads them in; then, per
 	// classifier, all cells back to back for pass 1 (no block left half empty at a tile boundary).
-	// Pass 2 either evaluates every haplotype pair a second time (from tile-major copies of the pair lists) or reads
-	// back the cell sums pass 1 stored, 8 bytes per sample, classifier and non-empty cell.  Measured on MI355X: a pair
-	// costs ~0.25 ps per sample, a stored cell ~2.2 ps (written in pass 1, read in pass 2, both HBM-bound), so storing pays
-	// from about nine pairs per cell (the HLA-B benchmark model: 8.5, measured break-even; the DRB1 shape: 73).  HIBAG_PASS2 overrides.
-	{
-		long long n_cells = 0;
-		for (int c = 0; c < C; c++) n_cells += cls_n[c];
-		m->store_cells = C > 0 && (double)m->pair_evals >= 14.0 * (double)std::max<long long>(n_cells, 1);
-		if (const char *e = getenv("HIBAG_PASS2")) {
-			if (!strcmp(e, "stream")) m->store_cells = C > 0;
-			else if (!strcmp(e, "recompute")) m->store_cells = false;
-		}
-	}
 	std::vector<uint32_t> plist;
 	std::vector<uint64_t> blk_off(std::max(C, 1), 0), seg_off((size_t)std::max(C, 1) * n_tile, 0);
 	std::vector<uint32_t> seg_nblk((size_t)std::max(C, 1) * n_tile, 0);
 	long long dbg_b1 = 0, dbg_b2 = 0, dbg_seg = 0;
-	for (int t = 0; t < n_tile && !m->store_cells; t++)
+	for (int t = 0; t < n_tile && store_mode != 1; t++)
 		for (int c = 0; c < C; c++) {
 			if (!mfma_nkb[c]) continue;
 			seg_off[(size_t)c * n_tile + t] = plist.size();
 			const int nb = append_pair_blocks(starts[c].data(), nh, tile_h1[t], tile_h2[t], tile_n[t],
-				(uint32_t)m->cls[c].freq.size(), plist);
+				(uint32_t)m->cls[c].freq.size(), plist, ~0ull, store_mode == 2 ? store_above : ~0ull);
 			seg_nblk[(size_t)c * n_tile + t] = (uint32_t)nb;
 			dbg_b2 += nb; dbg_seg += nb > 0;
 		}
@@ -599,17 +644,20 @@ int finalize_model(hibag_hip_model *m)
 	for (int c = 0; c < C; c++) {
 		if (!mfma_nkb[c]) continue;
 		blk_off[c] = plist.size();
-		cls_nblk[c] = append_pair_blocks(starts[c].data(), nh, 0, 0, P, (uint32_t)m->cls[c].freq.size(), plist);
+		cls_nblk[c] = append_pair_blocks(starts[c].data(), nh, 0, 0, P, (uint32_t)m->cls[c].freq.size(), plist,
+			store_mode == 1 ? 0 : store_mode == 2 ? store_above : ~0ull, ~0ull);
 		dbg_b1 += cls_nblk[c];
 		uint32_t closed = 0;
-		for (int b = 0; b < cls_nblk[c] && m->store_cells; b++) {
+		for (int b = 0; b < cls_nblk[c] && store_mode; b++) {      // stored cells closed before block b
 			blk_close.push_back(closed);
-			for (int i = 0; i < HIBAG_PLIST_DWORDS; i++) closed += plist[blk_off[c] + (size_t)b * HIBAG_PLIST_DWORDS + i] >> 31;
+			for (int i = 0; i < HIBAG_PLIST_DWORDS; i++) closed += (plist[blk_off[c] + (size_t)b * HIBAG_PLIST_DWORDS + i] >> 30) & 1u;
 		}
 	}
 	if (blk_close.empty()) blk_close.push_back(0);
 	std::vector<int> cell_row((size_t)C + 1, 0);
-	for (int c = 0; c < C; c++) cell_row[c + 1] = cell_row[c] + (m->store_cells || split_row[c] >= 0 ? cls_n[c] : 0);
+	for (int c = 0; c < C; c++)
+		cell_row[c + 1] = cell_row[c] + (store_mode == 1 || split_row[c] >= 0 ? cls_n[c] : store_mode == 2 ? n_stored_c[c] : 0);
+	m->second_pass_pairs += store_mode == 1 ? 0 : valu_pairs;
 	if (getenv("HIBAG_DEBUG_MODEL"))
 		fprintf(stderr, "[hibag model] %d classifiers, %d tiles, pairs %lld; blocks of 32: pass 1 %lld, pass 2 %lld in %lld (classifier, tile) segments; "
 			"pair lists %.1f MB, haplotype table %.1f KB, VALU-engine stream %.1f MB\n",
@@ -623,11 +671,14 @@ int finalize_model(hibag_hip_model *m)
 			const uint32_t *me = &tile_meta[((size_t)c * n_tile + t) * HIBAG_TILE_META];
 			const uint64_t off = seg_off[(size_t)c * n_tile + t];
 			if (bt_row[c] > 0xFFFF) return fail(HIBAG_HIP_EINVAL, "too many classifiers for the matrix engine's operand rows");
-			r[0] = (uint32_t)mfma_nkb[c] | ((uint32_t)n_snp_c[c] << 2 & 0xFCu) | (me[0] << 8) | ((uint32_t)bt_row[c] << 16);
+			(void)me;
+			r[0] = (uint32_t)mfma_nkb[c] | ((uint32_t)n_snp_c[c] << 2 & 0xFCu) | (tile_nlist[(size_t)c * n_tile + t] << 8) | ((uint32_t)bt_row[c] << 16);
 			r[1] = hap_off[c];
 			r[2] = (uint32_t)off; r[3] = (uint32_t)(off >> 32);
 			r[4] = seg_nblk[(size_t)c * n_tile + t];
-			r[5] = tile_k0[(size_t)c * n_tile + t]; r[6] = me[2]; r[7] = me[3];
+			if (tile_k0[(size_t)c * n_tile + t] >> 27) return fail(HIBAG_HIP_EINVAL, "classifier %d has too many allele pairs", c);
+			r[5] = tile_k0[(size_t)c * n_tile + t] | (tile_nstored[(size_t)c * n_tile + t] << 27);
+			r[6] = (uint32_t)tile_jpack[(size_t)c * n_tile + t]; r[7] = (uint32_t)(tile_jpack[(size_t)c * n_tile + t] >> 32);
 		}
 
 	// cost prefix sums of pass 2 (where the launcher cuts an item into chunks), in quarter-blocks: a matrix-engine visit costs its blocks
@@ -637,7 +688,7 @@ int finalize_model(hibag_hip_model *m)
 	for (int t = 0; t < n_tile; t++) {
 		uint64_t sum = 0;
 		for (int c = 0; c < C; c++) {
-			uint64_t cost = 3;
+			uint64_t cost = 3 + tile_nstored[(size_t)c * n_tile + t];
 			if (mfma_nkb[c]) cost += 4ull * seg_nblk[(size_t)c * n_tile + t];
 			else {
 				uint64_t chunks = 0;
@@ -719,7 +770,7 @@ int finalize_model(hibag_hip_model *m)
 	V.blk_close = (const uint32_t *)(tbase + tb_close);
 	V.p1_base = p1_base;
 	V.cell_row = base + o_crow;
-	V.store_cells = m->store_cells ? 1 : 0;
+	V.store_cells = store_mode;
 	m->cell_rows = cell_row[C];
 	V.plist = m->d_blk.as<uint32_t>();
 	V.plist_dwords = plist.size();
@@ -1105,7 +1156,12 @@ int64_t hibag_hip_model_pair_evals(const hibag_hip_model *m)
 
 int64_t hibag_hip_model_stored_cells(const hibag_hip_model *m)
 {
-	return m && m->finalized && m->store_cells ? (int64_t)m->cell_rows : 0;
+	return m && m->finalized && m->store_mode ? (int64_t)m->cell_rows : 0;
+}
+
+int64_t hibag_hip_model_second_pass_pairs(const hibag_hip_model *m)
+{
+	return m && m->finalized ? m->second_pass_pairs : 0;
 }
 
 int hibag_hip_model_mutation_table(const hibag_hip_model *m, double *out)

@@ -32,14 +32,16 @@
 //    of a pair (the reference's `ff = 2 * f1`, then `ff * f2`).  Entries H+1 .. 2H repeat the haplotypes
 //    with ff = f: the leading diagonal pair (i, i) of a cell (h, h), whose factor is f * f, is listed as
 //    (H + 1 + i, i).  Entry H is all zero and serves the padding slots.  The records are 4-byte
-//    words  i1 | i2 << 16 | end << 31  (end = this slot closes a cell; i2 < 2^15), in BLOCKS of 32 slots
+//    words  i1 | i2 << 16 | store << 30 | end << 31  (end = this slot closes a cell, store = pass 1 keeps the cell's
+//    sum for pass 2; i2 < 2^14), in BLOCKS of 32 slots
 //    (128 bytes); unused trailing slots of a segment's last block point at the zero entry.
 //    Each lane builds its record's A-operand rows from the two images (element-wise sum and AND)
 //    and the frequency factor ff[i1] * f[i2] -- one multiplication, rounded like the reference's
 //    (src/LibHLA.cpp:1786-1813) -- itself.  Cells are
 //    padded to an even slot count.  Two lists: all cells of a classifier back to back
 //    (pass 1), and per (tile, classifier) segments stored tile-major (pass 2: a wavefront
-//    walks one tile's segments classifier after classifier through contiguous memory).
+//    walks one tile's segments classifier after classifier through contiguous memory); the pass-2
+//    segments leave out the cells whose sums pass 1 stores (those with many pairs).
 //
 //  BATCH ("lane = sample": consecutive samples are consecutive addresses, so
 //  every per-lane access is one coalesced row segment of a wavefront):
@@ -71,7 +73,8 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 #define HIBAG_CHUNK_DWORDS(nwp) (HIBAG_CHUNK * ((nwp) + 2))
 // dwords of one 32-slot block of a pair list (matrix-core engine)
 #define HIBAG_PLIST_DWORDS 32
-#define HIBAG_PLIST_END 0x80000000u   // slot flag: closes a cell
+#define HIBAG_PLIST_END 0x80000000u
+#define HIBAG_PLIST_STORE 0x40000000u        // with END: pass 1 stores this cell's sum for pass 2 to read back
 // Matrix-engine variants (HibagModelView::engine[c]; 0 = VALU engine) and their haplotype-table entries:
 //   FP4  (up to 28 SNPs)  v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands: one instruction per sample half covers all
 //                         K = 64 positions.  Entry = { N[16] (nibble s = 2, the code of 1.0, where bit s is set), ff, f }: 8 dwords
@@ -150,14 +153,18 @@ struct HibagModelView {
 	const uint32_t *plist;       // pair lists: blocks of HIBAG_PLIST_DWORDS dwords
 	uint64_t plist_dwords;       // total size (a raw buffer is rebased per classifier / tile segment: no 4 GB limit)
 	const uint32_t *ctile;       // [C][n_tile][8]: everything pass 2 needs per (classifier, tile) in one s_load_dwordx8:
-	                             // {engine | k << 2 | #non-empty cells << 8 | bt_row << 16, dword offset of the first haplotype-table entry,
-	                             //  pair list dword offset lo/hi, #blocks, 0, row list lo/hi}
+	                             // {engine | k << 2 | #listed cells << 8 | bt_row << 16, dword offset of the first haplotype-table entry,
+	                             //  pair list dword offset lo/hi, #blocks, first stored row | #stored cells << 27, row list lo/hi}
+	                             // row list: 4 bits per cell -- the listed (evaluated) cells in closing order, then the stored ones
 
-	// stored cells: rows of HibagBatchView::cells.  store_cells = 1: pass 1 writes every cell sum and pass 2 reads
-	// them back (models with many haplotype pairs per cell, where that is cheaper than evaluating every pair again);
-	// 0: only a split classifier has rows (for k_total_scan), pass 2 evaluates the pairs again from its tile-major lists
+	// stored cells: rows of HibagBatchView::cells.  Evaluating a haplotype pair again in pass 2 costs ~0.25 ps per sample,
+	// writing a cell sum in pass 1 and reading it back ~2.2 ps, so a cell with more than ~8 pairs is better stored.
+	//   store_cells = 1: every cell of every classifier (models with many pairs per cell; pass 2 = k_accum_cells);
+	//   store_cells = 2: the cells with many pairs of the matrix-engine classifiers (pass 2 = k_accum: the small cells from
+	//                    their tile-major lists, the stored ones from memory);
+	//   store_cells = 0: none (only a split VALU-engine classifier has rows, for k_total_scan).
 	int store_cells;
-	const int *cell_row;         // [C + 1] first row of the classifier (one row per non-empty cell, in cls_cell order)
+	const int *cell_row;         // [C + 1] first row of the classifier (one row per stored cell, in cell order)
 	const uint32_t *blk_close;   // per pass-1 block: cells closed in the classifier's earlier blocks (where a chunk resumes)
 	uint64_t p1_base;            // dword offset of the first pass-1 list in plist (block number = (offset - p1_base) / 32)
 

@@ -271,7 +271,7 @@ __device__ __forceinline__ void block_own_sample(v16i &D0, v16i &D1, int n_valid
 }
 
 // cell += prod_i * TAB[d_i] for the first n_valid records of a block, in order;
-// `fin(cell)` at every record that closes a cell (end mask; cells are padded to
+// `fin(cell, stored)` at every record that closes a cell (end mask, store mask; cells are padded to
 // an even number of records, so only odd positions can close one).  Per group of
 // 8 records: 8 table look-ups (per-lane LDS gathers) and the 8 frequency factors
 // (4 wave-uniform 16-byte LDS reads, broadcast to all lanes) are in flight before
@@ -281,7 +281,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // G = records whose table look-ups and factors are in flight together: 8 in pass 2, 4 in pass 1 (12 registers
 // less: 96 instead of 109, a fifth wavefront per SIMD; measured -3 % on pass 1, +3 % on pass 2).
 template <int G, class Fin>
-__device__ __forceinline__ void block_accumulate(const double *stage, uint32_t endmask, int n_valid,
+__device__ __forceinline__ void block_accumulate(const double *stage, uint32_t endmask, uint32_t storemask, int n_valid,
 	const v16i &D0, const v16i &D1, double &cell, const double *tab_s, Fin &&fin)
 {
 #pragma unroll
@@ -310,7 +310,7 @@ __device__ __forceinline__ void block_accumulate(const double *stage, uint32_t e
 #pragma unroll
 		for (int q = 0; q < G; q++) {
 			cell += pv[q >> 1][q & 1] * t[q];
-			if ((q & 1) && (endmask & (1u << (G * g + q)))) { fin(cell); cell = 0; }
+			if ((q & 1) && (endmask & (1u << (G * g + q)))) { fin(cell, (storemask & (1u << (G * g + q))) != 0); cell = 0; }
 		}
 	}
 }
@@ -384,7 +384,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 	uint32_t idx_c = cur.idx, idx_n = cur.idx_n;
 	// One address per haplotype: entry * size + this lane's offset into the image.  The factors are read FO / FO + 8
 	// bytes behind it, which is right for lanes 0..31 (image offset 0) -- the only ones whose factors are used.
-	uint32_t o1 = (idx_c & 0xFFFFu) * ES + img, o2 = ((idx_c >> 16) & 0x7FFFu) * ES + img;
+	uint32_t o1 = (idx_c & 0xFFFFu) * ES + img, o2 = ((idx_c >> 16) & 0x3FFFu) * ES + img;
 	v4i e1 = load_hap_image(hp, o1), e2 = load_hap_image(hp, o2);
 	double ff = load_hap_factor<FO>(hp, o1, 0), f2 = load_hap_factor<FO>(hp, o2, 1);
 	for (int b = 0; b < nblk; b++) {
@@ -393,11 +393,12 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 		const v4i a1 = e1, a2 = e2;
 		const double prod = ff * f2;
 		const uint32_t endmask = (uint32_t)__ballot((idx_c & HIBAG_PLIST_END) != 0);          // lanes 32..63 mirror 0..31
+		const uint32_t storemask = (uint32_t)__ballot((idx_c & HIBAG_PLIST_STORE) != 0);      // (only pass 1 looks at it)
 		const uint32_t live = endmask | (uint32_t)__ballot(prod != 0.0);                      // low half: lanes 0..31
 		const int n_valid = live ? 32 - __builtin_clz(live) : 0;
 		// look-ahead: entries of block b+1, slot words of block b+2
 		idx_c = idx_n;
-		o1 = (idx_c & 0xFFFFu) * ES + img; o2 = ((idx_c >> 16) & 0x7FFFu) * ES + img;
+		o1 = (idx_c & 0xFFFFu) * ES + img; o2 = ((idx_c >> 16) & 0x3FFFu) * ES + img;
 		e1 = load_hap_image(hp, o1); e2 = load_hap_image(hp, o2);
 		ff = load_hap_factor<FO>(hp, o1, 0); f2 = load_hap_factor<FO>(hp, o2, 1);
 		idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + 2 * BB, 0);
@@ -406,7 +407,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 			v16i D0, D1;
 			block_mfma<ENG>(a1, a2, lane, cterm, T, D0, D1);
 			block_own_sample(D0, D1, n_valid);
-			block_accumulate<G>(buf, endmask, n_valid, D0, D1, cell, tab_s, fin);
+			block_accumulate<G>(buf, endmask, storemask, n_valid, D0, D1, cell, tab_s, fin);
 		}
 		soff += BB;
 	}
@@ -863,7 +864,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 5) void k_total(HibagModelView M, Hi
 	if (live) {
 		double total = 0;
 		const bool split = M.n_split > 0 && M.split_row[c] >= 0;    // a split classifier: k_total_scan adds its cells in order
-		double *__restrict__ rows = STORE || split ? cell_rows(M, B, c, group) : nullptr;   // this classifier's cell sums, one row each
+		// this classifier's stored cell sums, one row each (a VALU-engine classifier stores all or none)
+		double *__restrict__ rows = (STORE && (nkb > 0 || M.store_cells == 1)) || split ? cell_rows(M, B, c, group) : nullptr;
 		if (nkb > 0) {
 			double cell = 0;
 			if (!first) { total = load_parked(&B.tot[at]); cell = load_parked(&B.inv[at]); }
@@ -872,8 +874,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 5) void k_total(HibagModelView M, Hi
 			const int lane = threadIdx.x & 63;
 			// (a store issued where the cell closes; parking the sums in LDS and sending them a block later, so that
 			// the vmcnt waits of the look-ahead gathers never include a young store, measured 10 % slower)
-			auto fin = [&](double v) {
-				if (STORE) { __builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++; }
+			auto fin = [&](double v, bool stored) {
+				if (STORE && stored) { __builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++; }
 				total += v;
 				asm("" : "+v"(total));                    // keeps the cell end a scalar branch
 			};
@@ -899,7 +901,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 5) void k_total(HibagModelView M, Hi
 }
 
 // k_total_scan: the in-order total of a split classifier from its stored cell sums; thread = sample.
-// Eight loads in flight, then the eight additions in cell order (with one dependent load per addition the
+// Sixteen loads in flight, then the sixteen additions in cell order (with one dependent load per addition the
 // kernel would be pure memory latency: a few hundred cells, one wavefront per 64 samples).
 __global__ void k_total_scan(HibagModelView M, HibagBatchView B)
 {
@@ -910,12 +912,12 @@ __global__ void k_total_scan(HibagModelView M, HibagBatchView B)
 	const int n = M.cls_n[c];
 	double total = 0;
 	int i = 0;
-	for (; i + 8 <= n; i += 8) {
-		double v[8];
+	for (; i + 16 <= n; i += 16) {
+		double v[16];
 #pragma unroll
-		for (int j = 0; j < 8; j++) v[j] = rows[(size_t)(i + j) * HIBAG_WAVE];
+		for (int j = 0; j < 16; j++) v[j] = rows[(size_t)(i + j) * HIBAG_WAVE];
 #pragma unroll
-		for (int j = 0; j < 8; j++) total += v[j];
+		for (int j = 0; j < 16; j++) total += v[j];
 	}
 	for (; i < n; i++) total += rows[(size_t)i * HIBAG_WAVE];
 	B.tot[(size_t)c * B.n_pad + s] = total;
@@ -1008,51 +1010,98 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 	}
 
 	// Everything classifier c+1 needs that does not cost many registers is requested while
-	// classifier c is evaluated: its (classifier, tile) record (one s_load_dwordx8) and the
-	// lane's weight and 1/total.  Without this every classifier starts with a chain of
-	// dependent scalar and vector loads (~3000 cycles per classifier, measured with stamps).
+	// classifier c is evaluated: the lane's weight and 1/total, and the cell sums pass 1 stored for this tile
+	// (the cells with many haplotype pairs, which are not in the pair list: HibagModelView::store_cells == 2); its
+	// (classifier, tile) record (one s_load_dwordx8) and the position of its stored cells are requested TWO classifiers
+	// ahead, because the requests for the stored cells need them.  Without this every classifier starts with a chain
+	// of dependent scalar and vector loads (~3000 cycles per classifier, measured with stamps).
 	typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 	const u32x8 *__restrict__ ct = reinterpret_cast<const u32x8 *>(M.ctile) + tile;
+	const size_t n_group_z = (size_t)n_group;
+	constexpr int NS = 4;                             // stored cells of the next classifier kept in registers (more are rare)
+	double sv[NS];
+	// first stored cell of classifier c for this tile and sample group; rec5 = first row | #cells << 27
+	auto stored_row = [&](int row0, int row1, uint32_t rec5) {
+		return B.cells + ((size_t)row0 * n_group_z + (size_t)group * (size_t)(row1 - row0) + (rec5 & 0x7FFFFFFu)) * HIBAG_WAVE + lane;
+	};
+	auto request_stored = [&](int row0, int row1, uint32_t rec5) {
+		const int n = (int)(rec5 >> 27);
+		if (n == 0) return;
+		const double *__restrict__ src = stored_row(row0, row1, rec5);
+#pragma unroll
+		for (int i = 0; i < NS; i++) sv[i] = __builtin_nontemporal_load(src + (size_t)(i < n ? i : n - 1) * HIBAG_WAVE);
+	};
+	const int c_last = C - 1;
 	u32x8 rec_n = ct[(size_t)cb * M.n_tile];
+	int row0_n = M.cell_row[cb], row1_n = M.cell_row[cb + 1];
+	u32x8 rec_nn = ct[(size_t)(cb < c_last ? cb + 1 : c_last) * M.n_tile];
+	int row0_nn = row1_n, row1_nn = M.cell_row[(cb < c_last ? cb + 1 : c_last) + 1];
 	double w_n = B.cw[(size_t)cb * B.n_pad + s], inv_n = B.inv[(size_t)cb * B.n_pad + s];
+	request_stored(row0_n, row1_n, rec_n[5]);
 	ListCursor cur;                                   // the list look-ahead carries over from classifier to classifier
 	for (int c = cb; c < ce; c++) {
 		const u32x8 rec = rec_n;
+		const int row0 = row0_n, row1 = row1_n;
 		const double w = w_n, inv = inv_n;
+		rec_n = rec_nn; row0_n = row0_nn; row1_n = row1_nn;
 		{
-			const int cn = (c + 1 < C) ? c + 1 : c;
-			rec_n = ct[(size_t)cn * M.n_tile];
+			const int cn = (c + 1 < C) ? c + 1 : c, cnn = (c + 2 < C) ? c + 2 : c_last;
+			rec_nn = ct[(size_t)cnn * M.n_tile];
+			row0_nn = M.cell_row[cnn]; row1_nn = M.cell_row[cnn + 1];
 			w_n = B.cw[(size_t)cn * B.n_pad + s];
 			inv_n = B.inv[(size_t)cn * B.n_pad + s];
 		}
 		__builtin_amdgcn_sched_barrier(0);            // keep the requests above at the top of the iteration
 		const bool active = w > 0;
-		if (__ballot(active) == 0) continue;
-		const bool poison = __ballot(active && !(fabs(inv) <= 1.79769313486231570815e+308)) != 0;
+		const bool any = __ballot(active) != 0;
 		const int nkb = (int)(rec[0] & 3u);
+		// inactive lanes (weight 0) must keep their sums: with 1/total replaced by 0 their term is
+		// (cell * 0) * 0 = +0 and a + 0 == a, which spares a select per closed cell
+		const double inv_e = active ? inv : 0.0;
+		// row numbers of the tile's cells, 4 bits each: the listed ones in closing order, then the stored ones
+		uint64_t jpack = ((uint64_t)rec[7] << 32) | rec[6];
+		const int n_stored = (int)(rec[5] >> 27);
+		if (any && n_stored > 0) {
+			// the stored cells of this classifier (requested while the previous one was evaluated):
+			// S[p] += (cell * (1/total)) * w
+			uint64_t jps = jpack >> (4 * (int)((rec[0] >> 8) & 31u));
+#pragma unroll
+			for (int i = 0; i < NS; i++) {
+				if (i >= n_stored) break;
+				__hip_atomic_fetch_add(&acc[(int)(jps & 15)][lane], (sv[i] * inv_e) * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				jps >>= 4;
+			}
+			if (n_stored > NS) {                          // more than the registers hold: fetched here
+				const double *__restrict__ src = stored_row(row0, row1, rec[5]);
+				for (int i = NS; i < n_stored; i++) {
+					const double v = __builtin_nontemporal_load(src + (size_t)i * HIBAG_WAVE);
+					__hip_atomic_fetch_add(&acc[(int)(jps & 15)][lane], (v * inv_e) * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					jps >>= 4;
+				}
+			}
+		}
+		if (c + 1 < C) request_stored(row0_n, row1_n, rec_n[5]);
+		if (!any) continue;
+		const bool poison = __ballot(active && !(fabs(inv) <= 1.79769313486231570815e+308)) != 0;
 		if (nkb > 0) {
-			// Cells close in the order of the tile's non-empty entries; their row numbers j come
+			// Cells close in the order of the tile's listed entries; their row numbers j come
 			// packed 4 bits each in two SGPRs, so closing a cell needs no memory access.
-			uint64_t jpack = ((uint64_t)rec[7] << 32) | rec[6];
-			// inactive lanes (weight 0) must keep their sums: with 1/total replaced by 0 their term is
-			// (cell * 0) * 0 = +0 and a + 0 == a, which spares a select per closed cell
-			const double inv_e = active ? inv : 0.0;
 			// S[p] += v as one LDS floating-point add (ds_add_f64: the same IEEE addition, no register for the old
 			// sum, nothing to wait for)
-			auto fin = [&](double cell) {
+			auto fin = [&](double cell, bool) {
 				const double v = (cell * inv_e) * w;
 				__hip_atomic_fetch_add(&acc[(int)(jpack & 15)][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				jpack >>= 4;
 			};
 #define CALL(E) { LaneOperand T; load_operand_row<E>(B, (int)(rec[0] >> 16), c, group, lane, T);                          \
 			double cell = 0;                                                                                            \
-			walk_blocks<E, 8>(M, ((uint64_t)rec[3] << 32) | rec[2], (int)rec[4], lane, cur, hap_rsrc(M, rec[1]),        \
+			walk_blocks<E, 4>(M, ((uint64_t)rec[3] << 32) | rec[2], (int)rec[4], lane, cur, hap_rsrc(M, rec[1]),        \
 				(int)((rec[0] >> 2) & 63u), T, tab_s, stage_s[wave], cell, fin); }
-			HIBAG_DISPATCH_ENGINE(nkb, CALL)
+			if (rec[4] > 0) { HIBAG_DISPATCH_ENGINE(nkb, CALL) }
 #undef CALL
 			if (poison) {                                // empty cells: (0 * inv) * w is NaN where inv is not finite
 				const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + tile) * HIBAG_TILE_META;
-				for (int i = (int)((rec[0] >> 8) & 31u); i < ncell; i++) {
+				for (int i = (int)meta[0]; i < ncell; i++) {
 					const double v = (0.0 * inv) * w;
 					acc[meta[4 + i] >> 24][lane] += active ? v : 0.0;
 				}
@@ -1207,7 +1256,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_vote_best(HibagModelView M
 		// so the winner is remembered by its position in that list
 		double best = 0;
 		int best_i = -1, i = 0;
-		auto fin = [&](double cell) {
+		auto fin = [&](double cell, bool) {
 			const double prob = cell * inv;
 			if (best < prob) { best = prob; best_i = i; }
 			i++;
@@ -1475,7 +1524,7 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 
 void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStream_t st)
 {
-	if (M.store_cells && M.n_classifier > 0) {         // pass 1 stored the cells: read them back
+	if (M.store_cells == 1 && M.n_classifier > 0) {    // pass 1 stored every cell: read them back
 		const unsigned groups_x = (unsigned)((B.n_pad / HIBAG_WAVE + 7) / 8), tq = (unsigned)((M.n_tile + CELLS_WAVES - 1) / CELLS_WAVES);
 		hipLaunchKernelGGL(k_accum_cells, dim3(8 * groups_x * tq), dim3(CELLS_WAVES * HIBAG_WAVE), 0, st, M, B);
 		return;

@@ -113,8 +113,12 @@ class HlaAttrBagClass:
         return int(_lib.lib().hibag_hip_model_pair_evals(self.handle))
 
     def stored_cells(self) -> int:
-        """Cell sums per sample that pass 1 stores for pass 2 to read back (0: pass 2 evaluates every pair again)."""
+        """Cell sums per sample that pass 1 stores for pass 2 to read back."""
         return int(_lib.lib().hibag_hip_model_stored_cells(self.handle))
+
+    def second_pass_pairs(self) -> int:
+        """Haplotype pairs per sample that pass 2 evaluates again (those of the cells that are not stored)."""
+        return int(_lib.lib().hibag_hip_model_second_pass_pairs(self.handle))
 
     def mutation_table(self) -> np.ndarray:
         t = np.empty(257, np.float64)

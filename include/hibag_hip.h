@@ -97,10 +97,12 @@ int hibag_hip_model_n_snp(const hibag_hip_model *m);
 int hibag_hip_model_n_classifier(const hibag_hip_model *m);
 /* sum over classifiers of H_c(H_c+1)/2: haplotype-pair evaluations per sample */
 int64_t hibag_hip_model_pair_evals(const hibag_hip_model *m);
-/* How a finalized model runs its second pass: > 0 = pass 1 stores that many cell sums per sample (8 bytes each: one
- * per classifier and allele pair with at least one haplotype pair) and pass 2 reads them back; 0 = pass 2 evaluates
- * every haplotype pair a second time.  Chosen at finalize from pairs per cell. */
+/* How a finalized model runs its second pass: pass 1 stores `stored_cells` cell sums per sample
+ * (8 bytes each: a classifier's sum over the haplotype pairs of one allele pair) that pass 2 reads back, and pass 2
+ * evaluates `second_pass_pairs` haplotype pairs per sample again.  All cells / no pairs for models with many pairs per
+ * cell; otherwise the cells with many pairs are stored and the pairs of the others evaluated. */
 int64_t hibag_hip_model_stored_cells(const hibag_hip_model *m);
+int64_t hibag_hip_model_second_pass_pairs(const hibag_hip_model *m);
 /* the 257-entry mutation/error table the device uses, exp(d*log(1e-5))
  * (src/LibHLA.cpp:166-183); out[257] */
 int hibag_hip_model_mutation_table(const hibag_hip_model *m, double *out);

@@ -81,7 +81,9 @@ def test_chunked_work_items_equal_the_oracle(hib, oracle):
     model, founders, af = synth.make_model("hla-b")
     n = 3400
     G, truth = synth.make_samples(founders, af, n, seed=77)
-    assert hib.hlaModelFromObj(model).stored_cells() == 0  # 8.5 pairs per cell: pass 2 evaluates the pairs again
+    probe = hib.hlaModelFromObj(model)                     # 8.5 pairs per cell: the cells with many pairs are stored, the others evaluated again
+    assert 0 < probe.stored_cells() < 20_000 and 0 < probe.second_pass_pairs() < probe.pair_evals()
+    probe.close()
     G[5, :] = hib.NA_INTEGER
     G[64:128, :] = hib.NA_INTEGER                         # a whole wavefront without any genotype
     G[200:264, ::2] = hib.NA_INTEGER
@@ -101,7 +103,7 @@ def test_cfg4_hla_drb1_full_model_against_oracle(hib, oracle):
     model, founders, af = synth.make_model("hla-drb1")
     G, truth = synth.make_samples(founders, af, 2048)
     m = hib.hlaModelFromObj(model)
-    assert m.stored_cells() > 0                            # 73 pairs per cell: pass 1 stores the cell sums, pass 2 reads them back
+    assert m.stored_cells() > 0 and m.second_pass_pairs() == 0   # 73 pairs per cell: pass 1 stores every cell sum, pass 2 reads them back
     got = m.predict_raw(G, 1, want_dosage=True, want_prob=True)
     m.close()
     assert np.mean((got["h1"] == truth[:, 0]) & (got["h2"] == truth[:, 1])) > 0.9

@@ -303,14 +303,17 @@ def test_both_engines_give_the_same_bits(hib, oracle, monkeypatch):
     assert_same({k: v[:96] for k, v in a.items()}, oracle.predict(oracle.flatten(model), G[:96], avx2=True, n_threads=8))
 
 
-@pytest.mark.parametrize("mode", ["stream", "recompute"])
-def test_both_forms_of_pass_two(hib, oracle, monkeypatch, mode):
-    """Pass 2 either reads back the cell sums pass 1 stored or evaluates every haplotype pair again; the model picks
-    by pairs per cell (hibag_hip_model_stored_cells).  Both forms forced on models of every engine and width, on
+@pytest.mark.parametrize("mode", ["stream", "hybrid", "recompute"])
+def test_all_forms_of_pass_two(hib, oracle, monkeypatch, mode):
+    """Pass 2 reads back the cell sums pass 1 stored (all of them, or those of the cells with many pairs) and evaluates
+    the haplotype pairs of the other cells again; the model picks by pairs per cell (hibag_hip_model_stored_cells,
+    hibag_hip_model_second_pass_pairs).  Every form forced on models of every engine and width, on
     underflowing totals (NaN propagation through empty cells) and on unused classifiers: the same bits as the oracle."""
     from hibag_amd import synth
     from hibag_amd.model import Classifier, HlaAttrBagObj
     monkeypatch.setenv("HIBAG_PASS2", mode)
+    if mode == "hybrid":
+        monkeypatch.setenv("HIBAG_STORE_PAIRS", "3")      # cells with more than 3 haplotype pairs are stored
     ks = list(range(1, 41)) + [63, 64, 65, 66, 96, 127, 128]
     model, founders, af = synth.make_model("hla-a-small", seed=77, n_classifier=len(ks), n_snp=160,
                                            snp_counts=ks, wide_classifier=False)
@@ -318,7 +321,8 @@ def test_both_forms_of_pass_two(hib, oracle, monkeypatch, mode):
     G[3, :] = hib.NA_INTEGER
     G[64:128, :] = hib.NA_INTEGER                        # a whole wavefront that uses no classifier
     m = hib.hlaModelFromObj(model)
-    assert (m.stored_cells() > 0) == (mode == "stream")
+    assert (m.stored_cells() > 0) == (mode != "recompute")
+    assert (m.second_pass_pairs() == 0) == (mode == "stream")
     assert_same(m.predict_raw(G, 1, want_dosage=True, want_prob=True),
                 oracle.predict(oracle.flatten(model), G, avx2=True, n_threads=8))
     # the benchmark shape incl. its 100-SNP classifier, more work items than resident workgroups (chunked items)
