@@ -317,12 +317,12 @@ void build_pair_stream(const HostClassifier &k, int n_hla, int nwp, const int *s
 // cell is the reference's (src/LibHLA.cpp:1776-1821: i1 ascending, then i2; the leading diagonal pair
 // (i, i) first on the diagonal cells).  Cells are padded to an even slot count with the classifier's
 // all-zero haplotype `pad` (frequency 0: the slot adds +0.0); the end flag marks the slot that closes
-// a cell; the unused slots behind the last cell point at `pad` too.  (h1, h2) of cell p0 are given; returns the number of blocks.
-int append_pair_blocks(const int *st, int n_hla, int h1, int h2, int n_cells, uint32_t pad, std::vector<uint32_t> &out,
-	uint64_t store_above, uint64_t skip_above)
+// a cell; the unused slots behind the last cell point at `pad` too.  (h1, h2) of the first cell p0 are given; returns the number of blocks.
+int append_pair_blocks(const int *st, int n_hla, int h1, int h2, int p0, int n_cells, uint32_t pad, std::vector<uint32_t> &out,
+	const uint8_t *mark, const uint8_t *skip)
 {
-	// store_above: cells with more pairs carry the STORE flag on their closing slot; skip_above: cells with more
-	// pairs are left out (pass-2 lists: their sums come from memory)
+	// mark[p]: the closing slot of cell p carries the STORE flag; skip[p]: cell p is left out (pass-2 lists: its sum
+	// comes from memory); both indexed by posterior cell, either may be null
 	const uint32_t pad_idx = pad | (pad << 16);
 	size_t base = 0;
 	int fill = 32, n_blocks = 0;                 // slots used in the open block (32 = none open)
@@ -338,8 +338,8 @@ int append_pair_blocks(const int *st, int n_hla, int h1, int h2, int n_cells, ui
 	for (int c = 0; c < n_cells; c++) {
 		const int a0 = st[h1], a1 = st[h1 + 1], b0 = st[h2], b1 = st[h2 + 1];
 		const uint64_t n = h1 == h2 ? (uint64_t)(a1 - a0) * (a1 - a0 + 1) / 2 : (uint64_t)(a1 - a0) * (b1 - b0);
-		if (n && n <= skip_above) {
-			end_flags = HIBAG_PLIST_END | (n > store_above ? HIBAG_PLIST_STORE : 0u);
+		if (n && !(skip && skip[p0 + c])) {
+			end_flags = HIBAG_PLIST_END | (mark && mark[p0 + c] ? HIBAG_PLIST_STORE : 0u);
 			uint64_t i = 0;
 			const uint64_t total = n + (n & 1);
 			if (h1 == h2) {
@@ -511,8 +511,24 @@ int finalize_model(hibag_hip_model *m)
 		}
 	}
 	const int store_mode = m->store_mode;
+	// stored[c][p]: pass 1 stores the sum of cell p of classifier c.  Mode 2: the cells of a matrix-engine classifier with
+	// more than `store_above` pairs, at most HIBAG_STORED_PER_VISIT per (classifier, tile) -- the ones with the most pairs --
+	// which is what pass 2 keeps in registers for a visit; mode 1: every non-empty cell.
+	std::vector<std::vector<uint8_t>> stored(C);
+	for (int c = 0; c < C; c++) {
+		stored[c].assign(P, 0);
+		if (store_mode == 1) { for (int p = 0; p < P; p++) stored[c][p] = cell_chunks[c][p] != 0; }
+		else if (store_mode == 2 && mfma_nkb[c])
+			for (int t = 0; t < n_tile; t++) {
+				std::vector<std::pair<uint32_t, int>> big;
+				for (int j = 0; j < tile_n[t]; j++)
+					if (cell_pairs[c][tile_p0[t] + j] > store_above) big.push_back({cell_pairs[c][tile_p0[t] + j], tile_p0[t] + j});
+				std::stable_sort(big.begin(), big.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+				for (size_t i = 0; i < big.size() && i < HIBAG_STORED_PER_VISIT; i++) stored[c][big[i].second] = 1;
+			}
+	}
 	// a cell of a matrix-engine classifier whose sum pass 2 reads instead of evaluating its pairs (mode 2)
-	auto stored_big = [&](int c, int p) { return store_mode == 2 && mfma_nkb[c] && cell_pairs[c][p] > store_above; };
+	auto stored_big = [&](int c, int p) { return store_mode == 2 && stored[c][p]; };
 
 	// pass 1 lists (non-empty cells per classifier) and pass 2 tile entries
 	std::vector<uint32_t> cls_cnt, cls_cell, tile_meta((size_t)std::max(C, 1) * n_tile * HIBAG_TILE_META + 1, 0);
@@ -634,8 +650,8 @@ int finalize_model(hibag_hip_model *m)
 		for (int c = 0; c < C; c++) {
 			if (!mfma_nkb[c]) continue;
 			seg_off[(size_t)c * n_tile + t] = plist.size();
-			const int nb = append_pair_blocks(starts[c].data(), nh, tile_h1[t], tile_h2[t], tile_n[t],
-				(uint32_t)m->cls[c].freq.size(), plist, ~0ull, store_mode == 2 ? store_above : ~0ull);
+			const int nb = append_pair_blocks(starts[c].data(), nh, tile_h1[t], tile_h2[t], tile_p0[t], tile_n[t],
+				(uint32_t)m->cls[c].freq.size(), plist, nullptr, store_mode == 2 ? stored[c].data() : nullptr);
 			seg_nblk[(size_t)c * n_tile + t] = (uint32_t)nb;
 			dbg_b2 += nb; dbg_seg += nb > 0;
 		}
@@ -644,8 +660,8 @@ int finalize_model(hibag_hip_model *m)
 	for (int c = 0; c < C; c++) {
 		if (!mfma_nkb[c]) continue;
 		blk_off[c] = plist.size();
-		cls_nblk[c] = append_pair_blocks(starts[c].data(), nh, 0, 0, P, (uint32_t)m->cls[c].freq.size(), plist,
-			store_mode == 1 ? 0 : store_mode == 2 ? store_above : ~0ull, ~0ull);
+		cls_nblk[c] = append_pair_blocks(starts[c].data(), nh, 0, 0, 0, P, (uint32_t)m->cls[c].freq.size(), plist,
+			store_mode ? stored[c].data() : nullptr, nullptr);
 		dbg_b1 += cls_nblk[c];
 		uint32_t closed = 0;
 		for (int b = 0; b < cls_nblk[c] && store_mode; b++) {      // stored cells closed before block b

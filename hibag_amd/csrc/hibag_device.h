@@ -75,6 +75,7 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 #define HIBAG_PLIST_DWORDS 32
 #define HIBAG_PLIST_END 0x80000000u
 #define HIBAG_PLIST_STORE 0x40000000u        // with END: pass 1 stores this cell's sum for pass 2 to read back
+#define HIBAG_STORED_PER_VISIT 4             // mode 2: stored cells per (classifier, tile) -- what k_accum keeps in registers
 // Matrix-engine variants (HibagModelView::engine[c]; 0 = VALU engine) and their haplotype-table entries:
 //   FP4  (up to 28 SNPs)  v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands: one instruction per sample half covers all
 //                         K = 64 positions.  Entry = { N[16] (nibble s = 2, the code of 1.0, where bit s is set), ff, f }: 8 dwords

@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 	typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 	const u32x8 *__restrict__ ct = reinterpret_cast<const u32x8 *>(M.ctile) + tile;
 	const size_t n_group_z = (size_t)n_group;
-	constexpr int NS = 4;                             // stored cells of the next classifier kept in registers (more are rare)
+	constexpr int NS = HIBAG_STORED_PER_VISIT;        // stored cells of the next classifier, in registers
 	double sv[NS];
 	// first stored cell of classifier c for this tile and sample group; rec5 = first row | #cells << 27
 	auto stored_row = [&](int row0, int row1, uint32_t rec5) {
@@ -1029,7 +1029,10 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 		if (n == 0) return;
 		const double *__restrict__ src = stored_row(row0, row1, rec5);
 #pragma unroll
-		for (int i = 0; i < NS; i++) sv[i] = __builtin_nontemporal_load(src + (size_t)(i < n ? i : n - 1) * HIBAG_WAVE);
+		for (int i = 0; i < NS; i++) {
+			if (i >= n) break;
+			sv[i] = __builtin_nontemporal_load(src + (size_t)i * HIBAG_WAVE);
+		}
 	};
 	const int c_last = C - 1;
 	u32x8 rec_n = ct[(size_t)cb * M.n_tile];
@@ -1041,17 +1044,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 	ListCursor cur;                                   // the list look-ahead carries over from classifier to classifier
 	for (int c = cb; c < ce; c++) {
 		const u32x8 rec = rec_n;
-		const int row0 = row0_n, row1 = row1_n;
 		const double w = w_n, inv = inv_n;
-		rec_n = rec_nn; row0_n = row0_nn; row1_n = row1_nn;
-		{
-			const int cn = (c + 1 < C) ? c + 1 : c, cnn = (c + 2 < C) ? c + 2 : c_last;
-			rec_nn = ct[(size_t)cnn * M.n_tile];
-			row0_nn = M.cell_row[cnn]; row1_nn = M.cell_row[cnn + 1];
-			w_n = B.cw[(size_t)cn * B.n_pad + s];
-			inv_n = B.inv[(size_t)cn * B.n_pad + s];
-		}
-		__builtin_amdgcn_sched_barrier(0);            // keep the requests above at the top of the iteration
 		const bool active = w > 0;
 		const bool any = __ballot(active) != 0;
 		const int nkb = (int)(rec[0] & 3u);
@@ -1061,9 +1054,10 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 		// row numbers of the tile's cells, 4 bits each: the listed ones in closing order, then the stored ones
 		uint64_t jpack = ((uint64_t)rec[7] << 32) | rec[6];
 		const int n_stored = (int)(rec[5] >> 27);
+		// The stored cells of this classifier (requested while the previous one was evaluated) come FIRST, before
+		// anything new is requested: their wait is a wait for everything in flight, and must not include loads
+		// issued a moment ago.   S[p] += (cell * (1/total)) * w
 		if (any && n_stored > 0) {
-			// the stored cells of this classifier (requested while the previous one was evaluated):
-			// S[p] += (cell * (1/total)) * w
 			uint64_t jps = jpack >> (4 * (int)((rec[0] >> 8) & 31u));
 #pragma unroll
 			for (int i = 0; i < NS; i++) {
@@ -1071,16 +1065,18 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 				__hip_atomic_fetch_add(&acc[(int)(jps & 15)][lane], (sv[i] * inv_e) * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				jps >>= 4;
 			}
-			if (n_stored > NS) {                          // more than the registers hold: fetched here
-				const double *__restrict__ src = stored_row(row0, row1, rec[5]);
-				for (int i = NS; i < n_stored; i++) {
-					const double v = __builtin_nontemporal_load(src + (size_t)i * HIBAG_WAVE);
-					__hip_atomic_fetch_add(&acc[(int)(jps & 15)][lane], (v * inv_e) * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					jps >>= 4;
-				}
-			}
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		rec_n = rec_nn; row0_n = row0_nn; row1_n = row1_nn;
+		{
+			const int cn = (c + 1 < C) ? c + 1 : c, cnn = (c + 2 < C) ? c + 2 : c_last;
+			rec_nn = ct[(size_t)cnn * M.n_tile];
+			row0_nn = M.cell_row[cnn]; row1_nn = M.cell_row[cnn + 1];
+			w_n = B.cw[(size_t)cn * B.n_pad + s];
+			inv_n = B.inv[(size_t)cn * B.n_pad + s];
 		}
 		if (c + 1 < C) request_stored(row0_n, row1_n, rec_n[5]);
+		__builtin_amdgcn_sched_barrier(0);            // keep the requests above at the top of the iteration
 		if (!any) continue;
 		const bool poison = __ballot(active && !(fabs(inv) <= 1.79769313486231570815e+308)) != 0;
 		if (nkb > 0) {
