@@ -692,8 +692,10 @@ int finalize_model(hibag_hip_model *m)
 			r[1] = hap_off[c];
 			r[2] = (uint32_t)off; r[3] = (uint32_t)(off >> 32);
 			r[4] = seg_nblk[(size_t)c * n_tile + t];
-			if (tile_k0[(size_t)c * n_tile + t] >> 27) return fail(HIBAG_HIP_EINVAL, "classifier %d has too many allele pairs", c);
-			r[5] = tile_k0[(size_t)c * n_tile + t] | (tile_nstored[(size_t)c * n_tile + t] << 27);
+			// first stored row of the (classifier, tile) among all stored cells of the model
+			const uint64_t row = (uint64_t)cell_row[c] + tile_k0[(size_t)c * n_tile + t];
+			if (row >> 27) return fail(HIBAG_HIP_EINVAL, "the model has too many allele pairs to store their sums");
+			r[5] = (uint32_t)row | (tile_nstored[(size_t)c * n_tile + t] << 27);
 			r[6] = (uint32_t)tile_jpack[(size_t)c * n_tile + t]; r[7] = (uint32_t)(tile_jpack[(size_t)c * n_tile + t] >> 32);
 		}
 

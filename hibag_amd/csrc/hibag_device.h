@@ -165,7 +165,7 @@ struct HibagModelView {
 	//                    their tile-major lists, the stored ones from memory);
 	//   store_cells = 0: none (only a split VALU-engine classifier has rows, for k_total_scan).
 	int store_cells;
-	const int *cell_row;         // [C + 1] first row of the classifier (one row per stored cell, in cell order)
+	const int *cell_row;         // [C + 1] first row of the classifier (one row per stored cell, in cell order); cells[group][row][64]
 	const uint32_t *blk_close;   // per pass-1 block: cells closed in the classifier's earlier blocks (where a chunk resumes)
 	uint64_t p1_base;            // dword offset of the first pass-1 list in plist (block number = (offset - p1_base) / 32)
 
@@ -180,7 +180,7 @@ struct HibagBatchView {
 	double *cw;         // [C][n_pad]
 	double *tot;        // [C][n_pad]
 	double *inv;        // [C][n_pad]
-	double *cells;      // [cell_row[C]][n_pad] every (classifier, non-empty cell) sum of pass 1
+	double *cells;      // [n_pad / 64][cell_row[C]][64] the cell sums pass 1 stores
 	double *part;       // [P+3][n_pad]
 	// matrix-core engine: per classifier and sample group the B operand tiles
 	// (int8, MFMA lane layout; K layout above) and, for classifiers with 32 SNPs, the distance offsets

@@ -148,6 +148,13 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
+// Model tables read through the constant address space: a wave-uniform load from it is a scalar load (s_load) wherever
+// it stands.  Through a plain pointer the compiler only uses scalar loads while no store or atomic of the kernel can
+// precede them -- with the hand-over flags in the kernels, the per-classifier record loads of pass 2 had silently become
+// vector loads + eight v_readfirstlane each, waited for on the spot.  (The model is never written by a kernel.)
+template <class T> using ConstPtr = const __attribute__((address_space(4))) T *;
+template <class T> __device__ __forceinline__ ConstPtr<T> as_const(const T *p) { return (ConstPtr<T>)(uintptr_t)p; }
+
 struct LaneOperand {
 	v4i b[2][2];        // B operand of sample half n, K block kb (MFMA lane layout); the FP4 engine uses b[n][0] only
 	int bias[2];        // I8S (32 SNPs) only: the lane's distance offset (times 8) for each sample half
@@ -722,13 +729,13 @@ __global__ void k_unpack_tgeno(HibagModelView M, HibagBatchView B,
 // (src/LibHLA.cpp:1776-1826).  Empty cells add +0.0 and are skipped.
 // grid (ceil(groups/4), C) with the heaviest classifiers first; each of the 4
 // wavefronts of a block owns one group of 64 samples.
-// The cell sums pass 1 stores for pass 2: per classifier and 64-sample group one row of 64 doubles per non-empty cell
-// (cls_cell order), the rows of a group back to back -- a wavefront writes its classifier's cells as one
-// sequential stream, and pass 2 reads a tile's cells of a classifier as one contiguous piece.
+// The cell sums pass 1 stores for pass 2: per 64-sample group one row of 64 doubles per stored cell of the model
+// (classifier after classifier, cell order inside), the groups back to back -- a wavefront writes its classifier's
+// cells as one sequential stream, pass 2 reads a tile's cells of a classifier as one contiguous piece, and a row's
+// address needs nothing but its number (HibagModelView::cell_row[c] + position) and the group.
 __device__ __forceinline__ double *cell_rows(const HibagModelView &M, const HibagBatchView &B, int c, int group)
 {
-	const size_t n_group = (size_t)(B.n_pad / HIBAG_WAVE), n = (size_t)(M.cell_row[c + 1] - M.cell_row[c]);
-	return B.cells + ((size_t)M.cell_row[c] * n_group + (size_t)group * n) * HIBAG_WAVE;
+	return B.cells + ((size_t)group * (size_t)M.cell_row[M.n_classifier] + (size_t)M.cell_row[c]) * HIBAG_WAVE;
 }
 
 template <int NWP>
@@ -844,8 +851,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 5) void k_total(HibagModelView M, Hi
 	const bool chunked = blockIdx.x >= n_whole && nkb > 0;
 	if (blockIdx.x >= n_whole) {
 		if (nkb > 0) {
+			// (readfirstlane: the division runs on the vector ALU, and a list offset that lives in a vector register
+			// turns every list load of the walk into a waterfall loop)
 			const long long nb = b1;
-			b0 = (int)(nb * k / K); b1 = (int)(nb * (k + 1) / K);
+			b0 = __builtin_amdgcn_readfirstlane((int)(nb * k / K)); b1 = __builtin_amdgcn_readfirstlane((int)(nb * (k + 1) / K));
 			if (b0 >= b1 && !(k == K - 1 && nb == 0)) return;      // (fewer blocks than chunks: an empty list still needs its total written)
 		} else if (k > 0) return;                                  // VALU-engine items are not cut
 	}
@@ -1012,22 +1021,19 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 	// Everything classifier c+1 needs that does not cost many registers is requested while
 	// classifier c is evaluated: the lane's weight and 1/total, and the cell sums pass 1 stored for this tile
 	// (the cells with many haplotype pairs, which are not in the pair list: HibagModelView::store_cells == 2); its
-	// (classifier, tile) record (one s_load_dwordx8) and the position of its stored cells are requested TWO classifiers
-	// ahead, because the requests for the stored cells need them.  Without this every classifier starts with a chain
+	// (classifier, tile) record (one s_load_dwordx8) is requested TWO classifiers ahead, because the requests for the
+	// stored cells need it.  Without this every classifier starts with a chain
 	// of dependent scalar and vector loads (~3000 cycles per classifier, measured with stamps).
 	typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-	const u32x8 *__restrict__ ct = reinterpret_cast<const u32x8 *>(M.ctile) + tile;
-	const size_t n_group_z = (size_t)n_group;
+	const ConstPtr<u32x8> ct = as_const(reinterpret_cast<const u32x8 *>(M.ctile)) + tile;
 	constexpr int NS = HIBAG_STORED_PER_VISIT;        // stored cells of the next classifier, in registers
 	double sv[NS];
-	// first stored cell of classifier c for this tile and sample group; rec5 = first row | #cells << 27
-	auto stored_row = [&](int row0, int row1, uint32_t rec5) {
-		return B.cells + ((size_t)row0 * n_group_z + (size_t)group * (size_t)(row1 - row0) + (rec5 & 0x7FFFFFFu)) * HIBAG_WAVE + lane;
-	};
-	auto request_stored = [&](int row0, int row1, uint32_t rec5) {
+	// the stored cells of a (classifier, tile) for this sample group; rec5 = first row (of the model's stored cells) | #cells << 27
+	const double *__restrict__ const group_rows = B.cells + (size_t)group * (size_t)as_const(M.cell_row)[C] * HIBAG_WAVE + lane;
+	auto request_stored = [&](uint32_t rec5) {
 		const int n = (int)(rec5 >> 27);
 		if (n == 0) return;
-		const double *__restrict__ src = stored_row(row0, row1, rec5);
+		const double *__restrict__ src = group_rows + (size_t)(rec5 & 0x7FFFFFFu) * HIBAG_WAVE;
 #pragma unroll
 		for (int i = 0; i < NS; i++) {
 			if (i >= n) break;
@@ -1036,11 +1042,9 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 	};
 	const int c_last = C - 1;
 	u32x8 rec_n = ct[(size_t)cb * M.n_tile];
-	int row0_n = M.cell_row[cb], row1_n = M.cell_row[cb + 1];
 	u32x8 rec_nn = ct[(size_t)(cb < c_last ? cb + 1 : c_last) * M.n_tile];
-	int row0_nn = row1_n, row1_nn = M.cell_row[(cb < c_last ? cb + 1 : c_last) + 1];
 	double w_n = B.cw[(size_t)cb * B.n_pad + s], inv_n = B.inv[(size_t)cb * B.n_pad + s];
-	request_stored(row0_n, row1_n, rec_n[5]);
+	request_stored(rec_n[5]);
 	ListCursor cur;                                   // the list look-ahead carries over from classifier to classifier
 	for (int c = cb; c < ce; c++) {
 		const u32x8 rec = rec_n;
@@ -1067,15 +1071,18 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 			}
 		}
 		__builtin_amdgcn_sched_barrier(0);
-		rec_n = rec_nn; row0_n = row0_nn; row1_n = row1_nn;
+		// the requests for classifier c + 1 (its record arrived during the last iteration) ...
+		rec_n = rec_nn;
+		if (c + 1 < C) request_stored(rec_n[5]);
+		__builtin_amdgcn_sched_barrier(0);
+		// ... and only then the scalar loads for c + 2: scalar loads return out of order, so the first use of ANY earlier
+		// one behind them waits for them as well
 		{
 			const int cn = (c + 1 < C) ? c + 1 : c, cnn = (c + 2 < C) ? c + 2 : c_last;
-			rec_nn = ct[(size_t)cnn * M.n_tile];
-			row0_nn = M.cell_row[cnn]; row1_nn = M.cell_row[cnn + 1];
 			w_n = B.cw[(size_t)cn * B.n_pad + s];
 			inv_n = B.inv[(size_t)cn * B.n_pad + s];
+			rec_nn = ct[(size_t)cnn * M.n_tile];
 		}
-		if (c + 1 < C) request_stored(row0_n, row1_n, rec_n[5]);
 		__builtin_amdgcn_sched_barrier(0);            // keep the requests above at the top of the iteration
 		if (!any) continue;
 		const bool poison = __ballot(active && !(fabs(inv) <= 1.79769313486231570815e+308)) != 0;
@@ -1141,15 +1148,13 @@ __global__ __launch_bounds__(CELLS_WAVES * HIBAG_WAVE, 4) void k_accum_cells(Hib
 	for (int q = 0; q < HIBAG_TILE; q++) acc[q][lane] = 0;
 
 	typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-	const u32x8 *__restrict__ ct = reinterpret_cast<const u32x8 *>(M.ctile) + tile;
-	const size_t n_group_z = (size_t)n_group;
-	struct Visit { u32x8 rec; int row0, row1; double w, inv; };
-	// what classifier c contributes to the tile: its record (one s_load_dwordx8), where its cells start, the lane's
-	// weight and 1/total.  Requested two classifiers ahead, so that nothing below waits for a load it has just issued.
+	const ConstPtr<u32x8> ct = as_const(reinterpret_cast<const u32x8 *>(M.ctile)) + tile;
+	const double *__restrict__ const group_rows = B.cells + (size_t)group * (size_t)as_const(M.cell_row)[C] * HIBAG_WAVE + lane;
+	struct Visit { u32x8 rec; double w, inv; };
+	// what classifier c contributes to the tile: its record (one s_load_dwordx8), the lane's weight and 1/total.  Requested two classifiers ahead, so that nothing below waits for a load it has just issued.
 	auto visit = [&](int c) {
 		Visit x;
 		x.rec = ct[(size_t)c * M.n_tile];
-		x.row0 = M.cell_row[c]; x.row1 = M.cell_row[c + 1];
 		x.w = B.cw[(size_t)c * B.n_pad + s];
 		x.inv = B.inv[(size_t)c * B.n_pad + s];
 		return x;
@@ -1159,7 +1164,7 @@ __global__ __launch_bounds__(CELLS_WAVES * HIBAG_WAVE, 4) void k_accum_cells(Hib
 	// numbers, which `add` never looks at.)
 	auto fetch = [&](const Visit &x, double (&v)[HIBAG_TILE]) {
 		const int n = (int)((x.rec[0] >> 8) & 31u);
-		const double *__restrict__ rows = B.cells + ((size_t)x.row0 * n_group_z + (size_t)group * (size_t)(x.row1 - x.row0) + x.rec[5]) * HIBAG_WAVE + lane;
+		const double *__restrict__ rows = group_rows + (size_t)(x.rec[5] & 0x7FFFFFFu) * HIBAG_WAVE;
 #pragma unroll
 		for (int g = 0; g < HIBAG_TILE; g += 4) {
 			if (g >= n) break;
