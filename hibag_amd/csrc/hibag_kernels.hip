@@ -400,7 +400,8 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 		const v4i a1 = e1, a2 = e2;
 		const double prod = ff * f2;
 		const uint32_t endmask = (uint32_t)__ballot((idx_c & HIBAG_PLIST_END) != 0);          // lanes 32..63 mirror 0..31
-		const uint32_t storemask = (uint32_t)__ballot((idx_c & HIBAG_PLIST_STORE) != 0);      // (only pass 1 looks at it)
+		// (only pass 1 looks at it; STORE comes with END only, so both flags set = the two top bits set)
+		const uint32_t storemask = (uint32_t)__ballot(idx_c >= (HIBAG_PLIST_END | HIBAG_PLIST_STORE));
 		const uint32_t live = endmask | (uint32_t)__ballot(prod != 0.0);                      // low half: lanes 0..31
 		const int n_valid = live ? 32 - __builtin_clz(live) : 0;
 		// look-ahead: entries of block b+1, slot words of block b+2
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 5) void k_total(HibagModelView M, Hi
 }
 
 // k_total_scan: the in-order total of a split classifier from its stored cell sums; thread = sample.
-// Sixteen loads in flight, then the sixteen additions in cell order (with one dependent load per addition the
+// Thirty-two loads in flight, then the thirty-two additions in cell order (with one dependent load per addition the
 // kernel would be pure memory latency: a few hundred cells, one wavefront per 64 samples).
 __global__ void k_total_scan(HibagModelView M, HibagBatchView B)
 {
@@ -921,12 +922,12 @@ __global__ void k_total_scan(HibagModelView M, HibagBatchView B)
 	const int n = M.cls_n[c];
 	double total = 0;
 	int i = 0;
-	for (; i + 16 <= n; i += 16) {
-		double v[16];
+	for (; i + 32 <= n; i += 32) {
+		double v[32];
 #pragma unroll
-		for (int j = 0; j < 16; j++) v[j] = rows[(size_t)(i + j) * HIBAG_WAVE];
+		for (int j = 0; j < 32; j++) v[j] = rows[(size_t)(i + j) * HIBAG_WAVE];
 #pragma unroll
-		for (int j = 0; j < 16; j++) total += v[j];
+		for (int j = 0; j < 32; j++) total += v[j];
 	}
 	for (; i < n; i++) total += rows[(size_t)i * HIBAG_WAVE];
 	B.tot[(size_t)c * B.n_pad + s] = total;
