@@ -53,6 +53,9 @@
 #define BLOCK_WAVES 4                       // wavefronts per workgroup (each on its own work item)
 #endif
 #define BLOCK_THREADS (BLOCK_WAVES * HIBAG_WAVE)
+#ifndef HIBAG_TOT_OCC
+#define HIBAG_TOT_OCC 5                     // workgroups per CU pass 1 is compiled for (96 VGPRs; 4 -> 128: measured slower)
+#endif
 #ifndef ACCUM_WAVES
 #define ACCUM_WAVES 4                       // wavefronts per workgroup of pass 2 (sample groups that share a tile's lists in L1)
 #endif
@@ -833,7 +836,7 @@ __device__ __forceinline__ int chunk_bound(const uint32_t *__restrict__ cum, int
 // STORE: every cell sum goes to HibagBatchView::cells for pass 2 to read back (models whose pass 2 streams, see
 // k_accum_cells); otherwise only a split VALU-engine classifier stores its cells (for k_total_scan).
 template <bool STORE>
-__global__ __launch_bounds__(BLOCK_THREADS, 5) void k_total(HibagModelView M, HibagBatchView B, int gx, int n_whole, int rest, int stride, int K)
+__global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagModelView M, HibagBatchView B, int gx, int n_whole, int rest, int stride, int K)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
