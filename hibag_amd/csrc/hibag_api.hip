@@ -787,6 +787,7 @@ int finalize_model(hibag_hip_model *m)
 	V.acc_cum = (const uint32_t *)(tbase + tb_acum);
 	V.blk_close = (const uint32_t *)(tbase + tb_close);
 	V.p1_base = p1_base;
+	V.p1_blocks = dbg_b1;
 	V.cell_row = base + o_crow;
 	V.store_cells = store_mode;
 	m->cell_rows = cell_row[C];

@@ -168,6 +168,7 @@ struct HibagModelView {
 	const int *cell_row;         // [C + 1] first row of the classifier (one row per stored cell, in cell order); cells[group][row][64]
 	const uint32_t *blk_close;   // per pass-1 block: cells closed in the classifier's earlier blocks (where a chunk resumes)
 	uint64_t p1_base;            // dword offset of the first pass-1 list in plist (block number = (offset - p1_base) / 32)
+	long long p1_blocks;         // blocks of all pass-1 lists together
 
 	// chunked items (hibag_kernels.hip "hand-overs"): cost prefix sums in quarter-blocks of 32 records
 	const uint32_t *acc_cum;     // [n_tile][C + 1] pass 2: cost of the tile's classifiers 0 .. c-1

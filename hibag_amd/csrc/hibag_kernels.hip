@@ -1488,11 +1488,14 @@ static int resident_blocks(F kernel, int threads)
 	return per_cu > 0 && cus > 0 ? per_cu * cus : 0;
 }
 
-// chunks per item of the last rounds of passes 1 and 2 ("hand-overs"; HIBAG_TAIL_K=1: undivided items only)
-static int tail_chunks()
+// chunks per item of the last rounds of passes 1 and 2 ("hand-overs"; HIBAG_TAIL_K=1: undivided items only).
+// A hand-over costs about as much as a tenth of a block list of the benchmark model, so 4 chunks there (2 and 8 measure 1-3 %
+// worse); items of several thousand blocks (the DRB1 shape: 3,900) take 8 - 16 (-4 % against 4): one chunk per
+// `blocks_per_item` / 256, between 4 and 12.
+static int tail_chunks(long long blocks_per_item = 0)
 {
-	static const int k = getenv("HIBAG_TAIL_K") ? std::max(1, std::min(64, atoi(getenv("HIBAG_TAIL_K")))) : 4;
-	return k;
+	static const int k = getenv("HIBAG_TAIL_K") ? std::max(1, std::min(64, atoi(getenv("HIBAG_TAIL_K")))) : 0;
+	return k ? k : (int)std::max(4ll, std::min(12ll, blocks_per_item / 256));
 }
 
 void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st)
@@ -1512,8 +1515,9 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 	static const int slots = resident_blocks(k_total<false>, BLOCK_THREADS);
 	const unsigned n = gx * (unsigned)V.n_item;
 	unsigned n_whole = n, rest = 0, stride = 8, K = 1;
-	if (tail_chunks() > 1 && slots > 0 && n > (unsigned)slots) {
-		K = (unsigned)tail_chunks();
+	const int k_pass1 = tail_chunks(M.p1_blocks / std::max(M.n_classifier, 1));
+	if (k_pass1 > 1 && slots > 0 && n > (unsigned)slots) {
+		K = (unsigned)k_pass1;
 		rest = n % (unsigned)slots + (unsigned)slots;
 		n_whole = n - rest;
 		stride = (rest + 7) / 8 * 8;
