@@ -1306,13 +1306,14 @@ __global__ void k_scalars(HibagModelView M, HibagBatchView B, const int *__restr
 	const int s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= B.n_pad) return;
 	double sum_w = 0, sum_m = 0, num_m = 0;
-	for (int c0 = 0; c0 < M.n_classifier; c0 += 8) {
-		// eight classifiers' loads in flight, then the sums in classifier order (one thread per sample:
+	constexpr int NB = 16;
+	for (int c0 = 0; c0 < M.n_classifier; c0 += NB) {
+		// sixteen classifiers' loads in flight, then the sums in classifier order (one thread per sample:
 		// with dependent loads this kernel would be pure memory latency)
-		double wv[8], tv[8];
-		int bv[8];
+		double wv[NB], tv[NB];
+		int bv[NB];
 #pragma unroll
-		for (int j = 0; j < 8; j++) {
+		for (int j = 0; j < NB; j++) {
 			const bool in = c0 + j < M.n_classifier;
 			const size_t at = (size_t)(in ? c0 + j : c0) * B.n_pad + s;
 			wv[j] = in ? B.cw[at] : 0.0;
@@ -1320,7 +1321,7 @@ __global__ void k_scalars(HibagModelView M, HibagBatchView B, const int *__restr
 			bv[j] = best_cell ? best_cell[at] : 0;
 		}
 #pragma unroll
-		for (int j = 0; j < 8; j++) {
+		for (int j = 0; j < NB; j++) {
 			const double w = wv[j];
 			if (!(w > 0)) continue;
 			sum_m += tv[j] * w;
@@ -1365,7 +1366,18 @@ __global__ __launch_bounds__(64 * FIN_SEG) void k_finish_call(HibagModelView M, 
 	const int lo = seg * per, hi = min(P, lo + per);
 	double best = 0;
 	int cell = -1;
-	for (int p = lo; p < hi; p++) {
+	int p = lo;
+	for (; p + 8 <= hi; p += 8) {                 // eight rows in flight, compared in cell order
+		double v[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) v[j] = part[(size_t)(p + j) * np + s];
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const double x = normalised(v[j], scale, ff);
+			if (best < x) { best = x; cell = p + j; }
+		}
+	}
+	for (; p < hi; p++) {
 		const double v = normalised(part[(size_t)p * np + s], scale, ff);
 		if (best < v) { best = v; cell = p; }
 	}
@@ -1403,13 +1415,27 @@ __global__ void k_finish_dosage(HibagModelView M, HibagBatchView B, const double
 	const bool scale = sum_w > 0;
 	const double ff = 1.0 / sum_w;
 	double d = 0;
-	for (int g = 0; g < h; g++) {
-		const size_t p = (size_t)h + (size_t)g * (2 * n - g - 1) / 2;   // index of (g,h), src/LibHLA.cpp:1523
-		d += normalised(part[p * np + s], scale, ff);
+	// term g of allele h: the cell (g, h) for g < h, (h, g) for g >= h -- index p = h2 + h1 (2n - h1 - 1) / 2 (src/LibHLA.cpp:1523);
+	// eight cells in flight, added in order (the diagonal cell counts twice)
+	auto cell_of = [&](int g) {
+		const int h1 = g < h ? g : h, h2 = g < h ? h : g;
+		return (size_t)h2 + (size_t)h1 * (2 * n - h1 - 1) / 2;
+	};
+	int g = 0;
+	for (; g + 8 <= n; g += 8) {
+		double v[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) v[j] = part[cell_of(g + j) * np + s];
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const double x = normalised(v[j], scale, ff);
+			d += g + j == h ? 2 * x : x;
+		}
 	}
-	size_t p = (size_t)h + (size_t)h * (2 * n - h - 1) / 2;
-	d += 2 * normalised(part[p * np + s], scale, ff);
-	for (int g = h + 1; g < n; g++) { p++; d += normalised(part[p * np + s], scale, ff); }
+	for (; g < n; g++) {
+		const double x = normalised(part[cell_of(g) * np + s], scale, ff);
+		d += g == h ? 2 * x : x;
+	}
 	dosage[(size_t)s * n + h] = d;
 }
 
