@@ -498,12 +498,15 @@ int finalize_model(hibag_hip_model *m)
 	if (const char *e = getenv("HIBAG_STORE_PAIRS")) store_above = (uint64_t)std::max(0, atoi(e));
 	{
 		long long n_cells = 0, n_big = 0;
-		for (int c = 0; c < C; c++)
+		double cost = 0;                                   // pairs, a VALU-engine pair counted five times (what it costs)
+		for (int c = 0; c < C; c++) {
+			cost += (double)pairs[c] * (mfma_nkb[c] ? 1.0 : 5.0);
 			for (int p = 0; p < P; p++) {
 				n_cells += cell_chunks[c][p] != 0;
-				n_big += mfma_nkb[c] && cell_pairs[c][p] > store_above;
+				n_big += mfma_nkb[c] ? cell_pairs[c][p] > store_above : cell_chunks[c][p] != 0;
 			}
-		m->store_mode = C == 0 ? 0 : (double)m->pair_evals >= 14.0 * (double)std::max<long long>(n_cells, 1) ? 1 : n_big ? 2 : 0;
+		}
+		m->store_mode = C == 0 ? 0 : cost >= 14.0 * (double)std::max<long long>(n_cells, 1) ? 1 : n_big ? 2 : 0;
 		if (const char *e = getenv("HIBAG_PASS2")) {
 			if (!strcmp(e, "stream")) m->store_mode = C > 0;
 			else if (!strcmp(e, "recompute")) m->store_mode = 0;
@@ -513,12 +516,15 @@ int finalize_model(hibag_hip_model *m)
 	const int store_mode = m->store_mode;
 	// stored[c][p]: pass 1 stores the sum of cell p of classifier c.  Mode 2: the cells of a matrix-engine classifier with
 	// more than `store_above` pairs, at most HIBAG_STORED_PER_VISIT per (classifier, tile) -- the ones with the most pairs --
-	// which is what pass 2 keeps in registers for a visit; mode 1: every non-empty cell.
+	// which is what pass 2 keeps in registers for a visit, and every cell of a VALU-engine classifier; mode 1: every non-empty cell.
 	std::vector<std::vector<uint8_t>> stored(C);
 	for (int c = 0; c < C; c++) {
 		stored[c].assign(P, 0);
 		if (store_mode == 1) { for (int p = 0; p < P; p++) stored[c][p] = cell_chunks[c][p] != 0; }
-		else if (store_mode == 2 && mfma_nkb[c])
+		else if (store_mode == 2 && !mfma_nkb[c]) {
+			// a VALU-engine classifier (more than 32 SNPs) costs about five times as much per pair: all its cells
+			for (int p = 0; p < P; p++) stored[c][p] = cell_chunks[c][p] != 0;
+		} else if (store_mode == 2)
 			for (int t = 0; t < n_tile; t++) {
 				std::vector<std::pair<uint32_t, int>> big;
 				for (int j = 0; j < tile_n[t]; j++)
@@ -528,7 +534,7 @@ int finalize_model(hibag_hip_model *m)
 			}
 	}
 	// a cell of a matrix-engine classifier whose sum pass 2 reads instead of evaluating its pairs (mode 2)
-	auto stored_big = [&](int c, int p) { return store_mode == 2 && stored[c][p]; };
+	auto stored_big = [&](int c, int p) { return store_mode == 2 && stored[c][p] != 0; };
 
 	// pass 1 lists (non-empty cells per classifier) and pass 2 tile entries
 	std::vector<uint32_t> cls_cnt, cls_cell, tile_meta((size_t)std::max(C, 1) * n_tile * HIBAG_TILE_META + 1, 0);
@@ -673,7 +679,7 @@ int finalize_model(hibag_hip_model *m)
 	std::vector<int> cell_row((size_t)C + 1, 0);
 	for (int c = 0; c < C; c++)
 		cell_row[c + 1] = cell_row[c] + (store_mode == 1 || split_row[c] >= 0 ? cls_n[c] : store_mode == 2 ? n_stored_c[c] : 0);
-	m->second_pass_pairs += store_mode == 1 ? 0 : valu_pairs;
+	m->second_pass_pairs += store_mode == 0 ? valu_pairs : 0;
 	if (getenv("HIBAG_DEBUG_MODEL"))
 		fprintf(stderr, "[hibag model] %d classifiers, %d tiles, pairs %lld; blocks of 32: pass 1 %lld, pass 2 %lld in %lld (classifier, tile) segments; "
 			"pair lists %.1f MB, haplotype table %.1f KB, VALU-engine stream %.1f MB\n",

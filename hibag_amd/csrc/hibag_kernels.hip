@@ -878,7 +878,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagMod
 		double total = 0;
 		const bool split = M.n_split > 0 && M.split_row[c] >= 0;    // a split classifier: k_total_scan adds its cells in order
 		// this classifier's stored cell sums, one row each (a VALU-engine classifier stores all or none)
-		double *__restrict__ rows = (STORE && (nkb > 0 || M.store_cells == 1)) || split ? cell_rows(M, B, c, group) : nullptr;
+		double *__restrict__ rows = STORE || split ? cell_rows(M, B, c, group) : nullptr;
 		if (nkb > 0) {
 			double cell = 0;
 			if (!first) { total = load_parked(&B.tot[at]); cell = load_parked(&B.inv[at]); }
@@ -1073,6 +1073,20 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 				__hip_atomic_fetch_add(&acc[(int)(jps & 15)][lane], (sv[i] * inv_e) * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				jps >>= 4;
 			}
+			if (n_stored > NS) {                          // a VALU-engine classifier (all its cells are stored): the rest, fetched here
+				const double *__restrict__ src = group_rows + (size_t)(rec[5] & 0x7FFFFFFu) * HIBAG_WAVE;
+				for (int i0 = NS; i0 < n_stored; i0 += NS) {
+					double v[NS];
+#pragma unroll
+					for (int i = 0; i < NS; i++) v[i] = __builtin_nontemporal_load(src + (size_t)(i0 + i < n_stored ? i0 + i : n_stored - 1) * HIBAG_WAVE);
+#pragma unroll
+					for (int i = 0; i < NS; i++) {
+						if (i0 + i >= n_stored) break;
+						__hip_atomic_fetch_add(&acc[(int)(jps & 15)][lane], (v[i] * inv_e) * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						jps >>= 4;
+					}
+				}
+			}
 		}
 		__builtin_amdgcn_sched_barrier(0);
 		// the requests for classifier c + 1 (its record arrived during the last iteration) ...
@@ -1106,17 +1120,18 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 				(int)((rec[0] >> 2) & 63u), T, tab_s, stage_s[wave], cell, fin); }
 			if (rec[4] > 0) { HIBAG_DISPATCH_ENGINE(nkb, CALL) }
 #undef CALL
-			if (poison) {                                // empty cells: (0 * inv) * w is NaN where inv is not finite
-				const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + tile) * HIBAG_TILE_META;
-				for (int i = (int)meta[0]; i < ncell; i++) {
-					const double v = (0.0 * inv) * w;
-					acc[meta[4 + i] >> 24][lane] += active ? v : 0.0;
-				}
-			}
-		} else {
+		} else if (M.store_cells != 2) {
 #define CALL(N) accumulate_classifier<N>(M, B, c, s, tile, ncell, active, poison, inv, w, tab_s, acc)
 			HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
 #undef CALL
+		}
+		// (store_cells == 2: the cells of a VALU-engine classifier all came from memory above)
+		if (poison && (nkb > 0 || M.store_cells == 2)) {  // empty cells: (0 * inv) * w is NaN where inv is not finite
+			const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + tile) * HIBAG_TILE_META;
+			for (int i = (int)meta[0]; i < ncell; i++) {
+				const double v = (0.0 * inv) * w;
+				acc[meta[4 + i] >> 24][lane] += active ? v : 0.0;
+			}
 		}
 	}
 
