@@ -595,7 +595,6 @@ int finalize_model(hibag_hip_model *m)
 	// many times the duration of the rest of the pass, so they are cut into items of typical size
 	// that store per-cell sums, added in order afterwards (k_total_scan).
 	std::vector<int> item, item_whole, split_row(std::max(C, 1), -1), split_cls;
-	int cellsum_rows = 0;
 	double split_heavy_ns = 0, split_rest_ns = 0;
 	{
 		// rough wavefront-time per record: matrix engine 50 ns at full occupancy, VALU engine 18 ns per
@@ -620,8 +619,7 @@ int finalize_model(hibag_hip_model *m)
 				continue;
 			}
 			split_heavy_ns = std::max(split_heavy_ns, (double)pairs[c] * 18.0 * nwp[c]);       // measured: 1.1 ms for 5,050 pairs x 12 words
-			split_row[c] = cellsum_rows;
-			cellsum_rows += cls_n[c];
+			split_row[c] = 1;                              // (>= 0: split; its cells have rows in HibagBatchView::cells)
 			split_cls.push_back(c);
 			uint64_t total = 0, acc = 0, chunk0 = 0;
 			for (int i = 0; i < cls_n[c]; i++) total += cls_cnt[cls_off[c] + i] + 1;

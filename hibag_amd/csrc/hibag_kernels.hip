@@ -283,13 +283,14 @@ __device__ __forceinline__ void block_own_sample(v16i &D0, v16i &D1, int n_valid
 // cell += prod_i * TAB[d_i] for the first n_valid records of a block, in order;
 // `fin(cell, stored)` at every record that closes a cell (end mask, store mask; cells are padded to
 // an even number of records, so only odd positions can close one).  Per group of
-// 8 records: 8 table look-ups (per-lane LDS gathers) and the 8 frequency factors
-// (4 wave-uniform 16-byte LDS reads, broadcast to all lanes) are in flight before
+// G records: G table look-ups (per-lane LDS gathers) and the G frequency factors
+// (G / 2 wave-uniform 16-byte LDS reads, broadcast to all lanes) are in flight before
 // the first wait.  `stage` = this wavefront's copy of the block's factors in LDS.
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-// G = records whose table look-ups and factors are in flight together: 8 in pass 2, 4 in pass 1 (12 registers
-// less: 96 instead of 109, a fifth wavefront per SIMD; measured -3 % on pass 1, +3 % on pass 2).
+// G = records whose table look-ups and factors are in flight together: 4 in both passes (against 8: 12 registers
+// less -- in pass 1 that is a fifth wavefront per SIMD, -3 %; pass 2, whose visits are mostly one short block since it
+// reads the sums of the large cells from memory, needs the registers for those sums).
 template <int G, class Fin>
 __device__ __forceinline__ void block_accumulate(const double *stage, uint32_t endmask, uint32_t storemask, int n_valid,
 	const v16i &D0, const v16i &D1, double &cell, const double *tab_s, Fin &&fin)
