@@ -17,6 +17,20 @@ __global__ void k2(const uint32_t *A, const uint32_t *B, float *D)
 	for (int r = 0; r < 16; r++) D[l * 16 + r] = c[r];
 }
 
+// two K steps chained through the accumulator: does a denormal C operand survive?
+__global__ void k3(const uint32_t *A, const uint32_t *B, float *D)
+{
+	const int l = threadIdx.x;
+	v8i a = {0,0,0,0,0,0,0,0}, b = {0,0,0,0,0,0,0,0};
+	for (int i = 0; i < 4; i++) { a[i] = (int)A[l * 4 + i]; b[i] = (int)B[l * 4 + i]; }
+	v16f c = {};
+	const int sb = l < 32 ? 54 : 55;
+	c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 54, 0, sb);
+	c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 54, 0, sb);
+	c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 54, 0, sb);
+	for (int r = 0; r < 16; r++) D[l * 16 + r] = c[r];
+}
+
 __global__ void k(const uint32_t *A, const uint32_t *B, float *D, int sa, int sb)
 {
 	const int l = threadIdx.x;
@@ -106,6 +120,19 @@ int main()
 			if (bits != (uint32_t)(8 * want)) { if (bad < 5) printf("  mismatch lane %d reg %d: bits %08x want %g\n", l, r, bits, 8 * want); bad++; }
 		}
 		printf("trial 2 (per-lane B scale 54/55, signed operands): %s (%d mismatches, %d negative sums)\n", bad ? "MISMATCH" : "OK", bad, neg);
+		// trial 3: the same product three times through the C operand: bits = 3 x 8 x the dot product if denormal accumulators survive
+		hipLaunchKernelGGL(k3, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+		hipMemcpy(hD, dD, sizeof hD, hipMemcpyDeviceToHost);
+		int bad3 = 0;
+		for (int l = 0; l < 64; l++) for (int r = 0; r < 16; r++) {
+			const int col = l % 32, row = 8 * (r / 4) + 4 * (l / 32) + r % 4;
+			double want = 0;
+			for (int kk = 0; kk < 64; kk++) want += aval[ai(row, kk)] * bval[bi(kk, col)] * (kk < 32 ? 1 : 2);
+			uint32_t bits; memcpy(&bits, &hD[l * 16 + r], 4);
+			const uint32_t w = (uint32_t)(24 * (want < 0 ? -want : want)) | (want < 0 ? 0x80000000u : 0u);
+			if (bits != w) { if (bad3 < 5) printf("  chained: lane %d reg %d: bits %08x want %08x\n", l, r, bits, w); bad3++; }
+		}
+		printf("trial 3 (three K steps chained through a denormal accumulator): %s (%d mismatches)\n", bad3 ? "MISMATCH" : "OK", bad3);
 	}
 	float *dOut; hipMalloc(&dOut, 256 * 8 * 256 * 4);
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
