@@ -297,12 +297,12 @@ def issue_floor(obj, avg_ms, n, K):
     """(floor, achieved) SIMD time in ns per wavefront-pair (64 samples x one haplotype pair) for a kernel that
     took avg_ms over n samples: two FP64 ops per pair plus the pair's share of the int8 MFMAs of the distance
     dot product: per 32-record block two FP4 instructions (K = 64) up to 28 SNPs, four int8 ones (K = 32 each) for 29..32."""
-    from hibag_amd import engine_kind
+    from hibag_amd import engine_kind, engine_steps
     per_block = {"valu": 0.0, "fp4": 2 * K["mfma_fp4_32x32x64_ns"], "i8": 4 * K["mfma_i8_32x32x32_ns"]}
     mfma_ns, w = 0.0, 0
     for c in obj.classifiers:
         k, h = len(c.snpidx), len(c.freq)
-        mfma_ns += h * (h + 1) // 2 * per_block[engine_kind(k)] / 32.0
+        mfma_ns += h * (h + 1) // 2 * per_block[engine_kind(k)] * engine_steps(k) / 32.0
         w += h * (h + 1) // 2
     floor = 2 * K["fp64_op_ns"] + mfma_ns / max(w, 1)
     achieved = N_SIMD * avg_ms * 1e6 / (w * n / 64.0)

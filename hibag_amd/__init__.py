@@ -6,7 +6,7 @@ The compute lives in ``csrc/libhibag_hip.so`` (hand-written HIP for gfx950,
 C ABI in ``include/hibag_hip.h``); there is no CPU fallback in this package.
 """
 
-from .model import (NA_INTEGER, Classifier, HlaAttrBagObj, HlaSNPGeno, engine_kind, engine_nkb, load_geno, load_model,  # noqa: F401
+from .model import (NA_INTEGER, Classifier, HlaAttrBagObj, HlaSNPGeno, engine_kind, engine_nkb, engine_steps, load_geno, load_model,  # noqa: F401
                     model_to_robj, save_model)
 from .hibag import (HlaAlleleClass, HlaAttrBagClass, hlaClose, hlaModelFromObj, hlaModelToObj,   # noqa: F401
                     hlaPredict, hlaSetKernelTarget)
@@ -19,7 +19,7 @@ from .evaluate import (hlaAlleleSubset, hlaCompareAllele, hlaFlankingSNP, hlaGen
                        r_sample)
 from ._lib import HibagHipError  # noqa: F401
 
-__all__ = ["engine_kind", "engine_nkb", "NA_INTEGER", "Classifier", "HlaAttrBagObj", "HlaSNPGeno", "load_geno", "load_model", "model_to_robj", "save_model",
+__all__ = ["engine_kind", "engine_nkb", "engine_steps", "NA_INTEGER", "Classifier", "HlaAttrBagObj", "HlaSNPGeno", "load_geno", "load_model", "model_to_robj", "save_model",
            "HlaAlleleClass", "HlaAttrBagClass", "hlaClose", "hlaModelFromObj", "hlaModelToObj",
            "hlaPredict", "hlaSetKernelTarget", "hlaGenoSwitchStrand", "hlaSNPID", "HibagHipError",
            "HlaBEDGeno", "hlaBED2Geno", "hlaLociInfo", "RRandom", "hlaAllele", "hlaAttrBagging", "hlaParallelAttrBagging", "hlaUniqueAllele", "hlaAlleleDigit", "hlaPredMerge", "hlaAlleleSubset", "hlaCompareAllele", "hlaFlankingSNP", "hlaGenoSubset",

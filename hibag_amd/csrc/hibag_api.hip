@@ -159,6 +159,7 @@ struct hibag_hip_model {
 	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias, ws_cells, ws_sync;
 	int store_mode = 0;                    // which cell sums pass 1 stores for pass 2 (HibagModelView::store_cells)
 	int64_t second_pass_pairs = 0;         // haplotype pairs per sample pass 2 evaluates again
+	HibagSideStream side;                  // second stream for pass 1 of the classifiers with several K steps (created at finalize if any)
 	uint32_t epoch = 0;                    // batch counter for the hand-over flags (HibagBatchView::epoch)
 	int *h_err = nullptr;                  // host-mapped error word of the hand-overs
 	// plugin staging
@@ -174,6 +175,9 @@ struct hibag_hip_model {
 		(void)hipSetDevice(device);
 		timer.destroy();
 		if (h_err) (void)hipHostFree(h_err);
+		if (side.fork) (void)hipEventDestroy(side.fork);
+		if (side.join) (void)hipEventDestroy(side.join);
+		if (side.stream) (void)hipStreamDestroy(side.stream);
 		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_cells, &ws_sync, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
 		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_tgeno, &ws_weight, &ws_bed, &ws_bedidx})
 			b->release();
@@ -402,7 +406,7 @@ int finalize_model(hibag_hip_model *m)
 	// per classifier: records (haplotype pairs) of every cell, and 4-record chunks of every cell
 	std::vector<std::vector<uint32_t>> cell_chunks(C), cell_pairs(C);
 	std::vector<std::vector<int>> starts(C);
-	std::vector<int> engine(std::max(C, 1), 0), bt_row(std::max(C, 1), 0), cls_nblk(std::max(C, 1), 0);
+	std::vector<int> engine(std::max(C, 1), 0), bt_row(std::max(C, 1), 0), cls_nblk(std::max(C, 1), 0), n_step(std::max(C, 1), 1);
 	std::vector<int> &mfma_nkb = engine;                 // (non-zero = a matrix engine)
 	std::vector<uint32_t> hap, hap_off(std::max(C, 1), 0);
 	std::vector<int64_t> pairs(C);
@@ -410,6 +414,7 @@ int finalize_model(hibag_hip_model *m)
 	int rows = 0;
 	m->pair_evals = 0;
 	int64_t valu_pairs = 0;
+	const bool allow_wide = !(getenv("HIBAG_PASS2") && !strcmp(getenv("HIBAG_PASS2"), "recompute"));
 	for (int c = 0; c < C; c++) {
 		const HostClassifier &k = m->cls[c];
 		const int H = (int)k.freq.size();
@@ -426,30 +431,47 @@ int finalize_model(hibag_hip_model *m)
 		for (int h = 0; h < nh; h++) st[h + 1] += st[h];
 		// matrix-core engines: at most 32 SNPs; table indices: first haplotype < 2H + 1 in 16 bits, second < H + 1 in 14
 		engine[c] = (m->use_mfma && H < 16384) ? HIBAG_ENGINE_OF(k.n_snp, m->use_fp4) : HIBAG_ENGINE_VALU;
+		// (several K steps need their cells stored: not with pass 2 forced to evaluate every pair)
+		if (engine[c] == HIBAG_ENGINE_FP4 && k.n_snp > HIBAG_FP4_STEP_SNPS && !allow_wide) engine[c] = HIBAG_ENGINE_VALU;
+		n_step[c] = HIBAG_ENGINE_STEPS(engine[c], k.n_snp);
 		bt_row[c] = bt_rows;
-		bt_rows += HIBAG_ENGINE_ROWS(engine[c]);
+		bt_rows += HIBAG_ENGINE_ROWS(engine[c], k.n_snp);
 		cell_chunks[c].assign(P, 0);
 		cell_pairs[c].assign(P, 0);
 		if (mfma_nkb[c]) {
 			// no record stream: the kernels generate the records from the haplotype table
 			hap_off[c] = (uint32_t)hap.size();
 			const bool fp4 = engine[c] == HIBAG_ENGINE_FP4;
-			auto entry = [&](double ff, uint32_t bits, double f) {
-				uint32_t w[12] = {0};
+			const int steps = n_step[c];
+			// bits of a haplotype: SNPs [lo, lo + 32) of its 128-bit string
+			auto window = [&](int i, int lo) -> uint32_t {
+				if (i < 0) return 0u;
+				const unsigned __int128 v = ((unsigned __int128)k.bits[2 * (size_t)i + 1] << 64) | k.bits[2 * (size_t)i];
+				return (uint32_t)(v >> lo);
+			};
+			auto entry = [&](double ff, int i, double f) {
+				uint32_t w[8 + 4 * (HIBAG_FP4_MAX_STEPS - 1)] = {0};
 				int n = 0;
 				if (fp4) {                     // nibble s = 2 (the e2m1 code of 1.0) where bit s is set
+					const uint32_t bits = steps > 1 ? window(i, 0) & ((1u << HIBAG_FP4_STEP_SNPS) - 1) : window(i, 0);
 					for (int sb = 0; sb < 32; sb++) w[sb >> 3] |= ((bits >> sb) & 1u) << (4 * (sb & 7) + 1);
 					n = 4;
 				} else {                       // byte s = 1 where bit s is set
+					const uint32_t bits = window(i, 0);
 					for (int sb = 0; sb < 32; sb++) w[sb >> 2] |= ((bits >> sb) & 1u) << (8 * (sb & 3));
 					n = 8;
 				}
 				memcpy(&w[n], &ff, sizeof(double)); memcpy(&w[n + 2], &f, sizeof(double));
-				hap.insert(hap.end(), w, w + n + 4);
+				n += 4;
+				for (int j = 1; j < steps; j++, n += 4) {      // further K steps: the next 28 SNPs each
+					const uint32_t bits = window(i, HIBAG_FP4_STEP_SNPS * j) & ((1u << HIBAG_FP4_STEP_SNPS) - 1);
+					for (int sb = 0; sb < 32; sb++) w[n + (sb >> 3)] |= ((bits >> sb) & 1u) << (4 * (sb & 7) + 1);
+				}
+				hap.insert(hap.end(), w, w + n);
 			};
-			for (int i = 0; i < H; i++) entry(2 * k.freq[i], (uint32_t)k.bits[2 * (size_t)i], k.freq[i]);
-			entry(0.0, 0u, 0.0);                                   // H: the padding entry (frequency +0.0)
-			for (int i = 0; i < H; i++) entry(k.freq[i], (uint32_t)k.bits[2 * (size_t)i], k.freq[i]);   // H+1+i: first of a diagonal pair
+			for (int i = 0; i < H; i++) entry(2 * k.freq[i], i, k.freq[i]);
+			entry(0.0, -1, 0.0);                                   // H: the padding entry (frequency +0.0)
+			for (int i = 0; i < H; i++) entry(k.freq[i], i, k.freq[i]);   // H+1+i: first of a diagonal pair
 			size_t p = 0;
 			for (int h1 = 0; h1 < nh; h1++)
 				for (int h2 = h1; h2 < nh; h2++) {
@@ -503,13 +525,13 @@ int finalize_model(hibag_hip_model *m)
 			cost += (double)pairs[c] * (mfma_nkb[c] ? 1.0 : 5.0);
 			for (int p = 0; p < P; p++) {
 				n_cells += cell_chunks[c][p] != 0;
-				n_big += mfma_nkb[c] ? cell_pairs[c][p] > store_above : cell_chunks[c][p] != 0;
+				n_big += mfma_nkb[c] && n_step[c] == 1 ? cell_pairs[c][p] > store_above : cell_chunks[c][p] != 0;
 			}
 		}
 		m->store_mode = C == 0 ? 0 : cost >= 14.0 * (double)std::max<long long>(n_cells, 1) ? 1 : n_big ? 2 : 0;
 		if (const char *e = getenv("HIBAG_PASS2")) {
 			if (!strcmp(e, "stream")) m->store_mode = C > 0;
-			else if (!strcmp(e, "recompute")) m->store_mode = 0;
+			else if (!strcmp(e, "recompute")) m->store_mode = 0;       // (no classifier of several K steps then, see above)
 			else if (!strcmp(e, "hybrid")) m->store_mode = n_big ? 2 : 0;
 		}
 	}
@@ -521,8 +543,9 @@ int finalize_model(hibag_hip_model *m)
 	for (int c = 0; c < C; c++) {
 		stored[c].assign(P, 0);
 		if (store_mode == 1) { for (int p = 0; p < P; p++) stored[c][p] = cell_chunks[c][p] != 0; }
-		else if (store_mode == 2 && !mfma_nkb[c]) {
-			// a VALU-engine classifier (more than 32 SNPs) costs about five times as much per pair: all its cells
+		else if (store_mode == 2 && (!mfma_nkb[c] || n_step[c] > 1)) {
+			// a VALU-engine classifier costs about five times as much per pair, and one of several K steps has no
+			// walk in pass 2 at all: all their cells
 			for (int p = 0; p < P; p++) stored[c][p] = cell_chunks[c][p] != 0;
 		} else if (store_mode == 2)
 			for (int t = 0; t < n_tile; t++) {
@@ -594,7 +617,7 @@ int finalize_model(hibag_hip_model *m)
 	// whose work dwarfs the typical one: a single wavefront per sample group would walk them for
 	// many times the duration of the rest of the pass, so they are cut into items of typical size
 	// that store per-cell sums, added in order afterwards (k_total_scan).
-	std::vector<int> item, item_whole, split_row(std::max(C, 1), -1), split_cls;
+	std::vector<int> item, item_whole, split_row(std::max(C, 1), -1), split_cls, wide_cls;
 	double split_heavy_ns = 0, split_rest_ns = 0;
 	{
 		// rough wavefront-time per record: matrix engine 50 ns at full occupancy, VALU engine 18 ns per
@@ -603,13 +626,14 @@ int finalize_model(hibag_hip_model *m)
 		double typical = 0;
 		int n_typ = 0;
 		for (int c = 0; c < C; c++) {
-			work[c] = (double)pairs[c] * (mfma_nkb[c] ? 50.0 : 48.0 * nwp[c]);
+			work[c] = (double)pairs[c] * (mfma_nkb[c] ? 50.0 * (0.5 + 0.5 * n_step[c]) : 48.0 * nwp[c]);
 			if (mfma_nkb[c]) { typical += work[c]; n_typ++; }
 			split_rest_ns += work[c];
 		}
 		typical = n_typ ? typical / n_typ : 0;
 		std::vector<std::pair<double, std::vector<int>>> items, whole;
 		for (int c = 0; c < C; c++) {
+			if (n_step[c] > 1) { wide_cls.push_back(c); continue; }        // pass 1 in k_total_wide
 			whole.push_back({work[c], {c, 0, cls_n[c], 0}});
 			int nseg = 1;
 			if (!mfma_nkb[c] && typical > 0 && work[c] > 3 * typical)
@@ -692,7 +716,9 @@ int finalize_model(hibag_hip_model *m)
 			const uint64_t off = seg_off[(size_t)c * n_tile + t];
 			if (bt_row[c] > 0xFFFF) return fail(HIBAG_HIP_EINVAL, "too many classifiers for the matrix engine's operand rows");
 			(void)me;
-			r[0] = (uint32_t)mfma_nkb[c] | ((uint32_t)n_snp_c[c] << 2 & 0xFCu) | (tile_nlist[(size_t)c * n_tile + t] << 8) | ((uint32_t)bt_row[c] << 16);
+			const int k_last = n_snp_c[c] - HIBAG_FP4_STEP_SNPS * (n_step[c] - 1);        // SNPs of the last K step (all of them for one step)
+			r[0] = (uint32_t)mfma_nkb[c] | ((uint32_t)k_last << 2 & 0xFCu) | (tile_nlist[(size_t)c * n_tile + t] << 8) |
+			       ((uint32_t)(n_step[c] - 1) << 13) | ((uint32_t)bt_row[c] << 16);
 			r[1] = hap_off[c];
 			r[2] = (uint32_t)off; r[3] = (uint32_t)(off >> 32);
 			r[4] = seg_nblk[(size_t)c * n_tile + t];
@@ -735,8 +761,9 @@ int finalize_model(hibag_hip_model *m)
 	std::vector<int> hap_off_i(hap_off.begin(), hap_off.end());
 	const size_t o_nsnp = put(n_snp_c), o_nwp = put(nwp), o_snpoff = put(snp_off), o_snpidx = put(snp_index),
 		o_snpw = put(snp_weight), o_mrow = put(mask_row), o_order = put(c_order), o_tp0 = put(tile_p0), o_tn = put(tile_n),
-		o_coff = put(cls_off), o_cn = put(cls_n), o_nkb = put(mfma_nkb), o_btrow = put(bt_row), o_nblk = put(cls_nblk), o_hapoff = put(hap_off_i),
-		o_item = put(item), o_srow = put(split_row), o_scls = put(split_cls), o_itemw = put(item_whole), o_crow = put(cell_row);
+		o_coff = put(cls_off), o_cn = put(cls_n), o_nkb = put(mfma_nkb), o_nstep = put(n_step), o_btrow = put(bt_row), o_nblk = put(cls_nblk), o_hapoff = put(hap_off_i),
+		o_item = put(item), o_srow = put(split_row), o_scls = put(split_cls), o_itemw = put(item_whole), o_crow = put(cell_row),
+		o_wide = put(wide_cls);
 
 	if (int rc = m->d_int.reserve(arena.size() * sizeof(int))) return rc;
 	if (int rc = m->d_stream.reserve(stream.size() * sizeof(uint32_t))) return rc;
@@ -778,11 +805,17 @@ int finalize_model(hibag_hip_model *m)
 	V.cls_cnt = (const uint32_t *)(tbase + tb_cnt);
 	V.cls_cell = (const uint32_t *)(tbase + tb_cell);
 	V.cls_off = base + o_coff; V.cls_n = base + o_cn;
-	V.engine = base + o_nkb; V.bt_row = base + o_btrow; V.cls_nblk = base + o_nblk;
+	V.engine = base + o_nkb; V.n_step = base + o_nstep; V.bt_row = base + o_btrow; V.cls_nblk = base + o_nblk;
 	V.hap_off = (const uint32_t *)(base + o_hapoff);
 	V.n_item_split = (int)item.size() / 4; V.n_item_whole = (int)item_whole.size() / 4; V.n_split = (int)split_cls.size();
 	V.item_split = base + o_item; V.item_whole = base + o_itemw; V.item = V.item_whole; V.n_item = V.n_item_whole;
 	V.split_row = base + o_srow; V.split_cls = base + o_scls;
+	V.n_wide = (int)wide_cls.size(); V.wide_cls = base + o_wide;
+	if (V.n_wide > 0 && !m->side.stream) {
+		HIP_TRY(hipStreamCreateWithFlags(&m->side.stream, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&m->side.fork, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&m->side.join, hipEventDisableTiming));
+	}
 	V.split_heavy_ns = split_heavy_ns; V.split_rest_ns = split_rest_ns;
 	V.blk_off = (const uint64_t *)(tbase + tb_boff);
 	V.ctile = (const uint32_t *)(tbase + tb_ctile);
@@ -866,7 +899,7 @@ void run_core(hibag_hip_model *m, HibagBatchView &B, int vote_method, double *d_
 	KernelTimer &T = m->timer;
 	B.part = d_part;
 	T.begin(HIBAG_HIP_K_TOTAL, st);
-	hibag_launch_total(m->view, B, st);
+	hibag_launch_total(m->view, B, st, m->side);
 	T.end(st);
 	T.begin(HIBAG_HIP_K_ACCUM, st);
 	if (vote_method == 1) {

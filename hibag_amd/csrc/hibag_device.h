@@ -77,16 +77,26 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 #define HIBAG_PLIST_STORE 0x40000000u        // with END: pass 1 stores this cell's sum for pass 2 to read back
 #define HIBAG_STORED_PER_VISIT 4             // mode 2: stored cells per (classifier, tile) -- what k_accum keeps in registers
 // Matrix-engine variants (HibagModelView::engine[c]; 0 = VALU engine) and their haplotype-table entries:
-//   FP4  (up to 28 SNPs)  v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands: one instruction per sample half covers all
+//   FP4  (up to 28 SNPs; 33 .. 112 in several K steps, below)  v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands: one instruction per sample half covers all
 //                         K = 64 positions.  Entry = { N[16] (nibble s = 2, the code of 1.0, where bit s is set), ff, f }: 8 dwords
 //   I8   (29..31 SNPs), I8S (32 SNPs)  v_mfma_i32_32x32x32_i8, two K blocks.  Entry = { E[32] (byte s = bit s), ff, f }: 12 dwords
 #define HIBAG_ENGINE_VALU 0
 #define HIBAG_ENGINE_FP4 1
 #define HIBAG_ENGINE_I8 2
 #define HIBAG_ENGINE_I8S 3
-#define HIBAG_ENGINE_OF(k, fp4) ((k) > 32 ? HIBAG_ENGINE_VALU : ((fp4) && (k) <= 28 ? HIBAG_ENGINE_FP4 : ((k) == 32 ? HIBAG_ENGINE_I8S : HIBAG_ENGINE_I8)))
-#define HIBAG_ENGINE_ROWS(e) ((e) == HIBAG_ENGINE_FP4 ? 2 : ((e) == HIBAG_ENGINE_VALU ? 0 : 4))   // B-operand rows (16 B per lane each)
-#define HIBAG_ENGINE_HAP_DWORDS(e) ((e) == HIBAG_ENGINE_FP4 ? 8 : 12)
+// FP4 in several K steps (33 .. 112 SNPs): the SNPs are cut into groups of 28, each group a complete FP4 operand pair of its
+// own (its SNPs, its share of the offset), and the group's products are chained through the accumulator operand -- a
+// denormal accumulator survives the instruction exactly (tools/mfma_fp4_probe, trial 3).  Entry = the FP4 entry followed by
+// one more 16-byte image per further step; B operands: two rows per step.
+#define HIBAG_FP4_STEP_SNPS 28
+#define HIBAG_FP4_MAX_STEPS 4
+#define HIBAG_FP4_STEPS(k) (((k) + HIBAG_FP4_STEP_SNPS - 1) / HIBAG_FP4_STEP_SNPS)
+#define HIBAG_ENGINE_OF(k, fp4) ((fp4) && (k) <= 28 ? HIBAG_ENGINE_FP4 : (k) < 32 ? HIBAG_ENGINE_I8 : (k) == 32 ? HIBAG_ENGINE_I8S : \
+	(fp4) && (k) <= HIBAG_FP4_STEP_SNPS * HIBAG_FP4_MAX_STEPS ? HIBAG_ENGINE_FP4 : HIBAG_ENGINE_VALU)
+#define HIBAG_ENGINE_STEPS(e, k) ((e) == HIBAG_ENGINE_FP4 ? HIBAG_FP4_STEPS(k) < 1 ? 1 : HIBAG_FP4_STEPS(k) : 1)
+#define HIBAG_ENGINE_ROWS(e, k) ((e) == HIBAG_ENGINE_FP4 ? 2 * HIBAG_ENGINE_STEPS(e, k) : ((e) == HIBAG_ENGINE_VALU ? 0 : 4))   // B-operand rows (16 B per lane each)
+#define HIBAG_ENGINE_HAP_DWORDS(e) ((e) == HIBAG_ENGINE_FP4 ? 8 : 12)                             // (FP4: of a one-step entry)
+#define HIBAG_FP4_ENTRY_DWORDS(steps) (8 + 4 * ((steps) - 1))
 // K layout of the distance dot product for a classifier with k SNPs.  With the genotype g of the sample at SNP s:
 //   g = 0: h1 + h2      g = 2: 2 - h1 - h2      g = 1: [h1 == h2] = 1 - h1 - h2 + 2 h1 h2        (src/LibHLA.cpp:747-819)
 //   8 d = sum_s (h1_s + h2_s) * 8 t_s  +  sum_s (h1_s & h2_s) * 16 [g_s == 1]  +  8 * offset,
@@ -145,6 +155,9 @@ struct HibagModelView {
 
 	// matrix-core engine (classifiers with at most 32 SNPs; hibag_kernels.hip "MFMA engine")
 	const int *engine;           // [C] HIBAG_ENGINE_*
+	const int *n_step;           // [C] K steps of the FP4 engine (1 up to 28 SNPs; HIBAG_FP4_STEPS), 1 for the others
+	int n_wide;                  // classifiers with n_step > 1: pass 1 in k_total_wide, not among the work items; all their cells stored
+	const int *wide_cls;         // [n_wide]
 	const int *bt_row;           // [C] first operand row of the classifier in HibagBatchView::bt
 	const uint32_t *hap;         // haplotype table (entry size by engine, see below)
 	const uint32_t *hap_off;     // [C] dword offset of the classifier's first entry
@@ -154,7 +167,7 @@ struct HibagModelView {
 	const uint32_t *plist;       // pair lists: blocks of HIBAG_PLIST_DWORDS dwords
 	uint64_t plist_dwords;       // total size (a raw buffer is rebased per classifier / tile segment: no 4 GB limit)
 	const uint32_t *ctile;       // [C][n_tile][8]: everything pass 2 needs per (classifier, tile) in one s_load_dwordx8:
-	                             // {engine | k << 2 | #listed cells << 8 | bt_row << 16, dword offset of the first haplotype-table entry,
+	                             // {engine | k << 2 | #listed cells << 8 | (K steps - 1) << 13 | bt_row << 16    (k: SNPs of the LAST K step), dword offset of the first haplotype-table entry,
 	                             //  pair list dword offset lo/hi, #blocks, first stored row | #stored cells << 27, row list lo/hi}
 	                             // row list: 4 bits per cell -- the listed (evaluated) cells in closing order, then the stored ones
 

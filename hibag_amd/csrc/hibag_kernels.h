@@ -17,7 +17,10 @@ void hibag_launch_bed_geno(const uint8_t *d_bed, int mode, size_t stride, int n_
 	const int32_t *d_sel, int32_t *d_geno, hipStream_t st);
 void hibag_launch_unpack_tgeno(const HibagModelView &M, const HibagBatchView &B, const uint64_t *d_tgeno,
 	const double *d_weight, hipStream_t st);
-void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st);
+// `side`: a second stream and two events of the caller's, for the kernel that runs beside pass 1 where the model has
+// FP4 classifiers of several K steps (fork behind what is already on `st`, join before anything that follows)
+struct HibagSideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st, const HibagSideStream &side);
 void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStream_t st);
 void hibag_launch_vote(const HibagModelView &M, const HibagBatchView &B, int *d_best_cell, hipStream_t st);
 void hibag_launch_scalars(const HibagModelView &M, const HibagBatchView &B, const int *d_best_cell, hipStream_t st);

@@ -158,6 +158,19 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 template <class T> using ConstPtr = const __attribute__((address_space(4))) T *;
 template <class T> __device__ __forceinline__ ConstPtr<T> as_const(const T *p) { return (ConstPtr<T>)(uintptr_t)p; }
 
+// Template tag of the walk for FP4 classifiers with more than one K step (33 .. 112 SNPs); HibagModelView::engine says
+// HIBAG_ENGINE_FP4 for them, n_step > 1.
+#define HIBAG_ENGINE_FP4W 4
+
+// Where the further K steps of such a classifier find their B operands (all wave-uniform: the lane's address is only
+// formed where a step needs it): step j, sample half n = bt[((bt_row + 2 j + n) * n_group + group) * 64 + lane]
+struct WideSrc {
+	const uint4 *bt = nullptr;
+	size_t n_group = 0;
+	int bt_row = 0, group = 0;
+	int nstep = 1;
+};
+
 struct LaneOperand {
 	v4i b[2][2];        // B operand of sample half n, K block kb (MFMA lane layout); the FP4 engine uses b[n][0] only
 	int bias[2];        // I8S (32 SNPs) only: the lane's distance offset (times 8) for each sample half
@@ -168,7 +181,7 @@ template <int ENG>
 __device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt_row, int c, int group,
 	int lane, LaneOperand &T)
 {
-	constexpr int NKB = ENG == HIBAG_ENGINE_FP4 ? 1 : 2;
+	constexpr int NKB = (ENG == HIBAG_ENGINE_FP4 || ENG == HIBAG_ENGINE_FP4W) ? 1 : 2;
 	const size_t n_group = (size_t)(B.n_pad / HIBAG_WAVE);
 #pragma unroll
 	for (int n = 0; n < 2; n++) {
@@ -179,6 +192,13 @@ __device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt
 		}
 		T.bias[n] = ENG == HIBAG_ENGINE_I8S ? B.bias[((size_t)(2 * c + n) * n_group + group) * HIBAG_WAVE + lane] : 0;
 	}
+}
+
+__device__ __forceinline__ WideSrc wide_src(const HibagBatchView &B, int bt_row, int nstep, int group)
+{
+	WideSrc w;
+	w.bt = B.bt; w.n_group = (size_t)(B.n_pad / HIBAG_WAVE); w.bt_row = bt_row; w.group = group; w.nstep = nstep;
+	return w;
 }
 
 // 16 bits -> 16 bytes (bit i -> byte i = 0/1): per nibble (n * 0x00204081) & 0x01010101
@@ -215,29 +235,37 @@ __device__ __forceinline__ v4i fp4_offset_term(int k, int lane)
 //   FP4       the whole nibble image (32 nibbles of code 0 / 2); lanes 0..31 carry e1 + e2 (codes 0 / 2 / 4 = 0, 1, 2),
 //             lanes 32..63 e1 & e2, each plus its constant nibbles `cterm`; the f32 result is the denormal 8 d * 2^-149,
 //             i.e. its bits are the integer 8 d
+// One K step of the FP4 distance: d_n += A x B_n for the two sample halves, A built from this lane's images.
+__device__ __forceinline__ void fp4_step(const v4i &e1, const v4i &e2, int lane, const v4i &cterm, const v4i &b0v, const v4i &b1v,
+	v16f &d0, v16f &d1)
+{
+	const bool upper = lane >= 32;
+	v4i a;
+	if (upper) {
+#pragma unroll
+		for (int d = 0; d < 4; d++) a[d] = (e1[d] & e2[d]) | cterm[d];
+	} else {
+#pragma unroll
+		for (int d = 0; d < 4; d++) a[d] = e1[d] + e2[d] + cterm[d];       // nibbles 0 / 2 / 4 and the constants: no carry
+	}
+	const v8i a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+	const v8i b0 = {b0v[0], b0v[1], b0v[2], b0v[3], 0, 0, 0, 0};
+	const v8i b1 = {b1v[0], b1v[1], b1v[2], b1v[3], 0, 0, 0, 0};
+	const int sb = upper ? HIBAG_FP4_SCALE_B_HI : HIBAG_FP4_SCALE_B_LO;
+	d0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, d0, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sb);
+	d1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, d1, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sb);
+}
+
 template <int ENG>
 __device__ __forceinline__ void block_mfma(const v4i &e1, const v4i &e2, int lane, const v4i &cterm, const LaneOperand &T,
 	v16i &acc0, v16i &acc1)
 {
 	const bool upper = lane >= 32;
 	if (ENG == HIBAG_ENGINE_FP4) {
-		v4i a;
-		if (upper) {
+		v16f d0, d1;
 #pragma unroll
-			for (int d = 0; d < 4; d++) a[d] = (e1[d] & e2[d]) | cterm[d];
-		} else {
-#pragma unroll
-			for (int d = 0; d < 4; d++) a[d] = e1[d] + e2[d] + cterm[d];       // nibbles 0 / 2 / 4 and the constants: no carry
-		}
-		const v8i a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
-		const v8i b0 = {T.b[0][0][0], T.b[0][0][1], T.b[0][0][2], T.b[0][0][3], 0, 0, 0, 0};
-		const v8i b1 = {T.b[1][0][0], T.b[1][0][1], T.b[1][0][2], T.b[1][0][3], 0, 0, 0, 0};
-		const int sb = upper ? HIBAG_FP4_SCALE_B_HI : HIBAG_FP4_SCALE_B_LO;
-		v16f z;
-#pragma unroll
-		for (int r = 0; r < 16; r++) z[r] = 0.0f;
-		const v16f d0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, z, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sb);
-		const v16f d1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, z, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sb);
+		for (int r = 0; r < 16; r++) { d0[r] = 0.0f; d1[r] = 0.0f; }
+		fp4_step(e1, e2, lane, cterm, T.b[0][0], T.b[1][0], d0, d1);
 		acc0 = __builtin_bit_cast(v16i, d0);
 		acc1 = __builtin_bit_cast(v16i, d1);
 		return;
@@ -371,16 +399,19 @@ struct ListCursor {
 // so that the look-ahead stays in bounds.
 template <int ENG, int G, class Fin>
 __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at, int nblk, int lane, ListCursor &cur,
-	__amdgpu_buffer_rsrc_t hp, int k, const LaneOperand &T, const double *tab_s, double *stage, double &cell, Fin &&fin)
+	__amdgpu_buffer_rsrc_t hp, int k, const LaneOperand &T, const WideSrc &wide, const double *tab_s, double *stage, double &cell, Fin &&fin)
 {
 	if (nblk <= 0) return;
-	constexpr bool FP4 = ENG == HIBAG_ENGINE_FP4;
-	constexpr uint32_t ES = 4 * HIBAG_ENGINE_HAP_DWORDS(ENG);                // bytes per table entry
+	// FP4W: an FP4 classifier of `wide.nstep` K steps; `k` = SNPs of its LAST step, the others have HIBAG_FP4_STEP_SNPS
+	constexpr bool FP4W = ENG == HIBAG_ENGINE_FP4W;
+	constexpr bool FP4 = ENG == HIBAG_ENGINE_FP4 || FP4W;
+	const uint32_t ES = FP4W ? 4u * (uint32_t)HIBAG_FP4_ENTRY_DWORDS(wide.nstep)
+	                         : 4u * (uint32_t)HIBAG_ENGINE_HAP_DWORDS(FP4 ? HIBAG_ENGINE_FP4 : HIBAG_ENGINE_I8);   // bytes per table entry
 	constexpr int FO = FP4 ? 16 : 32;                                         // ff behind the image
 	const int vo_i = (lane & 31) * 4;                // this lane's slot inside a block
 	// this lane's 16 bytes of an image: the K half's bytes (int8), the whole nibble image (FP4)
 	const uint32_t img = FP4 ? 0u : (uint32_t)(lane >> 5) * 16u;
-	const v4i cterm = FP4 ? fp4_offset_term(k, lane) : v4i{0, 0, 0, 0};
+	const v4i cterm = FP4 ? fp4_offset_term(FP4W ? HIBAG_FP4_STEP_SNPS : k, lane) : v4i{0, 0, 0, 0};   // (of K step 0)
 	const uint32_t BB = 4 * HIBAG_PLIST_DWORDS;      // bytes per block
 	// The list is addressed as a raw buffer rebased at this segment, so that the 32-bit offsets inside
 	// the descriptor never limit the model size.
@@ -408,6 +439,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 		const uint32_t storemask = (uint32_t)__ballot(idx_c >= (HIBAG_PLIST_END | HIBAG_PLIST_STORE));
 		const uint32_t live = endmask | (uint32_t)__ballot(prod != 0.0);                      // low half: lanes 0..31
 		const int n_valid = live ? 32 - __builtin_clz(live) : 0;
+		const uint32_t ob1 = o1, ob2 = o2;           // (FP4W: where this block's entries are, for their further images)
 		// look-ahead: entries of block b+1, slot words of block b+2
 		idx_c = idx_n;
 		o1 = (idx_c & 0xFFFFu) * ES + img; o2 = ((idx_c >> 16) & 0x3FFFu) * ES + img;
@@ -417,7 +449,26 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 		if (n_valid > 0) {
 			if (lane < 32) buf[lane] = prod;
 			v16i D0, D1;
-			block_mfma<ENG>(a1, a2, lane, cterm, T, D0, D1);
+			if (FP4W) {
+				// K step 0 like a one-step classifier, then the further steps: their images and B operands are fetched here
+				// (no look-ahead: a classifier this wide is rare, and its registers would be everybody's), chained through the
+				// accumulators
+				v16f d0, d1;
+#pragma unroll
+				for (int r = 0; r < 16; r++) { d0[r] = 0.0f; d1[r] = 0.0f; }
+				fp4_step(a1, a2, lane, cterm, T.b[0][0], T.b[1][0], d0, d1);
+				for (int j = 1; j < wide.nstep; j++) {
+					const v4i s1 = load_hap_image(hp, ob1 + 16u + 16u * (uint32_t)j), s2 = load_hap_image(hp, ob2 + 16u + 16u * (uint32_t)j);
+					const uint4 *row = wide.bt + ((size_t)(wide.bt_row + 2 * j) * wide.n_group + wide.group) * HIBAG_WAVE;
+					const uint4 u0 = row[lane], u1 = row[wide.n_group * HIBAG_WAVE + lane];
+					const v4i cj = fp4_offset_term(j == wide.nstep - 1 ? k : HIBAG_FP4_STEP_SNPS, lane);
+					fp4_step(s1, s2, lane, cj, v4i{(int)u0.x, (int)u0.y, (int)u0.z, (int)u0.w}, v4i{(int)u1.x, (int)u1.y, (int)u1.z, (int)u1.w}, d0, d1);
+				}
+				D0 = __builtin_bit_cast(v16i, d0);
+				D1 = __builtin_bit_cast(v16i, d1);
+			} else {
+				block_mfma<ENG>(a1, a2, lane, cterm, T, D0, D1);
+			}
 			block_own_sample(D0, D1, n_valid);
 			block_accumulate<G>(buf, endmask, storemask, n_valid, D0, D1, cell, tab_s, fin);
 		}
@@ -441,6 +492,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t hap_rsrc(const HibagModelView 
 #define HIBAG_DISPATCH_ENGINE(code, CALL)              \
 	switch (code) {                                    \
 	case HIBAG_ENGINE_FP4: { CALL(HIBAG_ENGINE_FP4); } break;  \
+	case HIBAG_ENGINE_I8:  { CALL(HIBAG_ENGINE_I8); } break;   \
+	default:               { CALL(HIBAG_ENGINE_I8S); } break;  \
+	}
+// ... where FP4 classifiers of several K steps can turn up (k_total_wide, k_vote_best: the hot kernels never see them --
+// their extra registers would cost every classifier a spill in the block loop)
+#define HIBAG_DISPATCH_ENGINE_WIDE(code, nstep, CALL)  \
+	switch (code) {                                    \
+	case HIBAG_ENGINE_FP4: if ((nstep) > 1) { CALL(HIBAG_ENGINE_FP4W); } else { CALL(HIBAG_ENGINE_FP4); } break;  \
 	case HIBAG_ENGINE_I8:  { CALL(HIBAG_ENGINE_I8); } break;   \
 	default:               { CALL(HIBAG_ENGINE_I8S); } break;  \
 	}
@@ -593,11 +652,15 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 	const int nkb = M.engine[c];                      // matrix-engine variant, 0 = VALU engine
 	int num = 0, den = 0;
 	if (nkb > 0) {
-		// one pass over the classifier's k <= 32 SNPs (independent byte loads, several in flight)
-		uint32_t X = 0, Z = 0, E = 0;          // bit j: g == 2, g == 0, g == 1 at SNP j
+	// one pass over the SNPs of each K step (independent byte loads, several in flight): all k <= 32 of them, or 28 per
+	// step of a multi-step FP4 classifier
+	const int steps = M.n_step[c];
+	for (int st = 0; st < steps; st++) {
+		const int j0 = steps > 1 ? HIBAG_FP4_STEP_SNPS * st : 0, kj = steps > 1 ? min(HIBAG_FP4_STEP_SNPS, k - j0) : k;
+		uint32_t X = 0, Z = 0, E = 0;          // bit j: g == 2, g == 0, g == 1 at SNP j0 + j
 #pragma unroll 8
-		for (int j = 0; j < k; j++) {
-			const int snp = idx[j];
+		for (int j = 0; j < kj; j++) {
+			const int snp = idx[j0 + j];
 			const uint32_t g = codes[(size_t)snp * B.n_pad + s];
 			const int wt = M.snp_weight[snp];
 			den += wt;
@@ -625,10 +688,10 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 				const uint32_t digits = h == 0 ? ((offset & 1u) * 0x2u) | (((offset >> 1) & 1u) * 0x40u) | (((offset >> 2) & 1u) * 0x600u) |
 				                                 (((offset >> 3) & 1u) * 0x4000u)
 				                               : (((offset >> 4) & 1u) * 0x4u) | (((offset >> 5) & 1u) * 0x60u);
-				const unsigned __int128 d128 = (unsigned __int128)digits << (4 * k);
+				const unsigned __int128 d128 = (unsigned __int128)digits << (4 * kj);
 #pragma unroll
 				for (int q = 0; q < 4; q++) a[q] |= (uint32_t)(d128 >> (32 * q));
-				B.bt[((size_t)(M.bt_row[c] + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (lane & 31)] =
+				B.bt[((size_t)(M.bt_row[c] + 2 * st + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (lane & 31)] =
 					uint4{a[0], a[1], a[2], a[3]};
 			}
 		} else {
@@ -654,8 +717,9 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 				B.bias[at + 32] = 8 * (int)offset;
 			}
 		}
+	}
 	} else {
-		// VALU engine (more than 32 SNPs, or the plugin path): one pass over the k <= 128 SNPs builds the
+		// VALU engine (more than 112 SNPs, or the plugin path): one pass over the k <= 128 SNPs builds the
 		// three k-bit fields [g == 2], [g in {0, 2}], [g == 1] in LDS (four words each per lane); the 3k-bit
 		// strings are then put together word by word with wave-uniform bit offsets.
 		uint32_t (*fld)[4][HIBAG_WAVE] = pack_s[threadIdx.x >> 6];          // [field][word][lane]
@@ -896,7 +960,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagMod
 #define CALL(E) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, lane, T);                                       \
 			ListCursor cur;                                                                                                \
 			walk_blocks<E, 4>(M, M.blk_off[c] + (uint64_t)b0 * HIBAG_PLIST_DWORDS, b1 - b0, lane, cur,                 \
-				hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c], T, tab_s, stage_s[wave], cell, fin); }
+				hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c], T, WideSrc(), tab_s, stage_s[wave], cell, fin); }
 			HIBAG_DISPATCH_ENGINE(nkb, CALL)
 #undef CALL
 			if (!last) { B.tot[at] = total; B.inv[at] = cell; }
@@ -912,6 +976,39 @@ __global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagMod
 		}
 	}
 	if (!last) handover_post(flag, B.epoch, (uint32_t)b1);
+}
+
+// k_total_wide: pass 1 of the FP4 classifiers with several K steps (33 .. 112 SNPs; HibagModelView::wide_cls) -- a kernel
+// of their own, started beside k_total on a second stream: their walk needs a dozen registers more than k_total's 96.
+// They store every cell (pass 2 reads them back whatever the model's other classifiers do).  grid (group quads, wide classifiers).
+__global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total_wide(HibagModelView M, HibagBatchView B)
+{
+	__shared__ double tab_s[HIBAG_TAB_N];
+	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
+	stage_table(M, tab_s);
+	const int c = M.wide_cls[blockIdx.y];
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const int group = blockIdx.x * BLOCK_WAVES + wave;
+	if (group * HIBAG_WAVE >= B.n_pad) return;
+	const int s = group * HIBAG_WAVE + lane;
+	const size_t at = (size_t)c * B.n_pad + s;
+	if (__ballot(B.cw[at] > 0) == 0) return;          // nobody needs this classifier (src/LibHLA.cpp:2451)
+	double total = 0, cell = 0;
+	double *__restrict__ rows = cell_rows(M, B, c, group);
+	int row = 0;
+	auto fin = [&](double v, bool) {
+		__builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++;
+		total += v;
+		asm("" : "+v"(total));                        // keeps the cell end a scalar branch
+	};
+	const WideSrc wide = wide_src(B, M.bt_row[c], M.n_step[c], group);
+	LaneOperand T;
+	load_operand_row<HIBAG_ENGINE_FP4W>(B, M.bt_row[c], c, group, lane, T);
+	ListCursor cur;
+	walk_blocks<HIBAG_ENGINE_FP4W, 4>(M, M.blk_off[c], M.cls_nblk[c], lane, cur, hap_rsrc(M, M.hap_off[c]),
+		M.n_snp_c[c] - HIBAG_FP4_STEP_SNPS * (wide.nstep - 1), T, wide, tab_s, stage_s[wave], cell, fin);
+	B.tot[at] = total;
+	B.inv[at] = 1 / total;                            // src/LibHLA.cpp:1827 (inf when total == 0)
 }
 
 // k_total_scan: the in-order total of a split classifier from its stored cell sums; thread = sample.
@@ -1115,10 +1212,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 				__hip_atomic_fetch_add(&acc[(int)(jpack & 15)][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				jpack >>= 4;
 			};
+			// (an FP4 classifier of several K steps has all its cells stored: it never has a list here)
 #define CALL(E) { LaneOperand T; load_operand_row<E>(B, (int)(rec[0] >> 16), c, group, lane, T);                          \
 			double cell = 0;                                                                                            \
 			walk_blocks<E, 4>(M, ((uint64_t)rec[3] << 32) | rec[2], (int)rec[4], lane, cur, hap_rsrc(M, rec[1]),        \
-				(int)((rec[0] >> 2) & 63u), T, tab_s, stage_s[wave], cell, fin); }
+				(int)((rec[0] >> 2) & 63u), T, WideSrc(), tab_s, stage_s[wave], cell, fin); }
 			if (rec[4] > 0) { HIBAG_DISPATCH_ENGINE(nkb, CALL) }
 #undef CALL
 		} else if (M.store_cells != 2) {
@@ -1282,12 +1380,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_vote_best(HibagModelView M
 			if (best < prob) { best = prob; best_i = i; }
 			i++;
 		};
+		const WideSrc wide = wide_src(B, M.bt_row[c], M.n_step[c], group);
+		const int k_last = M.n_snp_c[c] - HIBAG_FP4_STEP_SNPS * (wide.nstep - 1);
 #define CALL(E) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, threadIdx.x & 63, T);                           \
 		ListCursor cur;                                                                                                \
 		double cell = 0;                                                                                               \
-		walk_blocks<E, 4>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c],    \
-			T, tab_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)], cell, fin); }
-		HIBAG_DISPATCH_ENGINE(nkb, CALL)
+		walk_blocks<E, 4>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), k_last,         \
+			T, wide, tab_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)], cell, fin); }
+		HIBAG_DISPATCH_ENGINE_WIDE(nkb, wide.nstep, CALL)
 #undef CALL
 		bp = best_i < 0 ? -1 : (int)M.cls_cell[M.cls_off[c] + best_i];
 	} else {
@@ -1540,9 +1640,26 @@ static int tail_chunks(long long blocks_per_item = 0)
 	return k ? k : (int)std::max(4ll, std::min(12ll, blocks_per_item / 256));
 }
 
-void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st)
+void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st, const HibagSideStream &side)
 {
 	if (M.n_classifier == 0) return;
+	const bool wide = M.n_wide > 0;
+	if (wide) {
+		// the classifiers of several K steps: their own kernel, beside k_total (more registers than k_total's hot loop may have)
+		const unsigned gq = (unsigned)((B.n_pad / HIBAG_WAVE + BLOCK_WAVES - 1) / BLOCK_WAVES);
+		if (side.stream) {
+			(void)hipEventRecord(side.fork, st);
+			(void)hipStreamWaitEvent(side.stream, side.fork, 0);
+			hipLaunchKernelGGL(k_total_wide, dim3(gq, M.n_wide), dim3(BLOCK_THREADS), 0, side.stream, M, B);
+			(void)hipEventRecord(side.join, side.stream);
+		} else {
+			hipLaunchKernelGGL(k_total_wide, dim3(gq, M.n_wide), dim3(BLOCK_THREADS), 0, st, M, B);
+		}
+	}
+	if (M.n_item_whole == 0) {                        // (every classifier is one of those)
+		if (wide && side.stream) (void)hipStreamWaitEvent(st, side.join, 0);
+		return;
+	}
 	const unsigned gx = (unsigned)((B.n_pad / HIBAG_WAVE + BLOCK_WAVES - 1) / BLOCK_WAVES);
 	// A classifier far heavier than the rest (VALU engine, > 32 SNPs) is only worth cutting up when its
 	// single-wavefront walk would outlast the rest of the pass, i.e. for small batches.
@@ -1571,6 +1688,7 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 		hipLaunchKernelGGL(k_total<false>, grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
 	if (split)
 		hipLaunchKernelGGL(k_total_scan, dim3(B.n_pad / 64, V.n_split), dim3(64), 0, st, V, B);
+	if (wide && side.stream) (void)hipStreamWaitEvent(st, side.join, 0);
 }
 
 void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStream_t st)

@@ -80,13 +80,24 @@ class HlaAttrBagObj:
 def engine_kind(n_snp_c: int) -> str:
     """The library's distance engine for a classifier with ``n_snp_c`` SNPs (``HIBAG_ENGINE_OF`` in
     csrc/hibag_device.h): ``"fp4"`` (up to 28 SNPs: one v_mfma_scale_f32_32x32x64_f8f6f4 per sample half and
-    32-record block), ``"i8"`` (29..32 SNPs: two v_mfma_i32_32x32x32_i8), ``"valu"`` (more than 32 SNPs)."""
+    32-record block; 33..112 SNPs: one per 28 SNPs, chained through the accumulator -- ``engine_steps``), ``"i8"``
+    (29..32 SNPs: two v_mfma_i32_32x32x32_i8), ``"valu"`` (more than 112 SNPs)."""
     k = int(n_snp_c)
-    if k > 32:
+    e = os.environ.get("HIBAG_ENGINE")
+    if e == "valu":
         return "valu"
-    if os.environ.get("HIBAG_ENGINE") == "valu":
-        return "valu"
-    return "fp4" if k <= 28 and os.environ.get("HIBAG_ENGINE") != "i8" else "i8"
+    if k <= 28 and e != "i8":
+        return "fp4"
+    if k <= 32:
+        return "i8"
+    if k <= 112 and e != "i8" and os.environ.get("HIBAG_PASS2") != "recompute":
+        return "fp4"
+    return "valu"
+
+
+def engine_steps(n_snp_c: int) -> int:
+    """K steps of the FP4 engine for a classifier with ``n_snp_c`` SNPs (1 for the other engines)."""
+    return max(1, -(-int(n_snp_c) // 28)) if engine_kind(n_snp_c) == "fp4" else 1
 
 
 def engine_nkb(n_snp_c: int) -> int:

@@ -90,9 +90,9 @@ def test_synthetic_models(hib, oracle, shape, n, vote):
 
 @pytest.mark.parametrize("vote", [1, 2])
 def test_every_classifier_width(hib, oracle, vote):
-    """One classifier per SNP count 1..40 and 63..66, 127, 128: every engine variant
-    (1, 2, 3 K blocks with the distance offset inside the dot product, k = 31/32 with
-    the accumulator offset, the VALU engine's word counts) and their boundaries."""
+    """One classifier per SNP count 1..40 and 63..66, 96, 127, 128: every engine variant (FP4 in one K step up to 28 SNPs,
+    int8 with the distance offset inside the dot product / in the accumulators for 29..31 / 32, FP4 in two to four
+    chained K steps up to 112, the VALU engine's word counts beyond) and their boundaries."""
     from hibag_amd import synth
     ks = list(range(1, 41)) + [63, 64, 65, 66, 96, 127, 128]
     model, founders, af = synth.make_model("hla-a-small", seed=77, n_classifier=len(ks), n_snp=160,
@@ -103,6 +103,24 @@ def test_every_classifier_width(hib, oracle, vote):
     want = oracle.predict(oracle.flatten(model), G, vote_method=vote, avx2=True, n_threads=8)
     got = hib.hlaModelFromObj(model).predict_raw(G, vote, want_dosage=True, want_prob=True)
     assert_same(got, want)
+
+
+def test_only_wide_classifiers(hib, oracle):
+    """Every classifier between 33 and 112 SNPs: the FP4 engine in two to four K steps chained through the accumulator
+    (pass 1 in k_total_wide beside an empty k_total, every cell stored), both vote methods, a batch of more than one
+    group quad."""
+    from hibag_amd import synth
+    ks = [33, 40, 56, 57, 84, 85, 100, 112]
+    model, founders, af = synth.make_model("hla-a-small", seed=31, n_classifier=len(ks), n_snp=130, snp_counts=ks, wide_classifier=False)
+    G, _ = synth.make_samples(founders, af, 700, seed=32, miss=0.03)
+    G[5, :] = hib.NA_INTEGER
+    G[128:192, :] = hib.NA_INTEGER
+    m = hib.hlaModelFromObj(model)
+    assert m.stored_cells() > 0 and m.second_pass_pairs() == 0
+    for vote in (1, 2):
+        assert_same(m.predict_raw(G, vote, want_dosage=True, want_prob=True),
+                    oracle.predict(oracle.flatten(model), G, vote_method=vote, avx2=True, n_threads=8))
+    m.close()
 
 
 def test_many_alleles(hib, oracle):
