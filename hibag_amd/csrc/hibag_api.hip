@@ -142,7 +142,7 @@ struct hibag_hip_model {
 	int n_hla = 0, n_snp = 0;
 	bool finalized = false;
 	bool have_snpidx = true;
-	bool use_mfma = true;                  // matrix-core engine for classifiers with <= 32 SNPs (HIBAG_ENGINE=valu disables)
+	bool use_mfma = true;                  // matrix-core engine for classifiers with <= 112 SNPs (HIBAG_ENGINE=valu disables)
 	bool use_fp4 = true;                   // its FP4 form for <= 28 SNPs (HIBAG_ENGINE=i8 keeps every classifier on the int8 form)
 	std::vector<HostClassifier> cls;
 	std::vector<int> snp_weight_override;   // classifier-sharded runs
@@ -429,7 +429,7 @@ int finalize_model(hibag_hip_model *m)
 		st.assign(nh + 1, 0);
 		for (int i = 0; i < H; i++) st[k.hla[i] + 1]++;
 		for (int h = 0; h < nh; h++) st[h + 1] += st[h];
-		// matrix-core engines: at most 32 SNPs; table indices: first haplotype < 2H + 1 in 16 bits, second < H + 1 in 14
+		// matrix-core engines: at most 112 SNPs; table indices: first haplotype < 2H + 1 in 16 bits, second < H + 1 in 14
 		engine[c] = (m->use_mfma && H < 16384) ? HIBAG_ENGINE_OF(k.n_snp, m->use_fp4) : HIBAG_ENGINE_VALU;
 		// (several K steps need their cells stored: not with pass 2 forced to evaluate every pair)
 		if (engine[c] == HIBAG_ENGINE_FP4 && k.n_snp > HIBAG_FP4_STEP_SNPS && !allow_wide) engine[c] = HIBAG_ENGINE_VALU;
@@ -613,7 +613,7 @@ int finalize_model(hibag_hip_model *m)
 	}
 	if (cls_cnt.empty()) { cls_cnt.push_back(0); cls_cell.push_back(0); }
 
-	// pass-1 work items.  One per classifier, except VALU-engine classifiers (more than 32 SNPs)
+	// pass-1 work items.  One per classifier, except VALU-engine classifiers (more than 112 SNPs)
 	// whose work dwarfs the typical one: a single wavefront per sample group would walk them for
 	// many times the duration of the rest of the pass, so they are cut into items of typical size
 	// that store per-cell sums, added in order afterwards (k_total_scan).

@@ -10,7 +10,7 @@
 //    For pass 2 the posterior cells are grouped in TILES of up to HIBAG_TILE consecutive
 //    cells with about equal work.
 //
-//    VALU-engine classifiers (more than 32 SNPs; every classifier of the per-sample plugin path)
+//    VALU-engine classifiers (more than 112 SNPs; every classifier of the per-sample plugin path)
 //    get the nest flattened into a PAIR STREAM, one record per haplotype pair, fetched with scalar loads:
 //        W[nwp]  the 3k-bit string  H1 | H2 << k | ~(H1^H2) << 2k   (k = #SNPs)
 //        prod    the frequency factor, rounded as the reference rounds it:
@@ -25,7 +25,7 @@
 //    (2 dwords), then one entry (j << 24 | chunks) per cell of the tile: the
 //    non-empty ones in order, then the empty ones }.
 //
-//    The matrix-core engine (classifiers with at most 32 SNPs) does not read pair
+//    The matrix-core engine (classifiers with at most 112 SNPs) does not read pair
 //    records at all: it GENERATES them from an O(H) haplotype table
 //        entry i of classifier c = { image of the haplotype's bits (bytes or nibbles, by engine), ff (double), f (double) }   48 / 32 bytes
 //    where f is the haplotype's frequency and ff = 2 f the factor it contributes as the FIRST haplotype
@@ -153,7 +153,7 @@ struct HibagModelView {
 	const uint32_t *stream;      // the pair records of the VALU-engine classifiers
 	const double *tab;           // [257] exp(d*log(1e-5))
 
-	// matrix-core engine (classifiers with at most 32 SNPs; hibag_kernels.hip "MFMA engine")
+	// matrix-core engine (classifiers with at most 112 SNPs; hibag_kernels.hip "MFMA engine")
 	const int *engine;           // [C] HIBAG_ENGINE_*
 	const int *n_step;           // [C] K steps of the FP4 engine (1 up to 28 SNPs; HIBAG_FP4_STEPS), 1 for the others
 	int n_wide;                  // classifiers with n_step > 1: pass 1 in k_total_wide, not among the work items; all their cells stored

@@ -19,10 +19,10 @@
 //                 v_mfma_i32_32x32x32_i8 (two K blocks) -- plus 16 v_permlane32_swap to give every lane its own
 //                 sample's column.  The records are generated: each lane gathers its pair's two haplotype
 //                 entries (nibble / byte images + frequency factors) from an O(H) table through a 4-byte index
-//                 pair.  Classifiers with at most 32 SNPs, i.e. all real ones; the default.
+//                 pair.  33..112 SNPs: FP4 again, 28 SNPs per K step, chained through the accumulator.  All real classifiers; the default.
 //   VALU engine   d = sum_w popc((W[w] ^ T'[w]) & M'[w]): v_bitop3_b32 + v_bcnt_u32_b32 per 32-bit
 //                 word of the stored 3k-bit pair string (W uniform in SGPRs, T'/M' the lane's genotype
-//                 masks); classifiers with more than 32 SNPs and the per-sample plugin path.
+//                 masks); classifiers with more than 112 SNPs and the per-sample plugin path.
 // In both, what the contract fixes stays on the vector ALU, per lane and in the reference's order:
 //     cell += prod * TAB[d]          ds_read_b64 (table in LDS), v_mul_f64, v_add_f64
 //
@@ -144,7 +144,7 @@ __device__ __forceinline__ double cell_sum(uint32_t n, const uint32_t *__restric
 // 4-byte index pair of the slot, and the frequency factor (2 f1) f2 with the reference's rounding
 // (src/LibHLA.cpp:1786-1813).  The FP64 accumulation below is per lane, in the reference's order, so
 // results stay bit-identical to the CPU kernels.
-// Used for classifiers with at most 32 SNPs; wider ones use the VALU engine above.
+// Used for classifiers with at most 112 SNPs; wider ones use the VALU engine above.
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void k_bed_geno(const uint8_t *__restrict__ be
 // k_pack: TGenotype::IntToSNP (src/LibHLA.cpp:662-706) for every (sample, classifier), plus the
 // classifier weight from missingness (src/LibHLA.cpp:2418-2431).  grid (n_pad/64, C / 4), one
 // wavefront per classifier, lane = sample: every code load is one coalesced 64-byte row segment.
-// Matrix-engine classifiers (at most 32 SNPs) get the sample's column of the B operand (int8 bytes or FP4 nibbles)
+// Matrix-engine classifiers (at most 112 SNPs) get the sample's column of the B operand (int8 bytes or FP4 nibbles)
 // in the K layout of hibag_device.h, written to the two lanes (K halves) that own it in the MFMA layout.
 // VALU-engine classifiers get the lane masks of the packed 3k-bit pair string
 //   bits [0,k)   first haplotype : x = [g==2], m = [g in {0,2}]
@@ -1661,7 +1661,7 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 		return;
 	}
 	const unsigned gx = (unsigned)((B.n_pad / HIBAG_WAVE + BLOCK_WAVES - 1) / BLOCK_WAVES);
-	// A classifier far heavier than the rest (VALU engine, > 32 SNPs) is only worth cutting up when its
+	// A classifier far heavier than the rest (VALU engine, > 112 SNPs) is only worth cutting up when its
 	// single-wavefront walk would outlast the rest of the pass, i.e. for small batches.
 	HibagModelView V = M;
 	const double groups = (double)(B.n_pad / HIBAG_WAVE);
