@@ -685,9 +685,41 @@ int finalize_model(hibag_hip_model *m)
 		}
 	const uint64_t p1_base = plist.size();
 	std::vector<uint32_t> blk_close;
+	// segments of the classifiers with several K steps (k_total_wide): {classifier, first stored row, blocks} + list offset
+	std::vector<int> wseg;
+	std::vector<uint64_t> wseg_off;
 	for (int c = 0; c < C; c++) {
 		if (!mfma_nkb[c]) continue;
 		blk_off[c] = plist.size();
+		if (n_step[c] > 1) {
+			// A classifier of several K steps: its list in segments of whole cells, each starting a block of its own, so
+			// that different workgroups can walk them (their cell sums are stored, k_total_scan adds them in order);
+			// walked as one list (majority vote) the padding between the segments adds nothing.
+			// (pairs per segment: about what a typical one-step classifier of 5,000 pairs costs)
+			const long long seg_pairs = std::max<long long>(512, 6000 / n_step[c]);
+			int p_lo = 0, h1_lo = 0, h2_lo = 0, row = 0, h1 = 0, h2 = 0;
+			long long acc_pairs = 0;
+			int rows_in_seg = 0;
+			for (int p = 0; p < P; p++) {
+				acc_pairs += cell_pairs[c][p];
+				rows_in_seg += cell_pairs[c][p] != 0;
+				int nh1 = h1, nh2 = h2 + 1;
+				if (nh2 == nh) { nh1++; nh2 = nh1; }
+				if (acc_pairs >= seg_pairs || p + 1 == P) {
+					const size_t off = plist.size();
+					const int nb = append_pair_blocks(starts[c].data(), nh, h1_lo, h2_lo, p_lo, p + 1 - p_lo, (uint32_t)m->cls[c].freq.size(),
+						plist, stored[c].data(), nullptr);
+					if (nb > 0) { wseg.insert(wseg.end(), {c, row, nb, 0}); wseg_off.push_back(off); }
+					row += rows_in_seg; rows_in_seg = 0; acc_pairs = 0;
+					p_lo = p + 1; h1_lo = nh1; h2_lo = nh2;
+				}
+				h1 = nh1; h2 = nh2;
+			}
+			cls_nblk[c] = (int)((plist.size() - blk_off[c]) / HIBAG_PLIST_DWORDS);
+			dbg_b1 += cls_nblk[c];
+			for (int b = 0; b < cls_nblk[c] && store_mode; b++) blk_close.push_back(0);     // (keeps the block numbering; not used for these)
+			continue;
+		}
 		cls_nblk[c] = append_pair_blocks(starts[c].data(), nh, 0, 0, 0, P, (uint32_t)m->cls[c].freq.size(), plist,
 			store_mode ? stored[c].data() : nullptr, nullptr);
 		dbg_b1 += cls_nblk[c];
@@ -763,7 +795,7 @@ int finalize_model(hibag_hip_model *m)
 		o_snpw = put(snp_weight), o_mrow = put(mask_row), o_order = put(c_order), o_tp0 = put(tile_p0), o_tn = put(tile_n),
 		o_coff = put(cls_off), o_cn = put(cls_n), o_nkb = put(mfma_nkb), o_nstep = put(n_step), o_btrow = put(bt_row), o_nblk = put(cls_nblk), o_hapoff = put(hap_off_i),
 		o_item = put(item), o_srow = put(split_row), o_scls = put(split_cls), o_itemw = put(item_whole), o_crow = put(cell_row),
-		o_wide = put(wide_cls);
+		o_wide = put(wide_cls), o_wseg = put(wseg);
 
 	if (int rc = m->d_int.reserve(arena.size() * sizeof(int))) return rc;
 	if (int rc = m->d_stream.reserve(stream.size() * sizeof(uint32_t))) return rc;
@@ -774,7 +806,8 @@ int finalize_model(hibag_hip_model *m)
 		tb_hap = (tb_ctile + ctile.size() * sizeof(uint32_t) + 15) & ~(size_t)15,
 		tb_acum = tb_hap + hap.size() * sizeof(uint32_t),
 		tb_close = tb_acum + acc_cum.size() * sizeof(uint32_t),
-		tb_end = tb_close + blk_close.size() * sizeof(uint32_t);
+		tb_wsoff = (tb_close + blk_close.size() * sizeof(uint32_t) + 7) & ~(size_t)7,
+		tb_end = tb_wsoff + std::max<size_t>(wseg_off.size(), 1) * sizeof(uint64_t);
 	if (int rc = m->d_tile.reserve(tb_end)) return rc;
 	if (int rc = m->d_tab.reserve(sizeof(m->tab))) return rc;
 	HIP_TRY(hipMemcpy(m->d_int.p, arena.data(), arena.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -790,6 +823,8 @@ int finalize_model(hibag_hip_model *m)
 	if (!acc_cum.empty())
 		HIP_TRY(hipMemcpy(tbase + tb_acum, acc_cum.data(), acc_cum.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_close, blk_close.data(), blk_close.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	if (!wseg_off.empty())
+		HIP_TRY(hipMemcpy(tbase + tb_wsoff, wseg_off.data(), wseg_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	if (int rc = m->d_blk.reserve(plist.size() * sizeof(uint32_t))) return rc;
 	HIP_TRY(hipMemcpy(m->d_blk.p, plist.data(), plist.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(m->d_tab.p, m->tab, sizeof(m->tab), hipMemcpyHostToDevice));
@@ -811,6 +846,7 @@ int finalize_model(hibag_hip_model *m)
 	V.item_split = base + o_item; V.item_whole = base + o_itemw; V.item = V.item_whole; V.n_item = V.n_item_whole;
 	V.split_row = base + o_srow; V.split_cls = base + o_scls;
 	V.n_wide = (int)wide_cls.size(); V.wide_cls = base + o_wide;
+	V.n_wide_seg = (int)wseg.size() / 4; V.wide_seg = base + o_wseg; V.wide_seg_off = (const uint64_t *)(tbase + tb_wsoff);
 	if (V.n_wide > 0 && !m->side.stream) {
 		HIP_TRY(hipStreamCreateWithFlags(&m->side.stream, hipStreamNonBlocking));
 		HIP_TRY(hipEventCreateWithFlags(&m->side.fork, hipEventDisableTiming));

@@ -978,37 +978,33 @@ __global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagMod
 	if (!last) handover_post(flag, B.epoch, (uint32_t)b1);
 }
 
-// k_total_wide: pass 1 of the FP4 classifiers with several K steps (33 .. 112 SNPs; HibagModelView::wide_cls) -- a kernel
-// of their own, started beside k_total on a second stream: their walk needs a dozen registers more than k_total's 96.
-// They store every cell (pass 2 reads them back whatever the model's other classifiers do).  grid (group quads, wide classifiers).
+// k_total_wide: pass 1 of the FP4 classifiers with several K steps (33 .. 112 SNPs) -- a kernel of their own, started
+// beside k_total on a second stream: their walk needs a dozen registers more than k_total's 96.  Their lists come in
+// segments of whole cells (HibagModelView::wide_seg), one workgroup per segment and group quad; every cell sum is
+// stored (pass 2 reads them back whatever the model's other classifiers do) and k_total_scan adds them in order.
+// grid (group quads, segments).
 __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total_wide(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
 	stage_table(M, tab_s);
-	const int c = M.wide_cls[blockIdx.y];
+	const int *__restrict__ seg = M.wide_seg + 4 * blockIdx.y;
+	const int c = seg[0];
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	const int group = blockIdx.x * BLOCK_WAVES + wave;
 	if (group * HIBAG_WAVE >= B.n_pad) return;
 	const int s = group * HIBAG_WAVE + lane;
-	const size_t at = (size_t)c * B.n_pad + s;
-	if (__ballot(B.cw[at] > 0) == 0) return;          // nobody needs this classifier (src/LibHLA.cpp:2451)
-	double total = 0, cell = 0;
+	if (__ballot(B.cw[(size_t)c * B.n_pad + s] > 0) == 0) return;          // nobody needs this classifier (src/LibHLA.cpp:2451)
+	double cell = 0;
 	double *__restrict__ rows = cell_rows(M, B, c, group);
-	int row = 0;
-	auto fin = [&](double v, bool) {
-		__builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++;
-		total += v;
-		asm("" : "+v"(total));                        // keeps the cell end a scalar branch
-	};
+	int row = seg[1];
+	auto fin = [&](double v, bool) { __builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++; };
 	const WideSrc wide = wide_src(B, M.bt_row[c], M.n_step[c], group);
 	LaneOperand T;
 	load_operand_row<HIBAG_ENGINE_FP4W>(B, M.bt_row[c], c, group, lane, T);
 	ListCursor cur;
-	walk_blocks<HIBAG_ENGINE_FP4W, 4>(M, M.blk_off[c], M.cls_nblk[c], lane, cur, hap_rsrc(M, M.hap_off[c]),
+	walk_blocks<HIBAG_ENGINE_FP4W, 4>(M, M.wide_seg_off[blockIdx.y], seg[2], lane, cur, hap_rsrc(M, M.hap_off[c]),
 		M.n_snp_c[c] - HIBAG_FP4_STEP_SNPS * (wide.nstep - 1), T, wide, tab_s, stage_s[wave], cell, fin);
-	B.tot[at] = total;
-	B.inv[at] = 1 / total;                            // src/LibHLA.cpp:1827 (inf when total == 0)
 }
 
 // k_total_scan: the in-order total of a split classifier from its stored cell sums; thread = sample.
@@ -1647,14 +1643,16 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 	if (wide) {
 		// the classifiers of several K steps: their own kernel, beside k_total (more registers than k_total's hot loop may have)
 		const unsigned gq = (unsigned)((B.n_pad / HIBAG_WAVE + BLOCK_WAVES - 1) / BLOCK_WAVES);
+		HibagModelView W = M;                         // k_total_scan over the classifiers of several K steps
+		W.split_cls = M.wide_cls;
+		const hipStream_t ws = side.stream ? side.stream : st;
 		if (side.stream) {
 			(void)hipEventRecord(side.fork, st);
 			(void)hipStreamWaitEvent(side.stream, side.fork, 0);
-			hipLaunchKernelGGL(k_total_wide, dim3(gq, M.n_wide), dim3(BLOCK_THREADS), 0, side.stream, M, B);
-			(void)hipEventRecord(side.join, side.stream);
-		} else {
-			hipLaunchKernelGGL(k_total_wide, dim3(gq, M.n_wide), dim3(BLOCK_THREADS), 0, st, M, B);
 		}
+		hipLaunchKernelGGL(k_total_wide, dim3(gq, M.n_wide_seg), dim3(BLOCK_THREADS), 0, ws, M, B);
+		hipLaunchKernelGGL(k_total_scan, dim3(B.n_pad / 64, M.n_wide), dim3(64), 0, ws, W, B);
+		if (side.stream) (void)hipEventRecord(side.join, side.stream);
 	}
 	if (M.n_item_whole == 0) {                        // (every classifier is one of those)
 		if (wide && side.stream) (void)hipStreamWaitEvent(st, side.join, 0);

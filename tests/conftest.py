@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_finish(session):
+    """GPU runs: let torch initialise its HIP context before anything else does.  With the test files in another order
+    than the alphabetical one (tests/test_hip_parity.py before tests/test_hip_configs.py) torch's lazy initialisation
+    came after the library's and the oracle's worker threads and failed with "No HIP GPUs are available"."""
+    if any(item.get_closest_marker("gpu") for item in session.items):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O
