@@ -97,6 +97,40 @@ def test_chunked_work_items_equal_the_oracle(hib, oracle):
         assert np.array_equal(again[k], want[k], equal_nan=True), k
 
 
+def test_device_entry_on_a_stream_of_the_callers(hib, oracle):
+    """hibag_hip_predict_device on a non-default stream, back to back without synchronising in between, with the
+    benchmark model (whose 100-SNP classifier runs pass 1 on the library's second stream, forked from and joined to
+    the caller's): every call's outputs equal the oracle's."""
+    import torch
+    from hibag_amd import synth
+    model, founders, af = synth.make_model("hla-b")
+    n = 2500
+    dev = torch.device("cuda", 0)
+    m = hib.hlaModelFromObj(model)
+    st = torch.cuda.Stream(dev)
+    outs, genos = [], []
+    with torch.cuda.stream(st):
+        for rep in range(3):
+            G, _ = synth.make_samples(founders, af, n, seed=200 + rep)
+            dg = torch.from_numpy(G).to(dev, non_blocking=False)
+            h1 = torch.empty(n, dtype=torch.int32, device=dev); h2 = torch.empty_like(h1)
+            pr = torch.empty(n, dtype=torch.float64, device=dev); mt = torch.empty_like(pr)
+            ds = torch.empty((n, model.n_hla), dtype=torch.float64, device=dev)
+            m.predict_device(dg.data_ptr(), n, 1, h1.data_ptr(), h2.data_ptr(), pr.data_ptr(), mt.data_ptr(), ds.data_ptr(), None,
+                             stream=st.cuda_stream)
+            outs.append((dg, h1, h2, pr, mt, ds)); genos.append(G)
+    st.synchronize()
+    flat = oracle.flatten(model)
+    for G, (dg, h1, h2, pr, mt, ds) in zip(genos, outs):
+        sub = np.arange(0, n, 25)
+        want = oracle.predict(flat, G[sub], vote_method=1, want_prob=False, avx2=True, n_threads=8)
+        assert np.array_equal(h1.cpu().numpy()[sub], want["h1"]) and np.array_equal(h2.cpu().numpy()[sub], want["h2"])
+        assert np.array_equal(pr.cpu().numpy()[sub], want["prob"], equal_nan=True)
+        assert np.array_equal(mt.cpu().numpy()[sub], want["matching"], equal_nan=True)
+        assert np.array_equal(ds.cpu().numpy()[sub], want["dosage"], equal_nan=True)
+    m.close()
+
+
 def test_cfg4_hla_drb1_full_model_against_oracle(hib, oracle):
     """The DRB1 shape at full size: 100 classifiers x 500 haplotypes (12.5 M haplotype pairs per sample)."""
     from hibag_amd import synth
