@@ -31,6 +31,9 @@ EXPORTS = [
     "hibag_hip_trainer_new", "hibag_hip_trainer_free", "hibag_hip_trainer_set_rng", "hibag_hip_trainer_set_seed",
     "hibag_hip_trainer_new_classifiers", "hibag_hip_trainer_n_classifier", "hibag_hip_trainer_classifier_dims",
     "hibag_hip_trainer_classifier_get",
+    "hibag_hip_model_status", "hibag_hip_model_clear_status", "hibag_hip_model_handover_faults",
+    "hibag_hip_test_inject_handover_fault", "hibag_hip_model_engine", "hibag_hip_model_replicate",
+    "hibag_hip_multi_slice", "hibag_hip_predict_multi",
 ]
 
 
@@ -107,6 +110,16 @@ def lib() -> C.CDLL:
     L.hibag_hip_predict_bed.argtypes = [vp, C.c_char_p, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.hibag_hip_predict_mapped.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.hibag_hip_predict_mapped_device.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.hibag_hip_model_status.argtypes = [vp]
+    L.hibag_hip_model_clear_status.argtypes = [vp]
+    L.hibag_hip_model_handover_faults.argtypes = [vp]
+    L.hibag_hip_model_handover_faults.restype = i64
+    L.hibag_hip_test_inject_handover_fault.argtypes = [vp, i32]
+    L.hibag_hip_model_engine.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.hibag_hip_model_replicate.argtypes = [vp, i32]
+    L.hibag_hip_model_replicate.restype = vp
+    L.hibag_hip_multi_slice.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.hibag_hip_predict_multi.argtypes = [C.POINTER(vp), i32, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -15,6 +15,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hibag_hip.h"
@@ -121,6 +122,9 @@ struct KernelTimer {
 	}
 };
 
+// streams and events of the host-pointer entries' slice pipeline (predict_staged_locked)
+struct StagedStreams { hipStream_t run = nullptr, in = nullptr, out = nullptr; hipEvent_t up[2] = {}, ran[2] = {}, down[2] = {}; };
+
 } // namespace
 
 // for the other translation units of the library (hibag_train.hip, hibag_build.hip)
@@ -157,11 +161,26 @@ struct hibag_hip_model {
 
 	// per-batch workspace (grow-only)
 	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias, ws_cells, ws_sync;
+	std::vector<int> engine_of, steps_of;  // per classifier: HIBAG_HIP_ENGINE_* and K steps, as finalized
 	int store_mode = 0;                    // which cell sums pass 1 stores for pass 2 (HibagModelView::store_cells)
 	int64_t second_pass_pairs = 0;         // haplotype pairs per sample pass 2 evaluates again
 	HibagSideStream side;                  // second stream for pass 1 of the classifiers with several K steps (created at finalize if any)
 	uint32_t epoch = 0;                    // batch counter for the hand-over flags (HibagBatchView::epoch)
 	int *h_err = nullptr;                  // host-mapped error word of the hand-overs
+	DevBuf ws_err;                         // its device twin: epoch of the last batch with a failed hand-over (HibagBatchView::err_dev)
+	// A failed hand-over: `fault` is sticky until hibag_hip_model_clear_status(); from the first one on
+	// the model launches without hand-overs (`no_chunks`: every work item undivided -- nothing left that could fail).
+	int fault = 0;
+	int64_t fault_count = 0;
+	bool no_chunks = false;
+	int drop_next = 0;                     // fault injection (hibag_hip_test_inject_handover_fault): pass whose first hand-over the next batch drops
+	uint32_t spin_limit = 1u << 19;        // polls a waiting workgroup makes before it gives up (set at finalize from the longest item)
+	// The workspace is one per model: calls on different streams are chained on the device through this event, each
+	// waits for the one enqueued before it.
+	hipEvent_t ws_done = nullptr;
+	bool ws_pending = false;
+	StagedStreams staged;                  // the host-pointer entries' slice pipeline (created on first use)
+	bool staged_ready = false;
 	// plugin staging
 	DevBuf ws_tgeno, ws_weight;
 	// PLINK BED payload + SNP map of hibag_hip_predict_bed
@@ -175,10 +194,14 @@ struct hibag_hip_model {
 		(void)hipSetDevice(device);
 		timer.destroy();
 		if (h_err) (void)hipHostFree(h_err);
+		if (ws_done) (void)hipEventDestroy(ws_done);
+		for (hipStream_t st : {staged.run, staged.in, staged.out}) if (st) (void)hipStreamDestroy(st);
+		for (int i = 0; i < 2; i++)
+			for (hipEvent_t e : {staged.up[i], staged.ran[i], staged.down[i]}) if (e) (void)hipEventDestroy(e);
 		if (side.fork) (void)hipEventDestroy(side.fork);
 		if (side.join) (void)hipEventDestroy(side.join);
 		if (side.stream) (void)hipStreamDestroy(side.stream);
-		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_cells, &ws_sync, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
+		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_cells, &ws_sync, &ws_err, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
 		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_tgeno, &ws_weight, &ws_bed, &ws_bedidx})
 			b->release();
 	}
@@ -863,6 +886,16 @@ int finalize_model(hibag_hip_model *m)
 	V.p1_blocks = dbg_b1;
 	V.cell_row = base + o_crow;
 	V.store_cells = store_mode;
+	hibag_query_slots(&V.slots_total[0], &V.slots_total[1], &V.slots_accum);
+	{
+		// A chunk waits for the chunk before it, which was dispatched a whole round earlier; in the worst case the chunks of
+		// an item run one after the other, so the wait is bounded by the item's own length.  One poll lasts ~1 us (s_sleep +
+		// an L2 round trip), a 32-slot block ~1.5 us of elapsed time at full occupancy: 16 polls per block of the longest
+		// item is an order of magnitude of slack on top of the fixed 2^19 (~0.5 s).
+		long long longest = 0;
+		for (int c = 0; c < C; c++) longest = std::max<long long>(longest, mfma_nkb[c] ? cls_nblk[c] : pairs[c] / 8);
+		m->spin_limit = (uint32_t)std::min<long long>(0xFFFFFFF0ll, (1ll << 19) + 16 * longest);
+	}
 	m->cell_rows = cell_row[C];
 	V.plist = m->d_blk.as<uint32_t>();
 	V.plist_dwords = plist.size();
@@ -871,6 +904,8 @@ int finalize_model(hibag_hip_model *m)
 	V.tab = m->d_tab.as<double>();
 	m->mask_rows = rows;
 	m->stream_bytes = stream.size() * sizeof(uint32_t);
+	m->engine_of.assign(engine.begin(), engine.begin() + C);
+	m->steps_of.assign(n_step.begin(), n_step.begin() + C);
 	m->finalized = true;
 	return 0;
 }
@@ -910,14 +945,26 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 		const size_t n_flag = n_flag2 + n_flag1;
 		const size_t had = m->ws_sync.cap;
 		if (int rc = m->ws_sync.reserve(n_flag * sizeof(unsigned long long))) return rc;
-		if (m->ws_sync.cap != had) { HIP_TRY(hipMemset(m->ws_sync.p, 0, m->ws_sync.cap)); m->epoch = 0; }
+		if (!m->ws_err.p) { if (int rc = m->ws_err.reserve(256)) return rc; HIP_TRY(hipMemset(m->ws_err.p, 0, 256)); }
+		if (m->ws_sync.cap != had) {               // new flags: the epochs start over (and so must the device error word)
+			HIP_TRY(hipDeviceSynchronize());
+			HIP_TRY(hipMemset(m->ws_sync.p, 0, m->ws_sync.cap)); HIP_TRY(hipMemset(m->ws_err.p, 0, 256)); m->epoch = 0;
+		}
 		if (!m->h_err) {
 			HIP_TRY(hipHostMalloc((void **)&m->h_err, sizeof(int), hipHostMallocMapped));
 			*m->h_err = 0;
 		}
-		if (++m->epoch == 0) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipMemset(m->ws_sync.p, 0, m->ws_sync.cap)); m->epoch = 1; }
+		if (++m->epoch == 0) {
+			HIP_TRY(hipDeviceSynchronize());
+			HIP_TRY(hipMemset(m->ws_sync.p, 0, m->ws_sync.cap)); HIP_TRY(hipMemset(m->ws_err.p, 0, 256)); m->epoch = 1;
+		}
 	}
 	B.sync = m->ws_sync.as<unsigned long long>(); B.epoch = m->epoch; B.err = m->h_err;
+	B.err_dev = m->ws_err.as<uint32_t>();
+	B.spin_limit = m->spin_limit;
+	B.tail_k = m->no_chunks ? 1 : 0;
+	B.drop_post = m->drop_next;
+	if (m->drop_next) { B.spin_limit = 4096; m->drop_next = 0; }     // (the injected fault should not take the full time-out)
 	B.sync_total = B.sync + 8 * (((size_t)(n_pad / HIBAG_WAVE + 7) / 8 + 3) / 4) * (size_t)std::max(m->view.n_tile, 1);
 	B.n_samp = n_samp; B.n_pad = n_pad;
 	B.masks = m->ws_planes.as<uint32_t>();
@@ -963,6 +1010,45 @@ int check_predict_args(hibag_hip_model *m, const void *geno, int n_samp, int vot
 	return 0;
 }
 
+// ---- failed hand-overs ------------------------------------------------------------------------------
+// The kernels report a hand-over that never arrived through the host-mapped word (and poison the batch's outputs on the
+// device, HibagBatchView::err_dev).  Whoever looks at the word first records it: the fault is counted, the model stops
+// cutting work items (K = 1: nothing left to hand over), and -- for launches whose results already went to the caller
+// through a device-pointer entry -- it becomes the model's sticky status.
+bool take_fault(hibag_hip_model *m)
+{
+	if (!m->h_err || !*m->h_err) return false;
+	*m->h_err = 0;
+	m->fault_count++;
+	m->no_chunks = true;
+	return true;
+}
+
+int sticky_fault(hibag_hip_model *m)
+{
+	if (take_fault(m)) m->fault = HIBAG_HIP_EHANDOVER;
+	if (m->fault)
+		return fail(m->fault, "a hand-over between workgroups failed in an earlier launch on this model: the outputs of that "
+			"call were poisoned (NA / NaN) and must be computed again; hibag_hip_model_clear_status() re-arms the model, "
+			"which from now on launches without hand-overs");
+	return 0;
+}
+
+// Device-pointer entries share the model's one workspace: chain them on the device, whatever streams they use.
+int workspace_enter(hibag_hip_model *m, hipStream_t st)
+{
+	if (!m->ws_done) HIP_TRY(hipEventCreateWithFlags(&m->ws_done, hipEventDisableTiming));
+	if (m->ws_pending) HIP_TRY(hipStreamWaitEvent(st, m->ws_done, 0));
+	return 0;
+}
+
+int workspace_leave(hibag_hip_model *m, hipStream_t st)
+{
+	HIP_TRY(hipEventRecord(m->ws_done, st));
+	m->ws_pending = true;
+	return 0;
+}
+
 // Where a batch's genotypes come from: the int32 matrix, or a PLINK BED payload.
 struct PackSource {
 	const int32_t *d_geno = nullptr;       // [n_samp][row_len]
@@ -980,6 +1066,7 @@ int predict_device_locked(hibag_hip_model *m, const PackSource &src, int n_samp,
 	double *d_postprob, hipStream_t st)
 {
 	HIP_TRY(hipSetDevice(m->device));
+	if (int rc = workspace_enter(m, st)) return rc;
 	const int lim = batch_limit(m);
 	const size_t P = (size_t)m->view.n_cell;
 	for (int s0 = 0; s0 < n_samp; s0 += lim) {
@@ -1004,54 +1091,120 @@ int predict_device_locked(hibag_hip_model *m, const PackSource &src, int n_samp,
 		m->timer.end(st);
 	}
 	HIP_TRY(hipGetLastError());
+	return workspace_leave(m, st);
+}
+
+// Host-pointer driver.  The cohort is cut into slices (bounded workspace, bounded genotype staging); consecutive slices
+// are pipelined over three streams of the model's -- upload of slice i+1 and download of slice i-1 beside the kernels of
+// slice i, genotype and output buffers doubled -- so that for cohorts of several slices only the first upload and the last
+// download are exposed (SURVEY.md section 8d's protocol counts both).  Genotypes come from the host int32 matrix or from a
+// BED payload already on the device.  A failed hand-over (poisoned outputs) is repaired here: the call is run again
+// with undivided work items, in this process, before anything is returned.
+int staged_streams(hibag_hip_model *m, StagedStreams **out)
+{
+	StagedStreams *ss = &m->staged;
+	if (!m->staged_ready) {
+		HIP_TRY(hipStreamCreateWithFlags(&ss->run, hipStreamNonBlocking));
+		HIP_TRY(hipStreamCreateWithFlags(&ss->in, hipStreamNonBlocking));
+		HIP_TRY(hipStreamCreateWithFlags(&ss->out, hipStreamNonBlocking));
+		for (int i = 0; i < 2; i++) {
+			HIP_TRY(hipEventCreateWithFlags(&ss->up[i], hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&ss->ran[i], hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&ss->down[i], hipEventDisableTiming));
+		}
+		m->staged_ready = true;
+	}
+	*out = ss;
 	return 0;
 }
 
-// Host-pointer driver: slices the cohort so that the posterior matrix never
-// needs more than a slice on the device; genotypes come from the host int32
-// matrix (uploaded slice by slice) or from a BED payload already on the device.
+// Samples per slice of the host-pointer entries: the workspace bound, at most ~1 GB of staged genotypes (a cohort matrix
+// may carry every SNP of the genome: `row_len` is the cohort's, not the model's), and -- for cohorts worth pipelining --
+// about a quarter of the cohort but no less than 16,384 samples (smaller batches leave the last round of a pass too empty).
+int staged_slice(const hibag_hip_model *m, int n_samp, size_t row_len)
+{
+	long long slice = std::min<long long>(batch_limit(m), std::max(n_samp, 64));
+	const long long by_geno = (long long)((1ull << 30) / (std::max<size_t>(row_len, 1) * sizeof(int32_t)));
+	slice = std::min(slice, std::max<long long>(64, by_geno));
+	if (n_samp >= 2 * 16384) slice = std::min(slice, std::max<long long>(16384, (n_samp + 3) / 4));
+	return (int)std::max<long long>(64, slice / 64 * 64);
+}
+
 int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSource *bed, int n_samp, int vote_method,
 	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob,
-	const PackSource *map = nullptr)
+	const PackSource *map = nullptr, bool is_retry = false)
 {
 	// `map`: geno is the cohort's own matrix (map->row_len SNPs per sample); map->d_col / d_flip sit on the device
+	if (int rc = sticky_fault(m)) return rc;
 	const size_t P = (size_t)m->view.n_cell, nh = (size_t)m->n_hla, S = map ? (size_t)map->row_len : (size_t)m->n_snp;
-	const int slice = batch_limit(m);
+	const int slice = staged_slice(m, n_samp, bed ? 1 : S);
 	const size_t geno_bytes = (size_t)slice * std::max<size_t>(S, 1) * sizeof(int32_t);
 	const size_t o_h1 = 0, o_h2 = o_h1 + (size_t)slice * 4, o_mp = (o_h2 + (size_t)slice * 4 + 7) / 8 * 8,
 		o_mt = o_mp + (size_t)slice * 8, o_ds = o_mt + (size_t)slice * 8, o_pp = o_ds + (size_t)slice * nh * 8,
-		out_bytes = o_pp + (postprob ? (size_t)slice * P * 8 : 0);
+		out_bytes = (o_pp + (postprob ? (size_t)slice * P * 8 : 0) + 255) / 256 * 256;
+	const int n_slice = (n_samp + slice - 1) / slice;
+	const int nbuf = n_slice > 1 ? 2 : 1;
 	if (!bed)
-		if (int rc = m->ws_geno.reserve(geno_bytes)) return rc;
-	if (int rc = m->ws_out.reserve(out_bytes)) return rc;
-	char *o = m->ws_out.as<char>();
-	for (int s0 = 0; s0 < n_samp; s0 += slice) {
-		const int n = std::min(slice, n_samp - s0);
+		if (int rc = m->ws_geno.reserve(geno_bytes * nbuf)) return rc;
+	if (int rc = m->ws_out.reserve(out_bytes * nbuf)) return rc;
+	StagedStreams *ss;
+	if (int rc = staged_streams(m, &ss)) return rc;
+	auto upload = [&](int i) -> int {
+		if (bed) return 0;
+		const int s0 = i * slice, n = std::min(slice, n_samp - s0);
+		// (the buffer was last read by the kernels of slice i - 2)
+		if (i >= 2) HIP_TRY(hipStreamWaitEvent(ss->in, ss->ran[i & 1], 0));
+		HIP_TRY(hipMemcpyAsync(m->ws_geno.as<char>() + (size_t)(i % nbuf) * geno_bytes, geno + (size_t)s0 * S, (size_t)n * S * sizeof(int32_t),
+			hipMemcpyHostToDevice, ss->in));
+		HIP_TRY(hipEventRecord(ss->up[i & 1], ss->in));
+		return 0;
+	};
+	auto download = [&](int i) -> int {
+		const int s0 = i * slice, n = std::min(slice, n_samp - s0);
+		const char *o = m->ws_out.as<char>() + (size_t)(i % nbuf) * out_bytes;
+		HIP_TRY(hipStreamWaitEvent(ss->out, ss->ran[i & 1], 0));
+		if (H1) {
+			HIP_TRY(hipMemcpyAsync(H1 + s0, o + o_h1, (size_t)n * 4, hipMemcpyDeviceToHost, ss->out));
+			HIP_TRY(hipMemcpyAsync(H2 + s0, o + o_h2, (size_t)n * 4, hipMemcpyDeviceToHost, ss->out));
+		}
+		if (max_prob) HIP_TRY(hipMemcpyAsync(max_prob + s0, o + o_mp, (size_t)n * 8, hipMemcpyDeviceToHost, ss->out));
+		if (matching) HIP_TRY(hipMemcpyAsync(matching + s0, o + o_mt, (size_t)n * 8, hipMemcpyDeviceToHost, ss->out));
+		if (dosage) HIP_TRY(hipMemcpyAsync(dosage + (size_t)s0 * nh, o + o_ds, (size_t)n * nh * 8, hipMemcpyDeviceToHost, ss->out));
+		if (postprob) HIP_TRY(hipMemcpyAsync(postprob + (size_t)s0 * P, o + o_pp, (size_t)n * P * 8, hipMemcpyDeviceToHost, ss->out));
+		HIP_TRY(hipEventRecord(ss->down[i & 1], ss->out));
+		return 0;
+	};
+	if (int rc = upload(0)) return rc;
+	for (int i = 0; i < n_slice; i++) {
+		const int s0 = i * slice, n = std::min(slice, n_samp - s0);
+		char *o = m->ws_out.as<char>() + (size_t)(i % nbuf) * out_bytes;
 		PackSource src;
 		if (bed) {
 			src = *bed;
 			src.samp0 = bed->samp0 + s0;
 		} else {
-			HIP_TRY(hipMemcpyAsync(m->ws_geno.p, geno + (size_t)s0 * S, (size_t)n * S * sizeof(int32_t),
-				hipMemcpyHostToDevice, 0));
 			if (map) src = *map;
-			src.d_geno = m->ws_geno.as<int32_t>();
+			src.d_geno = (const int32_t *)(m->ws_geno.as<char>() + (size_t)(i % nbuf) * geno_bytes);
+			HIP_TRY(hipStreamWaitEvent(ss->run, ss->up[i & 1], 0));
 		}
+		if (i >= 2) HIP_TRY(hipStreamWaitEvent(ss->run, ss->down[i & 1], 0));    // the output buffer of slice i - 2 has been read
 		if (int rc = predict_device_locked(m, src, n, vote_method,
 				H1 ? (int32_t *)(o + o_h1) : nullptr, H2 ? (int32_t *)(o + o_h2) : nullptr,
 				max_prob ? (double *)(o + o_mp) : nullptr, matching ? (double *)(o + o_mt) : nullptr,
-				dosage ? (double *)(o + o_ds) : nullptr, postprob ? (double *)(o + o_pp) : nullptr, 0))
+				dosage ? (double *)(o + o_ds) : nullptr, postprob ? (double *)(o + o_pp) : nullptr, ss->run))
 			return rc;
-		if (H1) {
-			HIP_TRY(hipMemcpyAsync(H1 + s0, o + o_h1, (size_t)n * 4, hipMemcpyDeviceToHost, 0));
-			HIP_TRY(hipMemcpyAsync(H2 + s0, o + o_h2, (size_t)n * 4, hipMemcpyDeviceToHost, 0));
-		}
-		if (max_prob) HIP_TRY(hipMemcpyAsync(max_prob + s0, o + o_mp, (size_t)n * 8, hipMemcpyDeviceToHost, 0));
-		if (matching) HIP_TRY(hipMemcpyAsync(matching + s0, o + o_mt, (size_t)n * 8, hipMemcpyDeviceToHost, 0));
-		if (dosage) HIP_TRY(hipMemcpyAsync(dosage + (size_t)s0 * nh, o + o_ds, (size_t)n * nh * 8, hipMemcpyDeviceToHost, 0));
-		if (postprob) HIP_TRY(hipMemcpyAsync(postprob + (size_t)s0 * P, o + o_pp, (size_t)n * P * 8, hipMemcpyDeviceToHost, 0));
-		HIP_TRY(hipStreamSynchronize(0));
-		if (m->h_err && *m->h_err) { *m->h_err = 0; return fail(HIBAG_HIP_ESTATE, "a hand-over between workgroups never arrived"); }
+		HIP_TRY(hipEventRecord(ss->ran[i & 1], ss->run));
+		// with the kernels of slice i enqueued: the next upload and the previous download run beside them
+		if (i + 1 < n_slice) if (int rc = upload(i + 1)) return rc;
+		if (i >= 1) if (int rc = download(i - 1)) return rc;
+	}
+	if (int rc = download(n_slice - 1)) return rc;
+	HIP_TRY(hipStreamSynchronize(ss->out));
+	HIP_TRY(hipStreamSynchronize(ss->run));
+	if (take_fault(m)) {
+		// poisoned outputs: once more, now without hand-overs (take_fault switched them off) -- never returned to the caller
+		if (is_retry) return fail(HIBAG_HIP_EHANDOVER, "a hand-over between workgroups failed in a launch without hand-overs");
+		return predict_staged_locked(m, geno, bed, n_samp, vote_method, H1, H2, max_prob, matching, dosage, postprob, map, true);
 	}
 	return 0;
 }
@@ -1269,6 +1422,7 @@ int hibag_hip_predict_device(hibag_hip_model *m, const int32_t *d_geno, int n_sa
 {
 	if (int rc = check_predict_args(m, d_geno, n_samp, vote_method, d_H1, d_H2)) return rc;
 	std::lock_guard<std::mutex> g(m->lock);
+	if (int rc = sticky_fault(m)) return rc;
 	PackSource src;
 	src.d_geno = d_geno;
 	return predict_device_locked(m, src, n_samp, vote_method, d_H1, d_H2, d_max_prob, d_matching,
@@ -1283,6 +1437,70 @@ int hibag_hip_predict(hibag_hip_model *m, const int32_t *geno, int n_samp, int v
 	std::lock_guard<std::mutex> g(m->lock);
 	HIP_TRY(hipSetDevice(m->device));
 	return predict_staged_locked(m, geno, nullptr, n_samp, vote_method, H1, H2, max_prob, matching, dosage, postprob);
+}
+
+// ---- several devices ------------------------------------------------------------------------------------
+
+hibag_hip_model *hibag_hip_model_replicate(const hibag_hip_model *src, int device)
+{
+	if (!src) { fail(HIBAG_HIP_EINVAL, "model is NULL"); return nullptr; }
+	const int n = hibag_hip_device_count();
+	if (device < 0 || device >= n) { fail(HIBAG_HIP_ENODEV, "HIP device %d not available (%d visible)", device, n); return nullptr; }
+	hibag_hip_model *m = new (std::nothrow) hibag_hip_model;
+	if (!m) { fail(HIBAG_HIP_ENOMEM, "out of host memory"); return nullptr; }
+	m->device = device;
+	m->n_hla = src->n_hla; m->n_snp = src->n_snp;
+	m->have_snpidx = src->have_snpidx; m->use_mfma = src->use_mfma; m->use_fp4 = src->use_fp4;
+	m->cls = src->cls;
+	m->snp_weight_override = src->snp_weight_override;
+	memcpy(m->tab, src->tab, sizeof(m->tab));
+	if (src->finalized && hibag_hip_model_finalize(m)) { delete m; return nullptr; }
+	return m;
+}
+
+int hibag_hip_multi_slice(int n_samp, int n_models, int i, int *first, int *count)
+{
+	if (n_samp < 0 || n_models <= 0 || i < 0 || i >= n_models) return fail(HIBAG_HIP_EINVAL, "bad slice query (n_samp=%d, n_models=%d, i=%d)", n_samp, n_models, i);
+	// contiguous slices whose boundaries fall on multiples of 64 samples (a wavefront's worth) wherever the cohort allows
+	const long long groups = ((long long)n_samp + 63) / 64;
+	const long long a = std::min<long long>(n_samp, groups * i / n_models * 64), b = std::min<long long>(n_samp, groups * (i + 1) / n_models * 64);
+	if (first) *first = (int)a;
+	if (count) *count = (int)(b - a);
+	return 0;
+}
+
+int hibag_hip_predict_multi(hibag_hip_model *const *models, int n_models, const int32_t *geno, int n_samp, int vote_method,
+	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob)
+{
+	if (!models || n_models <= 0) return fail(HIBAG_HIP_EINVAL, "no models given");
+	for (int i = 0; i < n_models; i++) {
+		if (int rc = check_predict_args(models[i], geno, n_samp, vote_method, H1, H2)) return rc;
+		if (models[i]->n_hla != models[0]->n_hla || models[i]->n_snp != models[0]->n_snp || models[i]->cls.size() != models[0]->cls.size())
+			return fail(HIBAG_HIP_EINVAL, "model %d is not a replica of model 0", i);
+	}
+	if (n_samp == 0) return 0;
+	const size_t S = (size_t)models[0]->n_snp, nh = (size_t)models[0]->n_hla, P = nh * (nh + 1) / 2;
+	std::vector<int> rc(n_models, 0);
+	std::vector<std::string> msg(n_models);
+	std::vector<std::thread> th;
+	// one host thread per replica: each drives its own device through the ordinary host-pointer entry on its slice of the
+	// cohort and writes its slice of every output in place -- samples are independent (src/LibHLA.cpp:2362-2411), nothing is merged
+	for (int i = 0; i < n_models; i++) {
+		int first = 0, count = 0;
+		(void)hibag_hip_multi_slice(n_samp, n_models, i, &first, &count);
+		if (count == 0) continue;
+		th.emplace_back([=, &rc, &msg]() {
+			rc[i] = hibag_hip_predict(models[i], geno + (size_t)first * S, count, vote_method,
+				H1 ? H1 + first : nullptr, H2 ? H2 + first : nullptr, max_prob ? max_prob + first : nullptr,
+				matching ? matching + first : nullptr, dosage ? dosage + (size_t)first * nh : nullptr,
+				postprob ? postprob + (size_t)first * P : nullptr);
+			if (rc[i]) msg[i] = hibag_hip_last_error();
+		});
+	}
+	for (auto &t : th) t.join();
+	for (int i = 0; i < n_models; i++)
+		if (rc[i]) return fail(rc[i], "replica %d (device %d): %s", i, models[i]->device, msg[i].c_str());
+	return 0;
 }
 
 int hibag_hip_predict_mapped(hibag_hip_model *m, const int32_t *geno, int n_samp, int n_geno_snp,
@@ -1321,6 +1539,7 @@ int hibag_hip_predict_mapped_device(hibag_hip_model *m, const int32_t *d_geno, i
 	if (int rc = check_predict_args(m, d_geno, n_samp, vote_method, d_H1, d_H2)) return rc;
 	if (n_geno_snp <= 0 || !d_snp_col) return fail(HIBAG_HIP_EINVAL, "n_geno_snp must be positive and d_snp_col given");
 	std::lock_guard<std::mutex> g(m->lock);
+	if (int rc = sticky_fault(m)) return rc;
 	PackSource src;
 	src.d_geno = d_geno; src.row_len = n_geno_snp; src.d_col = d_snp_col; src.d_flip = d_flip;
 	return predict_device_locked(m, src, n_samp, vote_method, d_H1, d_H2, d_max_prob, d_matching,
@@ -1412,6 +1631,8 @@ int hibag_hip_predict_partial_device(hibag_hip_model *m, const int32_t *d_geno, 
 	std::lock_guard<std::mutex> g(m->lock);
 	HIP_TRY(hipSetDevice(m->device));
 	hipStream_t st = (hipStream_t)stream;
+	if (int rc = sticky_fault(m)) return rc;
+	if (int rc = workspace_enter(m, st)) return rc;
 	HibagBatchView B;
 	if (int rc = make_batch(m, n_samp, false, B)) return rc;
 	m->timer.begin(HIBAG_HIP_K_PACK, st);
@@ -1419,7 +1640,7 @@ int hibag_hip_predict_partial_device(hibag_hip_model *m, const int32_t *d_geno, 
 	m->timer.end(st);
 	run_core(m, B, 1, d_partial, st);
 	HIP_TRY(hipGetLastError());
-	return 0;
+	return workspace_leave(m, st);
 }
 
 int hibag_hip_finish_device(hibag_hip_model *m, const double *d_partial, int n_samp,
@@ -1433,6 +1654,7 @@ int hibag_hip_finish_device(hibag_hip_model *m, const double *d_partial, int n_s
 	std::lock_guard<std::mutex> g(m->lock);
 	HIP_TRY(hipSetDevice(m->device));
 	hipStream_t st = (hipStream_t)stream;
+	if (int rc = sticky_fault(m)) return rc;
 	HibagBatchView B{};
 	B.n_samp = n_samp; B.n_pad = round_up(n_samp, HIBAG_WAVE);
 	m->timer.begin(HIBAG_HIP_K_FINISH, st);
@@ -1460,6 +1682,43 @@ int hibag_hip_get_timing(hibag_hip_model *m, int k, double *ms_total, int64_t *l
 	m->timer.resolve();
 	if (ms_total) *ms_total = m->timer.ms[k];
 	if (launches) *launches = m->timer.n[k];
+	return sticky_fault(m);                      // (the events have been waited for: a failed hand-over of a timed launch shows here)
+}
+
+int hibag_hip_model_status(hibag_hip_model *m)
+{
+	if (!m) return fail(HIBAG_HIP_EINVAL, "model is NULL");
+	std::lock_guard<std::mutex> g(m->lock);
+	HIP_TRY(hipSetDevice(m->device));
+	if (m->ws_pending) { HIP_TRY(hipEventSynchronize(m->ws_done)); m->ws_pending = false; }
+	return sticky_fault(m);
+}
+
+int hibag_hip_model_clear_status(hibag_hip_model *m)
+{
+	if (!m) return fail(HIBAG_HIP_EINVAL, "model is NULL");
+	std::lock_guard<std::mutex> g(m->lock);
+	(void)take_fault(m);
+	m->fault = 0;
+	return 0;
+}
+
+int64_t hibag_hip_model_handover_faults(const hibag_hip_model *m) { return m ? m->fault_count : 0; }
+
+int hibag_hip_test_inject_handover_fault(hibag_hip_model *m, int pass)
+{
+	if (!m || pass < 0 || pass > 2) return fail(HIBAG_HIP_EINVAL, "pass must be 0 (none), 1 or 2");
+	std::lock_guard<std::mutex> g(m->lock);
+	m->drop_next = pass;
+	return 0;
+}
+
+int hibag_hip_model_engine(const hibag_hip_model *m, int classifier, int *engine, int *k_steps)
+{
+	if (!m || !m->finalized) return fail(HIBAG_HIP_ESTATE, "model not finalized");
+	if (classifier < 0 || classifier >= (int)m->cls.size()) return fail(HIBAG_HIP_EINVAL, "classifier %d out of range", classifier);
+	if (engine) *engine = m->engine_of[classifier];
+	if (k_steps) *k_steps = m->steps_of[classifier];
 	return 0;
 }
 
@@ -1550,7 +1809,7 @@ int plugin_avg_prob(hibag_hip_model *m, const PluginGenotype geno[], const doubl
 	HIP_TRY(hipMemcpyAsync(out_prob, d_out, P * sizeof(double), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(out_match, d_out + P, sizeof(double), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
-	if (m->h_err && *m->h_err) { *m->h_err = 0; return fail(HIBAG_HIP_ESTATE, "a hand-over between workgroups never arrived"); }
+	if (take_fault(m)) return fail(HIBAG_HIP_EHANDOVER, "a hand-over between workgroups failed");   // (a one-sample launch is never cut: cannot happen)
 	return 0;
 }
 

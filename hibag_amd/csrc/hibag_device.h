@@ -188,6 +188,10 @@ struct HibagModelView {
 
 	// chunked items (hibag_kernels.hip "hand-overs"): cost prefix sums in quarter-blocks of 32 records
 	const uint32_t *acc_cum;     // [n_tile][C + 1] pass 2: cost of the tile's classifiers 0 .. c-1
+
+	// resident workgroups of k_total<false>, k_total<true> and k_accum on the model's device (0 = unknown), queried when
+	// the model is finalized (hibag_query_slots)
+	int slots_total[2], slots_accum;
 };
 
 struct HibagBatchView {
@@ -208,7 +212,16 @@ struct HibagBatchView {
 	unsigned long long *sync;         // pass 2: [8 XCDs][group quads][tiles]
 	unsigned long long *sync_total;   // pass 1: [items x group quads]
 	uint32_t epoch;
-	int *err;           // host-mapped: set when a hand-over never arrived (should not happen; the launch then gives wrong sums)
+	// A hand-over that never arrives (or crosses XCDs) must not go unnoticed: the waiting workgroup sets the host-mapped
+	// word `err` (what the host entries and hibag_hip_model_status() look at) AND stores the batch's epoch in the device
+	// word `err_dev`; k_scalars, which runs behind both passes, then turns the sample's three ensemble scalars into NaN, and
+	// every k_finish_* kernel writes NA / NaN outputs for a sample whose weight sum is NaN -- sums the kernels cannot vouch for
+	// never reach the caller as numbers.
+	int *err;           // host-mapped: 1 = a hand-over timed out, 2 = its flag was written on another XCD
+	uint32_t *err_dev;  // device memory: epoch of the last batch with a failed hand-over
+	uint32_t spin_limit;   // polls before a waiting workgroup gives up (scaled with the longest work item of the model)
+	int tail_k;         // chunks per item of the last rounds: 0 = the launcher's choice, 1 = none (no hand-overs at all)
+	int drop_post;      // fault injection (tests): 1 / 2 = the first chunked item of pass 1 / 2 never posts its first hand-over
 };
 
 #endif

@@ -850,27 +850,35 @@ __device__ __forceinline__ unsigned xcc_id()
 	return x & 15u;
 }
 
-__device__ __forceinline__ void handover_post(unsigned long long *flag, uint32_t epoch, uint32_t progress)
+__device__ __forceinline__ void handover_post(unsigned long long *flag, uint32_t epoch, uint32_t progress, bool drop = false)
 {
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wavefront's parked sums have reached L2
 	__syncthreads();
-	if (threadIdx.x == 0)
+	if (threadIdx.x == 0 && !drop)                              // (drop: fault injection, HibagBatchView::drop_post)
 		__hip_atomic_store(flag, ((unsigned long long)epoch << 32) | (xcc_id() << 24) | progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void handover_wait(unsigned long long *flag, uint32_t epoch, uint32_t progress, int *err)
+// Wait for the chunk before this one.  A flag that never comes (B.spin_limit polls: scaled with the model's longest
+// work item, hibag_api.hip make_batch) or that was written on another XCD is an error the caller must see: the host-mapped
+// word for the host (sticky model status), the device word for k_scalars, which poisons the batch's outputs.
+__device__ __forceinline__ void handover_wait(unsigned long long *flag, const HibagBatchView &B, uint32_t progress)
 {
 	if (threadIdx.x == 0) {
-		const unsigned long long want = ((unsigned long long)epoch << 32) | progress;
+		const unsigned long long want = ((unsigned long long)B.epoch << 32) | progress;
 		unsigned spins = 0;
+		int bad = 0;
 		for (;;) {
 			const unsigned long long v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if ((v & ~(15ull << 24)) == want) {
-				if (((unsigned)(v >> 24) & 15u) != xcc_id()) *err = 2;     // written on another XCD: not coherent through L2
+				if (((unsigned)(v >> 24) & 15u) != xcc_id()) bad = 2;     // written on another XCD: not coherent through L2
 				break;
 			}
 			__builtin_amdgcn_s_sleep(16);
-			if (++spins > (1u << 19)) { *err = 1; break; }      // ~0.3 s: give up rather than hang the device
+			if (++spins > B.spin_limit) { bad = 1; break; }     // give up rather than hang the device
+		}
+		if (bad) {
+			*B.err = bad;
+			__hip_atomic_store(B.err_dev, B.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 	__syncthreads();
@@ -938,7 +946,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagMod
 	bool live = group * HIBAG_WAVE < B.n_pad;
 	if (live) live = __ballot(B.cw[at] > 0) != 0;
 	unsigned long long *flag = B.sync_total + (li - n_whole);
-	if (!first) handover_wait(flag, B.epoch, (uint32_t)b0, B.err);
+	if (!first) handover_wait(flag, B, (uint32_t)b0);
 	if (live) {
 		double total = 0;
 		const bool split = M.n_split > 0 && M.split_row[c] >= 0;    // a split classifier: k_total_scan adds its cells in order
@@ -975,7 +983,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagMod
 			B.inv[at] = 1 / total;                        // src/LibHLA.cpp:1827 (inf when total == 0)
 		}
 	}
-	if (!last) handover_post(flag, B.epoch, (uint32_t)b1);
+	if (!last) handover_post(flag, B.epoch, (uint32_t)b1, B.drop_post == 1 && li == n_whole && k == 0);
 }
 
 // k_total_wide: pass 1 of the FP4 classifiers with several K steps (33 .. 112 SNPs) -- a kernel of their own, started
@@ -1099,7 +1107,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 	const int jq = item / M.n_tile, tile = item - jq * M.n_tile;
 	const int group = (jq * ACCUM_WAVES + wave) * 8 + xcd;
 	unsigned long long *flag = B.sync + (size_t)xcd * n_item_x + item;
-	if (cb > 0) handover_wait(flag, B.epoch, (uint32_t)cb, B.err);
+	if (cb > 0) handover_wait(flag, B, (uint32_t)cb);
 	if (group < n_group) {
 	const int s = group * HIBAG_WAVE + lane;
 	const int ncell = M.tile_n[tile];
@@ -1233,7 +1241,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 	// the item's sums, or -- parked -- what the workgroup behind continues from
 	for (int j = 0; j < ncell; j++) B.part[(size_t)(p0 + j) * B.n_pad + s] = acc[j][lane];
 	}
-	if (ce < C) handover_post(flag, B.epoch, (uint32_t)ce);
+	if (ce < C) handover_post(flag, B.epoch, (uint32_t)ce, B.drop_post == 2 && blockIdx.x == 8 * n_whole);
 }
 
 // ---------------------------------------------------------------------------
@@ -1442,6 +1450,10 @@ __global__ void k_scalars(HibagModelView M, HibagBatchView B, const int *__restr
 			else sum_w += w;
 		}
 	}
+	// A hand-over of this batch failed (see handover_wait): its sums are not to be trusted.  The weight sum is never NaN
+	// otherwise, so NaN here is the in-band mark every k_finish_* kernel (and a merge of partial sums) recognises.
+	if (__hip_atomic_load(B.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == B.epoch)
+		sum_w = sum_m = num_m = __builtin_nan("");
 	const size_t P = (size_t)M.n_cell;
 	B.part[(P + 0) * B.n_pad + s] = sum_w;
 	B.part[(P + 1) * B.n_pad + s] = sum_m;
@@ -1499,6 +1511,7 @@ __global__ __launch_bounds__(64 * FIN_SEG) void k_finish_call(HibagModelView M, 
 	if (seg != 0 || s >= B.n_samp) return;
 	for (int g = 1; g < FIN_SEG; g++)
 		if (best < best_s[g][lane]) { best = best_s[g][lane]; cell = cell_s[g][lane]; }
+	if (sum_w != sum_w) { cell = -1; best = sum_w; }     // poisoned batch (k_scalars): NA call, NaN probability and matching
 	int b1 = NA_INTEGER, b2 = NA_INTEGER;
 	if (cell >= 0) {
 		// invert p = h2 + h1*(2n-h1-1)/2 (src/LibHLA.cpp:1523)
@@ -1507,7 +1520,7 @@ __global__ __launch_bounds__(64 * FIN_SEG) void k_finish_call(HibagModelView M, 
 		b1 = h1; b2 = h1 + rem;
 	}
 	if (H1) { H1[s] = b1; H2[s] = b2; }
-	if (max_prob) max_prob[s] = (cell >= 0) ? best : 0.0;
+	if (max_prob) max_prob[s] = (cell >= 0 || sum_w != sum_w) ? best : 0.0;
 	if (matching) matching[s] = part[(size_t)(P + 1) * np + s] / part[(size_t)(P + 2) * np + s];
 }
 
@@ -1548,7 +1561,7 @@ __global__ void k_finish_dosage(HibagModelView M, HibagBatchView B, const double
 		const double x = normalised(part[cell_of(g) * np + s], scale, ff);
 		d += g == h ? 2 * x : x;
 	}
-	dosage[(size_t)s * n + h] = d;
+	dosage[(size_t)s * n + h] = sum_w != sum_w ? sum_w : d;      // (NaN weight sum: poisoned batch, see k_scalars)
 }
 
 // k_finish_prob: posterior matrix out, [n_samp][P] sample-major
@@ -1566,7 +1579,7 @@ __global__ __launch_bounds__(256) void k_finish_prob(HibagModelView M, HibagBatc
 	const double ff = 1.0 / sum_w;
 	for (int r = ty; r < 64; r += 4) {
 		const int p = p0 + r;
-		tile[r][tx] = (p < P) ? normalised(part[(size_t)p * B.n_pad + s0 + tx], scale, ff) : 0.0;
+		tile[r][tx] = (p < P) ? (sum_w != sum_w ? sum_w : normalised(part[(size_t)p * B.n_pad + s0 + tx], scale, ff)) : 0.0;   // (NaN weight sum: poisoned batch)
 	}
 	__syncthreads();
 	for (int r = ty; r < 64; r += 4) {
@@ -1630,10 +1643,21 @@ static int resident_blocks(F kernel, int threads)
 // A hand-over costs about as much as a tenth of a block list of the benchmark model, so 4 chunks there (2 and 8 measure 1-3 %
 // worse); items of several thousand blocks (the DRB1 shape: 3,900) take 8 - 16 (-4 % against 4): one chunk per
 // `blocks_per_item` / 256, between 4 and 12.
-static int tail_chunks(long long blocks_per_item = 0)
+// `forced` = HibagBatchView::tail_k: 1 after a failed hand-over on the model (its launches then have no hand-overs at all).
+static int tail_chunks(int forced, long long blocks_per_item = 0)
 {
+	if (forced > 0) return forced;
 	static const int k = getenv("HIBAG_TAIL_K") ? std::max(1, std::min(64, atoi(getenv("HIBAG_TAIL_K")))) : 0;
 	return k ? k : (int)std::max(4ll, std::min(12ll, blocks_per_item / 256));
+}
+
+// Resident workgroups of the chunked kernels on the current device; the model keeps them (HibagModelView::slots_*), so
+// that models on different devices, and the two instantiations of k_total, each get their own figure.
+void hibag_query_slots(int *total_plain, int *total_store, int *accum)
+{
+	*total_plain = resident_blocks(k_total<false>, BLOCK_THREADS);
+	*total_store = resident_blocks(k_total<true>, BLOCK_THREADS);
+	*accum = resident_blocks(k_accum, ACCUM_WAVES * HIBAG_WAVE);
 }
 
 void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st, const HibagSideStream &side)
@@ -1650,7 +1674,8 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 			(void)hipEventRecord(side.fork, st);
 			(void)hipStreamWaitEvent(side.stream, side.fork, 0);
 		}
-		hipLaunchKernelGGL(k_total_wide, dim3(gq, M.n_wide_seg), dim3(BLOCK_THREADS), 0, ws, M, B);
+		// (a classifier of several K steps without haplotypes has no segment: its total still has to be written)
+		if (M.n_wide_seg > 0) hipLaunchKernelGGL(k_total_wide, dim3(gq, M.n_wide_seg), dim3(BLOCK_THREADS), 0, ws, M, B);
 		hipLaunchKernelGGL(k_total_scan, dim3(B.n_pad / 64, M.n_wide), dim3(64), 0, ws, W, B);
 		if (side.stream) (void)hipEventRecord(side.join, side.stream);
 	}
@@ -1669,10 +1694,10 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 	V.n_item = split ? M.n_item_split : M.n_item_whole;
 	if (!split) V.n_split = 0;
 	// more items than resident workgroups: the last, incomplete round and the full round before it go in K chunks each
-	static const int slots = resident_blocks(k_total<false>, BLOCK_THREADS);
+	const int slots = M.slots_total[M.store_cells ? 1 : 0];
 	const unsigned n = gx * (unsigned)V.n_item;
 	unsigned n_whole = n, rest = 0, stride = 8, K = 1;
-	const int k_pass1 = tail_chunks(M.p1_blocks / std::max(M.n_classifier, 1));
+	const int k_pass1 = tail_chunks(B.tail_k, M.p1_blocks / std::max(M.n_classifier, 1));
 	if (k_pass1 > 1 && slots > 0 && n > (unsigned)slots) {
 		K = (unsigned)k_pass1;
 		rest = n % (unsigned)slots + (unsigned)slots;
@@ -1704,11 +1729,11 @@ void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStr
 		return;
 	}
 	// more items than resident workgroups: the last, incomplete round and the full round before it go in K chunks each
-	static const int slots = resident_blocks(k_accum, ACCUM_WAVES * HIBAG_WAVE);
+	const int slots = M.slots_accum;
 	const unsigned nx = n / 8, sx = (unsigned)slots / 8;
 	unsigned n_whole = nx, K = 1;
-	if (tail_chunks() > 1 && sx > 0 && nx > sx) {
-		K = (unsigned)tail_chunks();
+	if (tail_chunks(B.tail_k) > 1 && sx > 0 && nx > sx) {
+		K = (unsigned)tail_chunks(B.tail_k);
 		n_whole = nx - (nx % sx + sx);
 	}
 	hipLaunchKernelGGL(k_accum, dim3(8 * (n_whole + K * (nx - n_whole))), dim3(ACCUM_WAVES * HIBAG_WAVE), 0, st, M, B, (int)n_whole, (int)K);

@@ -99,6 +99,8 @@ class HlaAttrBagClass:
 
     def close(self):
         """``hlaClose`` (``R/HIBAG.R:1023-1035``)."""
+        for r in self.__dict__.pop("_replicas", {}).values():      # replicas made for hlaPredict(cl=[devices])
+            r.close()
         if getattr(self, "_h", None) is not None:
             _lib.lib().hibag_hip_model_free(self._h)
             self._h = None
@@ -119,6 +121,37 @@ class HlaAttrBagClass:
     def second_pass_pairs(self) -> int:
         """Haplotype pairs per sample that pass 2 evaluates again (those of the cells that are not stored)."""
         return int(_lib.lib().hibag_hip_model_second_pass_pairs(self.handle))
+
+    # --- launch status (include/hibag_hip.h "launch status of the device-pointer entries") ---
+    def status(self) -> int:
+        """0, or the model's sticky fault code (waits for the model's outstanding launches first)."""
+        return int(_lib.lib().hibag_hip_model_status(self.handle))
+
+    def clear_status(self):
+        _lib.check(_lib.lib().hibag_hip_model_clear_status(self.handle))
+
+    def handover_faults(self) -> int:
+        return int(_lib.lib().hibag_hip_model_handover_faults(self.handle))
+
+    def inject_handover_fault(self, which_pass: int):
+        """Tests only: the next batch drops the first hand-over of pass 1 or 2."""
+        _lib.check(_lib.lib().hibag_hip_test_inject_handover_fault(self.handle, int(which_pass)))
+
+    def engine(self, classifier: int):
+        """(engine name, K steps) of a classifier as the library finalized it."""
+        e, k = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().hibag_hip_model_engine(self.handle, int(classifier), C.byref(e), C.byref(k)))
+        return {0: "valu", 1: "fp4", 2: "i8", 3: "i8"}[e.value], k.value
+
+    def replicate(self, device: int) -> "HlaAttrBagClass":
+        """A finalized copy of the model on another (or the same) device: ``hibag_hip_model_replicate``."""
+        h = _lib.lib().hibag_hip_model_replicate(self.handle, int(device))
+        if not h:
+            raise HibagHipError(-2, _lib.lib().hibag_hip_last_error().decode())
+        r = object.__new__(HlaAttrBagClass)
+        r.obj = self.obj
+        r._h = C.c_void_p(h)
+        return r
 
     def mutation_table(self) -> np.ndarray:
         t = np.empty(257, np.float64)
@@ -229,6 +262,37 @@ class HlaAttrBagClass:
             p(d_postprob), p(stream)))
 
 
+def multi_slice(n_samp: int, n_models: int, i: int):
+    """(first, count) of replica i's contiguous sample slice (``hibag_hip_multi_slice``; host arithmetic only)."""
+    a, b = C.c_int(0), C.c_int(0)
+    _lib.check(_lib.lib().hibag_hip_multi_slice(int(n_samp), int(n_models), int(i), C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def predict_multi(models: Sequence[HlaAttrBagClass], genomat: np.ndarray, vote_method: int = 1, want_dosage: bool = True,
+                  want_prob: bool = False) -> dict:
+    """``hibag_hip_predict_multi``: one cohort over several replicas of a model (one per device, one host thread each,
+    contiguous sample slices, no collective) -- the counterpart of ``hlaPredict(cl=<cluster>)`` (``R/HIBAG.R:764-808``)."""
+    if not models:
+        raise ValueError("no models given")
+    obj = models[0].obj
+    g = np.ascontiguousarray(genomat, np.int32)
+    if g.ndim != 2 or g.shape[1] != obj.n_snp:
+        raise ValueError("genomat must be [n_samp, n.snp] int32")
+    n = g.shape[0]
+    out = dict(h1=np.zeros(n, np.int32), h2=np.zeros(n, np.int32),
+               prob=np.zeros(n, np.float64), matching=np.zeros(n, np.float64))
+    if want_dosage:
+        out["dosage"] = np.zeros((n, obj.n_hla), np.float64)
+    if want_prob:
+        out["postprob"] = np.zeros((n, obj.n_cell), np.float64)
+    hs = (C.c_void_p * len(models))(*[m.handle for m in models])
+    _lib.check(_lib.lib().hibag_hip_predict_multi(
+        hs, len(models), _as_ptr(g), n, int(vote_method), _as_ptr(out["h1"]), _as_ptr(out["h2"]),
+        _as_ptr(out["prob"]), _as_ptr(out["matching"]), _as_ptr(out.get("dosage")), _as_ptr(out.get("postprob"))))
+    return out
+
+
 def hlaModelFromObj(obj: HlaAttrBagObj, device: Optional[int] = None) -> HlaAttrBagClass:
     """``hlaModelFromObj`` (``R/HIBAG.R:1135-1178``)."""
     if not isinstance(obj, HlaAttrBagObj):
@@ -295,9 +359,12 @@ def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, HlaBEDGeno, np.nd
     """``hlaPredict`` (``R/HIBAG.R:481-818``).
 
     ``snp`` is an :class:`HlaSNPGeno` or a numeric matrix [n.snp, n.samp] (or a
-    vector of length n.snp) laid out like the R argument.  ``cl`` is accepted
-    for signature compatibility; the device processes the whole batch at once,
-    so there is nothing to spread over threads or cluster nodes.
+    vector of length n.snp) laid out like the R argument.  ``cl``: the reference takes a
+    ``parallel`` cluster and spreads contiguous sample slices over its workers
+    (``R/HIBAG.R:764-808``); here a list of device indices does the same over the GPUs of
+    the node (``hibag_hip_predict_multi``: one replica and one host thread per device, no
+    collective, results identical to one device).  ``False`` / ``None`` / a thread count:
+    the model's own device processes the whole cohort.
     Returns :class:`HlaAlleleClass`, or for ``type="prob"`` the posterior matrix
     [n_cell, n_samp] like the reference.
     """
@@ -362,7 +429,34 @@ def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, HlaBEDGeno, np.nd
 
     want_prob = type in ("prob", "response+prob")
     want_dosage = type != "response"
-    if bed_plan is not None:
+    devices = list(cl) if isinstance(cl, (list, tuple)) else None
+    if devices is not None and bed_plan is None:
+        # several devices: the model-order matrix is built on the host (the model's few hundred columns of the
+        # cohort), then sliced over the replicas
+        if map_plan is not None:
+            g = np.asarray(snp.genotype)
+            sel = np.asarray(map_plan.sel)
+            rows = g[np.maximum(sel, 0)]
+            if rows.dtype.kind == "f":
+                rows = np.where(np.isfinite(rows), rows, NA_INTEGER)
+            rows = rows.astype(np.int32)
+            ok = (rows >= 0) & (rows <= 2)
+            fl = np.asarray(map_plan.flip) != 0 if map_plan.flip is not None else np.zeros(len(sel), bool)
+            rows = np.where(ok & fl[:, None], 2 - rows, rows)
+            rows[sel < 0] = NA_INTEGER
+            genomat = np.ascontiguousarray(rows.T, np.int32)
+        else:
+            gi = np.where(np.isfinite(mat), mat, NA_INTEGER) if mat.dtype.kind == "f" else mat
+            genomat = np.ascontiguousarray(np.asarray(gi).T, np.int32)
+        cache = object.__dict__.setdefault("_replicas", {})
+        reps = []
+        for d in devices:
+            key = (int(d), len([r for r in reps if r[0] == int(d)]))      # (several replicas on one device are allowed)
+            if key not in cache:
+                cache[key] = object.replicate(int(d))
+            reps.append((int(d), cache[key]))
+        rv = predict_multi([r for _, r in reps], genomat, vote_method, want_dosage=want_dosage, want_prob=want_prob)
+    elif bed_plan is not None:
         col = np.where(bed_plan.sel >= 0, snp.bed_index[np.maximum(bed_plan.sel, 0)], -1)
         rv = object.predict_bed(snp.bed_fn, snp.n_bed_samp, snp.n_bed_snp, col, bed_plan.flip, vote_method,
                                 want_dosage=want_dosage, want_prob=want_prob)
@@ -370,16 +464,13 @@ def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, HlaBEDGeno, np.nd
         g = np.asarray(snp.genotype)
         if g.dtype.kind == "f":
             g = np.where(np.isfinite(g), g, NA_INTEGER)
-        cohort = np.ascontiguousarray(g.astype(np.int64).T.astype(np.int32))      # [n_samp, cohort SNPs]: R's memory order
+        cohort = np.ascontiguousarray(g.T, np.int32)      # [n_samp, cohort SNPs]: R's memory order
         rv = object.predict_mapped(cohort, map_plan.sel, map_plan.flip, vote_method,
                                    want_dosage=want_dosage, want_prob=want_prob)
     else:
         # as.integer(snp): R's NA -> NA_integer_ ; the C side treats anything outside 0..2 as missing
-        if mat.dtype.kind == "f":
-            gi = np.where(np.isfinite(mat), mat, NA_INTEGER).astype(np.int64)
-        else:
-            gi = mat.astype(np.int64)
-        genomat = np.ascontiguousarray(gi.T.astype(np.int32))     # [n_samp, n_snp]
+        gi = np.where(np.isfinite(mat), mat, NA_INTEGER) if mat.dtype.kind == "f" else mat
+        genomat = np.ascontiguousarray(np.asarray(gi).T, np.int32)     # [n_samp, n_snp]
         rv = object.predict_raw(genomat, vote_method, want_dosage=want_dosage, want_prob=want_prob)
 
     names = _pair_names(obj.hla_allele)

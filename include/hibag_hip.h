@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-#define HIBAG_HIP_ABI_VERSION 4   /* 2: + PLINK BED entries, training driver; 3: + hibag_hip_predict_mapped[_device]; 4: + hibag_hip_model_stored_cells */
+#define HIBAG_HIP_ABI_VERSION 5   /* 2: + PLINK BED entries, training driver; 3: + hibag_hip_predict_mapped[_device]; 4: + hibag_hip_model_stored_cells;
+                                     5: + hibag_hip_model_status / _clear_status, hibag_hip_predict_multi, hibag_hip_model_replicate, hibag_hip_model_engine */
 
 /* error codes */
 #define HIBAG_HIP_OK          0
@@ -29,6 +30,7 @@ extern "C" {
 #define HIBAG_HIP_ENODEV     (-2)  /* no usable HIP device / HIP runtime error     */
 #define HIBAG_HIP_ENOMEM     (-3)  /* host or device allocation failed             */
 #define HIBAG_HIP_ESTATE     (-4)  /* call order violated (e.g. predict before finalize) */
+#define HIBAG_HIP_EHANDOVER  (-5)  /* a launch could not vouch for its sums (see "launch status" below); outputs were poisoned */
 
 /* R's NA_integer_: what H1/H2 hold when no allele pair has positive
  * probability (src/LibHLA.cpp:1552), and the usual missing-genotype code. */
@@ -128,7 +130,9 @@ int hibag_hip_predict(hibag_hip_model *m, const int32_t *geno, int n_samp,
 
 /* Device-pointer form of the same call: every pointer is device memory on the
  * model's device, work is enqueued on `stream` (a hipStream_t, NULL = default
- * stream) and the call returns without synchronising. */
+ * stream) and the call returns without synchronising.  A return of 0 means
+ * "enqueued": whether the launch could vouch for its sums is the model's status,
+ * see "launch status" below (outputs are NA / NaN if it could not). */
 int hibag_hip_predict_device(hibag_hip_model *m, const int32_t *d_geno, int n_samp,
 	int vote_method, int32_t *d_H1, int32_t *d_H2, double *d_max_prob,
 	double *d_matching, double *d_dosage, double *d_postprob, void *stream);
@@ -148,6 +152,62 @@ int hibag_hip_predict_mapped_device(hibag_hip_model *m, const int32_t *d_geno, i
 	const int32_t *d_snp_col, const int32_t *d_flip, int vote_method,
 	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching, double *d_dosage,
 	double *d_postprob, void *stream);
+
+/* ---- launch status of the device-pointer entries ---------------------------------------------------------
+ *
+ * The last rounds of a pass are cut into chunks that hand their running sums over through the L2 of one XCD
+ * ("Hand-overs").  That rests on observed dispatch behaviour, so every hand-over is checked
+ * on the device, and one that never arrives (or crosses XCDs) can NOT come back to the caller as numbers:
+ *   - the launch's outputs are poisoned on the device: H1 = H2 = NA_integer_, max_prob / matching / dosage /
+ *     postprob = NaN for every sample of the batch (partial sums: the three scalar rows are NaN, which survives an
+ *     all-reduce and poisons hibag_hip_finish_device's outputs the same way);
+ *   - the model gets a STICKY status HIBAG_HIP_EHANDOVER: hibag_hip_model_status() (which waits for the model's
+ *     outstanding launches first), hibag_hip_get_timing() and every further compute entry on the model return it until
+ *     hibag_hip_model_clear_status() -- the convention of the reference, whose entries never return garbage
+ *     (CORE_TRY / CORE_CATCH, src/HIBAG.cpp:41-60; the RAII try_final_* guards, src/LibHLA.cpp:2307-2315);
+ *   - from the first such fault on the model launches WITHOUT hand-overs (every work item undivided), so the
+ *     caller's second attempt -- clear the status, call again, same process -- cannot fail the same way.
+ * The host-pointer entries (hibag_hip_predict, _mapped, _bed, _multi, the plugin table) do all of that themselves:
+ * they see the fault when they synchronise, run the call again without hand-overs and return the repaired result
+ * with code 0; hibag_hip_model_handover_faults() counts how often that (or a sticky fault) happened.
+ *
+ * Protocol for a device-pointer caller:   enqueue ... ; synchronise the stream ;
+ *     if (hibag_hip_model_status(m) == HIBAG_HIP_EHANDOVER) { hibag_hip_model_clear_status(m); enqueue again; }
+ *
+ * Streams: a model owns ONE workspace.  Calls on the same model from different streams (or host threads) are legal:
+ * the library chains them on the device with an event, each waits for the one enqueued before it.  For concurrency
+ * across streams or devices use one model per stream / device (hibag_hip_model_replicate). */
+int hibag_hip_model_status(hibag_hip_model *m);
+int hibag_hip_model_clear_status(hibag_hip_model *m);
+int64_t hibag_hip_model_handover_faults(const hibag_hip_model *m);
+/* Fault injection for the tests of the above: the next batch on the model drops the first hand-over of pass `pass`
+ * (1 or 2; 0 = disarm) and uses a short time-out.  Not for production use. */
+int hibag_hip_test_inject_handover_fault(hibag_hip_model *m, int pass);
+
+/* How classifier `classifier` of a finalized model computes its distances: *engine = HIBAG_HIP_ENGINE_VALU (bit logic +
+ * popcount on the vector ALU), _FP4 (v_mfma_scale_f32_32x32x64_f8f6f4, *k_steps instructions per sample half and
+ * 32-pair block) or _I8 / _I8S (v_mfma_i32_32x32x32_i8, two K blocks); what bench.py prices its issue floor with. */
+#define HIBAG_HIP_ENGINE_VALU 0
+#define HIBAG_HIP_ENGINE_FP4  1
+#define HIBAG_HIP_ENGINE_I8   2
+#define HIBAG_HIP_ENGINE_I8S  3
+int hibag_hip_model_engine(const hibag_hip_model *m, int classifier, int *engine, int *k_steps);
+
+/* ---- several devices of one node: replaces hlaPredict(cl = <cluster>) ----------------------------------------
+ *
+ * The reference spreads a cohort over the workers of a `parallel` cluster: contiguous sample slices, every worker
+ * holding the whole model, results concatenated (R/HIBAG.R:764-808).  Here a "worker" is a device:
+ *   hibag_hip_model_replicate  a finalized copy of `m` on `device` (the model is a few MB; every device holds all of it)
+ *   hibag_hip_predict_multi    hibag_hip_predict over `n_models` replicas at once: one host thread per replica, each
+ *                              takes the contiguous slice hibag_hip_multi_slice gives it and writes its part of every
+ *                              output in place.  Samples are independent (src/LibHLA.cpp:2362-2411): no collective, and
+ *                              every output is bit-identical to the single-device call.  The replicas may sit on any
+ *                              devices, also several on one.
+ *   hibag_hip_multi_slice      the slice of replica i: [*first, *first + *count) -- boundaries on multiples of 64 samples. */
+hibag_hip_model *hibag_hip_model_replicate(const hibag_hip_model *m, int device);
+int hibag_hip_multi_slice(int n_samp, int n_models, int i, int *first, int *count);
+int hibag_hip_predict_multi(hibag_hip_model *const *models, int n_models, const int32_t *geno, int n_samp,
+	int vote_method, int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob);
 
 /* Classifier-sharded partial pass for multi-GPU runs: each rank owns a model
  * holding a subset of the classifiers but built with the FULL model's per-SNP

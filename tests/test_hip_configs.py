@@ -183,3 +183,94 @@ def test_large_model_1500_haplotypes_per_classifier(hib, oracle):
     want = oracle.predict(oracle.flatten(model), G[sub], vote_method=1, avx2=True, n_threads=8)
     for k in ("h1", "h2", "prob", "matching", "dosage", "postprob"):
         assert np.array_equal(got[k][sub], want[k], equal_nan=True), k
+
+
+def test_cfg4_at_the_benchmarks_size_chunked_items_against_oracle(hib, oracle):
+    """The DRB1 shape at the 4,096 samples bench.py times: 1,600 pass-1 items on 1,280 resident workgroups, so the last
+    rounds run as chunks (12 per item) that resume at HibagModelView::blk_close rows with every cell stored -- the split of
+    the loop at src/LibHLA.cpp:1776-1829.  (The 2,048-sample test above has 800 items: no chunks.)"""
+    from hibag_amd import synth
+    model, founders, af = synth.make_model("hla-drb1")
+    n = 4096
+    G, truth = synth.make_samples(founders, af, n)
+    m = hib.hlaModelFromObj(model)
+    assert m.stored_cells() > 0 and m.second_pass_pairs() == 0
+    got = m.predict_raw(G, 1, want_dosage=True, want_prob=True)
+    assert m.handover_faults() == 0
+    m.close()
+    assert np.mean((got["h1"] == truth[:, 0]) & (got["h2"] == truth[:, 1])) > 0.9
+    sub = np.concatenate([np.arange(0, n, 171)[:22], [n - 65, n - 1]])     # 24 samples, the last sample groups included
+    want = oracle.predict(oracle.flatten(model), G[sub], vote_method=1, avx2=True, n_threads=8)
+    for k in ("h1", "h2", "prob", "matching", "dosage", "postprob"):
+        assert np.array_equal(got[k][sub], want[k], equal_nan=True), k
+
+
+_TAIL_K_SCRIPT = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["HIBAG_REPO"])
+import hibag_amd as hib
+from hibag_amd import synth
+from oracle import oracle as O
+O.build()
+hib.hlaSetKernelTarget("hip")
+shape, n = sys.argv[1], int(sys.argv[2])
+model, founders, af = synth.make_model(shape)
+G, _ = synth.make_samples(founders, af, n)
+m = hib.hlaModelFromObj(model)
+got = m.predict_raw(G, 1, want_dosage=True, want_prob=True)
+faults = m.handover_faults()
+m.close()
+sub = np.arange(0, n, max(1, n // 40))[:40]
+want = O.predict(O.flatten(model), G[sub], vote_method=1, avx2=True, n_threads=8)
+bad = [k for k in ("h1", "h2", "prob", "matching", "dosage", "postprob") if not np.array_equal(got[k][sub], want[k], equal_nan=True)]
+print(json.dumps({"bad": bad, "faults": int(faults)}))
+"""
+
+
+@pytest.mark.parametrize("tail_k", [1, 2, 8, 12])
+def test_cfg2_every_number_of_chunks_per_item_equals_the_oracle(tail_k, tmp_path):
+    """HIBAG_TAIL_K = chunks per work item of the last rounds of both passes (read once per process, hence a child
+    process per value): 1 = undivided items, 2 / 8 / 12 around the default of 4.  The benchmark configuration
+    (10,000 samples, HLA-B shape), 40 samples against the oracle, every output bit for bit."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "tail_k.py"
+    script.write_text(_TAIL_K_SCRIPT)
+    env = dict(os.environ, HIBAG_TAIL_K=str(tail_k), HIBAG_REPO=root)
+    p = subprocess.run([sys.executable, str(script), "hla-b", "10000"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res == {"bad": [], "faults": 0}
+
+
+def test_predict_multi_two_replicas_on_one_device_equal_the_single_call(hib, oracle):
+    """hibag_hip_predict_multi with the device list [0, 0]: two replicas, two host threads, contiguous slices written in
+    place -- bit-equal to the single call (samples are independent, src/LibHLA.cpp:2362-2411; the reference's
+    hlaPredict(cl=) does the same over cluster workers, R/HIBAG.R:764-808)."""
+    from hibag_amd import synth
+    from hibag_amd.hibag import predict_multi
+    model, founders, af = synth.make_model("hla-b")
+    n = 5003                                       # ragged: the second slice ends inside a group of 64
+    G, _ = synth.make_samples(founders, af, n)
+    m = hib.hlaModelFromObj(model)
+    single = m.predict_raw(G, 1, want_dosage=True, want_prob=True)
+    r0, r1 = m.replicate(0), m.replicate(0)
+    both = predict_multi([r0, r1], G, 1, want_dosage=True, want_prob=True)
+    three = predict_multi([m, r0, r1], G[:130], 2, want_dosage=True, want_prob=False)   # more replicas than it is worth: still right
+    single2 = m.predict_raw(G[:130], 2, want_dosage=True)
+    for k in ("h1", "h2", "prob", "matching", "dosage", "postprob"):
+        assert np.array_equal(both[k], single[k], equal_nan=True), k
+    for k in ("h1", "h2", "prob", "matching", "dosage"):
+        assert np.array_equal(three[k], single2[k], equal_nan=True), k
+    # through the front end: hlaPredict(cl = [devices])
+    res1 = hib.hlaPredict(m, synth.as_snp_geno(model, G[:700]), type="response+dosage", verbose=False)
+    res2 = hib.hlaPredict(m, synth.as_snp_geno(model, G[:700]), cl=[0, 0], type="response+dosage", verbose=False)
+    assert res1.allele1 == res2.allele1 and res1.allele2 == res2.allele2
+    assert np.array_equal(res1.prob, res2.prob, equal_nan=True) and np.array_equal(res1.dosage, res2.dosage, equal_nan=True)
+    with pytest.raises(hib.HibagHipError):
+        m.replicate(99)
+    for r in (r0, r1):
+        r.close()
+    m.close()

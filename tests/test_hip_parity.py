@@ -412,3 +412,21 @@ def test_random_models(hib, oracle, seed):
         got = m.predict_raw(G, vote, want_dosage=True, want_prob=True)
         assert_same(got, want)
 
+
+
+@pytest.mark.parametrize("k_empty", [5, 30, 40, 120])
+def test_classifier_without_haplotypes(hib, oracle, k_empty):
+    """A classifier whose haplotype list is empty (every engine: FP4, int8, FP4 in several K steps -- which has a kernel
+    of its own and no list segment to launch it on --, VALU): its total is 0, 1/total infinite, and the reference's
+    0 * inf = NaN reaches every cell of every sample that uses it (src/LibHLA.cpp:1826-1828)."""
+    from hibag_amd import synth
+    model, founders, af = synth.make_model("hla-a-small", seed=5, n_classifier=3, n_snp=130, wide_classifier=False)
+    empty = hib.Classifier(snpidx=np.arange(k_empty), freq=np.zeros(0), hla=np.zeros(0, np.int32), haplo=[])
+    model.classifiers.insert(1, empty)
+    G, _ = synth.make_samples(founders, af, 100, seed=6)
+    G[7, :] = hib.NA_INTEGER
+    G[9, :k_empty] = hib.NA_INTEGER                   # a sample that does not use the empty classifier at all
+    for vote in (1, 2):
+        want = oracle.predict(oracle.flatten(model), G, vote_method=vote)
+        got = hib.hlaModelFromObj(model).predict_raw(G, vote, want_dosage=True, want_prob=True)
+        assert_same(got, want)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.hibag_hip_abi_version() == 4
+    assert L.hibag_hip_abi_version() == 5
 
 
 def test_no_cpu_fallback_in_product():
@@ -237,3 +237,44 @@ def test_rdata_writer_reproduces_r_bytes(tmp_path, model_oob):
     got = body(out).replace(b"\x00\x04\x00\x09\x00\x00\x00\x08appendix", b"\x00\x04\x00\x09\x00\x00\x00\x00")
     assert got == want
 
+
+
+def test_multi_device_slices_cover_the_cohort_contiguously():
+    """hibag_hip_multi_slice: the contiguous sample slices hibag_hip_predict_multi hands its replicas (the reference cuts the
+    cohort the same way for its cluster workers, R/HIBAG.R:767-781) -- disjoint, in order, complete, boundaries on
+    multiples of 64 samples except the cohort's end.  Pure host arithmetic: runs without a GPU."""
+    from hibag_amd.hibag import multi_slice
+    import hibag_amd
+    for n in (0, 1, 63, 64, 65, 1000, 10_000, 100_000, 123_457):
+        for k in (1, 2, 3, 4, 8):
+            at = 0
+            for i in range(k):
+                first, count = multi_slice(n, k, i)
+                assert first == at and count >= 0
+                assert first % 64 == 0
+                at += count
+            assert at == n
+            sizes = [multi_slice(n, k, i)[1] for i in range(k)]
+            assert max(sizes) - min(sizes) <= 64 or n < 64 * k
+    with pytest.raises(hibag_amd.HibagHipError):
+        multi_slice(10, 0, 0)
+    with pytest.raises(hibag_amd.HibagHipError):
+        multi_slice(10, 2, 2)
+
+
+def test_status_entries_reject_bad_arguments_without_a_gpu():
+    from hibag_amd import _lib
+    L = _lib.lib()
+    assert L.hibag_hip_model_status(None) == -1
+    assert L.hibag_hip_model_clear_status(None) == -1
+    assert L.hibag_hip_model_handover_faults(None) == 0
+    assert L.hibag_hip_test_inject_handover_fault(None, 1) == -1
+    assert L.hibag_hip_predict_multi(None, 0, None, 0, 1, None, None, None, None, None, None) == -1
+    m = L.hibag_hip_model_new(4, 10)
+    assert m
+    m = C.c_void_p(m)
+    assert L.hibag_hip_test_inject_handover_fault(m, 3) == -1
+    e, k = C.c_int(0), C.c_int(0)
+    assert L.hibag_hip_model_engine(m, 0, C.byref(e), C.byref(k)) == -4          # not finalized
+    assert L.hibag_hip_model_status(m) in (0, -2)                                # no launches; -2 where there is no device
+    L.hibag_hip_model_free(m)
