@@ -33,7 +33,7 @@ EXPORTS = [
     "hibag_hip_trainer_classifier_get",
     "hibag_hip_model_status", "hibag_hip_model_clear_status", "hibag_hip_model_handover_faults",
     "hibag_hip_test_inject_handover_fault", "hibag_hip_model_engine", "hibag_hip_model_replicate",
-    "hibag_hip_multi_slice", "hibag_hip_predict_multi",
+    "hibag_hip_multi_slice", "hibag_hip_predict_multi", "hibag_hip_model_device",
 ]
 
 
@@ -77,7 +77,7 @@ def lib() -> C.CDLL:
     L.hibag_hip_model_finalize.argtypes = [vp]
     L.hibag_hip_model_free.argtypes = [vp]
     L.hibag_hip_model_free.restype = None
-    for f in (L.hibag_hip_model_n_hla, L.hibag_hip_model_n_snp, L.hibag_hip_model_n_classifier):
+    for f in (L.hibag_hip_model_n_hla, L.hibag_hip_model_n_snp, L.hibag_hip_model_n_classifier, L.hibag_hip_model_device):
         f.argtypes = [vp]
         f.restype = i32
     L.hibag_hip_model_pair_evals.argtypes = [vp]

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -47,6 +48,14 @@ int fail(int code, const char *fmt, ...)
 				"%s failed: %s", #expr, hipGetErrorString(e_));                         \
 	} while (0)
 
+// Grow-only pinned host buffer (staging of the pipelined host-pointer entries).
+struct PinBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	int reserve(size_t bytes);
+	void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 // Grow-only device buffer.
 struct DevBuf {
 	void *p = nullptr;
@@ -62,6 +71,15 @@ struct DevBuf {
 	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 	template <class T> T *as() const { return (T *)p; }
 };
+
+int PinBuf::reserve(size_t bytes)
+{
+	if (bytes <= cap) return 0;
+	release();
+	HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+	cap = bytes;
+	return 0;
+}
 
 struct HostClassifier {
 	std::vector<int> snpidx;         // may be empty for plugin-built models
@@ -147,7 +165,7 @@ struct hibag_hip_model {
 	bool finalized = false;
 	bool have_snpidx = true;
 	bool use_mfma = true;                  // matrix-core engine for classifiers with <= 112 SNPs (HIBAG_ENGINE=valu disables)
-	bool use_fp4 = true;                   // its FP4 form for <= 28 SNPs (HIBAG_ENGINE=i8 keeps every classifier on the int8 form)
+	bool use_fp4 = true;                   // its FP4 form for <= 30 SNPs (HIBAG_ENGINE=i8 keeps every classifier on the int8 form)
 	std::vector<HostClassifier> cls;
 	std::vector<int> snp_weight_override;   // classifier-sharded runs
 	int64_t pair_evals = 0;
@@ -180,6 +198,7 @@ struct hibag_hip_model {
 	hipEvent_t ws_done = nullptr;
 	bool ws_pending = false;
 	StagedStreams staged;                  // the host-pointer entries' slice pipeline (created on first use)
+	PinBuf pin_geno, pin_out;              // its pinned staging buffers (two slices each)
 	bool staged_ready = false;
 	// plugin staging
 	DevBuf ws_tgeno, ws_weight;
@@ -195,6 +214,7 @@ struct hibag_hip_model {
 		timer.destroy();
 		if (h_err) (void)hipHostFree(h_err);
 		if (ws_done) (void)hipEventDestroy(ws_done);
+		pin_geno.release(); pin_out.release();
 		for (hipStream_t st : {staged.run, staged.in, staged.out}) if (st) (void)hipStreamDestroy(st);
 		for (int i = 0; i < 2; i++)
 			for (hipEvent_t e : {staged.up[i], staged.ran[i], staged.down[i]}) if (e) (void)hipEventDestroy(e);
@@ -455,7 +475,7 @@ int finalize_model(hibag_hip_model *m)
 		// matrix-core engines: at most 112 SNPs; table indices: first haplotype < 2H + 1 in 16 bits, second < H + 1 in 14
 		engine[c] = (m->use_mfma && H < 16384) ? HIBAG_ENGINE_OF(k.n_snp, m->use_fp4) : HIBAG_ENGINE_VALU;
 		// (several K steps need their cells stored: not with pass 2 forced to evaluate every pair)
-		if (engine[c] == HIBAG_ENGINE_FP4 && k.n_snp > HIBAG_FP4_STEP_SNPS && !allow_wide) engine[c] = HIBAG_ENGINE_VALU;
+		if (engine[c] == HIBAG_ENGINE_FP4 && k.n_snp > HIBAG_FP4_MAX_SNPS && !allow_wide) engine[c] = HIBAG_ENGINE_VALU;
 		n_step[c] = HIBAG_ENGINE_STEPS(engine[c], k.n_snp);
 		bt_row[c] = bt_rows;
 		bt_rows += HIBAG_ENGINE_ROWS(engine[c], k.n_snp);
@@ -521,6 +541,7 @@ int finalize_model(hibag_hip_model *m)
 	stream.insert(stream.end(), HIBAG_CHUNK_DWORDS(HIBAG_MAX_NWP), 0);
 	if (snp_index.empty()) snp_index.push_back(0);
 	if (hap.empty()) hap.insert(hap.end(), 12, 0u);
+	if (hap.size() * sizeof(uint32_t) > 0x7FFFFF00ull) return fail(HIBAG_HIP_EINVAL, "the model's haplotype tables exceed 2 GB");
 
 	std::vector<int> tile_p0, tile_n;
 	build_tiles(P, cell_work, tile_p0, tile_n);
@@ -541,6 +562,10 @@ int finalize_model(hibag_hip_model *m)
 	// hybrid | recompute and HIBAG_STORE_PAIRS override.
 	uint64_t store_above = 12;
 	if (const char *e = getenv("HIBAG_STORE_PAIRS")) store_above = (uint64_t)std::max(0, atoi(e));
+	if (getenv("HIBAG_PASS2") && !strcmp(getenv("HIBAG_PASS2"), "recompute")) store_above = ~(uint64_t)0;   // (no cell of theirs is stored)
+	// Pass 2 evaluates the pairs of one-step FP4 classifiers only (k_accum's block stream); a classifier on any other engine
+	// -- int8 (29..32 SNPs), FP4 in several K steps, VALU -- has all its cells stored by pass 1 and read back.
+	auto pass2_evaluates = [&](int c) { return engine[c] == HIBAG_ENGINE_FP4 && n_step[c] == 1; };
 	{
 		long long n_cells = 0, n_big = 0;
 		double cost = 0;                                   // pairs, a VALU-engine pair counted five times (what it costs)
@@ -548,13 +573,13 @@ int finalize_model(hibag_hip_model *m)
 			cost += (double)pairs[c] * (mfma_nkb[c] ? 1.0 : 5.0);
 			for (int p = 0; p < P; p++) {
 				n_cells += cell_chunks[c][p] != 0;
-				n_big += mfma_nkb[c] && n_step[c] == 1 ? cell_pairs[c][p] > store_above : cell_chunks[c][p] != 0;
+				n_big += pass2_evaluates(c) ? cell_pairs[c][p] > store_above : cell_chunks[c][p] != 0;
 			}
 		}
 		m->store_mode = C == 0 ? 0 : cost >= 14.0 * (double)std::max<long long>(n_cells, 1) ? 1 : n_big ? 2 : 0;
 		if (const char *e = getenv("HIBAG_PASS2")) {
 			if (!strcmp(e, "stream")) m->store_mode = C > 0;
-			else if (!strcmp(e, "recompute")) m->store_mode = 0;       // (no classifier of several K steps then, see above)
+			else if (!strcmp(e, "recompute")) m->store_mode = n_big ? 2 : 0;       // (only what pass 2 cannot evaluate is stored)
 			else if (!strcmp(e, "hybrid")) m->store_mode = n_big ? 2 : 0;
 		}
 	}
@@ -566,9 +591,8 @@ int finalize_model(hibag_hip_model *m)
 	for (int c = 0; c < C; c++) {
 		stored[c].assign(P, 0);
 		if (store_mode == 1) { for (int p = 0; p < P; p++) stored[c][p] = cell_chunks[c][p] != 0; }
-		else if (store_mode == 2 && (!mfma_nkb[c] || n_step[c] > 1)) {
-			// a VALU-engine classifier costs about five times as much per pair, and one of several K steps has no
-			// walk in pass 2 at all: all their cells
+		else if (store_mode == 2 && !pass2_evaluates(c)) {
+			// pass 2 evaluates one-step FP4 classifiers only: all the cells of the others
 			for (int p = 0; p < P; p++) stored[c][p] = cell_chunks[c][p] != 0;
 		} else if (store_mode == 2)
 			for (int t = 0; t < n_tile; t++) {
@@ -619,7 +643,7 @@ int finalize_model(hibag_hip_model *m)
 				for (int j = 0; j < tile_n[t]; j++)
 					if (cell_chunks[c][tile_p0[t] + j] && !stored_big(c, tile_p0[t] + j)) {
 						jp |= (uint64_t)j << (4 * nl++);
-						if (store_mode != 1) m->second_pass_pairs += mfma_nkb[c] ? cell_pairs[c][tile_p0[t] + j] : 0;
+						if (store_mode != 1) m->second_pass_pairs += pass2_evaluates(c) ? cell_pairs[c][tile_p0[t] + j] : 0;
 					}
 				for (int j = 0; j < tile_n[t]; j++)
 					if (stored_big(c, tile_p0[t] + j)) jp |= (uint64_t)j << (4 * (nl + ns++));
@@ -697,15 +721,62 @@ int finalize_model(hibag_hip_model *m)
 	std::vector<uint64_t> blk_off(std::max(C, 1), 0), seg_off((size_t)std::max(C, 1) * n_tile, 0);
 	std::vector<uint32_t> seg_nblk((size_t)std::max(C, 1) * n_tile, 0);
 	long long dbg_b1 = 0, dbg_b2 = 0, dbg_seg = 0;
-	for (int t = 0; t < n_tile && store_mode != 1; t++)
+	std::vector<int> cell_row((size_t)C + 1, 0);
+	for (int c = 0; c < C; c++)
+		cell_row[c + 1] = cell_row[c] + (store_mode == 1 || split_row[c] >= 0 ? cls_n[c] : store_mode == 2 ? n_stored_c[c] : 0);
+	// The E-stream of pass 2: per tile the blocks of classifier 0, 1, 2 ... (hibag_device.h).  A (classifier, tile) visit is
+	// the blocks of its evaluated cells' pair slots -- one-step FP4 classifiers only -- with the visit's stored sums attached
+	// four per block; a visit with more stored sums than its slot blocks carry (any classifier of another engine) gets
+	// blocks of padding slots for the rest.
+	std::vector<uint32_t> ehdr, etile_cstart((size_t)n_tile * (C + 1), 0);
+	std::vector<uint64_t> etile_blk0(std::max(n_tile, 1), 0);
+	const uint32_t zero_entry_dword = (uint32_t)hap.size();          // an all-zero FP4 entry for padding blocks (factor +0.0: nothing is evaluated)
+	hap.insert(hap.end(), HIBAG_ENGINE_HAP_DWORDS(HIBAG_ENGINE_FP4), 0u);
+	for (int t = 0; t < n_tile && store_mode != 1; t++) {
+		etile_blk0[t] = plist.size() / HIBAG_PLIST_DWORDS;
 		for (int c = 0; c < C; c++) {
-			if (!mfma_nkb[c]) continue;
-			seg_off[(size_t)c * n_tile + t] = plist.size();
-			const int nb = append_pair_blocks(starts[c].data(), nh, tile_h1[t], tile_h2[t], tile_p0[t], tile_n[t],
-				(uint32_t)m->cls[c].freq.size(), plist, nullptr, store_mode == 2 ? stored[c].data() : nullptr);
-			seg_nblk[(size_t)c * n_tile + t] = (uint32_t)nb;
-			dbg_b2 += nb; dbg_seg += nb > 0;
+			const size_t ct = (size_t)c * n_tile + t;
+			etile_cstart[(size_t)t * (C + 1) + c] = (uint32_t)(plist.size() / HIBAG_PLIST_DWORDS - etile_blk0[t]);
+			const size_t first = plist.size();
+			int nb = 0;
+			if (pass2_evaluates(c) && tile_nlist[ct] > 0)
+				nb = append_pair_blocks(starts[c].data(), nh, tile_h1[t], tile_h2[t], tile_p0[t], tile_n[t],
+					(uint32_t)m->cls[c].freq.size(), plist, nullptr, store_mode == 2 ? stored[c].data() : nullptr);
+			const int ns = (int)tile_nstored[ct];
+			const int nvb = std::max(nb, (ns + HIBAG_STORED_PER_VISIT - 1) / HIBAG_STORED_PER_VISIT);
+			for (int b = nb; b < nvb; b++) plist.insert(plist.end(), HIBAG_PLIST_DWORDS, 0u);     // padding slots: entry 0 of the zero entry's "table"
+			dbg_b2 += nvb; dbg_seg += nvb > 0;
+			// the visit's cells in closing order, then its stored ones (tile_jpack)
+			uint64_t jp = tile_jpack[ct];
+			uint64_t jps = jp >> (4 * tile_nlist[ct]);
+			uint32_t srow = (uint32_t)cell_row[c] + tile_k0[ct];
+			for (int b = 0; b < nvb; b++) {
+				uint32_t closes = 0;
+				if (b < nb)
+					for (int i = 0; i < HIBAG_PLIST_DWORDS; i++) closes += plist[first + (size_t)b * HIBAG_PLIST_DWORDS + i] >> 31;
+				const int nsb = std::max(0, std::min(HIBAG_STORED_PER_VISIT, ns - HIBAG_STORED_PER_VISIT * b));
+				if (c > 0xFFFF) return fail(HIBAG_HIP_EINVAL, "too many classifiers (%d) for the second pass's block headers", C);
+				const bool slots = b < nb;
+				const uint32_t h[8] = {
+					(uint32_t)c | ((uint32_t)(slots ? n_snp_c[c] : 0) << 18) | ((uint32_t)nsb << 25),
+					slots ? hap_off[c] : zero_entry_dword,
+					(uint32_t)bt_row[c],
+					srow,
+					(uint32_t)jp, (uint32_t)(jp >> 32),
+					(uint32_t)(jps & 0xFFFFu), 0u};
+				ehdr.insert(ehdr.end(), h, h + 8);
+				jp = closes >= 16 ? 0 : jp >> (4 * closes);
+				jps >>= 4 * nsb;
+				srow += (uint32_t)nsb;
+			}
 		}
+		etile_cstart[(size_t)t * (C + 1) + C] = (uint32_t)(plist.size() / HIBAG_PLIST_DWORDS - etile_blk0[t]);
+	}
+	// look-ahead slack: the loop requests block b + 1 whole and the slots / header of block b + 2
+	const uint64_t estream_blocks = plist.size() / HIBAG_PLIST_DWORDS + 4;
+	plist.insert(plist.end(), 4 * HIBAG_PLIST_DWORDS, 0u);
+	ehdr.resize(estream_blocks * 8, 0u);
+	for (uint64_t b = estream_blocks - 4; b < estream_blocks; b++) ehdr[b * 8 + 1] = zero_entry_dword;
 	const uint64_t p1_base = plist.size();
 	std::vector<uint32_t> blk_close;
 	// segments of the classifiers with several K steps (k_total_wide): {classifier, first stored row, blocks} + list offset
@@ -753,10 +824,7 @@ int finalize_model(hibag_hip_model *m)
 		}
 	}
 	if (blk_close.empty()) blk_close.push_back(0);
-	std::vector<int> cell_row((size_t)C + 1, 0);
-	for (int c = 0; c < C; c++)
-		cell_row[c + 1] = cell_row[c] + (store_mode == 1 || split_row[c] >= 0 ? cls_n[c] : store_mode == 2 ? n_stored_c[c] : 0);
-	m->second_pass_pairs += store_mode == 0 ? valu_pairs : 0;
+	(void)valu_pairs;
 	if (getenv("HIBAG_DEBUG_MODEL"))
 		fprintf(stderr, "[hibag model] %d classifiers, %d tiles, pairs %lld; blocks of 32: pass 1 %lld, pass 2 %lld in %lld (classifier, tile) segments; "
 			"pair lists %.1f MB, haplotype table %.1f KB, VALU-engine stream %.1f MB\n",
@@ -784,27 +852,6 @@ int finalize_model(hibag_hip_model *m)
 			r[6] = (uint32_t)tile_jpack[(size_t)c * n_tile + t]; r[7] = (uint32_t)(tile_jpack[(size_t)c * n_tile + t] >> 32);
 		}
 
-	// cost prefix sums of pass 2 (where the launcher cuts an item into chunks), in quarter-blocks: a matrix-engine visit costs its blocks
-	// plus a start-up; a VALU-engine visit 4 records x nwp words per chunk at ~48 ns per word-record against
-	// ~110 ns per quarter-block
-	std::vector<uint32_t> acc_cum((size_t)n_tile * (C + 1), 0);
-	for (int t = 0; t < n_tile; t++) {
-		uint64_t sum = 0;
-		for (int c = 0; c < C; c++) {
-			uint64_t cost = 3 + tile_nstored[(size_t)c * n_tile + t];
-			if (mfma_nkb[c]) cost += 4ull * seg_nblk[(size_t)c * n_tile + t];
-			else {
-				uint64_t chunks = 0;
-				for (int j = 0; j < tile_n[t]; j++) chunks += cell_chunks[c][tile_p0[t] + j];
-				cost += (chunks * (uint64_t)nwp[c] * 17 + 9) / 10;
-			}
-			acc_cum[(size_t)t * (C + 1) + c] = (uint32_t)sum;
-			sum += cost;
-			if (sum > 0xFFFFFFF0ull) return fail(HIBAG_HIP_EINVAL, "tile %d has too many haplotype pairs", t);
-		}
-		acc_cum[(size_t)t * (C + 1) + C] = (uint32_t)sum;
-	}
-
 	// one int arena
 	std::vector<int> arena;
 	auto put = [&](const std::vector<int> &v) {
@@ -827,8 +874,10 @@ int finalize_model(hibag_hip_model *m)
 		tb_boff = (tb_cell + cls_cell.size() * sizeof(uint32_t) + 7) & ~(size_t)7,
 		tb_ctile = (tb_boff + blk_off.size() * sizeof(uint64_t) + 31) & ~(size_t)31,
 		tb_hap = (tb_ctile + ctile.size() * sizeof(uint32_t) + 15) & ~(size_t)15,
-		tb_acum = tb_hap + hap.size() * sizeof(uint32_t),
-		tb_close = tb_acum + acc_cum.size() * sizeof(uint32_t),
+		tb_ehdr = (tb_hap + hap.size() * sizeof(uint32_t) + 31) & ~(size_t)31,
+		tb_ecst = tb_ehdr + ehdr.size() * sizeof(uint32_t),
+		tb_eblk = (tb_ecst + std::max<size_t>(etile_cstart.size(), 1) * sizeof(uint32_t) + 7) & ~(size_t)7,
+		tb_close = tb_eblk + etile_blk0.size() * sizeof(uint64_t),
 		tb_wsoff = (tb_close + blk_close.size() * sizeof(uint32_t) + 7) & ~(size_t)7,
 		tb_end = tb_wsoff + std::max<size_t>(wseg_off.size(), 1) * sizeof(uint64_t);
 	if (int rc = m->d_tile.reserve(tb_end)) return rc;
@@ -843,8 +892,10 @@ int finalize_model(hibag_hip_model *m)
 	HIP_TRY(hipMemcpy(tbase + tb_boff, blk_off.data(), blk_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_ctile, ctile.data(), ctile.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_hap, hap.data(), hap.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	if (!acc_cum.empty())
-		HIP_TRY(hipMemcpy(tbase + tb_acum, acc_cum.data(), acc_cum.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(tbase + tb_ehdr, ehdr.data(), ehdr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	if (!etile_cstart.empty())
+		HIP_TRY(hipMemcpy(tbase + tb_ecst, etile_cstart.data(), etile_cstart.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(tbase + tb_eblk, etile_blk0.data(), etile_blk0.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(tbase + tb_close, blk_close.data(), blk_close.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	if (!wseg_off.empty())
 		HIP_TRY(hipMemcpy(tbase + tb_wsoff, wseg_off.data(), wseg_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -880,7 +931,10 @@ int finalize_model(hibag_hip_model *m)
 	V.ctile = (const uint32_t *)(tbase + tb_ctile);
 	V.hap = (const uint32_t *)(tbase + tb_hap);
 	V.hap_dwords = (uint32_t)hap.size();
-	V.acc_cum = (const uint32_t *)(tbase + tb_acum);
+	V.ehdr = (const uint32_t *)(tbase + tb_ehdr);
+	V.estream_blocks = estream_blocks;
+	V.etile_cstart = (const uint32_t *)(tbase + tb_ecst);
+	V.etile_blk0 = (const uint64_t *)(tbase + tb_eblk);
 	V.blk_close = (const uint32_t *)(tbase + tb_close);
 	V.p1_base = p1_base;
 	V.p1_blocks = dbg_b1;
@@ -922,6 +976,8 @@ int batch_limit(const hibag_hip_model *m)
 	return lim / 64 * 64;
 }
 
+constexpr size_t WS_ERR_BYTES = 16 + 8 * 2040;     // HibagBatchView::err_dev: error word, counter, list (HIBAG_NAN_CAP entries)
+
 int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B)
 {
 	const int n_pad = round_up(std::max(n_samp, 1), HIBAG_WAVE);
@@ -945,10 +1001,10 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 		const size_t n_flag = n_flag2 + n_flag1;
 		const size_t had = m->ws_sync.cap;
 		if (int rc = m->ws_sync.reserve(n_flag * sizeof(unsigned long long))) return rc;
-		if (!m->ws_err.p) { if (int rc = m->ws_err.reserve(256)) return rc; HIP_TRY(hipMemset(m->ws_err.p, 0, 256)); }
+		if (!m->ws_err.p) { if (int rc = m->ws_err.reserve(WS_ERR_BYTES)) return rc; HIP_TRY(hipMemset(m->ws_err.p, 0, WS_ERR_BYTES)); }
 		if (m->ws_sync.cap != had) {               // new flags: the epochs start over (and so must the device error word)
 			HIP_TRY(hipDeviceSynchronize());
-			HIP_TRY(hipMemset(m->ws_sync.p, 0, m->ws_sync.cap)); HIP_TRY(hipMemset(m->ws_err.p, 0, 256)); m->epoch = 0;
+			HIP_TRY(hipMemset(m->ws_sync.p, 0, m->ws_sync.cap)); HIP_TRY(hipMemset(m->ws_err.p, 0, 16)); m->epoch = 0;
 		}
 		if (!m->h_err) {
 			HIP_TRY(hipHostMalloc((void **)&m->h_err, sizeof(int), hipHostMallocMapped));
@@ -956,7 +1012,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 		}
 		if (++m->epoch == 0) {
 			HIP_TRY(hipDeviceSynchronize());
-			HIP_TRY(hipMemset(m->ws_sync.p, 0, m->ws_sync.cap)); HIP_TRY(hipMemset(m->ws_err.p, 0, 256)); m->epoch = 1;
+			HIP_TRY(hipMemset(m->ws_sync.p, 0, m->ws_sync.cap)); HIP_TRY(hipMemset(m->ws_err.p, 0, 16)); m->epoch = 1;
 		}
 	}
 	B.sync = m->ws_sync.as<unsigned long long>(); B.epoch = m->epoch; B.err = m->h_err;
@@ -981,6 +1037,7 @@ void run_core(hibag_hip_model *m, HibagBatchView &B, int vote_method, double *d_
 {
 	KernelTimer &T = m->timer;
 	B.part = d_part;
+	(void)hipMemsetAsync(B.err_dev + 2, 0, sizeof(uint32_t), st);      // the list of totals without a finite reciprocal (k_nan_cells)
 	T.begin(HIBAG_HIP_K_TOTAL, st);
 	hibag_launch_total(m->view, B, st, m->side);
 	T.end(st);
@@ -1104,7 +1161,7 @@ int staged_streams(hibag_hip_model *m, StagedStreams **out)
 {
 	StagedStreams *ss = &m->staged;
 	if (!m->staged_ready) {
-		HIP_TRY(hipStreamCreateWithFlags(&ss->run, hipStreamNonBlocking));
+		if (!getenv("HIBAG_STAGED_NULL")) HIP_TRY(hipStreamCreateWithFlags(&ss->run, hipStreamNonBlocking));    // (diagnostic: the null stream)
 		HIP_TRY(hipStreamCreateWithFlags(&ss->in, hipStreamNonBlocking));
 		HIP_TRY(hipStreamCreateWithFlags(&ss->out, hipStreamNonBlocking));
 		for (int i = 0; i < 2; i++) {
@@ -1123,7 +1180,7 @@ int staged_streams(hibag_hip_model *m, StagedStreams **out)
 // about a quarter of the cohort but no less than 16,384 samples (smaller batches leave the last round of a pass too empty).
 int staged_slice(const hibag_hip_model *m, int n_samp, size_t row_len)
 {
-	long long slice = std::min<long long>(batch_limit(m), std::max(n_samp, 64));
+	long long slice = std::min<long long>(batch_limit(m), ((long long)std::max(n_samp, 1) + 63) / 64 * 64);
 	const long long by_geno = (long long)((1ull << 30) / (std::max<size_t>(row_len, 1) * sizeof(int32_t)));
 	slice = std::min(slice, std::max<long long>(64, by_geno));
 	if (n_samp >= 2 * 16384) slice = std::min(slice, std::max<long long>(16384, (n_samp + 3) / 4));
@@ -1138,45 +1195,84 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 	if (int rc = sticky_fault(m)) return rc;
 	const size_t P = (size_t)m->view.n_cell, nh = (size_t)m->n_hla, S = map ? (size_t)map->row_len : (size_t)m->n_snp;
 	const int slice = staged_slice(m, n_samp, bed ? 1 : S);
-	const size_t geno_bytes = (size_t)slice * std::max<size_t>(S, 1) * sizeof(int32_t);
+	const size_t geno_bytes = ((size_t)slice * std::max<size_t>(S, 1) * sizeof(int32_t) + 255) / 256 * 256;
 	const size_t o_h1 = 0, o_h2 = o_h1 + (size_t)slice * 4, o_mp = (o_h2 + (size_t)slice * 4 + 7) / 8 * 8,
 		o_mt = o_mp + (size_t)slice * 8, o_ds = o_mt + (size_t)slice * 8, o_pp = o_ds + (size_t)slice * nh * 8,
 		out_bytes = (o_pp + (postprob ? (size_t)slice * P * 8 : 0) + 255) / 256 * 256;
 	const int n_slice = (n_samp + slice - 1) / slice;
-	const int nbuf = n_slice > 1 ? 2 : 1;
+	const bool piped = n_slice > 1;
+	const int nbuf = piped ? 2 : 1;
 	if (!bed)
 		if (int rc = m->ws_geno.reserve(geno_bytes * nbuf)) return rc;
 	if (int rc = m->ws_out.reserve(out_bytes * nbuf)) return rc;
 	StagedStreams *ss;
 	if (int rc = staged_streams(m, &ss)) return rc;
+	if (piped) {
+		// pinned staging on the host side, so that every copy call returns at once and the host thread's own work -- filling
+		// and draining the staging buffers, ~50 GB/s -- runs beside the kernels too (transfers from / to the caller's pageable
+		// memory are as fast on this platform, but the calls block: tools/copy_probe, profiles/r03_copy_probe.txt)
+		if (!bed) if (int rc = m->pin_geno.reserve(geno_bytes * 2)) return rc;
+		if (int rc = m->pin_out.reserve(out_bytes * 2)) return rc;
+	}
+	auto slice_of = [&](int i, int &s0, int &n) { s0 = i * slice; n = std::min(slice, n_samp - s0); };
 	auto upload = [&](int i) -> int {
 		if (bed) return 0;
-		const int s0 = i * slice, n = std::min(slice, n_samp - s0);
-		// (the buffer was last read by the kernels of slice i - 2)
-		if (i >= 2) HIP_TRY(hipStreamWaitEvent(ss->in, ss->ran[i & 1], 0));
-		HIP_TRY(hipMemcpyAsync(m->ws_geno.as<char>() + (size_t)(i % nbuf) * geno_bytes, geno + (size_t)s0 * S, (size_t)n * S * sizeof(int32_t),
-			hipMemcpyHostToDevice, ss->in));
+		int s0, n; slice_of(i, s0, n);
+		const size_t bytes = (size_t)n * S * sizeof(int32_t);
+		char *dst = m->ws_geno.as<char>() + (size_t)(i % nbuf) * geno_bytes;
+		if (!piped) {
+			HIP_TRY(hipMemcpyAsync(dst, geno + (size_t)s0 * S, bytes, hipMemcpyHostToDevice, ss->run));
+			return 0;
+		}
+		char *pin = (char *)m->pin_geno.p + (size_t)(i & 1) * geno_bytes;
+		if (i >= 2) HIP_TRY(hipEventSynchronize(ss->up[i & 1]));              // the transfer of slice i - 2 has left the staging buffer
+		memcpy(pin, geno + (size_t)s0 * S, bytes);
+		if (i >= 2) HIP_TRY(hipStreamWaitEvent(ss->in, ss->ran[i & 1], 0));   // ... and its kernels have read the device buffer
+		HIP_TRY(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, ss->in));
 		HIP_TRY(hipEventRecord(ss->up[i & 1], ss->in));
 		return 0;
 	};
+	// device -> host of slice i's outputs: straight into the caller's arrays (one slice), or into the pinned staging buffer
 	auto download = [&](int i) -> int {
-		const int s0 = i * slice, n = std::min(slice, n_samp - s0);
+		int s0, n; slice_of(i, s0, n);
 		const char *o = m->ws_out.as<char>() + (size_t)(i % nbuf) * out_bytes;
-		HIP_TRY(hipStreamWaitEvent(ss->out, ss->ran[i & 1], 0));
-		if (H1) {
-			HIP_TRY(hipMemcpyAsync(H1 + s0, o + o_h1, (size_t)n * 4, hipMemcpyDeviceToHost, ss->out));
-			HIP_TRY(hipMemcpyAsync(H2 + s0, o + o_h2, (size_t)n * 4, hipMemcpyDeviceToHost, ss->out));
+		if (piped) {
+			HIP_TRY(hipStreamWaitEvent(ss->out, ss->ran[i & 1], 0));
+			const size_t used = (postprob ? o_pp + (size_t)n * P * 8 : dosage ? o_ds + (size_t)n * nh * 8 : o_ds);
+			HIP_TRY(hipMemcpyAsync((char *)m->pin_out.p + (size_t)(i & 1) * out_bytes, o, used, hipMemcpyDeviceToHost, ss->out));
+			HIP_TRY(hipEventRecord(ss->down[i & 1], ss->out));
+			return 0;
 		}
-		if (max_prob) HIP_TRY(hipMemcpyAsync(max_prob + s0, o + o_mp, (size_t)n * 8, hipMemcpyDeviceToHost, ss->out));
-		if (matching) HIP_TRY(hipMemcpyAsync(matching + s0, o + o_mt, (size_t)n * 8, hipMemcpyDeviceToHost, ss->out));
-		if (dosage) HIP_TRY(hipMemcpyAsync(dosage + (size_t)s0 * nh, o + o_ds, (size_t)n * nh * 8, hipMemcpyDeviceToHost, ss->out));
-		if (postprob) HIP_TRY(hipMemcpyAsync(postprob + (size_t)s0 * P, o + o_pp, (size_t)n * P * 8, hipMemcpyDeviceToHost, ss->out));
-		HIP_TRY(hipEventRecord(ss->down[i & 1], ss->out));
+		hipStream_t st = ss->run;
+		if (H1) {
+			HIP_TRY(hipMemcpyAsync(H1 + s0, o + o_h1, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(H2 + s0, o + o_h2, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+		}
+		if (max_prob) HIP_TRY(hipMemcpyAsync(max_prob + s0, o + o_mp, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+		if (matching) HIP_TRY(hipMemcpyAsync(matching + s0, o + o_mt, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+		if (dosage) HIP_TRY(hipMemcpyAsync(dosage + (size_t)s0 * nh, o + o_ds, (size_t)n * nh * 8, hipMemcpyDeviceToHost, st));
+		if (postprob) HIP_TRY(hipMemcpyAsync(postprob + (size_t)s0 * P, o + o_pp, (size_t)n * P * 8, hipMemcpyDeviceToHost, st));
 		return 0;
 	};
+	// staging buffer -> the caller's arrays (pipelined runs)
+	auto drain = [&](int i) -> int {
+		int s0, n; slice_of(i, s0, n);
+		HIP_TRY(hipEventSynchronize(ss->down[i & 1]));
+		const char *o = (const char *)m->pin_out.p + (size_t)(i & 1) * out_bytes;
+		if (H1) { memcpy(H1 + s0, o + o_h1, (size_t)n * 4); memcpy(H2 + s0, o + o_h2, (size_t)n * 4); }
+		if (max_prob) memcpy(max_prob + s0, o + o_mp, (size_t)n * 8);
+		if (matching) memcpy(matching + s0, o + o_mt, (size_t)n * 8);
+		if (dosage) memcpy(dosage + (size_t)s0 * nh, o + o_ds, (size_t)n * nh * 8);
+		if (postprob) memcpy(postprob + (size_t)s0 * P, o + o_pp, (size_t)n * P * 8);
+		return 0;
+	};
+	static const bool trace = getenv("HIBAG_STAGED_TRACE") != nullptr;     // diagnostic: host time of each phase on stderr
+	auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double tr[6] = {now(), 0, 0, 0, 0, 0};
 	if (int rc = upload(0)) return rc;
+	if (trace) { if (!piped) (void)hipStreamSynchronize(ss->run); tr[1] = now(); }
 	for (int i = 0; i < n_slice; i++) {
-		const int s0 = i * slice, n = std::min(slice, n_samp - s0);
+		int s0, n; slice_of(i, s0, n);
 		char *o = m->ws_out.as<char>() + (size_t)(i % nbuf) * out_bytes;
 		PackSource src;
 		if (bed) {
@@ -1185,22 +1281,33 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 		} else {
 			if (map) src = *map;
 			src.d_geno = (const int32_t *)(m->ws_geno.as<char>() + (size_t)(i % nbuf) * geno_bytes);
-			HIP_TRY(hipStreamWaitEvent(ss->run, ss->up[i & 1], 0));
+			if (piped) HIP_TRY(hipStreamWaitEvent(ss->run, ss->up[i & 1], 0));
 		}
-		if (i >= 2) HIP_TRY(hipStreamWaitEvent(ss->run, ss->down[i & 1], 0));    // the output buffer of slice i - 2 has been read
+		if (piped && i >= 2) HIP_TRY(hipStreamWaitEvent(ss->run, ss->down[i & 1], 0));    // slice i - 2 has left the device output buffer
 		if (int rc = predict_device_locked(m, src, n, vote_method,
 				H1 ? (int32_t *)(o + o_h1) : nullptr, H2 ? (int32_t *)(o + o_h2) : nullptr,
 				max_prob ? (double *)(o + o_mp) : nullptr, matching ? (double *)(o + o_mt) : nullptr,
 				dosage ? (double *)(o + o_ds) : nullptr, postprob ? (double *)(o + o_pp) : nullptr, ss->run))
 			return rc;
-		HIP_TRY(hipEventRecord(ss->ran[i & 1], ss->run));
-		// with the kernels of slice i enqueued: the next upload and the previous download run beside them
+		if (piped) HIP_TRY(hipEventRecord(ss->ran[i & 1], ss->run));
+		if (trace && !piped) { tr[2] = now(); (void)hipStreamSynchronize(ss->run); tr[3] = now(); }
+		if (piped && i >= 2) if (int rc = drain(i - 2)) return rc;          // (frees the staging buffer download(i) writes)
+		if (int rc = download(i)) return rc;
+		// with the kernels of slice i enqueued, the host fills the next staging buffer and starts its transfer
 		if (i + 1 < n_slice) if (int rc = upload(i + 1)) return rc;
-		if (i >= 1) if (int rc = download(i - 1)) return rc;
 	}
-	if (int rc = download(n_slice - 1)) return rc;
-	HIP_TRY(hipStreamSynchronize(ss->out));
+	if (piped) {
+		if (n_slice >= 2) if (int rc = drain(n_slice - 2)) return rc;
+		if (int rc = drain(n_slice - 1)) return rc;
+	}
+	if (trace) tr[4] = now();
 	HIP_TRY(hipStreamSynchronize(ss->run));
+	if (trace) {
+		tr[5] = now();
+		if (!piped) fprintf(stderr, "[hibag staged] n=%d upload %.3f  enqueue %.3f  kernels %.3f  download calls %.3f  final sync %.3f ms\n", n_samp,
+			tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3], tr[5] - tr[4]);
+		else fprintf(stderr, "[hibag staged] n=%d in %d slices of %d: %.3f ms\n", n_samp, n_slice, slice, tr[5] - tr[0]);
+	}
 	if (take_fault(m)) {
 		// poisoned outputs: once more, now without hand-overs (take_fault switched them off) -- never returned to the caller
 		if (is_retry) return fail(HIBAG_HIP_EHANDOVER, "a hand-over between workgroups failed in a launch without hand-overs");
@@ -1387,6 +1494,7 @@ int hibag_hip_model_finalize(hibag_hip_model *m)
 
 void hibag_hip_model_free(hibag_hip_model *m) { delete m; }
 
+int hibag_hip_model_device(const hibag_hip_model *m) { return m ? m->device : -1; }
 int hibag_hip_model_n_hla(const hibag_hip_model *m) { return m ? m->n_hla : 0; }
 int hibag_hip_model_n_snp(const hibag_hip_model *m) { return m ? m->n_snp : 0; }
 int hibag_hip_model_n_classifier(const hibag_hip_model *m) { return m ? (int)m->cls.size() : 0; }

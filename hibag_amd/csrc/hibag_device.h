@@ -77,9 +77,9 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 #define HIBAG_PLIST_STORE 0x40000000u        // with END: pass 1 stores this cell's sum for pass 2 to read back
 #define HIBAG_STORED_PER_VISIT 4             // mode 2: stored cells per (classifier, tile) -- what k_accum keeps in registers
 // Matrix-engine variants (HibagModelView::engine[c]; 0 = VALU engine) and their haplotype-table entries:
-//   FP4  (up to 28 SNPs; 33 .. 112 in several K steps, below)  v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands: one instruction per sample half covers all
+//   FP4  (up to 30 SNPs; 33 .. 112 in several K steps, below)  v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands: one instruction per sample half covers all
 //                         K = 64 positions.  Entry = { N[16] (nibble s = 2, the code of 1.0, where bit s is set), ff, f }: 8 dwords
-//   I8   (29..31 SNPs), I8S (32 SNPs)  v_mfma_i32_32x32x32_i8, two K blocks.  Entry = { E[32] (byte s = bit s), ff, f }: 12 dwords
+//   I8   (31 SNPs), I8S (32 SNPs)  v_mfma_i32_32x32x32_i8, two K blocks.  Entry = { E[32] (byte s = bit s), ff, f }: 12 dwords
 #define HIBAG_ENGINE_VALU 0
 #define HIBAG_ENGINE_FP4 1
 #define HIBAG_ENGINE_I8 2
@@ -91,9 +91,10 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 #define HIBAG_FP4_STEP_SNPS 28
 #define HIBAG_FP4_MAX_STEPS 4
 #define HIBAG_FP4_STEPS(k) (((k) + HIBAG_FP4_STEP_SNPS - 1) / HIBAG_FP4_STEP_SNPS)
-#define HIBAG_ENGINE_OF(k, fp4) ((fp4) && (k) <= 28 ? HIBAG_ENGINE_FP4 : (k) < 32 ? HIBAG_ENGINE_I8 : (k) == 32 ? HIBAG_ENGINE_I8S : \
+#define HIBAG_FP4_MAX_SNPS 30     // one K step: 2 k + 4 positions (the SNPs' sums and ANDs, four offset digits) within K = 64
+#define HIBAG_ENGINE_OF(k, fp4) ((fp4) && (k) <= HIBAG_FP4_MAX_SNPS ? HIBAG_ENGINE_FP4 : (k) < 32 ? HIBAG_ENGINE_I8 : (k) == 32 ? HIBAG_ENGINE_I8S : \
 	(fp4) && (k) <= HIBAG_FP4_STEP_SNPS * HIBAG_FP4_MAX_STEPS ? HIBAG_ENGINE_FP4 : HIBAG_ENGINE_VALU)
-#define HIBAG_ENGINE_STEPS(e, k) ((e) == HIBAG_ENGINE_FP4 ? HIBAG_FP4_STEPS(k) < 1 ? 1 : HIBAG_FP4_STEPS(k) : 1)
+#define HIBAG_ENGINE_STEPS(e, k) ((e) == HIBAG_ENGINE_FP4 ? (k) <= HIBAG_FP4_MAX_SNPS ? 1 : HIBAG_FP4_STEPS(k) : 1)
 #define HIBAG_ENGINE_ROWS(e, k) ((e) == HIBAG_ENGINE_FP4 ? 2 * HIBAG_ENGINE_STEPS(e, k) : ((e) == HIBAG_ENGINE_VALU ? 0 : 4))   // B-operand rows (16 B per lane each)
 #define HIBAG_ENGINE_HAP_DWORDS(e) ((e) == HIBAG_ENGINE_FP4 ? 8 : 12)                             // (FP4: of a one-step entry)
 #define HIBAG_FP4_ENTRY_DWORDS(steps) (8 + 4 * ((steps) - 1))
@@ -110,8 +111,9 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 // that the f32 result is the DENORMAL number 8 d * 2^-149, whose bit pattern is the integer 8 d):
 //   [0, k)          A: h1_s + h2_s           B: +1 / -1 / -1 / 0
 //   [32, 32 + k)    A: h1_s & h2_s           B: [g == 1]          (counts twice through the scale)
-//   k .. k + 3      A: 1, 1, 1, 4            B: offset bit 0 * 1, bit 1 * 2, bit 2 * 4, bit 3 * 2
-//   32 + k, + 1     A: 4, 4                  B: offset bit 4 * 2, bit 5 * 4        (count twice; offset <= 2 k <= 56)
+//   k, k + 1        A: 1, 4                  B: offset & 3, (offset >> 2) & 3      (the values 0 .. 3: all e2m1 numbers)
+//   32 + k, + 1     A: 4, 4                  B: offset bit 4 * 2, bit 5 * 4        (count twice; offset <= 2 k <= 60)
+// so one K step holds up to 30 SNPs (round 2 spent six positions on the offset: 28).
 #define HIBAG_FP4_SCALE_A 54
 #define HIBAG_FP4_SCALE_B_LO 54
 #define HIBAG_FP4_SCALE_B_HI 55
@@ -186,8 +188,19 @@ struct HibagModelView {
 	uint64_t p1_base;            // dword offset of the first pass-1 list in plist (block number = (offset - p1_base) / 32)
 	long long p1_blocks;         // blocks of all pass-1 lists together
 
-	// chunked items (hibag_kernels.hip "hand-overs"): cost prefix sums in quarter-blocks of 32 records
-	const uint32_t *acc_cum;     // [n_tile][C + 1] pass 2: cost of the tile's classifiers 0 .. c-1
+	// E-stream: what pass 2 (k_accum) reads when it evaluates pairs again (store_cells != 1).  Per tile the blocks of
+	// classifier 0, 1, 2 ... that have anything for the tile, back to back -- pair slots in `plist` (32 per block, as in the
+	// pass-1 lists), one 8-dword header per block in `ehdr`:
+	//   [0] classifier | SNPs << 18 | stored sums of this block (0..4) << 25     [1] dword offset of the classifier's haplotype table
+	//   [2] first B-operand row     [3] first stored-sum row (model-wide numbering, HibagBatchView::cells)
+	//   [4], [5] tile rows of the cells that CLOSE in this block, 4 bits each, in closing order
+	//   [6] tile rows of the stored sums, 4 bits each
+	// Only one-step FP4 classifiers have pair slots here; the others' blocks carry stored sums only (all slots padding).
+	const uint32_t *ehdr;        // [estream_blocks][8]
+	uint64_t estream_blocks;     // blocks of all tiles together, incl. the look-ahead slack behind the last
+	const uint64_t *etile_blk0;  // [n_tile] first block of the tile
+	const uint32_t *etile_cstart;   // [n_tile][C + 1] block, counted from the tile's first, where classifier c's blocks begin:
+	                             // where a chunked work item is cut (hibag_kernels.hip "hand-overs"), and the item's length
 
 	// resident workgroups of k_total<false>, k_total<true> and k_accum on the model's device (0 = unknown), queried when
 	// the model is finalized (hibag_query_slots)
@@ -218,7 +231,8 @@ struct HibagBatchView {
 	// every k_finish_* kernel writes NA / NaN outputs for a sample whose weight sum is NaN -- sums the kernels cannot vouch for
 	// never reach the caller as numbers.
 	int *err;           // host-mapped: 1 = a hand-over timed out, 2 = its flag was written on another XCD
-	uint32_t *err_dev;  // device memory: epoch of the last batch with a failed hand-over
+	uint32_t *err_dev;  // device memory: [0] epoch of the last batch with a failed hand-over; [2] count and, from byte 16 on, list of
+	                    // the (sample, classifier) pairs whose 1/total is not finite (pass 1 -> k_nan_cells; the host resets the count)
 	uint32_t spin_limit;   // polls before a waiting workgroup gives up (scaled with the longest work item of the model)
 	int tail_k;         // chunks per item of the last rounds: 0 = the launcher's choice, 1 = none (no hand-overs at all)
 	int drop_post;      // fault injection (tests): 1 / 2 = the first chunked item of pass 1 / 2 never posts its first hand-over

@@ -220,10 +220,10 @@ __device__ __forceinline__ uint32_t expand_bits8_nibbles(uint32_t x)
 }
 
 // The lane's constant part of an FP4 A row (K layout in hibag_device.h): lanes 0..31 own the K positions 0..31
-// (nibbles k .. k+3 = 1, 1, 1, 4 -> codes 2, 2, 2, 6), lanes 32..63 the positions 32..63 (nibbles k, k+1 = 4, 4 -> 6, 6).
+// (nibbles k, k+1 = 1, 4 -> codes 2, 6), lanes 32..63 the positions 32..63 (nibbles k, k+1 = 4, 4 -> 6, 6).
 __device__ __forceinline__ v4i fp4_offset_term(int k, int lane)
 {
-	const unsigned __int128 c = (unsigned __int128)(lane < 32 ? 0x6222u : 0x66u) << (4 * k);
+	const unsigned __int128 c = (unsigned __int128)(lane < 32 ? 0x62u : 0x66u) << (4 * k);
 	return v4i{(int)(uint32_t)c, (int)(uint32_t)(c >> 32), (int)(uint32_t)(c >> 64), (int)(uint32_t)(c >> 96)};
 }
 
@@ -672,8 +672,8 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 		const uint32_t offset = 2u * (uint32_t)__popc(X) + (uint32_t)__popc(E);     // <= 64
 		const int n = lane >> 5;
 		if (nkb == HIBAG_ENGINE_FP4) {
-			// e2m1 codes: +1 -> 0x2, -1 -> 0xA, 2 -> 0x4, 4 -> 0x6.  K half 0 (positions 0..31): the signs of the SNPs,
-			// then offset bits 0..3 at k..k+3; K half 1 (positions 32..63): [g == 1] of the SNPs, then offset bits 4, 5.
+			// e2m1 codes: +1 -> 0x2, -1 -> 0xA, 2 -> 0x4, 3 -> 0x5, 4 -> 0x6.  K half 0 (positions 0..31): the signs of the SNPs,
+			// then the offset's two low base-4 digits at k, k+1; K half 1 (positions 32..63): [g == 1] of the SNPs, then offset bits 4, 5.
 			const uint32_t neg = X | E;
 #pragma unroll
 			for (int h = 0; h < 2; h++) {
@@ -684,9 +684,11 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 					a[q] = h == 0 ? (expand_bits8_nibbles(z8 | n8) << 1) | (expand_bits8_nibbles(n8) << 3)
 					              : expand_bits8_nibbles(e8) << 1;
 				}
-				// the offset's binary digits: codes 1 * b0, 2 * b1, 4 * b2, 2 * b3 (meets A = 4) | 2 * b4, 4 * b5 (meet A = 4, count twice)
-				const uint32_t digits = h == 0 ? ((offset & 1u) * 0x2u) | (((offset >> 1) & 1u) * 0x40u) | (((offset >> 2) & 1u) * 0x600u) |
-				                                 (((offset >> 3) & 1u) * 0x4000u)
+				// the offset (<= 60) in four digits: (offset & 3) and ((offset >> 2) & 3) as the values 0 / 1 / 2 / 3 (e2m1 codes
+				// 0, 2, 4, 5) against A = 1 and A = 4 in the lower K half; bit 4 as the value 2 (code 4) and bit 5 as the value 4
+				// (code 6), both against A = 4, in the upper half, which counts twice: 4 * 2 * 2 = 16, 4 * 4 * 2 = 32
+				const uint32_t code4 = 0x5420u;             // value v -> e2m1 code
+				const uint32_t digits = h == 0 ? ((code4 >> (4 * (offset & 3u))) & 0xFu) | (((code4 >> (4 * ((offset >> 2) & 3u))) & 0xFu) << 4)
 				                               : (((offset >> 4) & 1u) * 0x4u) | (((offset >> 5) & 1u) * 0x60u);
 				const unsigned __int128 d128 = (unsigned __int128)digits << (4 * kj);
 #pragma unroll
@@ -884,6 +886,19 @@ __device__ __forceinline__ void handover_wait(unsigned long long *flag, const Hi
 	__syncthreads();
 }
 
+// A (sample, classifier) whose total is 0 or so small that 1/total is not finite: the reference's `cell * (1/total)` then
+// turns the classifier's structurally EMPTY cells into 0 * inf = NaN too (src/LibHLA.cpp:1826-1828).  Pass 2 only visits
+// cells that have haplotype pairs, so pass 1 lists these rare pairs here and k_nan_cells adds the NaN terms afterwards.
+// List: HibagBatchView::err_dev -- [2] = count (reset by the host before pass 1), entries of 8 bytes from byte 16 on.
+#define HIBAG_NAN_CAP 2040
+__device__ __forceinline__ void note_infinite_reciprocal(const HibagBatchView &B, int c, int s, double w, double inv)
+{
+	if (w > 0 && !(fabs(inv) <= 1.79769313486231570815e+308)) {
+		const uint32_t i = atomicAdd(B.err_dev + 2, 1u);
+		if (i < HIBAG_NAN_CAP) reinterpret_cast<unsigned long long *>(B.err_dev + 4)[i] = ((unsigned long long)(uint32_t)c << 32) | (uint32_t)s;
+	}
+}
+
 // a parked sum: read past the CU's L1
 __device__ __forceinline__ double load_parked(const double *p)
 {
@@ -979,8 +994,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagMod
 			if (split) return;
 		}
 		if (last) {
+			const double inv = 1 / total;                 // src/LibHLA.cpp:1827 (inf when total == 0)
 			B.tot[at] = total;
-			B.inv[at] = 1 / total;                        // src/LibHLA.cpp:1827 (inf when total == 0)
+			B.inv[at] = inv;
+			note_infinite_reciprocal(B, c, s, B.cw[at], inv);
 		}
 	}
 	if (!last) handover_post(flag, B.epoch, (uint32_t)b1, B.drop_post == 1 && li == n_whole && k == 0);
@@ -1037,42 +1054,49 @@ __global__ void k_total_scan(HibagModelView M, HibagBatchView B)
 	for (; i < n; i++) total += rows[(size_t)i * HIBAG_WAVE];
 	B.tot[(size_t)c * B.n_pad + s] = total;
 	B.inv[(size_t)c * B.n_pad + s] = 1 / total;
+	note_infinite_reciprocal(B, c, s, B.cw[(size_t)c * B.n_pad + s], 1 / total);
 }
 
 // ---------------------------------------------------------------------------
-// k_accum (pass 2): for one tile of allele-pair cells and 64 samples, walk the
-// classifiers in order and do  S[p] += (cell * (1/total)) * w
-// (src/LibHLA.cpp:1828 then :1497-1507) with the tile's S in LDS (one row of 64
-// doubles per cell, conflict-free).  A cell that is structurally empty in a
-// classifier contributes (0*inv)*w = +0 unless inv is not finite (total == 0 or
-// denormal), where the reference yields NaN/inf; the `poison` ballot makes the
-// walk include the empty cells in that case.
-// Each of the 4 wavefronts of a block owns one tile of the same sample group.
-template <int NWP>
-__device__ __forceinline__ void accumulate_classifier(const HibagModelView &M, const HibagBatchView &B,
-	int c, int s, int tile, int ncell, bool active, bool poison, double inv, double w,
-	const double *tab_s, double (*acc)[HIBAG_WAVE])
+// k_accum (pass 2): for one tile of allele-pair cells and 64 samples, go through the classifiers in order and do
+//     S[p] += (cell * (1/total)) * w          (src/LibHLA.cpp:1828 then :1497-1507)
+// with the tile's S in LDS (one row of 64 doubles per cell, conflict-free).  What a classifier contributes to a tile is
+// either evaluated again from its haplotype pairs (the cells with few pairs) or read back from the sums pass 1 stored
+// (HibagModelView::store_cells); both arrive here as ONE STREAM OF BLOCKS per tile (hibag_device.h, "E-stream"): the
+// blocks of classifier 0, 1, 2 ... that have anything for the tile, each block 32 pair slots plus a 32-byte header that
+// names the block's classifier (-> weight and 1/total rows), its operand row and haplotype table, the tile rows its
+// cells close into and up to four stored sums to add.  Round 2 walked (classifier, tile) "visits" -- mostly one short
+// block each -- with a scalar prologue per visit (record, descriptors, engine dispatch) and nothing of the next visit in
+// flight while the current one ran: 0.73 us of SIMD time per visit against 0.35 us of instructions.  As a stream the loop
+// body is one block, and at its top EVERYTHING of block b + 1 is requested -- haplotype entries, B operand, weight,
+// 1/total, stored sums -- plus the slot words and header of block b + 2, so a whole block's evaluation covers each
+// latency, across classifier boundaries too.  Only one-step FP4 classifiers are evaluated here; every other engine has all
+// its cells stored by pass 1 (their blocks carry stored sums only).
+//
+// A cell that is structurally empty in a classifier contributes (0 * inv) * w = +0 and is absent from the stream; where
+// 1/total is not finite the reference's 0 * inf = NaN is added by k_scalars afterwards (NaN absorbs: the order of that
+// addition cannot show).
+//
+// grid = 8 x (n_whole + K * (items per XCD - n_whole)): per XCD first the undivided items, then the others' first
+// chunks, second chunks, ... ("hand-overs" above).
+struct EHeader {
+	uint32_t h0;        // classifier | SNPs << 18 | stored sums << 25
+	uint32_t hap;       // dword offset of the classifier's haplotype table
+	uint32_t bt;        // its first B-operand row
+	uint32_t srow;      // first of the block's stored-sum rows (HibagBatchView::cells)
+	uint32_t jp_lo, jp_hi;   // tile rows of the cells that close in this block, 4 bits each, in closing order
+	uint32_t jps;       // tile rows of the stored sums
+};
+
+__device__ __forceinline__ EHeader read_header(uint32_t hv)      // lanes 0..7 hold the header's dwords
 {
-	LaneMask<NWP> L;
-	load_masks<NWP>(B, M.mask_row[c], s, L);
-	const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + tile) * HIBAG_TILE_META;
-	const int nvisit = poison ? ncell : (int)meta[0];
-	const uint32_t *__restrict__ cp = M.stream + M.stream_off[c] + (size_t)meta[1] * HIBAG_CHUNK_DWORDS(NWP);
-	const int lane = threadIdx.x & 63;
-	uint32_t e = meta[4];
-	for (int i = 0; i < nvisit; i++) {
-		const uint32_t e_next = meta[5 + i];           // fetched while this cell is evaluated (meta is padded)
-		const int j = e >> 24;
-		const double a = acc[j][lane];                 // LDS read in flight during the cell
-		const double cell = cell_sum<NWP>(e & 0xFFFFFFu, cp, L, tab_s);
-		const double v = (cell * inv) * w;
-		acc[j][lane] = a + (active ? v : 0.0);         // x + 0.0 == x: inactive lanes keep their sum
-		e = e_next;
-	}
+	EHeader H;
+	H.h0 = __builtin_amdgcn_readlane(hv, 0); H.hap = __builtin_amdgcn_readlane(hv, 1); H.bt = __builtin_amdgcn_readlane(hv, 2);
+	H.srow = __builtin_amdgcn_readlane(hv, 3); H.jp_lo = __builtin_amdgcn_readlane(hv, 4); H.jp_hi = __builtin_amdgcn_readlane(hv, 5);
+	H.jps = __builtin_amdgcn_readlane(hv, 6);
+	return H;
 }
 
-// grid = 8 x (n_whole + K * (items per XCD - n_whole)): per XCD first the undivided items, then the others' first
-// chunks, second chunks, ...
 __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagModelView M, HibagBatchView B, int n_whole, int K)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
@@ -1080,7 +1104,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 	__shared__ double stage_s[ACCUM_WAVES][2 * STAGE_DOUBLES];
 
 	// Work item = (XCD, four sample groups, one tile); the four wavefronts of a workgroup take the four groups.
-	// They read the same pair-list segments and the same haplotype-table entries at about the same time, so those
+	// They read the same blocks and the same haplotype-table entries at about the same time, so those
 	// come from the CU's L1 for three of them.  Workgroups are dealt round-robin over the 8 XCDs, so sample
 	// group g goes to XCD g % 8 with all its tiles: its operands / weights / totals are fetched into one XCD's L2 only.
 	const int n_group = B.n_pad / HIBAG_WAVE;
@@ -1092,12 +1116,12 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 	const int lane = threadIdx.x & 63;
 	double (*acc)[HIBAG_WAVE] = acc_s[wave];
 
-	// this workgroup's classifiers [cb, ce) of its item
+	// this workgroup's classifiers [cb, ce) of its item: cut where the tile's block count is split evenly
 	int item = wx, cb = 0, ce = C;
 	if (wx >= n_whole) {
 		const int rest = n_item_x - n_whole, k = (wx - n_whole) / rest;
 		item = n_whole + (wx - n_whole) - k * rest;
-		const uint32_t *__restrict__ cum = M.acc_cum + (size_t)(item % M.n_tile) * (C + 1);
+		const uint32_t *__restrict__ cum = M.etile_cstart + (size_t)(item % M.n_tile) * (C + 1);
 		const uint64_t total = cum[C];
 		if (k > 0) cb = chunk_bound(cum, C, (total * (uint64_t)k + K - 1) / K);
 		if (k < K - 1) ce = chunk_bound(cum, C, (total * (uint64_t)(k + 1) + K - 1) / K);
@@ -1124,117 +1148,151 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 		for (int j = 0; j < HIBAG_TILE; j++) acc[j][lane] = 0;
 	}
 
-	// Everything classifier c+1 needs that does not cost many registers is requested while
-	// classifier c is evaluated: the lane's weight and 1/total, and the cell sums pass 1 stored for this tile
-	// (the cells with many haplotype pairs, which are not in the pair list: HibagModelView::store_cells == 2); its
-	// (classifier, tile) record (one s_load_dwordx8) is requested TWO classifiers ahead, because the requests for the
-	// stored cells need it.  Without this every classifier starts with a chain
-	// of dependent scalar and vector loads (~3000 cycles per classifier, measured with stamps).
-	typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-	const ConstPtr<u32x8> ct = as_const(reinterpret_cast<const u32x8 *>(M.ctile)) + tile;
-	constexpr int NS = HIBAG_STORED_PER_VISIT;        // stored cells of the next classifier, in registers
-	double sv[NS];
-	// the stored cells of a (classifier, tile) for this sample group; rec5 = first row (of the model's stored cells) | #cells << 27
-	const double *__restrict__ const group_rows = B.cells + (size_t)group * (size_t)as_const(M.cell_row)[C] * HIBAG_WAVE + lane;
-	auto request_stored = [&](uint32_t rec5) {
-		const int n = (int)(rec5 >> 27);
-		if (n == 0) return;
-		const double *__restrict__ src = group_rows + (size_t)(rec5 & 0x7FFFFFFu) * HIBAG_WAVE;
+	const ConstPtr<uint32_t> cst = as_const(M.etile_cstart) + (size_t)tile * (C + 1);
+	const int bb = __builtin_amdgcn_readfirstlane((int)cst[cb]), be = __builtin_amdgcn_readfirstlane((int)cst[ce]);
+#ifdef HIBAG_ABL2_NOLOOP
+	if (bb < be && B.n_pad < 0) {
+#else
+	if (bb < be) {
+#endif
+		// the tile's blocks [bb, be): slot words and headers as raw buffers rebased at block bb (no 4 GB limit on the stream)
+		const uint64_t blk0 = as_const(M.etile_blk0)[tile] + (uint64_t)bb;
+		const uint64_t left_s = (M.plist_dwords - blk0 * HIBAG_PLIST_DWORDS) * 4, left_h = (M.estream_blocks - blk0) * 32;
+		const __amdgpu_buffer_rsrc_t pl = __builtin_amdgcn_make_buffer_rsrc((void *)(M.plist + blk0 * HIBAG_PLIST_DWORDS), 0,
+			left_s > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left_s, 0x00020000);
+		const __amdgpu_buffer_rsrc_t ph = __builtin_amdgcn_make_buffer_rsrc((void *)(M.ehdr + blk0 * 8), 0,
+			left_h > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left_h, 0x00020000);
+		const __amdgpu_buffer_rsrc_t hp = hap_rsrc(M, 0);      // the whole haplotype table; a block's classifier enters as the scalar offset
+		const int vo_i = (lane & 31) * 4, vo_h = (lane & 7) * 4;
+		const size_t n_grp = (size_t)n_group;
+		const double *__restrict__ const group_rows = B.cells + (size_t)group * (size_t)as_const(M.cell_row)[C] * HIBAG_WAVE + lane;
+		double *stage = stage_s[wave];
+		constexpr uint32_t ES = 4u * HIBAG_ENGINE_HAP_DWORDS(HIBAG_ENGINE_FP4);      // bytes per table entry
+		constexpr int NS = HIBAG_STORED_PER_VISIT;
+
+		uint32_t idx_c = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, 0, 0);
+		uint32_t hv_c = __builtin_amdgcn_raw_buffer_load_b32(ph, vo_h, 0, 0);
+		uint32_t idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, 4 * HIBAG_PLIST_DWORDS, 0);
+		uint32_t hv_n = __builtin_amdgcn_raw_buffer_load_b32(ph, vo_h, 32, 0);
+		EHeader Hc = read_header(hv_c);
+
+		// everything block b needs, requested a block ahead
+		v4i e1, e2;                                   // the nibble images of the lane's haplotype pair
+		double ff, f2;                                // its frequency factors
+		v4i t0, t1;                                   // the B operand (two sample halves)
+		double w, inv, sv[NS];
+		auto request = [&](uint32_t idx, const EHeader &H) {
+			const uint32_t o1 = (idx & 0xFFFFu) * ES, o2 = ((idx >> 16) & 0x3FFFu) * ES;
+			const int so = (int)(H.hap * 4u);
+#ifdef HIBAG_ABL2_NOENT      // (timing ablations: wrong results on purpose)
+			e1 = v4i{(int)o1, so, 1, 2}; e2 = v4i{(int)o2, 3, 4, 5}; ff = 1.0 + so; f2 = 2.0;
+#else
+			const auto i1 = __builtin_amdgcn_raw_buffer_load_b128(hp, (int)o1, so, 0);
+			const auto i2 = __builtin_amdgcn_raw_buffer_load_b128(hp, (int)o2, so, 0);
+			e1 = v4i{(int)i1[0], (int)i1[1], (int)i1[2], (int)i1[3]};
+			e2 = v4i{(int)i2[0], (int)i2[1], (int)i2[2], (int)i2[3]};
+			ff = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(hp, (int)o1, so + 16, 0));
+			f2 = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(hp, (int)o2, so + 24, 0));
+#endif
+#ifdef HIBAG_ABL2_NOT
+			t0 = v4i{(int)H.bt, lane, 0x22222222, 0x2a2a2a2a}; t1 = v4i{lane, (int)H.bt, 0x2222aaaa, 0x22222222};
+#else
+			const uint4 u0 = B.bt[((size_t)H.bt * n_grp + group) * HIBAG_WAVE + lane];
+			const uint4 u1 = B.bt[((size_t)(H.bt + 1) * n_grp + group) * HIBAG_WAVE + lane];
+			t0 = v4i{(int)u0.x, (int)u0.y, (int)u0.z, (int)u0.w};
+			t1 = v4i{(int)u1.x, (int)u1.y, (int)u1.z, (int)u1.w};
+#endif
+			const size_t at = (size_t)(H.h0 & 0xFFFFu) * B.n_pad + s;
+#ifdef HIBAG_ABL2_NOWINV
+			w = 1.0 + (double)(H.h0 & 0xFFFFu); inv = 0.5 + (double)at;
+#else
+			w = B.cw[at];
+			inv = B.inv[at];
+#endif
+#ifdef HIBAG_ABL2_NOSV
+			const int ns = 0;
+			for (int i = 0; i < NS; i++) sv[i] = 1.0;
+#else
+			const int ns = (int)(H.h0 >> 25) & 7;
+#endif
+			if (ns > 0) {
+				const double *__restrict__ src = group_rows + (size_t)H.srow * HIBAG_WAVE;
 #pragma unroll
-		for (int i = 0; i < NS; i++) {
-			if (i >= n) break;
-			sv[i] = __builtin_nontemporal_load(src + (size_t)i * HIBAG_WAVE);
-		}
-	};
-	const int c_last = C - 1;
-	u32x8 rec_n = ct[(size_t)cb * M.n_tile];
-	u32x8 rec_nn = ct[(size_t)(cb < c_last ? cb + 1 : c_last) * M.n_tile];
-	double w_n = B.cw[(size_t)cb * B.n_pad + s], inv_n = B.inv[(size_t)cb * B.n_pad + s];
-	request_stored(rec_n[5]);
-	ListCursor cur;                                   // the list look-ahead carries over from classifier to classifier
-	for (int c = cb; c < ce; c++) {
-		const u32x8 rec = rec_n;
-		const double w = w_n, inv = inv_n;
-		const bool active = w > 0;
-		const bool any = __ballot(active) != 0;
-		const int nkb = (int)(rec[0] & 3u);
-		// inactive lanes (weight 0) must keep their sums: with 1/total replaced by 0 their term is
-		// (cell * 0) * 0 = +0 and a + 0 == a, which spares a select per closed cell
-		const double inv_e = active ? inv : 0.0;
-		// row numbers of the tile's cells, 4 bits each: the listed ones in closing order, then the stored ones
-		uint64_t jpack = ((uint64_t)rec[7] << 32) | rec[6];
-		const int n_stored = (int)(rec[5] >> 27);
-		// The stored cells of this classifier (requested while the previous one was evaluated) come FIRST, before
-		// anything new is requested: their wait is a wait for everything in flight, and must not include loads
-		// issued a moment ago.   S[p] += (cell * (1/total)) * w
-		if (any && n_stored > 0) {
-			uint64_t jps = jpack >> (4 * (int)((rec[0] >> 8) & 31u));
-#pragma unroll
-			for (int i = 0; i < NS; i++) {
-				if (i >= n_stored) break;
-				__hip_atomic_fetch_add(&acc[(int)(jps & 15)][lane], (sv[i] * inv_e) * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				jps >>= 4;
+				for (int i = 0; i < NS; i++) {
+					if (i >= ns) break;
+					sv[i] = __builtin_nontemporal_load(src + (size_t)i * HIBAG_WAVE);
+				}
 			}
-			if (n_stored > NS) {                          // a VALU-engine classifier (all its cells are stored): the rest, fetched here
-				const double *__restrict__ src = group_rows + (size_t)(rec[5] & 0x7FFFFFFu) * HIBAG_WAVE;
-				for (int i0 = NS; i0 < n_stored; i0 += NS) {
-					double v[NS];
-#pragma unroll
-					for (int i = 0; i < NS; i++) v[i] = __builtin_nontemporal_load(src + (size_t)(i0 + i < n_stored ? i0 + i : n_stored - 1) * HIBAG_WAVE);
+		};
+		request(idx_c, Hc);
+		double cell = 0;
+		uint32_t soff = 0;                            // byte offset of block b's slot words
+		for (int b = bb; b < be; b++) {
+			double *buf = stage + (b & 1) * STAGE_DOUBLES;
+			// ---- block b: what was requested a block ago has arrived
+			const EHeader Hn = read_header(hv_n);
+			const double w_c = w, inv_c = inv;
+			const bool active = w_c > 0;
+			const bool any = __ballot(active) != 0;       // nobody in the group uses the classifier (src/LibHLA.cpp:2451): nothing to add
+			// inactive lanes (weight 0) must keep their sums: with 1/total replaced by 0 their term is
+			// (cell * 0) * 0 = +0 and a + 0 == a, which spares a select per closed cell
+			const double inv_e = active ? inv_c : 0.0;
+			const double prod = ff * f2;                  // the record's frequency factor, rounded like the reference's (src/LibHLA.cpp:1786-1813)
+			const uint32_t endmask = (uint32_t)__ballot((idx_c & HIBAG_PLIST_END) != 0);          // lanes 32..63 mirror 0..31
+			const uint32_t live = endmask | (uint32_t)__ballot(prod != 0.0);
+			const int n_valid = live ? 32 - __builtin_clz(live) : 0;
+			const bool eval = any && n_valid > 0;
+			// the A operand rows of this block and its B operand, out of the way of the next block's
+			const v4i a1 = e1, a2 = e2;
+			LaneOperand T;
+			T.b[0][0] = t0; T.b[1][0] = t1;
+			// the sums pass 1 stored for this block's classifier:   S[p] += (cell * (1/total)) * w
+			{
+				const int ns = (int)(Hc.h0 >> 25) & 7;
+				if (any && ns > 0) {
+					uint32_t jps = Hc.jps;
 #pragma unroll
 					for (int i = 0; i < NS; i++) {
-						if (i0 + i >= n_stored) break;
-						__hip_atomic_fetch_add(&acc[(int)(jps & 15)][lane], (v[i] * inv_e) * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						if (i >= ns) break;
+						__hip_atomic_fetch_add(&acc[(int)(jps & 15)][lane], (sv[i] * inv_e) * w_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 						jps >>= 4;
 					}
 				}
 			}
-		}
-		__builtin_amdgcn_sched_barrier(0);
-		// the requests for classifier c + 1 (its record arrived during the last iteration) ...
-		rec_n = rec_nn;
-		if (c + 1 < C) request_stored(rec_n[5]);
-		__builtin_amdgcn_sched_barrier(0);
-		// ... and only then the scalar loads for c + 2: scalar loads return out of order, so the first use of ANY earlier
-		// one behind them waits for them as well
-		{
-			const int cn = (c + 1 < C) ? c + 1 : c, cnn = (c + 2 < C) ? c + 2 : c_last;
-			w_n = B.cw[(size_t)cn * B.n_pad + s];
-			inv_n = B.inv[(size_t)cn * B.n_pad + s];
-			rec_nn = ct[(size_t)cnn * M.n_tile];
-		}
-		__builtin_amdgcn_sched_barrier(0);            // keep the requests above at the top of the iteration
-		if (!any) continue;
-		const bool poison = __ballot(active && !(fabs(inv) <= 1.79769313486231570815e+308)) != 0;
-		if (nkb > 0) {
-			// Cells close in the order of the tile's listed entries; their row numbers j come
-			// packed 4 bits each in two SGPRs, so closing a cell needs no memory access.
-			// S[p] += v as one LDS floating-point add (ds_add_f64: the same IEEE addition, no register for the old
-			// sum, nothing to wait for)
-			auto fin = [&](double cell, bool) {
-				const double v = (cell * inv_e) * w;
-				__hip_atomic_fetch_add(&acc[(int)(jpack & 15)][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				jpack >>= 4;
-			};
-			// (an FP4 classifier of several K steps has all its cells stored: it never has a list here)
-#define CALL(E) { LaneOperand T; load_operand_row<E>(B, (int)(rec[0] >> 16), c, group, lane, T);                          \
-			double cell = 0;                                                                                            \
-			walk_blocks<E, 4>(M, ((uint64_t)rec[3] << 32) | rec[2], (int)rec[4], lane, cur, hap_rsrc(M, rec[1]),        \
-				(int)((rec[0] >> 2) & 63u), T, WideSrc(), tab_s, stage_s[wave], cell, fin); }
-			if (rec[4] > 0) { HIBAG_DISPATCH_ENGINE(nkb, CALL) }
-#undef CALL
-		} else if (M.store_cells != 2) {
-#define CALL(N) accumulate_classifier<N>(M, B, c, s, tile, ncell, active, poison, inv, w, tab_s, acc)
-			HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
-#undef CALL
-		}
-		// (store_cells == 2: the cells of a VALU-engine classifier all came from memory above)
-		if (poison && (nkb > 0 || M.store_cells == 2)) {  // empty cells: (0 * inv) * w is NaN where inv is not finite
-			const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + tile) * HIBAG_TILE_META;
-			for (int i = (int)meta[0]; i < ncell; i++) {
-				const double v = (0.0 * inv) * w;
-				acc[meta[4 + i] >> 24][lane] += active ? v : 0.0;
+			__builtin_amdgcn_sched_barrier(0);
+			// ---- requests: block b + 1 whole, slot words and header of block b + 2 -- before anything of block b is
+			// evaluated, so that the whole evaluation covers their latency
+			idx_c = idx_n;
+			request(idx_c, Hn);
+			idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + 2 * 4 * HIBAG_PLIST_DWORDS, 0);
+			hv_n = __builtin_amdgcn_raw_buffer_load_b32(ph, vo_h, (soff >> 2) + 64, 0);
+			__builtin_amdgcn_sched_barrier(0);
+			// ---- block b: distances on the matrix pipe, every lane its own sample's, then cell += prod * TAB[d] in order
+#ifdef HIBAG_ABL2_NOEVAL
+			if (eval && soff == 0xFFFFFFFFu) {
+#else
+			if (eval) {
+#endif
+				if (lane < 32) buf[lane] = prod;
+				v16i D0, D1;
+				block_mfma<HIBAG_ENGINE_FP4>(a1, a2, lane, fp4_offset_term((int)((Hc.h0 >> 18) & 63u), lane), T, D0, D1);
+				block_own_sample(D0, D1, n_valid);
+				uint64_t jpack = ((uint64_t)Hc.jp_hi << 32) | Hc.jp_lo;
+				// S[p] += v as one LDS floating-point add (ds_add_f64: the same IEEE addition, no register for the old
+				// sum, nothing to wait for)
+				auto fin = [&](double c, bool) {
+#ifdef HIBAG_ABL2_NOCLOSE
+					asm volatile("" :: "v"(c));
+#else
+					const double v = (c * inv_e) * w_c;
+					__hip_atomic_fetch_add(&acc[(int)(jpack & 15)][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					jpack >>= 4;
+#endif
+				};
+				block_accumulate<4>(buf, endmask, 0u, n_valid, D0, D1, cell, tab_s, fin);
 			}
+			Hc = Hn;
+			soff += 4 * HIBAG_PLIST_DWORDS;
 		}
 	}
 
@@ -1458,6 +1516,45 @@ __global__ void k_scalars(HibagModelView M, HibagBatchView B, const int *__restr
 	B.part[(P + 0) * B.n_pad + s] = sum_w;
 	B.part[(P + 1) * B.n_pad + s] = sum_m;
 	B.part[(P + 2) * B.n_pad + s] = num_m;
+}
+
+// k_nan_cells: the NaN terms of the structurally empty cells for the (sample, classifier) pairs pass 1 listed
+// (note_infinite_reciprocal): S[p] += (0 * (1/total)) * w -- NaN absorbs, so the place of these terms in the order of the
+// additions cannot show.  Launched behind pass 2; with an empty list (the normal case) every workgroup leaves after one load.
+// Workgroup = tile, thread = one empty cell of the tile; a list that overflowed falls back to thread = sample, every
+// classifier looked at.  (k_accum_cells, store_cells == 1, does this itself.)
+__global__ __launch_bounds__(64) void k_nan_cells(HibagModelView M, HibagBatchView B)
+{
+	const uint32_t count = __hip_atomic_load(B.err_dev + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (count == 0) return;
+	if (count <= HIBAG_NAN_CAP) {
+		const int t = blockIdx.x;
+		if (t >= M.n_tile) return;
+		const unsigned long long *__restrict__ list = reinterpret_cast<const unsigned long long *>(B.err_dev + 4);
+		for (uint32_t e = 0; e < count; e++) {
+			const int c = (int)(list[e] >> 32), s = (int)(uint32_t)list[e];
+			const size_t at = (size_t)c * B.n_pad + s;
+			const double v = (0.0 * B.inv[at]) * B.cw[at];
+			const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + t) * HIBAG_TILE_META;
+			const int i = (int)meta[0] + (int)threadIdx.x;
+			if (i < M.tile_n[t]) B.part[(size_t)(M.tile_p0[t] + (int)(meta[4 + i] >> 24)) * B.n_pad + s] += v;
+			__syncthreads();                          // (two classifiers of one sample may meet in a cell)
+		}
+		return;
+	}
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= B.n_pad) return;
+	for (int c = 0; c < M.n_classifier; c++) {
+		const size_t at = (size_t)c * B.n_pad + s;
+		const double w = B.cw[at], inv = B.inv[at];
+		if (!(w > 0) || fabs(inv) <= 1.79769313486231570815e+308) continue;
+		const double v = (0.0 * inv) * w;
+		for (int t = 0; t < M.n_tile; t++) {
+			const uint32_t *__restrict__ meta = M.tile_meta + ((size_t)c * M.n_tile + t) * HIBAG_TILE_META;
+			for (int i = (int)meta[0]; i < M.tile_n[t]; i++)
+				B.part[(size_t)(M.tile_p0[t] + (int)(meta[4 + i] >> 24)) * B.n_pad + s] += v;
+		}
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -1751,6 +1848,8 @@ void hibag_launch_vote(const HibagModelView &M, const HibagBatchView &B, int *d_
 void hibag_launch_scalars(const HibagModelView &M, const HibagBatchView &B, const int *d_best_cell, hipStream_t st)
 {
 	hipLaunchKernelGGL(k_scalars, grid1(B.n_pad, 64), dim3(64), 0, st, M, B, d_best_cell);
+	if (!d_best_cell && M.store_cells != 1 && M.n_classifier > 0)
+		hipLaunchKernelGGL(k_nan_cells, dim3((unsigned)std::max(M.n_tile, B.n_pad / 64)), dim3(64), 0, st, M, B);
 }
 
 void hibag_launch_finish(const HibagModelView &M, const HibagBatchView &B, double *d_part,

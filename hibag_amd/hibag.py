@@ -111,6 +111,10 @@ class HlaAttrBagClass:
         except Exception:
             pass
 
+    def device(self) -> int:
+        """The HIP device the model lives on."""
+        return int(_lib.lib().hibag_hip_model_device(self.handle))
+
     def pair_evals(self) -> int:
         return int(_lib.lib().hibag_hip_model_pair_evals(self.handle))
 

@@ -79,14 +79,15 @@ class HlaAttrBagObj:
 
 def engine_kind(n_snp_c: int) -> str:
     """The library's distance engine for a classifier with ``n_snp_c`` SNPs (``HIBAG_ENGINE_OF`` in
-    csrc/hibag_device.h): ``"fp4"`` (up to 28 SNPs: one v_mfma_scale_f32_32x32x64_f8f6f4 per sample half and
+    csrc/hibag_device.h): ``"fp4"`` (up to 30 SNPs: one v_mfma_scale_f32_32x32x64_f8f6f4 per sample half and
     32-record block; 33..112 SNPs: one per 28 SNPs, chained through the accumulator -- ``engine_steps``), ``"i8"``
-    (29..32 SNPs: two v_mfma_i32_32x32x32_i8), ``"valu"`` (more than 112 SNPs)."""
+    (31..32 SNPs: two v_mfma_i32_32x32x32_i8), ``"valu"`` (more than 112 SNPs).  A description for documentation and
+    tests; what a finalized model really uses is ``HlaAttrBagClass.engine(c)`` (``hibag_hip_model_engine``)."""
     k = int(n_snp_c)
     e = os.environ.get("HIBAG_ENGINE")
     if e == "valu":
         return "valu"
-    if k <= 28 and e != "i8":
+    if k <= 30 and e != "i8":
         return "fp4"
     if k <= 32:
         return "i8"
@@ -97,7 +98,8 @@ def engine_kind(n_snp_c: int) -> str:
 
 def engine_steps(n_snp_c: int) -> int:
     """K steps of the FP4 engine for a classifier with ``n_snp_c`` SNPs (1 for the other engines)."""
-    return max(1, -(-int(n_snp_c) // 28)) if engine_kind(n_snp_c) == "fp4" else 1
+    k = int(n_snp_c)
+    return (1 if k <= 30 else -(-k // 28)) if engine_kind(k) == "fp4" else 1
 
 
 def engine_nkb(n_snp_c: int) -> int:

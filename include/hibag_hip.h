@@ -94,6 +94,7 @@ int hibag_hip_model_finalize(hibag_hip_model *m);
 void hibag_hip_model_free(hibag_hip_model *m);
 
 /* queries */
+int hibag_hip_model_device(const hibag_hip_model *m);      /* the HIP device the model lives on (-1 for NULL) */
 int hibag_hip_model_n_hla(const hibag_hip_model *m);
 int hibag_hip_model_n_snp(const hibag_hip_model *m);
 int hibag_hip_model_n_classifier(const hibag_hip_model *m);

@@ -181,7 +181,9 @@ def test_training_runs_on_the_selected_device(hib, oracle):
     hib.set_seed(11)
     mod = hib.hlaAttrBagging(hla, snp, nclassifier=2, mtry=6, mono_rm=False, verbose=False, device=dev)
     assert len(mod.obj.classifiers) == 2
-    assert torch.cuda.mem_get_info(dev)[0] < free_before          # the model (and the build state) sit on `dev`
+    assert mod.device() == dev                                    # the model (and the build state) sit on `dev`
+    # (free memory on `dev` is not a reliable witness: the runtime serves small allocations from blocks earlier tests freed)
+    assert torch.cuda.mem_get_info(dev)[0] <= free_before + (64 << 20)
     if n_dev > 1:
         assert abs(torch.cuda.mem_get_info(0)[0] - free_other) < (8 << 20)      # nothing landed on device 0
     assert L.hibag_hip_set_device(0) == 0
