@@ -493,10 +493,26 @@ int finalize_model(hibag_hip_model *m)
 				return (uint32_t)(v >> lo);
 			};
 			auto entry = [&](double ff, int i, double f) {
-				uint32_t w[8 + 4 * (HIBAG_FP4_MAX_STEPS - 1)] = {0};
+				uint32_t w[12 + 4 * (HIBAG_FP4_MAX_STEPS - 1)] = {0};
 				int n = 0;
-				if (fp4) {                     // nibble s = 2 (the e2m1 code of 1.0) where bit s is set
-					const uint32_t bits = steps > 1 ? window(i, 0) & ((1u << HIBAG_FP4_STEP_SNPS) - 1) : window(i, 0);
+				if (fp4 && steps == 1) {       // two nibble images: nibble s = 2 (the e2m1 code of 1.0) where bit s is set ...
+					const uint32_t bits = window(i, 0);
+					for (int sb = 0; sb < 32; sb++) w[sb >> 3] |= ((bits >> sb) & 1u) << (4 * (sb & 7) + 1);
+					for (int d = 0; d < 4; d++) w[4 + d] = w[d];
+					if (i >= 0) {
+						// ... plus the A-row constants of the offset digits at nibbles k, k + 1 (K layout in hibag_device.h): the "sum"
+						// image carries half of each (codes 1 and 3: 0.5 + 0.5 = 1, 1.5 + 1.5 = 3 + 3 = code 6 = 4), the "AND" image
+						// the codes 6, 6 themselves.  (Not the padding entry: its rows must stay zero.)
+						const int ks = k.n_snp;
+						for (int q = 0; q < 2; q++) {
+							const int nib = ks + q;
+							w[nib >> 3] |= (q == 0 ? 1u : 3u) << (4 * (nib & 7));
+							w[4 + (nib >> 3)] |= 6u << (4 * (nib & 7));
+						}
+					}
+					n = 8;
+				} else if (fp4) {              // nibble s = 2 (the e2m1 code of 1.0) where bit s is set
+					const uint32_t bits = window(i, 0) & ((1u << HIBAG_FP4_STEP_SNPS) - 1);
 					for (int sb = 0; sb < 32; sb++) w[sb >> 3] |= ((bits >> sb) & 1u) << (4 * (sb & 7) + 1);
 					n = 4;
 				} else {                       // byte s = 1 where bit s is set
@@ -562,7 +578,9 @@ int finalize_model(hibag_hip_model *m)
 	// hybrid | recompute and HIBAG_STORE_PAIRS override.
 	uint64_t store_above = 12;
 	if (const char *e = getenv("HIBAG_STORE_PAIRS")) store_above = (uint64_t)std::max(0, atoi(e));
-	if (getenv("HIBAG_PASS2") && !strcmp(getenv("HIBAG_PASS2"), "recompute")) store_above = ~(uint64_t)0;   // (no cell of theirs is stored)
+	uint32_t fit_min = 5;
+	if (const char *e = getenv("HIBAG_STORE_FIT")) fit_min = atoi(e) > 0 ? (uint32_t)atoi(e) : ~0u;
+	if (getenv("HIBAG_PASS2") && !strcmp(getenv("HIBAG_PASS2"), "recompute")) { store_above = ~(uint64_t)0; fit_min = ~0u; }   // (no cell of theirs is stored)
 	// Pass 2 evaluates the pairs of one-step FP4 classifiers only (k_accum's block stream); a classifier on any other engine
 	// -- int8 (29..32 SNPs), FP4 in several K steps, VALU -- has all its cells stored by pass 1 and read back.
 	auto pass2_evaluates = [&](int c) { return engine[c] == HIBAG_ENGINE_FP4 && n_step[c] == 1; };
@@ -596,11 +614,22 @@ int finalize_model(hibag_hip_model *m)
 			for (int p = 0; p < P; p++) stored[c][p] = cell_chunks[c][p] != 0;
 		} else if (store_mode == 2)
 			for (int t = 0; t < n_tile; t++) {
-				std::vector<std::pair<uint32_t, int>> big;
-				for (int j = 0; j < tile_n[t]; j++)
-					if (cell_pairs[c][tile_p0[t] + j] > store_above) big.push_back({cell_pairs[c][tile_p0[t] + j], tile_p0[t] + j});
-				std::stable_sort(big.begin(), big.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
-				for (size_t i = 0; i < big.size() && i < HIBAG_STORED_PER_VISIT; i++) stored[c][big[i].second] = 1;
+				// Largest cells first: a cell with more than `store_above` pairs is stored; so is -- while the visit's
+				// remaining pair slots would not fit ONE 32-slot block -- any cell of at least `fit_min` pairs: a second,
+				// mostly empty block costs pass 2 more than a stored sum (HIBAG_STORE_FIT=0 switches that off).
+				std::vector<std::pair<uint32_t, int>> cells;
+				uint32_t slots = 0;                            // pair slots of the visit (cells padded to an even count)
+				for (int j = 0; j < tile_n[t]; j++) {
+					const uint32_t n = cell_pairs[c][tile_p0[t] + j];
+					if (n) { cells.push_back({n, tile_p0[t] + j}); slots += n + (n & 1u); }
+				}
+				std::stable_sort(cells.begin(), cells.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+				for (size_t i = 0; i < cells.size() && i < HIBAG_STORED_PER_VISIT; i++) {
+					const uint32_t n = cells[i].first;
+					if (!(n > store_above || (slots > HIBAG_PLIST_DWORDS && n >= fit_min))) break;
+					stored[c][cells[i].second] = 1;
+					slots -= n + (n & 1u);
+				}
 			}
 	}
 	// a cell of a matrix-engine classifier whose sum pass 2 reads instead of evaluating its pairs (mode 2)
@@ -732,6 +761,7 @@ int finalize_model(hibag_hip_model *m)
 	std::vector<uint64_t> etile_blk0(std::max(n_tile, 1), 0);
 	const uint32_t zero_entry_dword = (uint32_t)hap.size();          // an all-zero FP4 entry for padding blocks (factor +0.0: nothing is evaluated)
 	hap.insert(hap.end(), HIBAG_ENGINE_HAP_DWORDS(HIBAG_ENGINE_FP4), 0u);
+	while (hap.size() % 4) hap.push_back(0u);
 	for (int t = 0; t < n_tile && store_mode != 1; t++) {
 		etile_blk0[t] = plist.size() / HIBAG_PLIST_DWORDS;
 		for (int c = 0; c < C; c++) {
@@ -951,6 +981,8 @@ int finalize_model(hibag_hip_model *m)
 		m->spin_limit = (uint32_t)std::min<long long>(0xFFFFFFF0ll, (1ll << 19) + 16 * longest);
 	}
 	m->cell_rows = cell_row[C];
+	if (store_mode != 1 && (uint64_t)cell_row[C] >= (1ull << 23))      // (k_accum: a stored row's byte offset within a sample group in 32 bits)
+		return fail(HIBAG_HIP_EINVAL, "the model stores too many cell sums per sample (%d) for the second pass", cell_row[C]);
 	V.plist = m->d_blk.as<uint32_t>();
 	V.plist_dwords = plist.size();
 	m->bt_rows = bt_rows;
@@ -971,7 +1003,11 @@ int batch_limit(const hibag_hip_model *m)
 {
 	const double per_sample = 8.0 * (m->view.n_cell + 3) + 24.0 * m->view.n_classifier +
 		4.0 * m->mask_rows + 4.0 * m->view.n_classifier + 16.0 * m->bt_rows + 8.0 * m->view.n_classifier + 8.0 * m->cell_rows;
-	int lim = (int)(16e9 / std::max(per_sample, 1.0));
+	double cap = 16e9 / std::max(per_sample, 1.0);
+	// k_accum addresses the operand, weight and 1/total arrays through raw buffers with 32-bit offsets: each stays below 4 GB
+	cap = std::min(cap, 3.5e9 / (16.0 * std::max(m->bt_rows, 1)));
+	cap = std::min(cap, 3.5e9 / (8.0 * std::max(m->view.n_classifier, 1)));
+	int lim = (int)std::min(cap, 1e9);
 	lim = std::max(64, std::min(lim, 1 << 17));
 	return lim / 64 * 64;
 }

@@ -78,7 +78,11 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 #define HIBAG_STORED_PER_VISIT 4             // mode 2: stored cells per (classifier, tile) -- what k_accum keeps in registers
 // Matrix-engine variants (HibagModelView::engine[c]; 0 = VALU engine) and their haplotype-table entries:
 //   FP4  (up to 30 SNPs; 33 .. 112 in several K steps, below)  v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands: one instruction per sample half covers all
-//                         K = 64 positions.  Entry = { N[16] (nibble s = 2, the code of 1.0, where bit s is set), ff, f }: 8 dwords
+//                         K = 64 positions.  Entry = { N[16], A[16], ff, f }: 12 dwords.  N and A both have nibble s = 2 (the code of 1.0)
+//                         where bit s is set; N ("sum" image, fetched by lanes 0..31) has the codes 1, 3 (0.5, 1.5) at nibbles k, k+1 --
+//                         two of them add up to the A-row constants 1 and 4 of the lower K half --, A ("AND" image, lanes 32..63)
+//                         the codes 6, 6 (4, 4), which survive the AND: the offset digits' constants cost no instruction.
+//                         (Several K steps: { N[16], ff, f, N'[16] ... }, 8 + 4 (steps - 1) dwords, constants added by the kernel.)
 //   I8   (31 SNPs), I8S (32 SNPs)  v_mfma_i32_32x32x32_i8, two K blocks.  Entry = { E[32] (byte s = bit s), ff, f }: 12 dwords
 #define HIBAG_ENGINE_VALU 0
 #define HIBAG_ENGINE_FP4 1
@@ -96,7 +100,7 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 	(fp4) && (k) <= HIBAG_FP4_STEP_SNPS * HIBAG_FP4_MAX_STEPS ? HIBAG_ENGINE_FP4 : HIBAG_ENGINE_VALU)
 #define HIBAG_ENGINE_STEPS(e, k) ((e) == HIBAG_ENGINE_FP4 ? (k) <= HIBAG_FP4_MAX_SNPS ? 1 : HIBAG_FP4_STEPS(k) : 1)
 #define HIBAG_ENGINE_ROWS(e, k) ((e) == HIBAG_ENGINE_FP4 ? 2 * HIBAG_ENGINE_STEPS(e, k) : ((e) == HIBAG_ENGINE_VALU ? 0 : 4))   // B-operand rows (16 B per lane each)
-#define HIBAG_ENGINE_HAP_DWORDS(e) ((e) == HIBAG_ENGINE_FP4 ? 8 : 12)                             // (FP4: of a one-step entry)
+#define HIBAG_ENGINE_HAP_DWORDS(e) 12                                                             // (FP4: of a one-step entry)
 #define HIBAG_FP4_ENTRY_DWORDS(steps) (8 + 4 * ((steps) - 1))
 // K layout of the distance dot product for a classifier with k SNPs.  With the genotype g of the sample at SNP s:
 //   g = 0: h1 + h2      g = 2: 2 - h1 - h2      g = 1: [h1 == h2] = 1 - h1 - h2 + 2 h1 h2        (src/LibHLA.cpp:747-819)

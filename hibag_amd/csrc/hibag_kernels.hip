@@ -262,10 +262,21 @@ __device__ __forceinline__ void block_mfma(const v4i &e1, const v4i &e2, int lan
 {
 	const bool upper = lane >= 32;
 	if (ENG == HIBAG_ENGINE_FP4) {
+		// one K step: each lane has fetched ITS image of the two haplotypes -- lanes 0..31 the one whose nibbles add up to the
+		// A row of the lower K half (the offset digits' constants 1, 4 as 0.5 + 0.5, 1.5 + 1.5), lanes 32..63 the one whose
+		// AND is the row of the upper half (constants 4, 4) -- so the row is one instruction per dword
 		v16f d0, d1;
 #pragma unroll
 		for (int r = 0; r < 16; r++) { d0[r] = 0.0f; d1[r] = 0.0f; }
-		fp4_step(e1, e2, lane, cterm, T.b[0][0], T.b[1][0], d0, d1);
+		v4i a;
+#pragma unroll
+		for (int d = 0; d < 4; d++) a[d] = upper ? (e1[d] & e2[d]) : (e1[d] + e2[d]);
+		const v8i a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+		const v8i b0 = {T.b[0][0][0], T.b[0][0][1], T.b[0][0][2], T.b[0][0][3], 0, 0, 0, 0};
+		const v8i b1 = {T.b[1][0][0], T.b[1][0][1], T.b[1][0][2], T.b[1][0][3], 0, 0, 0, 0};
+		const int sb = upper ? HIBAG_FP4_SCALE_B_HI : HIBAG_FP4_SCALE_B_LO;
+		d0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, d0, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sb);
+		d1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, d1, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sb);
 		acc0 = __builtin_bit_cast(v16i, d0);
 		acc1 = __builtin_bit_cast(v16i, d1);
 		return;
@@ -404,14 +415,14 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 	if (nblk <= 0) return;
 	// FP4W: an FP4 classifier of `wide.nstep` K steps; `k` = SNPs of its LAST step, the others have HIBAG_FP4_STEP_SNPS
 	constexpr bool FP4W = ENG == HIBAG_ENGINE_FP4W;
-	constexpr bool FP4 = ENG == HIBAG_ENGINE_FP4 || FP4W;
 	const uint32_t ES = FP4W ? 4u * (uint32_t)HIBAG_FP4_ENTRY_DWORDS(wide.nstep)
-	                         : 4u * (uint32_t)HIBAG_ENGINE_HAP_DWORDS(FP4 ? HIBAG_ENGINE_FP4 : HIBAG_ENGINE_I8);   // bytes per table entry
-	constexpr int FO = FP4 ? 16 : 32;                                         // ff behind the image
+	                         : 4u * (uint32_t)HIBAG_ENGINE_HAP_DWORDS(ENG);   // bytes per table entry (one-step FP4 and int8: 48)
+	constexpr int FO = FP4W ? 16 : 32;                                        // ff behind the image(s)
 	const int vo_i = (lane & 31) * 4;                // this lane's slot inside a block
-	// this lane's 16 bytes of an image: the K half's bytes (int8), the whole nibble image (FP4)
-	const uint32_t img = FP4 ? 0u : (uint32_t)(lane >> 5) * 16u;
-	const v4i cterm = FP4 ? fp4_offset_term(FP4W ? HIBAG_FP4_STEP_SNPS : k, lane) : v4i{0, 0, 0, 0};   // (of K step 0)
+	// this lane's 16 bytes of an entry: the K half's bytes (int8), the K half's nibble image (one-step FP4: the "sum" image
+	// for lanes 0..31, the "AND" image for lanes 32..63), the one nibble image (FP4 of several steps)
+	const uint32_t img = FP4W ? 0u : (uint32_t)(lane >> 5) * 16u;
+	const v4i cterm = FP4W ? fp4_offset_term(HIBAG_FP4_STEP_SNPS, lane) : v4i{0, 0, 0, 0};   // (of K step 0)
 	const uint32_t BB = 4 * HIBAG_PLIST_DWORDS;      // bytes per block
 	// The list is addressed as a raw buffer rebased at this segment, so that the 32-bit offsets inside
 	// the descriptor never limit the model size.
@@ -424,7 +435,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 		cur.idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + BB, 0);
 	}
 	uint32_t idx_c = cur.idx, idx_n = cur.idx_n;
-	// One address per haplotype: entry * size + this lane's offset into the image.  The factors are read FO / FO + 8
+	// One address per haplotype: entry * size + this lane's offset into the image(s).  The factors are read FO / FO + 8
 	// bytes behind it, which is right for lanes 0..31 (image offset 0) -- the only ones whose factors are used.
 	uint32_t o1 = (idx_c & 0xFFFFu) * ES + img, o2 = ((idx_c >> 16) & 0x3FFFu) * ES + img;
 	v4i e1 = load_hap_image(hp, o1), e2 = load_hap_image(hp, o2);
@@ -1163,11 +1174,20 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 		const __amdgpu_buffer_rsrc_t ph = __builtin_amdgcn_make_buffer_rsrc((void *)(M.ehdr + blk0 * 8), 0,
 			left_h > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left_h, 0x00020000);
 		const __amdgpu_buffer_rsrc_t hp = hap_rsrc(M, 0);      // the whole haplotype table; a block's classifier enters as the scalar offset
+		// the batch's operand / weight / 1/total rows and this group's stored sums as raw buffers too: a row is then a scalar
+		// offset (classifier or row number times the row size, SALU) added to one constant per-lane offset -- no 64-bit address
+		// arithmetic on the vector ALU.  (hibag_api.hip batch_limit keeps every one of these arrays below 4 GB.)
+		const __amdgpu_buffer_rsrc_t r_bt = __builtin_amdgcn_make_buffer_rsrc((void *)B.bt, 0, (int)0xFFFFFFF0u, 0x00020000);
+		const __amdgpu_buffer_rsrc_t r_cw = __builtin_amdgcn_make_buffer_rsrc((void *)B.cw, 0, (int)0xFFFFFFF0u, 0x00020000);
+		const __amdgpu_buffer_rsrc_t r_inv = __builtin_amdgcn_make_buffer_rsrc((void *)B.inv, 0, (int)0xFFFFFFF0u, 0x00020000);
+		const __amdgpu_buffer_rsrc_t r_sv = __builtin_amdgcn_make_buffer_rsrc(
+			(void *)(B.cells + (size_t)group * (size_t)as_const(M.cell_row)[C] * HIBAG_WAVE), 0, (int)0xFFFFFFF0u, 0x00020000);
 		const int vo_i = (lane & 31) * 4, vo_h = (lane & 7) * 4;
-		const size_t n_grp = (size_t)n_group;
-		const double *__restrict__ const group_rows = B.cells + (size_t)group * (size_t)as_const(M.cell_row)[C] * HIBAG_WAVE + lane;
+		const int vo_bt = (group * HIBAG_WAVE + lane) * 16, vo_s = s * 8, vo_sv = lane * 8;
+		const uint32_t bt_stride = (uint32_t)B.n_pad * 16u, s_stride = (uint32_t)B.n_pad * 8u;      // bytes per operand row / per classifier's row
 		double *stage = stage_s[wave];
-		constexpr uint32_t ES = 4u * HIBAG_ENGINE_HAP_DWORDS(HIBAG_ENGINE_FP4);      // bytes per table entry
+		constexpr uint32_t ES = 4u * HIBAG_ENGINE_HAP_DWORDS(HIBAG_ENGINE_FP4);      // bytes per table entry: sum image, AND image, ff, f
+		const uint32_t img = (uint32_t)(lane >> 5) * 16u;     // lanes 0..31 fetch the "sum" image of their haplotypes, lanes 32..63 the "AND" image
 		constexpr int NS = HIBAG_STORED_PER_VISIT;
 
 		uint32_t idx_c = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, 0, 0);
@@ -1177,54 +1197,41 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 		EHeader Hc = read_header(hv_c);
 
 		// everything block b needs, requested a block ahead
-		v4i e1, e2;                                   // the nibble images of the lane's haplotype pair
-		double ff, f2;                                // its frequency factors
+		v4i e1, e2;                                   // the lane's images of its haplotype pair
+		double ff, f2;                                // the pair's frequency factors (used by lanes 0..31)
 		v4i t0, t1;                                   // the B operand (two sample halves)
 		double w, inv, sv[NS];
 		auto request = [&](uint32_t idx, const EHeader &H) {
-			const uint32_t o1 = (idx & 0xFFFFu) * ES, o2 = ((idx >> 16) & 0x3FFFu) * ES;
+			const uint32_t o1 = (idx & 0xFFFFu) * ES + img, o2 = ((idx >> 16) & 0x3FFFu) * ES + img;
 			const int so = (int)(H.hap * 4u);
-#ifdef HIBAG_ABL2_NOENT      // (timing ablations: wrong results on purpose)
-			e1 = v4i{(int)o1, so, 1, 2}; e2 = v4i{(int)o2, 3, 4, 5}; ff = 1.0 + so; f2 = 2.0;
-#else
 			const auto i1 = __builtin_amdgcn_raw_buffer_load_b128(hp, (int)o1, so, 0);
 			const auto i2 = __builtin_amdgcn_raw_buffer_load_b128(hp, (int)o2, so, 0);
 			e1 = v4i{(int)i1[0], (int)i1[1], (int)i1[2], (int)i1[3]};
 			e2 = v4i{(int)i2[0], (int)i2[1], (int)i2[2], (int)i2[3]};
-			ff = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(hp, (int)o1, so + 16, 0));
-			f2 = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(hp, (int)o2, so + 24, 0));
-#endif
-#ifdef HIBAG_ABL2_NOT
-			t0 = v4i{(int)H.bt, lane, 0x22222222, 0x2a2a2a2a}; t1 = v4i{lane, (int)H.bt, 0x2222aaaa, 0x22222222};
-#else
-			const uint4 u0 = B.bt[((size_t)H.bt * n_grp + group) * HIBAG_WAVE + lane];
-			const uint4 u1 = B.bt[((size_t)(H.bt + 1) * n_grp + group) * HIBAG_WAVE + lane];
-			t0 = v4i{(int)u0.x, (int)u0.y, (int)u0.z, (int)u0.w};
-			t1 = v4i{(int)u1.x, (int)u1.y, (int)u1.z, (int)u1.w};
-#endif
-			const size_t at = (size_t)(H.h0 & 0xFFFFu) * B.n_pad + s;
-#ifdef HIBAG_ABL2_NOWINV
-			w = 1.0 + (double)(H.h0 & 0xFFFFu); inv = 0.5 + (double)at;
-#else
-			w = B.cw[at];
-			inv = B.inv[at];
-#endif
-#ifdef HIBAG_ABL2_NOSV
-			const int ns = 0;
-			for (int i = 0; i < NS; i++) sv[i] = 1.0;
-#else
+			ff = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(hp, (int)o1, so + 32, 0));
+			f2 = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(hp, (int)o2, so + 40, 0));
+			const int sc = (int)((H.h0 & 0xFFFFu) * s_stride);
+			w = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_cw, vo_s, sc, 0));
+			inv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_inv, vo_s, sc, 0));
 			const int ns = (int)(H.h0 >> 25) & 7;
-#endif
 			if (ns > 0) {
-				const double *__restrict__ src = group_rows + (size_t)H.srow * HIBAG_WAVE;
+				const int sr = (int)(H.srow * (uint32_t)(HIBAG_WAVE * 8));
 #pragma unroll
 				for (int i = 0; i < NS; i++) {
 					if (i >= ns) break;
-					sv[i] = __builtin_nontemporal_load(src + (size_t)i * HIBAG_WAVE);
+					sv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_sv, vo_sv, sr + i * HIBAG_WAVE * 8, 2));   // (read once: nt)
 				}
 			}
 		};
+		auto request_operand = [&](const EHeader &H) {
+			const int sb = (int)(H.bt * bt_stride);
+			const auto u0 = __builtin_amdgcn_raw_buffer_load_b128(r_bt, vo_bt, sb, 0);
+			const auto u1 = __builtin_amdgcn_raw_buffer_load_b128(r_bt, vo_bt, sb + (int)bt_stride, 0);
+			t0 = v4i{(int)u0[0], (int)u0[1], (int)u0[2], (int)u0[3]};
+			t1 = v4i{(int)u1[0], (int)u1[1], (int)u1[2], (int)u1[3]};
+		};
 		request(idx_c, Hc);
+		request_operand(Hc);
 		double cell = 0;
 		uint32_t soff = 0;                            // byte offset of block b's slot words
 		for (int b = bb; b < be; b++) {
@@ -1242,10 +1249,10 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 			const uint32_t live = endmask | (uint32_t)__ballot(prod != 0.0);
 			const int n_valid = live ? 32 - __builtin_clz(live) : 0;
 			const bool eval = any && n_valid > 0;
-			// the A operand rows of this block and its B operand, out of the way of the next block's
-			const v4i a1 = e1, a2 = e2;
-			LaneOperand T;
-			T.b[0][0] = t0; T.b[1][0] = t1;
+			// this block's A operand row: the two images' sum (lower K half) or AND (upper K half)
+			v4i arow;
+#pragma unroll
+			for (int d = 0; d < 4; d++) arow[d] = lane >= 32 ? (e1[d] & e2[d]) : (e1[d] + e2[d]);
 			// the sums pass 1 stored for this block's classifier:   S[p] += (cell * (1/total)) * w
 			{
 				const int ns = (int)(Hc.h0 >> 25) & 7;
@@ -1260,34 +1267,43 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagMode
 				}
 			}
 			__builtin_amdgcn_sched_barrier(0);
-			// ---- requests: block b + 1 whole, slot words and header of block b + 2 -- before anything of block b is
-			// evaluated, so that the whole evaluation covers their latency
+			// ---- requests: block b + 1 (all but its B operand), slot words and header of block b + 2 -- before anything of
+			// block b is evaluated, so that the whole evaluation covers their latency
 			idx_c = idx_n;
 			request(idx_c, Hn);
 			idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + 2 * 4 * HIBAG_PLIST_DWORDS, 0);
 			hv_n = __builtin_amdgcn_raw_buffer_load_b32(ph, vo_h, (soff >> 2) + 64, 0);
 			__builtin_amdgcn_sched_barrier(0);
-			// ---- block b: distances on the matrix pipe, every lane its own sample's, then cell += prod * TAB[d] in order
-#ifdef HIBAG_ABL2_NOEVAL
-			if (eval && soff == 0xFFFFFFFFu) {
-#else
+			// ---- block b: distances on the matrix pipe; behind the two instructions the next block's B operand is requested
+			// into the registers they have just read
+			v16i D0, D1;
 			if (eval) {
-#endif
 				if (lane < 32) buf[lane] = prod;
-				v16i D0, D1;
-				block_mfma<HIBAG_ENGINE_FP4>(a1, a2, lane, fp4_offset_term((int)((Hc.h0 >> 18) & 63u), lane), T, D0, D1);
+				v16f d0, d1;
+#pragma unroll
+				for (int r = 0; r < 16; r++) { d0[r] = 0.0f; d1[r] = 0.0f; }
+				const v8i a8 = {arow[0], arow[1], arow[2], arow[3], 0, 0, 0, 0};
+				const v8i b0 = {t0[0], t0[1], t0[2], t0[3], 0, 0, 0, 0};
+				const v8i b1 = {t1[0], t1[1], t1[2], t1[3], 0, 0, 0, 0};
+				const int sbs = lane >= 32 ? HIBAG_FP4_SCALE_B_HI : HIBAG_FP4_SCALE_B_LO;
+				d0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, d0, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sbs);
+				d1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, d1, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sbs);
+				D0 = __builtin_bit_cast(v16i, d0);
+				D1 = __builtin_bit_cast(v16i, d1);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			request_operand(Hn);
+			__builtin_amdgcn_sched_barrier(0);
+			// ---- every lane its own sample's distances, then cell += prod * TAB[d] in order
+			if (eval) {
 				block_own_sample(D0, D1, n_valid);
 				uint64_t jpack = ((uint64_t)Hc.jp_hi << 32) | Hc.jp_lo;
 				// S[p] += v as one LDS floating-point add (ds_add_f64: the same IEEE addition, no register for the old
 				// sum, nothing to wait for)
 				auto fin = [&](double c, bool) {
-#ifdef HIBAG_ABL2_NOCLOSE
-					asm volatile("" :: "v"(c));
-#else
 					const double v = (c * inv_e) * w_c;
 					__hip_atomic_fetch_add(&acc[(int)(jpack & 15)][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					jpack >>= 4;
-#endif
 				};
 				block_accumulate<4>(buf, endmask, 0u, n_valid, D0, D1, cell, tab_s, fin);
 			}
