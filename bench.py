@@ -76,8 +76,14 @@ def main():
                          "slice of the classifiers on the SAME samples, merged by one RCCL all-reduce of the partial "
                          "posterior sums per step (BASELINE config 3's 'RCCL posterior merge'; strong scaling)")
     ap.add_argument("--no-extras", action="store_true", help="skip host_inclusive / other_configs (profiling runs)")
+    ap.add_argument("--launcher", choices=("ranks", "threads"), default="ranks",
+                    help="--gpus N > 1: one process per GPU under torch.distributed (default; RCCL rendezvous), or ONE process "
+                         "with one host thread per GPU through the C ABI (hibag_hip_model_replicate + the device entry), "
+                         "the way an R / C++ host would drive a node (INTEGRATION.md section B)")
     args = ap.parse_args()
 
+    if args.launcher == "threads" and "WORLD_SIZE" not in os.environ:
+        return main_threads(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` starts its own ranks: one child process per GPU through
         # torch.distributed.run (a CHILD, never an exec: nothing here has touched the GPU yet, but the
@@ -207,7 +213,7 @@ def main():
     pairs2 = model.second_pass_pairs() if vote_method == 1 else pe_rank        # (majority vote: k_vote_best walks every pair)
     stored = model.stored_cells()
     obj_rank = sub if by_classifier else model_obj
-    floor_ns, ns1 = issue_floor(obj_rank, ms1, n, K)
+    floor_ns, ns1 = issue_floor(obj_rank, ms1, n, K, model)
     ns2 = N_SIMD * ms2 * 1e6 / (max(pairs2, 1) * n / 64.0)
     ns_both = N_SIMD * (ms1 + ms2) * 1e6 / ((pe_rank + pairs2) * n / 64.0)
     roofline = {
@@ -276,9 +282,16 @@ def main():
         out["classifier_shard_check"] = shard_check
 
     if rank == 0 and world == 1 and not args.no_extras and not by_classifier:
-        # SURVEY.md 8(d) protocol column: H2D of the genotypes + D2H of the requested outputs included
+        # SURVEY.md 8(d) protocol: median of >= 10 individually timed repetitions; the device-resident step (what `value`
+        # is made of) next to the host-pointer entry, which includes H2D of the genotypes and D2H of the requested outputs
+        def one():
+            step(); torch.cuda.synchronize(dev)
+        out["protocol"] = {"repetitions": 12, "device_resident_median_ms": median_ms(one, 12)}
+        out["protocol"]["device_resident_median_samples_per_s"] = n / out["protocol"]["device_resident_median_ms"] * 1e3
         out["host_inclusive"] = host_inclusive(model, geno, n)
+        out["host_inclusive"]["frac_of_device_resident"] = out["host_inclusive"]["value"] / out["protocol"]["device_resident_median_samples_per_s"]
         if args.shape == SHAPE and n == SAMPLES_PER_GPU:
+            out["host_inclusive_100k"] = host_inclusive_cohort(model, model_obj, founders, afreq, dev, 100_000)
             model.close()
             out["other_configs"] = other_configs(K)
 
@@ -293,33 +306,87 @@ def main():
         dist.destroy_process_group()
 
 
-def issue_floor(obj, avg_ms, n, K):
+def issue_floor(obj, avg_ms, n, K, dev_model):
     """(floor, achieved) SIMD time in ns per wavefront-pair (64 samples x one haplotype pair) for a kernel that
-    took avg_ms over n samples: two FP64 ops per pair plus the pair's share of the int8 MFMAs of the distance
-    dot product: per 32-record block two FP4 instructions (K = 64) up to 28 SNPs, four int8 ones (K = 32 each) for 29..32."""
-    from hibag_amd import engine_kind, engine_steps
+    took avg_ms over n samples: two FP64 ops per pair plus the pair's share of the MFMAs of the distance dot product --
+    per 32-record block two FP4 instructions (K = 64) per K step, or four int8 ones (K = 32 each).  Which engine a
+    classifier runs on is asked of the finalized model (hibag_hip_model_engine), not re-derived here."""
     per_block = {"valu": 0.0, "fp4": 2 * K["mfma_fp4_32x32x64_ns"], "i8": 4 * K["mfma_i8_32x32x32_ns"]}
     mfma_ns, w = 0.0, 0
-    for c in obj.classifiers:
-        k, h = len(c.snpidx), len(c.freq)
-        mfma_ns += h * (h + 1) // 2 * per_block[engine_kind(k)] * engine_steps(k) / 32.0
+    for ci, c in enumerate(obj.classifiers):
+        h = len(c.freq)
+        kind, steps = dev_model.engine(ci)
+        mfma_ns += h * (h + 1) // 2 * per_block[kind] * steps / 32.0
         w += h * (h + 1) // 2
     floor = 2 * K["fp64_op_ns"] + mfma_ns / max(w, 1)
     achieved = N_SIMD * avg_ms * 1e6 / (w * n / 64.0)
     return floor, achieved
 
 
-def host_inclusive(model, geno, n, reps=5):
-    """hibag_hip_predict with host pointers: pageable int32 genotypes up, calls / prob / matching / dosage down."""
-    for _ in range(2):
-        model.predict_raw(geno, 1, want_dosage=True)
-    t = time.perf_counter()
+def median_ms(fn, reps=12, warm=2):
+    import numpy as np
+    for _ in range(warm):
+        fn()
+    ts = []
     for _ in range(reps):
-        model.predict_raw(geno, 1, want_dosage=True)
-    dt = (time.perf_counter() - t) / reps
-    return {"value": n / dt, "unit": "samples/s", "ms_per_step": dt * 1e3,
+        t = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t)
+    return float(np.median(ts)) * 1e3
+
+
+def host_inclusive(model, geno, n, reps=12):
+    """hibag_hip_predict with host pointers: pageable int32 genotypes up, calls / prob / matching / dosage down; one
+    call = one 10k-sample batch, so nothing of it can overlap (the upload precedes the first kernel, the download
+    follows the last).  Median of `reps` calls."""
+    import ctypes as C
+    import numpy as np
+    from hibag_amd import _lib
+    L = _lib.lib()
+    nh = model.obj.n_hla
+    h1 = np.zeros(n, np.int32); h2 = np.zeros(n, np.int32); pr = np.zeros(n); mt = np.zeros(n); ds = np.zeros((n, nh))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    g = np.ascontiguousarray(geno, np.int32)
+
+    def call():
+        _lib.check(L.hibag_hip_predict(model.handle, p(g), n, 1, p(h1), p(h2), p(pr), p(mt), p(ds), None))
+    ms = median_ms(call, reps)
+    return {"value": n / ms * 1e3, "unit": "samples/s", "ms_per_step": ms, "repetitions": reps,
             "what": "hibag_hip_predict: H2D of the int32 genotype matrix + kernels + D2H of H1, H2, prob, matching, dosage "
-                    "(pageable host memory); never `value`"}
+                    "(pageable host memory), median; never `value`"}
+
+
+def host_inclusive_cohort(model, model_obj, founders, afreq, dev, n_big):
+    """The same entry on a cohort of several slices (BASELINE config 3's size on one GPU): upload of slice i + 1 and
+    download of slice i - 1 run beside the kernels of slice i (pinned staging, three streams), against the same
+    cohort resident in HBM."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from hibag_amd import _lib, synth
+    L = _lib.lib()
+    G, _ = synth.make_samples(founders, afreq, n_big, seed=synth.DEFAULT_SEED + 77)
+    nh = model_obj.n_hla
+    h1 = np.zeros(n_big, np.int32); h2 = np.zeros(n_big, np.int32); pr = np.zeros(n_big); mt = np.zeros(n_big); ds = np.zeros((n_big, nh))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def call():
+        _lib.check(L.hibag_hip_predict(model.handle, p(G), n_big, 1, p(h1), p(h2), p(pr), p(mt), p(ds), None))
+    ms_host = median_ms(call, 5, 1)
+    dg = torch.from_numpy(G).to(dev)
+    d = [torch.empty(n_big, dtype=torch.int32, device=dev), torch.empty(n_big, dtype=torch.int32, device=dev),
+         torch.empty(n_big, dtype=torch.float64, device=dev), torch.empty(n_big, dtype=torch.float64, device=dev),
+         torch.empty((n_big, nh), dtype=torch.float64, device=dev)]
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def resident():
+        model.predict_device(dg.data_ptr(), n_big, 1, *[x.data_ptr() for x in d], None, stream=st)
+        torch.cuda.synchronize(dev)
+    ms_dev = median_ms(resident, 5, 1)
+    return {"samples": n_big, "host_pointers_samples_per_s": n_big / ms_host * 1e3, "device_resident_samples_per_s": n_big / ms_dev * 1e3,
+            "frac_of_device_resident": ms_dev / ms_host,
+            "what": "hibag_hip_predict on 100,000 samples in host memory (slices pipelined: H2D of slice i+1 and D2H of slice i-1 "
+                    "beside the kernels of slice i) against hibag_hip_predict_device on the same cohort in HBM; medians of 5"}
 
 
 def m_pad(n):
@@ -334,6 +401,61 @@ def other_configs(K):
     import hibag_amd
     from hibag_amd import synth, train
     res = {}
+    dev = torch.device("cuda", torch.cuda.current_device())
+    # the metric's configuration with the other output sets of hlaPredict(): type = "response+prob" (the whole posterior
+    # matrix, 10.2 KB per sample) and vote = "majority"; and through the reference's actual GPU hook, one sample per call
+    try:
+        obj, founders, af = synth.make_model(SHAPE)
+        n2 = SAMPLES_PER_GPU
+        G, truth = synth.make_samples(founders, af, n2, seed=synth.DEFAULT_SEED + 1)
+        m = hibag_amd.hlaModelFromObj(obj)
+        dg = torch.from_numpy(G).to(dev)
+        h1 = torch.empty(n2, dtype=torch.int32, device=dev); h2 = torch.empty_like(h1)
+        pr = torch.empty(n2, dtype=torch.float64, device=dev); mt = torch.empty_like(pr)
+        ds = torch.empty((n2, obj.n_hla), dtype=torch.float64, device=dev)
+        pp = torch.empty((n2, obj.n_cell), dtype=torch.float64, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        for name, vote, post in (("cfg2_prob", 1, pp), ("cfg2_vote2", 2, None)):
+            def one():
+                m.predict_device(dg.data_ptr(), n2, vote, h1.data_ptr(), h2.data_ptr(), pr.data_ptr(), mt.data_ptr(), ds.data_ptr(),
+                                 None if post is None else post.data_ptr(), stream=st)
+                torch.cuda.synchronize(dev)
+            ms = median_ms(one, 10)
+            acc = float(np.mean((h1.cpu().numpy() == truth[:, 0]) & (h2.cpu().numpy() == truth[:, 1])))
+            res[name] = {"samples_per_s": n2 / ms * 1e3, "ms_per_step": ms, "repetitions": 10, "call_accuracy_vs_truth": acc,
+                         "what": ("type='response+prob': also the posterior matrix, %d B per sample" % (8 * obj.n_cell)) if post is not None
+                                 else "vote='majority' (k_vote_best + k_vote_tally instead of pass 2)"}
+        m.close()
+    except Exception as e:
+        res["cfg2_prob"] = {"error": repr(e)}
+    try:
+        from hibag_amd.plugin import PluginHost
+        obj, founders, af = synth.make_model(SHAPE)
+        ns = 400
+        G, truth = synth.make_samples(founders, af, ns, seed=synth.DEFAULT_SEED + 1)
+        host = PluginHost(obj)                       # predict_init: the host's haplotype lists
+        geno, wt = host.pack(G)                      # the host's own work per sample (IntToSNP, weights), done up front
+        prob = np.zeros(obj.n_cell); match = np.zeros(1)
+        for i in range(20):
+            host.avg_prob(geno[i], wt[i], prob, match)
+        best = np.zeros(ns, np.int64)
+        t = time.perf_counter()
+        for i in range(ns):
+            host.avg_prob(geno[i], wt[i], prob, match)
+            best[i] = int(np.argmax(prob))
+        dt = time.perf_counter() - t
+        host.close()
+        nh = obj.n_hla
+        cell = {(a, b): b + a * (2 * nh - a - 1) // 2 for a in range(nh) for b in range(a, nh)}
+        want = np.array([cell[(min(a, b), max(a, b))] for a, b in truth])
+        res["plugin_per_sample"] = {"samples_per_s": ns / dt, "us_per_call": dt / ns * 1e6, "samples": ns,
+                                    "call_accuracy_vs_truth": float(np.mean(best == want)),
+                                    "what": "the reference's own GPU hook, TypeGPUExtProc.predict_avg_prob: ONE sample per call "
+                                            "(src/LibHLA.cpp:2433-2441), genotypes packed by the host beforehand; upload of 100 "
+                                            "TGenotype + weights, the kernels with one live lane, download of the posterior, a "
+                                            "synchronisation -- latency-bound by construction, the batched entry is the product"}
+    except Exception as e:
+        res["plugin_per_sample"] = {"error": repr(e)}
     try:
         obj, founders, af = synth.make_model("hla-drb1")
         n4 = 4096
@@ -341,7 +463,6 @@ def other_configs(K):
         t = time.perf_counter()
         m = hibag_amd.hlaModelFromObj(obj)
         t_fin = time.perf_counter() - t
-        dev = torch.device("cuda", torch.cuda.current_device())
         dg = torch.from_numpy(G).to(dev)
         h1 = torch.empty(n4, dtype=torch.int32, device=dev); h2 = torch.empty_like(h1)
         pr = torch.empty(n4, dtype=torch.float64, device=dev); mt = torch.empty_like(pr)
@@ -360,7 +481,7 @@ def other_configs(K):
         tm = m.get_timing(); m.set_timing(False)
         acc_ms = tm["accum"][0] / max(tm["accum"][1], 1)
         tot_ms = tm["total"][0] / max(tm["total"][1], 1)
-        floor, ach_tot = issue_floor(obj, tot_ms, n4, K)
+        floor, ach_tot = issue_floor(obj, tot_ms, n4, K, m)
         stored = m.stored_cells()
         acc = float(np.mean((h1.cpu().numpy() == truth[:, 0]) & (h2.cpu().numpy() == truth[:, 1])))
         res["cfg4_hla_drb1"] = {"samples_per_s": n4 / dt, "samples": n4, "ms_per_step": dt * 1e3,
@@ -376,7 +497,7 @@ def other_configs(K):
                                          "pass2_hbm_read_gb_per_s": round(gb / (acc_ms * 1e-3), 1),
                                          "pass2_hbm_frac_of_8tb_s": round(gb / (acc_ms * 1e-3) / 8000.0, 3)})
         else:
-            floor2, ach2 = issue_floor(obj, acc_ms, n4, K)
+            floor2, ach2 = issue_floor(obj, acc_ms, n4, K, m)
             res["cfg4_hla_drb1"].update({"pass2": "evaluates every haplotype pair again", "k_accum_issue_frac": round(floor2 / ach2, 4)})
         m.close()
     except Exception as e:                       # an extra must not take the metric line down
@@ -401,6 +522,88 @@ def other_configs(K):
     except Exception as e:
         res["cfg5_training"] = {"error": repr(e)}
     return res
+
+
+def main_threads(args):
+    """`--launcher threads`: ONE process, one host thread per GPU, no torch.distributed: every thread drives its own replica
+    of the model (hibag_hip_model_replicate) through the device entry of the C ABI on its own 10,000 resident samples --
+    what an R / C++ host does with a node's GPUs.  Timing as in the ranks mode: a barrier over
+    the threads and a device synchronisation on both sides of exactly K steps, the slowest thread's time."""
+    import threading
+    import numpy as np
+    import torch
+    import hibag_amd
+    from hibag_amd import synth
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: hibag_amd has no CPU fallback")
+    n_dev = torch.cuda.device_count()
+    N = args.gpus
+    devices = [i % n_dev for i in range(N)]          # (more replicas than devices: several on one, for a dry run on a 1-GPU box)
+    target = hibag_amd.hlaSetKernelTarget("hip")[0]
+    model_obj, founders, afreq = synth.make_model(args.shape, wide_classifier=not args.no_wide)
+    n = args.samples
+    vote_method = 2 if args.vote == "majority" else 1
+    first = hibag_amd.hlaModelFromObj(model_obj, device=devices[0])
+    models = [first] + [first.replicate(d) for d in devices[1:]]
+    bar = threading.Barrier(N)
+    times, accs, errs = [0.0] * N, [0.0] * N, []
+
+    def worker(r):
+        try:
+            dev = torch.device("cuda", devices[r])
+            torch.cuda.set_device(dev)
+            geno, truth = synth.make_samples(founders, afreq, n, seed=synth.DEFAULT_SEED + 1 + r)
+            m = models[r]
+            dg = torch.from_numpy(geno).to(dev)
+            h1 = torch.empty(n, dtype=torch.int32, device=dev); h2 = torch.empty_like(h1)
+            pr = torch.empty(n, dtype=torch.float64, device=dev); mt = torch.empty_like(pr)
+            ds = torch.empty((n, model_obj.n_hla), dtype=torch.float64, device=dev)
+            st = torch.cuda.Stream(dev)               # (a stream per thread: replicas on one device run side by side)
+
+            def step():
+                m.predict_device(dg.data_ptr(), n, vote_method, h1.data_ptr(), h2.data_ptr(), pr.data_ptr(), mt.data_ptr(),
+                                 ds.data_ptr(), None, stream=st.cuda_stream)
+            for _ in range(args.warmup):
+                step()
+            st.synchronize(); bar.wait(); st.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            st.synchronize(); bar.wait(); st.synchronize()
+            times[r] = time.perf_counter() - t0
+            if m.status() != 0:
+                raise RuntimeError("a launch reported a failed hand-over")
+            accs[r] = float(np.mean((h1.cpu().numpy() == truth[:, 0]) & (h2.cpu().numpy() == truth[:, 1])))
+        except Exception as e:                        # noqa: BLE001
+            errs.append(repr(e))
+            bar.abort()
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(N)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        sys.exit("bench.py --launcher threads: " + "; ".join(errs))
+    dt = max(times)
+    pair_evals = model_obj.pair_evals_per_sample()
+    out = {
+        "metric": "hlaPredict() samples/sec, 10k samples x 100-classifier HLA-B",
+        "value": n * N * args.steps / dt, "unit": "samples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"synthetic {args.shape} model ({model_obj.n_hla} alleles, {len(model_obj.classifiers)} classifiers, "
+                               f"{model_obj.n_snp} SNPs, {pair_evals} haplotype-pair evaluations/sample), {n} samples per GPU per step, "
+                               f"type=response+dosage, vote={args.vote}",
+                   "samples_per_gpu": n, "parallelism": f"sample-sharded x{N} (no collective)", "kernel_target": target,
+                   "launcher": f"threads: one process, one host thread and one model replica per GPU through the C ABI "
+                               f"(devices {devices})"},
+        "pair_evals_per_s": n * N * args.steps / dt * pair_evals,
+        "call_accuracy_vs_truth": float(np.mean(accs)), "rccl_ranks": None,
+    }
+    print(json.dumps(out))
+    for m in models[1:]:
+        m.close()
+    first.close()
 
 
 def spawn_ranks(n_gpus):

@@ -601,6 +601,12 @@ int finalize_model(hibag_hip_model *m)
 			else if (!strcmp(e, "hybrid")) m->store_mode = n_big ? 2 : 0;
 		}
 	}
+	{
+		// nothing pass 2 could evaluate (no one-step FP4 classifier, e.g. the per-sample plugin path): read everything back
+		bool any_eval = false;
+		for (int c = 0; c < C; c++) any_eval |= pass2_evaluates(c);
+		if (m->store_mode == 2 && !any_eval) m->store_mode = 1;
+	}
 	const int store_mode = m->store_mode;
 	// stored[c][p]: pass 1 stores the sum of cell p of classifier c.  Mode 2: the cells of a matrix-engine classifier with
 	// more than `store_above` pairs, at most HIBAG_STORED_PER_VISIT per (classifier, tile) -- the ones with the most pairs --
@@ -1213,14 +1219,17 @@ int staged_streams(hibag_hip_model *m, StagedStreams **out)
 
 // Samples per slice of the host-pointer entries: the workspace bound, at most ~1 GB of staged genotypes (a cohort matrix
 // may carry every SNP of the genome: `row_len` is the cohort's, not the model's), and -- for cohorts worth pipelining --
-// about a quarter of the cohort but no less than 16,384 samples (smaller batches leave the last round of a pass too empty).
+// 12,288 samples: measured on the benchmark model at 100,000 samples (tools/host_path_probe.py, profiles/r03_staged_slices.txt)
+// slices of 10-12k give 17.0 ms against 15.4 with the cohort resident in HBM; 25k: 18.0, 50k: 19.4, one slice: 18.5 (what is
+// exposed is the first upload and the last download, and a batch of 12k runs within 2 % of the speed of one of 100k).
 int staged_slice(const hibag_hip_model *m, int n_samp, size_t row_len)
 {
 	long long slice = std::min<long long>(batch_limit(m), ((long long)std::max(n_samp, 1) + 63) / 64 * 64);
 	const long long by_geno = (long long)((1ull << 30) / (std::max<size_t>(row_len, 1) * sizeof(int32_t)));
 	slice = std::min(slice, std::max<long long>(64, by_geno));
-	if (n_samp >= 2 * 16384) slice = std::min(slice, std::max<long long>(16384, (n_samp + 3) / 4));
-	return (int)std::max<long long>(64, slice / 64 * 64);
+	if (n_samp >= 2 * 12288) slice = std::min<long long>(slice, 12288);
+	if (const char *e = getenv("HIBAG_STAGED_SLICE")) slice = std::min<long long>(batch_limit(m), std::max(64, atoi(e)));     // (diagnostic)
+	return (int)std::max<long long>(64, (slice + 63) / 64 * 64);
 }
 
 int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSource *bed, int n_samp, int vote_method,
@@ -1326,11 +1335,15 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 				dosage ? (double *)(o + o_ds) : nullptr, postprob ? (double *)(o + o_pp) : nullptr, ss->run))
 			return rc;
 		if (piped) HIP_TRY(hipEventRecord(ss->ran[i & 1], ss->run));
+		if (trace && piped) fprintf(stderr, "[hibag staged] slice %d enqueued at %.3f ms\n", i, now() - tr[0]);
 		if (trace && !piped) { tr[2] = now(); (void)hipStreamSynchronize(ss->run); tr[3] = now(); }
+		// With the kernels of slice i enqueued, the host fills the next staging buffer and starts its transfer -- BEFORE the
+		// download of slice i is queued: the copy engine takes transfers in submission order, and a download that waits for
+		// its kernels would hold up every upload submitted behind it (measured: no overlap at all the other way round).
+		if (i + 1 < n_slice) if (int rc = upload(i + 1)) return rc;
 		if (piped && i >= 2) if (int rc = drain(i - 2)) return rc;          // (frees the staging buffer download(i) writes)
 		if (int rc = download(i)) return rc;
-		// with the kernels of slice i enqueued, the host fills the next staging buffer and starts its transfer
-		if (i + 1 < n_slice) if (int rc = upload(i + 1)) return rc;
+		if (trace && piped) fprintf(stderr, "[hibag staged] slice %d: download queued, next upload staged at %.3f ms\n", i, now() - tr[0]);
 	}
 	if (piped) {
 		if (n_slice >= 2) if (int rc = drain(n_slice - 2)) return rc;

@@ -1108,7 +1108,10 @@ __device__ __forceinline__ EHeader read_header(uint32_t hv)      // lanes 0..7 h
 	return H;
 }
 
-__global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, 4) void k_accum(HibagModelView M, HibagBatchView B, int n_whole, int K)
+#ifndef ACCUM_OCC
+#define ACCUM_OCC 4                         // workgroups per CU pass 2 is compiled for
+#endif
+__global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(HibagModelView M, HibagBatchView B, int n_whole, int K)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double acc_s[ACCUM_WAVES][HIBAG_TILE][HIBAG_WAVE];

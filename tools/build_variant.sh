@@ -1,11 +1,12 @@
 #!/bin/bash
-# tools/build_variant.sh NAME [-DFLAG ...]: libhibag_hip.so with extra compiler flags on the kernels, as
-# gpurun_var_NAME.so at the repo root (tools/run_variants.sh times each of them on the GPU box).
+# tools/build_variant.sh NAME [-DFLAG ...]: libhibag_hip.so with extra compiler flags on the kernels and the host code that
+# shares their headers, as gpurun_var_NAME.so at the repo root (tools/run_variants.sh times each of them on the GPU box).
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 src=hibag_amd/csrc
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -Wall -Wno-unused-result"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $src/hibag_kernels.hip -o /tmp/var_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_var_$name.so /tmp/var_$name.o $src/hibag_api.o $src/hibag_build.o $src/hibag_train.o
+/opt/rocm/bin/hipcc $FLAGS "$@" -c $src/hibag_api.hip -o /tmp/var_${name}_api.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_var_$name.so /tmp/var_$name.o /tmp/var_${name}_api.o $src/hibag_build.o $src/hibag_train.o
 echo built gpurun_var_$name.so

@@ -31,5 +31,14 @@ d = [torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.i
 st = torch.cuda.current_stream(dev).cuda_stream
 def resident():
     m.predict_device(dg.data_ptr(), n, 1, *[x.data_ptr() for x in d], None, stream=st); torch.cuda.synchronize(dev)
+sub = int(os.environ.get("PROBE_SUB", "0"))
+if sub:
+    def resident_sub():
+        for a in range(0, n, sub):
+            k = min(sub, n - a)
+            m.predict_device(dg[a:].data_ptr(), k, 1, d[0][a:].data_ptr(), d[1][a:].data_ptr(), d[2][a:].data_ptr(), d[3][a:].data_ptr(),
+                             d[4][a:].data_ptr(), None, stream=st)
+        torch.cuda.synchronize(dev)
+    print(f"device-resident in sub-batches of {sub}: {med(resident_sub):.3f} ms")
 print(f"n={n}  fresh outputs {med(lambda: m.predict_raw(G, 1, want_dosage=True)):.3f} ms   reused outputs {med(reused):.3f} ms   device-resident {med(resident):.3f} ms"
       f"   (HIBAG_STAGED_NULL={os.environ.get('HIBAG_STAGED_NULL')})")
