@@ -509,13 +509,14 @@ def other_configs(K):
         tr = train._Trainer(G, truth[:, 0], truth[:, 1], mdl.n_hla)
         tr.set_seed(100)
         tr.new_classifiers(1, mtry, True, False, False)           # warm-up (allocations, first launches)
-        ncl = 4
+        ncl = 100                                                 # BASELINE config 5: 100 individual classifiers
         t = time.perf_counter()
         tr.new_classifiers(ncl, mtry, True, False, False)
         dt = (time.perf_counter() - t) / ncl
-        cls = tr.classifiers()
+        cls = tr.classifiers()[1:]
         tr.close()
-        res["cfg5_training"] = {"s_per_classifier": dt, "classifiers_per_s": 1.0 / dt, "n_samp": 1000, "n_snp": 300,
+        res["cfg5_training"] = {"s_per_classifier": dt, "classifiers_per_s": 1.0 / dt, "model_of_100_classifiers_s": dt * ncl,
+                                "n_samp": 1000, "n_snp": 300,
                                 "n_hla": mdl.n_hla, "mtry": mtry, "classifiers_timed": ncl,
                                 "mean_snps": float(np.mean([len(c.snpidx) for c in cls])),
                                 "mean_haplo": float(np.mean([len(c.freq) for c in cls]))}

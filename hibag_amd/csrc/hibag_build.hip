@@ -69,6 +69,7 @@ void reserve(void *&p, size_t &cap, size_t bytes, const char *what)
 {
 	if (bytes <= cap && p) return;
 	dev_free(p);
+	bytes = std::max(bytes, cap + cap / 2);      // geometric growth: a free + allocation of ~100 MB costs about a millisecond
 	HIP_OK(hipMalloc(&p, bytes), what);
 	cap = bytes;
 }
@@ -187,17 +188,77 @@ struct BatchView {
 	const uint32_t *planes;    // [2*NW][n_pad] base genotypes (candidate position missing)
 	const uint32_t *cand_w;    // [n_cand][2][n_pad]: words `word` of S1 / S2 with the candidate SNP set
 	const int *cells;          // [n_cand][max_cells] packed (h1 << 16 | h2) of the non-empty cells, posterior order
+	const int4 *cellb;         // [n_cand][max_cells] the cell's haplotype ranges {a0, a1, b0, b1} (absolute indices): one 16-byte
+	                           // scalar load per cell, requested a cell ahead, instead of a chain of five dependent ones
 	const int *seg;            // [n_cand][n_seg+1] segment bounds in that list
 	int max_cells;
 	const int *true_cell;      // [n_pad]
+	const int *wpos;           // [n_cand][n_pad] position of the sample's true pair in the candidate's cell list (-1: an empty cell)
 	const double *tab;
-	double *cellv;             // [n_cand][max_cells][n_pad]
+	double *cellv;             // [n_cand][n_pad / 64][max_cells][64]: a sample group's cell sums of a candidate are one contiguous stream
 	int *best;                 // [n_cand][2][n_pad]
 	double *post;              // [n_cand][n_pad]
 };
 
+#define SCAN_NB 32          // cells k_batch_scan has in flight; BatchView::max_cells is a multiple of it
+
+// One workgroup = (four sample groups, cell segment, candidate): the candidate's haplotype words and frequencies are staged
+// in LDS once for the four wavefronts (round 2 fetched them pair by pair through the scalar cache -- two dependent loads
+// per pair with one or two wavefronts per SIMD to hide them: 93 us per launch, profiles/r03_cfg5_*), lane = sample.
+// A candidate with more haplotypes than the staging area holds (BATCH_LDS_HAPLO) keeps the direct path.
+#define BATCH_WAVES 4
+#define BATCH_LDS_HAPLO 1024
+
 template <int W>
-__device__ __forceinline__ void batch_cells(const BatchView &B, int c, int sg, int s, const double *tab_s)
+__device__ __forceinline__ double batch_cell(const uint32_t *hb, const double *hf, int n_haplo, int a0, int a1, int b0, int b1,
+	bool diagonal, const LaneG<W> &G, const double *tab_s)
+{
+	// (the arithmetic and its order are build_cell's: src/LibHLA.cpp:1653-1668 diagonal, :1680-1691 off-diagonal)
+	double cell = 0;
+	for (int a = a0; a < a1; a++) {
+		uint32_t A[W];
+		int ca = 0;
+#pragma unroll
+		for (int w = 0; w < W; w++) { A[w] = hb[w * n_haplo + a]; ca += __popc((A[w] ^ G.t[w]) & G.zt[w]); }
+		const double fa = hf[a];
+		int b = b0;
+		if (diagonal) { cell += (fa * fa) * tab_s[2 * ca + G.n_het]; b = a + 1; }
+		const double ff = 2 * fa;
+		for (; b + 4 <= b1; b += 4) {                 // four pairs' look-ups in flight
+			int d[4];
+			double fb[4];
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				d[q] = ca;
+#pragma unroll
+				for (int w = 0; w < W; w++) {
+					const uint32_t Bw = hb[w * n_haplo + b + q];
+					d[q] += __popc((Bw ^ G.t[w]) & G.zt[w]) + __popc(~(A[w] ^ Bw) & G.e[w]);
+				}
+				fb[q] = hf[b + q];
+			}
+			double t[4];
+#pragma unroll
+			for (int q = 0; q < 4; q++) t[q] = tab_s[d[q]];
+#pragma unroll
+			for (int q = 0; q < 4; q++) cell += (ff * fb[q]) * t[q];
+		}
+		for (; b < b1; b++) {
+			int d = ca;
+#pragma unroll
+			for (int w = 0; w < W; w++) {
+				const uint32_t Bw = hb[w * n_haplo + b];
+				d += __popc((Bw ^ G.t[w]) & G.zt[w]) + __popc(~(A[w] ^ Bw) & G.e[w]);
+			}
+			cell += (ff * hf[b]) * tab_s[d];
+		}
+	}
+	return cell;
+}
+
+template <int W>
+__device__ __forceinline__ void batch_cells(const BatchView &B, int c, int sg, int s, const double *tab_s,
+	const uint32_t *hb_s, const double *hf_s, int h_lo, int n_h)
 {
 	LaneG<W> G;
 	G.n_het = 0;
@@ -208,29 +269,48 @@ __device__ __forceinline__ void batch_cells(const BatchView &B, int c, int sg, i
 		G.zt[w] = ~(s1 ^ s2); G.t[w] = s1 & s2; G.e[w] = s1 & ~s2;
 		G.n_het += __popc(G.e[w]);
 	}
-	BuildView V{};
-	V.n_haplo = B.n_haplo_total; V.hb = B.hb; V.hf = B.hf;
-	const int *st = B.start + (size_t)c * (B.n_hla + 1);
-	const int *cl = B.cells + (size_t)c * B.max_cells;
+	const int4 *__restrict__ cb = B.cellb + (size_t)c * B.max_cells;
 	const int i0 = B.seg[c * (B.n_seg + 1) + sg], i1 = B.seg[c * (B.n_seg + 1) + sg + 1];
+	double *__restrict__ out = B.cellv + ((size_t)c * (B.n_pad / HIBAG_WAVE) + (s >> 6)) * B.max_cells * HIBAG_WAVE + (s & 63);
+	int4 nb = cb[i0 < i1 ? i0 : 0];
 	for (int i = i0; i < i1; i++) {
-		const int h1 = cl[i] >> 16, h2 = cl[i] & 0xFFFF;
-		const double cell = build_cell<W>(V, st[h1], st[h1 + 1], st[h2], st[h2 + 1], h1 == h2, G, tab_s);
-		B.cellv[((size_t)c * B.max_cells + i) * B.n_pad + s] = cell;
+		const int4 r = nb;
+		nb = cb[i + 1 < i1 ? i + 1 : i];         // the next cell's ranges travel while this cell is summed
+		double cell;
+		if (hb_s)      // the candidate's list sits in LDS, indices relative to its first haplotype
+			cell = batch_cell<W>(hb_s, hf_s, n_h, r.x - h_lo, r.y - h_lo, r.z - h_lo, r.w - h_lo, r.x == r.z, G, tab_s);
+		else
+			cell = batch_cell<W>(B.hb, B.hf, B.n_haplo_total, r.x, r.y, r.z, r.w, r.x == r.z, G, tab_s);
+		out[(size_t)i * HIBAG_WAVE] = cell;
 	}
+	if (sg == B.n_seg - 1)                      // k_batch_scan reads whole groups of SCAN_NB cells: the list's end is padded with +0.0
+		for (int i = i1; i < (i1 + SCAN_NB - 1) / SCAN_NB * SCAN_NB; i++) out[(size_t)i * HIBAG_WAVE] = 0.0;
 }
 
-__global__ __launch_bounds__(HIBAG_WAVE) void k_batch_cells(BatchView B)
+__global__ __launch_bounds__(BATCH_WAVES * HIBAG_WAVE) void k_batch_cells(BatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
+	__shared__ double hf_s[BATCH_LDS_HAPLO];
+	__shared__ uint32_t hb_s[NW * BATCH_LDS_HAPLO];
+	const int c = blockIdx.z;
+	const int *st = B.start + (size_t)c * (B.n_hla + 1);
+	const int h_lo = st[0], n_h = st[B.n_hla] - st[0];
+	const bool staged = n_h <= BATCH_LDS_HAPLO;
 	for (int i = threadIdx.x; i < HIBAG_TAB_N; i += blockDim.x) tab_s[i] = B.tab[i];
+	if (staged) {
+		for (int i = threadIdx.x; i < n_h; i += blockDim.x) hf_s[i] = B.hf[h_lo + i];
+		for (int w = 0; w < B.nw; w++)
+			for (int i = threadIdx.x; i < n_h; i += blockDim.x) hb_s[w * n_h + i] = B.hb[(size_t)w * B.n_haplo_total + h_lo + i];
+	}
 	__syncthreads();
-	const int s = blockIdx.x * HIBAG_WAVE + threadIdx.x;
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= B.n_pad) return;
+	const uint32_t *hbp = staged ? hb_s : nullptr;
 	switch (B.nw) {
-	case 1:  batch_cells<1>(B, blockIdx.z, blockIdx.y, s, tab_s); break;
-	case 2:  batch_cells<2>(B, blockIdx.z, blockIdx.y, s, tab_s); break;
-	case 3:  batch_cells<3>(B, blockIdx.z, blockIdx.y, s, tab_s); break;
-	default: batch_cells<4>(B, blockIdx.z, blockIdx.y, s, tab_s); break;
+	case 1:  batch_cells<1>(B, c, blockIdx.y, s, tab_s, hbp, hf_s, h_lo, n_h); break;
+	case 2:  batch_cells<2>(B, c, blockIdx.y, s, tab_s, hbp, hf_s, h_lo, n_h); break;
+	case 3:  batch_cells<3>(B, c, blockIdx.y, s, tab_s, hbp, hf_s, h_lo, n_h); break;
+	default: batch_cells<4>(B, c, blockIdx.y, s, tab_s, hbp, hf_s, h_lo, n_h); break;
 	}
 }
 
@@ -240,28 +320,29 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_batch_scan(BatchView B)
 	const int s = blockIdx.x * HIBAG_WAVE + threadIdx.x;
 	const int *cl = B.cells + (size_t)c * B.max_cells;
 	const int n = B.seg[c * (B.n_seg + 1) + B.n_seg];
-	const int want = B.true_cell[s];
+	const int wpos = B.wpos[(size_t)c * B.n_pad + s];
 	double best = 0, total = 0, hit = 0;
-	int b1 = -2147483647 - 1, b2 = -2147483647 - 1;
-	const double *__restrict__ col = B.cellv + (size_t)c * B.max_cells * B.n_pad + s;
-	for (int i0 = 0; i0 < n; i0 += 64) {
-		// 64 loads in flight, then the strictly ordered scan over them: one load per dependent
-		// iteration would make this kernel pure memory latency (hundreds of cells per candidate)
-		double v[64];
+	int bi = -1;
+	const double *__restrict__ col = B.cellv + ((size_t)c * (B.n_pad / HIBAG_WAVE) + (s >> 6)) * B.max_cells * HIBAG_WAVE + (s & 63);
+	for (int i0 = 0; i0 < n; i0 += SCAN_NB, col += (size_t)SCAN_NB * HIBAG_WAVE) {
+		// SCAN_NB loads in flight, then the strictly ordered scan over them: one load per dependent iteration would make
+		// this kernel pure memory latency (hundreds of cells per candidate).  No condition anywhere near the loads -- with
+		// one branch per load (round 2's form) the compiler serialised them: 146 us per launch (profiles/r03_cfg5_*) -- the list
+		// is padded with +0.0 instead, which can neither become the maximum nor change the total.
+		double v[SCAN_NB];
 #pragma unroll
-		for (int j = 0; j < 64; j++) v[j] = (i0 + j < n) ? col[(size_t)(i0 + j) * B.n_pad] : 0.0;
+		for (int j = 0; j < SCAN_NB; j++) v[j] = __builtin_nontemporal_load(col + (size_t)j * HIBAG_WAVE);
 #pragma unroll
-		for (int j = 0; j < 64; j++) {
-			if (i0 + j >= n) break;
-			const int h1 = cl[i0 + j] >> 16, h2 = cl[i0 + j] & 0xFFFF;
+		for (int j = 0; j < SCAN_NB; j++) {
 			const double cell = v[j];
-			if (best < cell) { best = cell; b1 = h1; b2 = h2; }
-			if (h2 + h1 * (2 * B.n_hla - h1 - 1) / 2 == want) hit = cell;
+			if (best < cell) { best = cell; bi = i0 + j; }          // first strict maximum (_BestGuess, src/LibHLA.cpp:1639-1704)
+			if (i0 + j == wpos) hit = cell;                         // the true pair's cell (_PostProb, :1706-1767)
 			total += cell;
 		}
 	}
-	B.best[((size_t)c * 2) * B.n_pad + s] = b1;
-	B.best[((size_t)c * 2 + 1) * B.n_pad + s] = b2;
+	const int hh = bi >= 0 ? cl[bi] : 0;
+	B.best[((size_t)c * 2) * B.n_pad + s] = bi >= 0 ? hh >> 16 : -2147483647 - 1;
+	B.best[((size_t)c * 2 + 1) * B.n_pad + s] = bi >= 0 ? hh & 0xFFFF : -2147483647 - 1;
 	B.post[(size_t)c * B.n_pad + s] = hit / total;
 }
 
@@ -567,7 +648,7 @@ uint32_t *hibag_build_haplomatch(const PluginHaplotype haplo[], const size_t n_h
 // build_acc_ib calls returns for n_cand candidate SNPs that extend the same genotype list
 // (src/LibHLA.cpp:2018-2038), evaluated together.  base_geno holds the committed SNPs
 // (position n_snp-1 missing); cand[i].column is the raw genotype of candidate i per sample.
-double g_batch_prof[4] = {0, 0, 0, 0};     // host packing, copies + kernels, read-back, host reductions (s)
+double g_batch_prof[6] = {0, 0, 0, 0, 0, 0};     // host packing, copies + kernels, read-back, host reductions; of the packing: staging copy, (re)allocation (s)
 static double batch_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const HibagBuildCandidate cand[], int n_cand,
@@ -585,7 +666,7 @@ void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const H
 	std::vector<uint32_t> hb((size_t)nw * Hs, 0), cw((size_t)n_cand * 2 * np);
 	std::vector<double> hf(Hs, 0.0);
 	std::vector<int> start((size_t)n_cand * (nh + 1), 0), cells, seg;
-	static const int wave_target = getenv("HIBAG_BATCH_WAVES") ? atoi(getenv("HIBAG_BATCH_WAVES")) : 2048;
+	static const int wave_target = getenv("HIBAG_BATCH_WAVES") ? atoi(getenv("HIBAG_BATCH_WAVES")) : 8192;
 	const int n_seg = std::max(1, std::min(64, wave_target / std::max(1, (np / HIBAG_WAVE) * n_cand)));
 	int max_cells = 1;
 	std::vector<std::vector<int>> cell_list(n_cand);
@@ -634,7 +715,17 @@ void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const H
 			cw[((size_t)c * 2 + 1) * np + s] = s2;
 		}
 	}
+	max_cells = (max_cells + SCAN_NB - 1) / SCAN_NB * SCAN_NB;
 	cells.assign((size_t)n_cand * max_cells, 0);
+	std::vector<int> cellb((size_t)n_cand * max_cells * 4, 0);
+	for (int c = 0; c < n_cand; c++) {
+		const int *st = &start[(size_t)c * (nh + 1)];
+		for (size_t i = 0; i < cell_list[c].size(); i++) {
+			const int h1 = cell_list[c][i] >> 16, h2 = cell_list[c][i] & 0xFFFF;
+			int *r = &cellb[((size_t)c * max_cells + i) * 4];
+			r[0] = st[h1]; r[1] = st[h1 + 1]; r[2] = st[h2]; r[3] = st[h2 + 1];
+		}
+	}
 	seg.assign((size_t)n_cand * (n_seg + 1), 0);
 	for (int c = 0; c < n_cand; c++) {
 		std::copy(cell_list[c].begin(), cell_list[c].end(), cells.begin() + (size_t)c * max_cells);
@@ -667,17 +758,32 @@ void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const H
 		true_cell[s] = a2 + a1 * (2 * nh - a1 - 1) / 2;
 	}
 
+	// where each sample's true pair sits in each candidate's cell list
+	std::vector<int> wpos((size_t)n_cand * np, -1);
+	{
+		std::vector<int> at((size_t)nh * (nh + 1) / 2);
+		for (int c = 0; c < n_cand; c++) {
+			std::fill(at.begin(), at.end(), -1);
+			for (size_t i = 0; i < cell_list[c].size(); i++) {
+				const int h1 = cell_list[c][i] >> 16, h2 = cell_list[c][i] & 0xFFFF;
+				at[h2 + h1 * (2 * nh - h1 - 1) / 2] = (int)i;
+			}
+			for (int s = 0; s < n; s++) wpos[(size_t)c * np + s] = at[true_cell[s]];
+		}
+	}
+
 	// One device arena = [inputs | outputs | scratch]; the inputs travel in ONE copy from a pinned
 	// staging buffer and the outputs come back in one: a growth step is a handful of small arrays,
 	// and a dozen separate pageable copies cost more than the kernels.
 	size_t o = 0;
 	auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
 	const size_t o_hb = take(hb.size() * 4), o_cw = take(cw.size() * 4), o_start = take(start.size() * 4),
-		o_cells = take(cells.size() * 4), o_seg = take(seg.size() * 4), o_planes = take(planes.size() * 4),
-		o_true = take(true_cell.size() * 4), o_hf = take(hf.size() * 8), in_end = o;
+		o_cells = take(cells.size() * 4), o_cellb = take(cellb.size() * 4), o_seg = take(seg.size() * 4), o_planes = take(planes.size() * 4),
+		o_true = take(true_cell.size() * 4), o_wpos = take(wpos.size() * 4), o_hf = take(hf.size() * 8), in_end = o;
 	const size_t b_best = (size_t)n_cand * 2 * np * 4, b_post = (size_t)n_cand * np * 8;
 	const size_t o_best = take(b_best), o_post = take(b_post), out_end = o;
 	const size_t o_cellv = take((size_t)n_cand * max_cells * np * 8);
+	const double t_res0 = batch_now();
 	reserve(g.d_batch, g.cap_batch, o, "hipMalloc(batch)");
 	if (out_end > g.cap_stage) {
 		if (g.h_stage) (void)hipHostFree(g.h_stage);
@@ -685,22 +791,26 @@ void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const H
 		HIP_OK(hipHostMalloc(&g.h_stage, out_end * 2, hipHostMallocDefault), "hipHostMalloc(staging)");
 		g.cap_stage = out_end * 2;
 	}
+	const double t_res1 = batch_now();
 	char *d = (char *)g.d_batch, *h = (char *)g.h_stage;
 	memcpy(h + o_hb, hb.data(), hb.size() * 4);
 	memcpy(h + o_cw, cw.data(), cw.size() * 4);
 	memcpy(h + o_start, start.data(), start.size() * 4);
 	memcpy(h + o_cells, cells.data(), cells.size() * 4);
+	memcpy(h + o_cellb, cellb.data(), cellb.size() * 4);
 	memcpy(h + o_seg, seg.data(), seg.size() * 4);
 	memcpy(h + o_planes, planes.data(), planes.size() * 4);
 	memcpy(h + o_true, true_cell.data(), true_cell.size() * 4);
+	memcpy(h + o_wpos, wpos.data(), wpos.size() * 4);
 	memcpy(h + o_hf, hf.data(), hf.size() * 8);
 	const double t1 = batch_now();
+	g_batch_prof[4] += t1 - t_res1; g_batch_prof[5] += t_res1 - t_res0;
 	HIP_OK(hipMemcpyAsync(d, h, in_end, hipMemcpyHostToDevice, 0), "copy batch");
 	BatchView B{nh, np, nw, n_cand, n_seg, word, (const uint32_t *)(d + o_hb), (const double *)(d + o_hf), (int)Hs,
 		(const int *)(d + o_start), (const uint32_t *)(d + o_planes), (const uint32_t *)(d + o_cw), (const int *)(d + o_cells),
-		(const int *)(d + o_seg), max_cells, (const int *)(d + o_true), (const double *)g.d_tab, (double *)(d + o_cellv),
+		(const int4 *)(d + o_cellb), (const int *)(d + o_seg), max_cells, (const int *)(d + o_true), (const int *)(d + o_wpos), (const double *)g.d_tab, (double *)(d + o_cellv),
 		(int *)(d + o_best), (double *)(d + o_post)};
-	hipLaunchKernelGGL(k_batch_cells, dim3(np / HIBAG_WAVE, n_seg, n_cand), dim3(HIBAG_WAVE), 0, 0, B);
+	hipLaunchKernelGGL(k_batch_cells, dim3((np / HIBAG_WAVE + BATCH_WAVES - 1) / BATCH_WAVES, n_seg, n_cand), dim3(BATCH_WAVES * HIBAG_WAVE), 0, 0, B);
 	hipLaunchKernelGGL(k_batch_scan, dim3(np / HIBAG_WAVE, n_cand), dim3(HIBAG_WAVE), 0, 0, B);
 	HIP_OK(hipGetLastError(), "k_batch");
 	const double t2 = batch_now();

@@ -44,7 +44,7 @@
 
 int hibag_fail(int code, const char *fmt, ...);       // hibag_api.hip: sets the thread's last error
 int hibag_selected_device();                          // hibag_api.hip: the thread's hibag_hip_set_device() choice
-extern double g_batch_prof[4];                        // hibag_build.hip
+extern double g_batch_prof[6];                        // hibag_build.hip
 
 namespace {
 
@@ -260,7 +260,7 @@ typedef hibag_hip_trainer T;
 
 // wall-clock split of a training call, printed when HIBAG_TRAIN_PROFILE is set
 struct Profile {
-	double t[5] = {0, 0, 0, 0, 0};
+	double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 };
 Profile g_prof;
@@ -529,7 +529,7 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 {
 	const double rare_prob = std::max(FRACTION_HAPLO / (2 * t.n_samp), MIN_RARE_FREQ);
 	HapList out_haplo, next, minh;
-	init_haplotype(t, out_haplo);
+	{ Tick tk(6); init_haplotype(t, out_haplo); }
 	o.snpidx.clear();
 	const int num_oob = (int)t.outbag.size();
 	int global_max_acc = 0;
@@ -539,12 +539,13 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 		{ Tick tk(0); prepare_haplotypes(t, out_haplo, next); }
 		int max_acc = global_max_acc, min_i = -1;
 		double min_loss = global_min_loss;
-		select(t, vs, mtry);
+		{ Tick tk(4); select(t, vs, mtry); }
 
 		// The candidates of a step are independent until they are compared (each starts from
 		// OutHaplo, :2020-2025): fit them concurrently on the host, score them in one device
 		// pass, then apply the reference's sequential comparison to the results.
 		const int m = vs.m_try;
+		g_prof.t[7] += 1;                                               // growth steps
 		std::vector<HapList> cand(m);
 		std::vector<char> valid(m, 0);
 		{
@@ -585,6 +586,7 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 			hibag_build_eval_batch(t.g.data(), t.g_nsnp + 1, bc.data(), (int)bc.size(), a.data(), l.data());
 			for (size_t j = 0; j < which.size(); j++) { accv[which[j]] = a[j]; lossv[which[j]] = l[j]; }
 		}
+		Tick tk3(3);
 		for (int i = 0; i < m; i++) {                                   // :2018-2069
 			if (!valid[i]) continue;
 			const int acc = accv[i];
@@ -662,7 +664,7 @@ void build_classifiers(T &t, int nclassifier, int mtry, bool prune, bool verbose
 		init_selection(t, S);
 		OutClassifier o;
 		o.samp_num.assign(S.begin(), S.end());
-		search(t, vs, o, mtry, prune, verbose_detail);
+		{ Tick tk(5); search(t, vs, o, mtry, prune, verbose_detail); }
 		t.out.push_back(std::move(o));
 		if (verbose) {
 			const OutClassifier &c = t.out.back();
@@ -739,8 +741,9 @@ int hibag_hip_trainer_new_classifiers(hibag_hip_trainer *t, int nclassifier, int
 		build_classifiers(*t, nclassifier, mtry, prune != 0, verbose != 0 || verbose_detail != 0, verbose_detail != 0);
 		if (getenv("HIBAG_TRAIN_PROFILE"))
 			fprintf(stderr, "[hibag train] total %.3f s: pair lists (device) %.3f, EM (host) %.3f, scoring (device) %.3f "
-				"[pack %.3f, copy+kernels %.3f, read-back %.3f, reductions %.3f]\n",
-				Profile::now() - t0, g_prof.t[0], g_prof.t[1], g_prof.t[2], g_batch_prof[0], g_batch_prof[1], g_batch_prof[2], g_batch_prof[3]);
+				"[pack %.3f (staging %.3f, allocation %.3f), copy+kernels %.3f, read-back %.3f, reductions %.3f], compare + accept %.3f, select %.3f; search() %.3f, %d growth steps\n",
+				Profile::now() - t0, g_prof.t[0], g_prof.t[1], g_prof.t[2], g_batch_prof[0], g_batch_prof[4], g_batch_prof[5], g_batch_prof[1], g_batch_prof[2], g_batch_prof[3],
+				g_prof.t[3], g_prof.t[4], g_prof.t[5], (int)g_prof.t[7]);
 	} catch (const char *msg) {
 		t->out.resize(before);                         // a failed call adds nothing
 		return hibag_fail(hibag_hip_device_count() <= 0 ? HIBAG_HIP_ENODEV : HIBAG_HIP_EINVAL, "%s", msg);
