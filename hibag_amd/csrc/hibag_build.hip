@@ -51,6 +51,18 @@ struct BuildState {
 		*d_best = nullptr, *d_post = nullptr, *d_tab = nullptr, *d_match = nullptr, *d_batch = nullptr;
 	void *h_stage = nullptr;                // pinned host staging of the batched evaluation
 	size_t cap_h = 0, cap_s = 0, cap_match = 0, cap_batch = 0, cap_stage = 0;
+	// small uploads of the pair-list step: staged in pinned memory and sent asynchronously (a pageable hipMemcpy is a
+	// synchronisation each; a growth step made a dozen of them)
+	// the batched evaluation runs in up to two slots at a time (hibag_build_eval_launch / _collect): while the device scores
+	// one half of a growth step's candidates the host threads still fit the other half
+	struct Slot {
+		void *d = nullptr, *h = nullptr; size_t cap_d = 0, cap_h = 0;
+		hipEvent_t done = nullptr;
+		int n_cand = 0, np = 0; size_t o_best = 0, o_post = 0;
+		double t_launch = 0;
+	} slot[2];
+	void *h_up = nullptr; size_t cap_up = 0, up_at = 0;
+	void *d_pairs = nullptr; size_t cap_pairs = 0;
 };
 BuildState g;
 thread_local char g_msg[400];
@@ -64,6 +76,27 @@ thread_local char g_msg[400];
 #define HIP_OK(expr, what) do { hipError_t e_ = (expr); if (e_ != hipSuccess) build_throw(what, e_); } while (0)
 
 void dev_free(void *&p) { if (p) (void)hipFree(p); p = nullptr; }
+
+// Host -> device through the pinned staging area, asynchronously on the null stream (in order with the kernels that
+// follow).  The area is rewound by upload_rewind() at a point where everything sent before has been consumed.
+void upload_rewind() { g.up_at = 0; }
+void upload(void *dst, const void *src, size_t bytes, const char *what)
+{
+	if (bytes == 0) return;
+	if (g.up_at + bytes > g.cap_up) {
+		// (rare: grow; what is in flight from the old area must land first)
+		HIP_OK(hipStreamSynchronize(0), what);
+		if (g.h_up) (void)hipHostFree(g.h_up);
+		g.h_up = nullptr;
+		g.cap_up = std::max<size_t>((g.up_at + bytes) * 2, 1 << 20);
+		HIP_OK(hipHostMalloc(&g.h_up, g.cap_up, hipHostMallocDefault), "hipHostMalloc(upload staging)");
+		g.up_at = 0;
+	}
+	char *at = (char *)g.h_up + g.up_at;
+	memcpy(at, src, bytes);
+	g.up_at += (bytes + 63) & ~(size_t)63;
+	HIP_OK(hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, 0), what);
+}
 
 void reserve(void *&p, size_t &cap, size_t bytes, const char *what)
 {
@@ -451,9 +484,9 @@ void upload_haplo(const PluginHaplotype haplo[], int n_haplo, int n_snp, bool al
 	if (start[nh] != n_haplo) build_throw("haplotype counts per allele do not add up");
 	reserve(g.d_hb, g.cap_h, (size_t)NW * std::max(n_haplo, 1) * 4 + std::max(n_haplo, 1) * 8 + 64, "hipMalloc(haplotypes)");
 	g.d_hf = (char *)g.d_hb + (((size_t)NW * std::max(n_haplo, 1) * 4 + 7) & ~(size_t)7);
-	HIP_OK(hipMemcpy(g.d_hb, hb.data(), (size_t)nw * std::max(n_haplo, 1) * 4, hipMemcpyHostToDevice), "copy haplotypes");
-	HIP_OK(hipMemcpy(g.d_hf, hf.data(), hf.size() * 8, hipMemcpyHostToDevice), "copy frequencies");
-	HIP_OK(hipMemcpy(g.d_start, start.data(), (nh + 1) * sizeof(int), hipMemcpyHostToDevice), "copy allele starts");
+	upload(g.d_hb, hb.data(), (size_t)nw * std::max(n_haplo, 1) * 4, "copy haplotypes");
+	upload(g.d_hf, hf.data(), hf.size() * 8, "copy frequencies");
+	upload(g.d_start, start.data(), (nh + 1) * sizeof(int), "copy allele starts");
 }
 
 void upload_geno(const PluginGenotype geno[])
@@ -474,8 +507,8 @@ void upload_geno(const PluginGenotype geno[])
 		g.true1[s] = a1; g.true2[s] = a2;
 		true_cell[s] = a2 + a1 * (2 * nh - a1 - 1) / 2;    // src/LibHLA.cpp:1712
 	}
-	HIP_OK(hipMemcpy(g.d_planes, planes.data(), planes.size() * 4, hipMemcpyHostToDevice), "copy genotypes");
-	HIP_OK(hipMemcpy(g.d_true, true_cell.data(), np * sizeof(int), hipMemcpyHostToDevice), "copy true pairs");
+	upload(g.d_planes, planes.data(), planes.size() * 4, "copy genotypes");
+	upload(g.d_true, true_cell.data(), np * sizeof(int), "copy true pairs");
 }
 
 void evaluate()
@@ -538,10 +571,19 @@ void hibag_build_init(int n_hla, int n_sample)
 void hibag_build_done()
 {
 	for (void **p : {&g.d_hb, &g.d_start, &g.d_planes, &g.d_true, &g.d_best, &g.d_post, &g.d_tab, &g.d_match, &g.d_batch}) dev_free(*p);
+	for (BuildState::Slot &sl : g.slot) {
+		dev_free(sl.d);
+		if (sl.h) (void)hipHostFree(sl.h);
+		if (sl.done) (void)hipEventDestroy(sl.done);
+		sl = BuildState::Slot();
+	}
 	g.d_hf = nullptr;
 	if (g.h_stage) (void)hipHostFree(g.h_stage);
 	g.h_stage = nullptr;
-	g.cap_h = g.cap_s = g.cap_match = g.cap_batch = g.cap_stage = 0;
+	if (g.h_up) (void)hipHostFree(g.h_up);
+	g.h_up = nullptr;
+	dev_free(g.d_pairs);
+	g.cap_h = g.cap_s = g.cap_match = g.cap_batch = g.cap_stage = g.cap_up = g.up_at = g.cap_pairs = 0;
 	g.active = false; g.evaluated = false;
 }
 
@@ -560,6 +602,8 @@ void hibag_build_set_haplo_geno(const PluginHaplotype haplo[], int n_haplo, cons
 {
 	if (!g.active) build_throw("build_set_haplo_geno before build_init");
 	if (n_snp < 0 || n_snp > 128 || n_haplo < 0) build_throw("build_set_haplo_geno: invalid sizes");
+	HIP_OK(hipStreamSynchronize(0), "build_set_haplo_geno");       // (nothing of an earlier call may still read the staging area)
+	upload_rewind();
 	upload_haplo(haplo, n_haplo, n_snp, true, nullptr);
 	upload_geno(geno);
 	g.evaluated = false;
@@ -598,6 +642,7 @@ uint32_t *hibag_build_haplomatch(const PluginHaplotype haplo[], const size_t n_h
 		if (n_haplo[h] > 65535) build_throw("There are too many HLA allele-specific haplotypes (# > 65535).");
 		H += n_haplo[h];
 	}
+	upload_rewind();                               // (every earlier upload was consumed: the entries end with a blocking read)
 	upload_haplo(haplo, (int)H, n_snp, false, n_haplo);
 	upload_geno(geno);
 	g.evaluated = false;
@@ -614,9 +659,9 @@ uint32_t *hibag_build_haplomatch(const PluginHaplotype haplo[], const size_t n_h
 	const size_t ints = (size_t)6 * nib;
 	reserve(g.d_match, g.cap_match, ints * sizeof(int) + 64, "hipMalloc(match)");
 	int *d_i = (int *)g.d_match;
-	HIP_OK(hipMemcpy(d_i, samp.data(), nib * sizeof(int), hipMemcpyHostToDevice), "copy match args");
-	HIP_OK(hipMemcpy(d_i + nib, a1.data(), nib * sizeof(int), hipMemcpyHostToDevice), "copy match args");
-	HIP_OK(hipMemcpy(d_i + 2 * nib, a2.data(), nib * sizeof(int), hipMemcpyHostToDevice), "copy match args");
+	upload(d_i, samp.data(), nib * sizeof(int), "copy match args");
+	upload(d_i + nib, a1.data(), nib * sizeof(int), "copy match args");
+	upload(d_i + 2 * nib, a2.data(), nib * sizeof(int), "copy match args");
 	MatchView V{(int)H, std::max(1, (n_snp + 31) / 32), g.n_pad, (const uint32_t *)g.d_hb, (const int *)g.d_start,
 		(const uint32_t *)g.d_planes, d_i, d_i + nib, d_i + 2 * nib, d_i + 3 * nib, d_i + 4 * nib, d_i + 5 * nib, nullptr};
 	hipLaunchKernelGGL(k_build_match<0>, dim3(nib), dim3(HIBAG_WAVE), 0, 0, V);
@@ -628,16 +673,13 @@ uint32_t *hibag_build_haplomatch(const PluginHaplotype haplo[], const size_t n_h
 	if (!buf) build_throw("out of memory");
 	buf[0] = (uint32_t)(2 * total);
 	if (total > 0) {
-		void *d_out = nullptr;
-		if (hipMalloc(&d_out, 2 * total * sizeof(uint32_t)) != hipSuccess) { free(buf); build_throw("hipMalloc(pairs)"); }
-		V.out = (uint32_t *)d_out;
-		hipError_t e = hipMemcpy(d_i + 5 * nib, offset.data(), nib * sizeof(int), hipMemcpyHostToDevice);
-		if (e == hipSuccess) {
-			hipLaunchKernelGGL(k_build_match<1>, dim3(nib), dim3(HIBAG_WAVE), 0, 0, V);
-			e = hipMemcpy(buf + 1, d_out, 2 * total * sizeof(uint32_t), hipMemcpyDeviceToHost);
-		}
-		(void)hipFree(d_out);
-		if (e != hipSuccess) { free(buf); build_throw("build_haplomatch", e); }
+		struct Guard { uint32_t *b; ~Guard() { free(b); } } guard{buf};       // (the calls below throw on failure)
+		reserve(g.d_pairs, g.cap_pairs, 2 * total * sizeof(uint32_t), "hipMalloc(pairs)");
+		V.out = (uint32_t *)g.d_pairs;
+		upload(d_i + 5 * nib, offset.data(), nib * sizeof(int), "copy match offsets");
+		hipLaunchKernelGGL(k_build_match<1>, dim3(nib), dim3(HIBAG_WAVE), 0, 0, V);
+		HIP_OK(hipMemcpy(buf + 1, g.d_pairs, 2 * total * sizeof(uint32_t), hipMemcpyDeviceToHost), "read haplotype pairs");
+		guard.b = nullptr;
 	}
 	out_n = 1 + 2 * total;
 	return buf;
@@ -652,11 +694,23 @@ double g_batch_prof[6] = {0, 0, 0, 0, 0, 0};     // host packing, copies + kerne
 static double batch_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const HibagBuildCandidate cand[], int n_cand,
-	int acc_oob[], double loss_ib[])
+	int acc_floor, int acc_oob[], double loss_ib[])
+{
+	hibag_build_eval_launch(0, base_geno, n_snp, cand, n_cand);
+	hibag_build_eval_collect(0, &acc_floor, acc_oob, loss_ib);
+}
+
+// The two halves of the above: `launch` packs the candidates, sends them and enqueues the kernels and the read-back of the
+// results -- it returns while the device works; `collect` waits for the slot and forms the two scores per candidate.
+// *acc_floor carries the comparison's running maximum from one collect to the next (candidates in their order).
+void hibag_build_eval_launch(int slot, const PluginGenotype base_geno[], int n_snp, const HibagBuildCandidate cand[], int n_cand)
 {
 	const double t0 = batch_now();
 	if (!g.active) build_throw("build_eval_batch before build_init");
+	if (slot < 0 || slot > 1) build_throw("build_eval_launch: slot must be 0 or 1");
 	if (n_snp < 1 || n_snp > 128 || n_cand < 0) build_throw("build_eval_batch: invalid sizes");
+	BuildState::Slot &SL = g.slot[slot];
+	SL.n_cand = n_cand;
 	if (n_cand == 0) return;
 	const int nh = g.n_hla, n = g.n_sample, np = g.n_pad;
 	const int nw = (n_snp + 31) / 32, word = (n_snp - 1) >> 5, bit = (n_snp - 1) & 31;
@@ -669,6 +723,11 @@ void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const H
 	static const int wave_target = getenv("HIBAG_BATCH_WAVES") ? atoi(getenv("HIBAG_BATCH_WAVES")) : 8192;
 	const int n_seg = std::max(1, std::min(64, wave_target / std::max(1, (np / HIBAG_WAVE) * n_cand)));
 	int max_cells = 1;
+	std::vector<uint32_t> base_w1(np), base_w2(np);            // word `word` of every sample's base genotype
+	for (int s = 0; s < n; s++) {
+		base_w1[s] = (uint32_t)((uint64_t)base_geno[s].snp1[word >> 1] >> (32 * (word & 1)));
+		base_w2[s] = (uint32_t)((uint64_t)base_geno[s].snp2[word >> 1] >> (32 * (word & 1)));
+	}
 	std::vector<std::vector<int>> cell_list(n_cand);
 	std::vector<std::vector<uint64_t>> cell_work(n_cand);
 	size_t off = 0;
@@ -701,18 +760,18 @@ void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const H
 			}
 		}
 		max_cells = std::max(max_cells, (int)cell_list[c].size());
-		// the candidate SNP's bit in the two planes of its word
-		for (int s = 0; s < np; s++) {
-			uint32_t s1 = s < n ? (uint32_t)((uint64_t)base_geno[s].snp1[word >> 1] >> (32 * (word & 1))) : 0u;
-			uint32_t s2 = s < n ? (uint32_t)((uint64_t)base_geno[s].snp2[word >> 1] >> (32 * (word & 1))) : 0xFFFFFFFFu;
-			if (s < n) {
-				const int v = cand[c].column[s];
-				const bool b1 = v == 1 || v == 2, b2 = !(v == 0 || v == 1);          // TGenotype::_SetSNP, src/LibHLA.cpp:609-622
-				s1 = b1 ? (s1 | (1u << bit)) : (s1 & ~(1u << bit));
-				s2 = b2 ? (s2 | (1u << bit)) : (s2 & ~(1u << bit));
+		// the candidate SNP's bit in the two planes of its word (branch-free: the compiler vectorises it)
+		{
+			uint32_t *o1 = &cw[((size_t)c * 2) * np], *o2 = &cw[((size_t)c * 2 + 1) * np];
+			const int32_t *col = cand[c].column;
+			const uint32_t keep = ~(1u << bit);
+			for (int s = 0; s < n; s++) {
+				const uint32_t v = (uint32_t)col[s];
+				const uint32_t b1 = (uint32_t)(v == 1u) | (uint32_t)(v == 2u), b2 = (uint32_t)(v > 1u);   // TGenotype::_SetSNP, src/LibHLA.cpp:609-622
+				o1[s] = (base_w1[s] & keep) | (b1 << bit);
+				o2[s] = (base_w2[s] & keep) | (b2 << bit);
 			}
-			cw[((size_t)c * 2) * np + s] = s1;
-			cw[((size_t)c * 2 + 1) * np + s] = s2;
+			for (int s = n; s < np; s++) { o1[s] = 0u; o2[s] = 0xFFFFFFFFu; }      // padding lanes: all missing
 		}
 	}
 	max_cells = (max_cells + SCAN_NB - 1) / SCAN_NB * SCAN_NB;
@@ -784,15 +843,16 @@ void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const H
 	const size_t o_best = take(b_best), o_post = take(b_post), out_end = o;
 	const size_t o_cellv = take((size_t)n_cand * max_cells * np * 8);
 	const double t_res0 = batch_now();
-	reserve(g.d_batch, g.cap_batch, o, "hipMalloc(batch)");
-	if (out_end > g.cap_stage) {
-		if (g.h_stage) (void)hipHostFree(g.h_stage);
-		g.h_stage = nullptr; g.cap_stage = 0;
-		HIP_OK(hipHostMalloc(&g.h_stage, out_end * 2, hipHostMallocDefault), "hipHostMalloc(staging)");
-		g.cap_stage = out_end * 2;
+	reserve(SL.d, SL.cap_d, o, "hipMalloc(batch)");
+	if (out_end > SL.cap_h) {
+		if (SL.h) (void)hipHostFree(SL.h);
+		SL.h = nullptr; SL.cap_h = 0;
+		HIP_OK(hipHostMalloc(&SL.h, out_end * 2, hipHostMallocDefault), "hipHostMalloc(staging)");
+		SL.cap_h = out_end * 2;
 	}
+	if (!SL.done) HIP_OK(hipEventCreateWithFlags(&SL.done, hipEventDisableTiming), "hipEventCreate");
 	const double t_res1 = batch_now();
-	char *d = (char *)g.d_batch, *h = (char *)g.h_stage;
+	char *d = (char *)SL.d, *h = (char *)SL.h;
 	memcpy(h + o_hb, hb.data(), hb.size() * 4);
 	memcpy(h + o_cw, cw.data(), cw.size() * 4);
 	memcpy(h + o_start, start.data(), start.size() * 4);
@@ -813,21 +873,39 @@ void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const H
 	hipLaunchKernelGGL(k_batch_cells, dim3((np / HIBAG_WAVE + BATCH_WAVES - 1) / BATCH_WAVES, n_seg, n_cand), dim3(BATCH_WAVES * HIBAG_WAVE), 0, 0, B);
 	hipLaunchKernelGGL(k_batch_scan, dim3(np / HIBAG_WAVE, n_cand), dim3(HIBAG_WAVE), 0, 0, B);
 	HIP_OK(hipGetLastError(), "k_batch");
-	const double t2 = batch_now();
 	HIP_OK(hipMemcpyAsync(h + o_best, d + o_best, out_end - o_best, hipMemcpyDeviceToHost, 0), "read batch");
-	HIP_OK(hipStreamSynchronize(0), "batch");
-	const int *best = (const int *)(h + o_best);
-	const double *post = (const double *)(h + o_post);
+	HIP_OK(hipEventRecord(SL.done, 0), "hipEventRecord");
+	const double t2 = batch_now();
+	SL.np = np; SL.o_best = o_best; SL.o_post = o_post; SL.t_launch = t2;
+	g_batch_prof[0] += t1 - t0; g_batch_prof[1] += t2 - t1;
+}
+
+void hibag_build_eval_collect(int slot, int *acc_floor, int acc_oob[], double loss_ib[])
+{
+	if (slot < 0 || slot > 1) build_throw("build_eval_collect: slot must be 0 or 1");
+	BuildState::Slot &SL = g.slot[slot];
+	const int n_cand = SL.n_cand, np = SL.np;
+	if (n_cand == 0) return;
+	const double t2 = batch_now();
+	HIP_OK(hipEventSynchronize(SL.done), "batch");
+	const char *h = (const char *)SL.h;
+	const int *best = (const int *)(h + SL.o_best);
+	const double *post = (const double *)(h + SL.o_post);
 	const double t3 = batch_now();
+	int run_max = *acc_floor;
 	for (int c = 0; c < n_cand; c++) {
 		int correct = 0;                                               // build_acc_oob
 		for (int s : g.oob)
 			correct += compare_hla(best[((size_t)c * 2) * np + s], best[((size_t)c * 2 + 1) * np + s], g.true1[s], g.true2[s]);
 		acc_oob[c] = correct;
+		loss_ib[c] = 0;
+		if (correct < run_max) continue;                               // its loss is never looked at (src/LibHLA.cpp:2033-2034)
+		if (correct > run_max) run_max = correct;
 		double loglik = 0;                                             // build_acc_ib
 		for (int s : g.inbag) loglik += g.boot[s] * std::log(post[(size_t)c * np + s]);
 		loss_ib[c] = loglik * -2;
 	}
+	*acc_floor = run_max;
 	g.evaluated = false;
-	g_batch_prof[0] += t1 - t0; g_batch_prof[1] += t2 - t1; g_batch_prof[2] += t3 - t2; g_batch_prof[3] += batch_now() - t3;
+	g_batch_prof[2] += t3 - t2; g_batch_prof[3] += batch_now() - t3;
 }

@@ -50,7 +50,13 @@ struct HibagBuildCandidate {
 	int n_haplo;
 	const int32_t *column;          // [n_sample] raw genotype of the candidate SNP
 };
+// acc_floor: the search's best out-of-bag count so far.  The reference looks at a candidate's in-bag loss only when its
+// out-of-bag count reaches the running maximum of the comparison (src/LibHLA.cpp:2033-2034); the same rule decides here
+// which candidates' losses are computed at all (the others get 0 -- they are never read).
 void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const HibagBuildCandidate cand[], int n_cand,
-	int acc_oob[], double loss_ib[]);
+	int acc_floor, int acc_oob[], double loss_ib[]);
+
+void hibag_build_eval_launch(int slot, const PluginGenotype base_geno[], int n_snp, const HibagBuildCandidate cand[], int n_cand);
+void hibag_build_eval_collect(int slot, int *acc_floor, int acc_oob[], double loss_ib[]);
 
 #endif

@@ -548,14 +548,21 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 		g_prof.t[7] += 1;                                               // growth steps
 		std::vector<HapList> cand(m);
 		std::vector<char> valid(m, 0);
-		{
+		std::vector<int> accv(m, 0);
+		std::vector<double> lossv(m, 0.0);
+		// (Fitting in two halves, the first being scored while the second is fitted -- hibag_build_eval_launch / _collect have
+		// two slots for that -- was measured and dropped: the fits of a step differ so much in length that each half lasts
+		// about as long as the whole, 0.58 ms against 0.37 per step; profiles/r03_cfg5_notes.txt.)
+		const int half = m;
+		struct Part { std::vector<HibagBuildCandidate> bc; std::vector<std::vector<int32_t>> cols; std::vector<int> which; } part[2];
+		auto fit = [&](int lo, int hi) {
 			Tick tk(1);
-			std::atomic<int> next_i(0);
+			std::atomic<int> next_i(lo);
 			auto work = [&]() {
 				HapList nx;
 				PairSet pls;
 				std::vector<double> log_buf;
-				for (int i; (i = next_i.fetch_add(1)) < m;) {
+				for (int i; (i = next_i.fetch_add(1)) < hi;) {
 					nx = next; pls = t.pl;
 					if (!prepare_new_snp(t, vs.at(i), out_haplo, nx, pls)) continue;
 					expectation_maximization(t, nx, pls, log_buf);
@@ -565,27 +572,34 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 				}
 			};
 			if (t.pool) t.pool->run(work); else work();
-		}
-		std::vector<int> accv(m, 0);
-		std::vector<double> lossv(m, 0.0);
-		{
+		};
+		auto launch = [&](int slot, int lo, int hi) {
 			Tick tk(2);
-			std::vector<HibagBuildCandidate> bc;
-			std::vector<std::vector<int32_t>> cols;
-			std::vector<int> which;
-			for (int i = 0; i < m; i++) {
+			Part &P = part[slot];
+			for (int i = lo; i < hi; i++) {
 				if (!valid[i]) continue;
-				cols.emplace_back(t.n_samp);
-				for (int k = 0; k < t.n_samp; k++) cols.back()[k] = t.geno[(size_t)k * t.n_snp + vs.at(i)];
-				which.push_back(i);
+				P.cols.emplace_back(t.n_samp);
+				for (int k = 0; k < t.n_samp; k++) P.cols.back()[k] = t.geno[(size_t)k * t.n_snp + vs.at(i)];
+				P.which.push_back(i);
 			}
-			for (size_t j = 0; j < which.size(); j++)
-				bc.push_back(HibagBuildCandidate{cand[which[j]].list.data(), (int)cand[which[j]].list.size(), cols[j].data()});
-			std::vector<int> a(bc.size());
-			std::vector<double> l(bc.size());
-			hibag_build_eval_batch(t.g.data(), t.g_nsnp + 1, bc.data(), (int)bc.size(), a.data(), l.data());
-			for (size_t j = 0; j < which.size(); j++) { accv[which[j]] = a[j]; lossv[which[j]] = l[j]; }
-		}
+			for (size_t j = 0; j < P.which.size(); j++)
+				P.bc.push_back(HibagBuildCandidate{cand[P.which[j]].list.data(), (int)cand[P.which[j]].list.size(), P.cols[j].data()});
+			hibag_build_eval_launch(slot, t.g.data(), t.g_nsnp + 1, P.bc.data(), (int)P.bc.size());
+		};
+		int acc_floor = global_max_acc;
+		auto collect = [&](int slot) {
+			Tick tk(2);
+			Part &P = part[slot];
+			std::vector<int> a(P.bc.size());
+			std::vector<double> l(P.bc.size());
+			hibag_build_eval_collect(slot, &acc_floor, a.data(), l.data());
+			for (size_t j = 0; j < P.which.size(); j++) { accv[P.which[j]] = a[j]; lossv[P.which[j]] = l[j]; }
+		};
+		fit(0, half);
+		launch(0, 0, half);
+		if (half < m) { fit(half, m); launch(1, half, m); }
+		collect(0);
+		if (half < m) collect(1);
 		Tick tk3(3);
 		for (int i = 0; i < m; i++) {                                   // :2018-2069
 			if (!valid[i]) continue;
