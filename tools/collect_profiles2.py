@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-src = os.path.join(ROOT, "gpurun_out", "r02prof")
+src = os.path.join(ROOT, "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "r02prof")      # r03: gpurun_out/r03prof (tools/r03_profiles.sh)
 dst = os.path.join(ROOT, "profiles")
 
 
@@ -54,7 +54,7 @@ for name in sorted(os.listdir(src)):
         t["hbm_read_bytes_per_launch"], t["hbm_write_bytes_per_launch"], t["hbm_bytes_per_launch"] = rd, wr, rd + wr
     if traffic:
         traffic["_source"] = {"tag": f"{tag}_{name}", "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of "
-                              "bench.py (see tools/r02_profiles.sh for the arguments); read side doubled per MI355X_MICROARCH.md"}
+                              "bench.py (see tools/r02_profiles.sh / r03_profiles.sh for the arguments); read side doubled per MI355X_MICROARCH.md"}
         json.dump(traffic, open(os.path.join(dst, f"{tag}_{name}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
         if name == "cfg2":
             json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)

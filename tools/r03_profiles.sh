@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round-3 profiles (GPU box, via gpurun): rocprofv3 kernel stats + separate FETCH_SIZE / WRITE_SIZE passes for
+#   cfg2 (the metric's configuration), cfg2 with type="response+prob", cfg2 with vote="majority", cfg4 (HLA-DRB1 shape)
+# Outputs under gpurun_out/r03prof/<name>/{stats,fetch,write}; tools/collect_profiles2.py copies the summaries into profiles/.
+R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/r03prof; rm -rf $out; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+run() {  # name, bench args
+  name=$1; shift
+  mkdir -p $out/$name
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name/stats -- python3 $R/bench.py --no-cpu-baseline --no-extras "$@" > $out/$name/stats.log 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/$name/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > $out/$name/fetch.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/$name/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > $out/$name/write.log 2>&1
+  tail -1 $out/$name/stats.log | cut -c1-300
+}
+run cfg2
+run cfg2_prob --prob
+run cfg2_vote2 --vote majority
+run cfg4 --shape hla-drb1 --samples 4096 --steps 10 --warmup 2
+cd $R
+timeout 900 python3 bench.py > $out/bench.json 2> $out/bench.log
+tail -c 1200 $out/bench.json
