@@ -1079,7 +1079,6 @@ void run_core(hibag_hip_model *m, HibagBatchView &B, int vote_method, double *d_
 {
 	KernelTimer &T = m->timer;
 	B.part = d_part;
-	(void)hipMemsetAsync(B.err_dev + 2, 0, sizeof(uint32_t), st);      // the list of totals without a finite reciprocal (k_nan_cells)
 	T.begin(HIBAG_HIP_K_TOTAL, st);
 	hibag_launch_total(m->view, B, st, m->side);
 	T.end(st);

@@ -652,6 +652,7 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 	const uint8_t *__restrict__ codes)
 {
 	__shared__ uint32_t pack_s[PACK_WAVES][3][4][HIBAG_WAVE];
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) B.err_dev[2] = 0;     // the batch's list of totals without a finite reciprocal (pass 1 -> k_nan_cells)
 	const int c = blockIdx.y * PACK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (c >= M.n_classifier) return;
 	const int lane = threadIdx.x & 63;
@@ -780,6 +781,7 @@ __global__ void k_unpack_tgeno(HibagModelView M, HibagBatchView B,
 {
 	const int c = blockIdx.x;
 	const int lane = threadIdx.x;
+	if (c == 0 && lane == 0) B.err_dev[2] = 0;            // (as k_pack: the batch's list for k_nan_cells starts empty)
 	const int k = M.n_snp_c[c];
 	const int nwp = M.nwp[c];
 	const int row0 = M.mask_row[c];
@@ -1068,6 +1070,53 @@ __global__ void k_total_scan(HibagModelView M, HibagBatchView B)
 	note_infinite_reciprocal(B, c, s, B.cw[(size_t)c * B.n_pad + s], 1 / total);
 }
 
+// The per-sample ensemble scalars, classifiers in order (k_scalars, or the tile-0 workgroups of k_accum):
+//   part[P]   = sum of weights   (_Sum_Weight, src/LibHLA.cpp:1505; for the
+//               majority vote the number of classifiers that produced a call)
+//   part[P+1] = sum_matching = sum_c total_c * w_c        (:2458)
+//   part[P+2] = num_matching = sum_c w_c                  (:2459)
+__device__ __forceinline__ void ensemble_scalars(const HibagModelView &M, const HibagBatchView &B, int s, const int *__restrict__ best_cell)
+{
+	double sum_w = 0, sum_m = 0, num_m = 0;
+	constexpr int NB = 16;
+	for (int c0 = 0; c0 < M.n_classifier; c0 += NB) {
+		// sixteen classifiers' loads in flight, then the sums in classifier order (one thread per sample:
+		// with dependent loads this would be pure memory latency)
+		double wv[NB], tv[NB];
+		int bv[NB];
+#pragma unroll
+		for (int j = 0; j < NB; j++) {
+			const bool in = c0 + j < M.n_classifier;
+			const size_t at = (size_t)(in ? c0 + j : c0) * B.n_pad + s;
+			wv[j] = in ? B.cw[at] : 0.0;
+			tv[j] = B.tot[at];
+			bv[j] = best_cell ? best_cell[at] : 0;
+		}
+#pragma unroll
+		for (int j = 0; j < NB; j++) {
+			const double w = wv[j];
+			if (!(w > 0)) continue;
+			sum_m += tv[j] * w;
+			num_m += w;
+			if (best_cell) { if (bv[j] >= 0) sum_w += 1.0; }
+			else sum_w += w;
+		}
+	}
+	const size_t P = (size_t)M.n_cell;
+	B.part[(P + 0) * B.n_pad + s] = sum_w;
+	B.part[(P + 1) * B.n_pad + s] = sum_m;
+	B.part[(P + 2) * B.n_pad + s] = num_m;
+}
+
+// A hand-over of this batch failed (see handover_wait): its sums are not to be trusted.  The weight sum is never NaN
+// otherwise, so NaN there is the in-band mark every k_finish_* kernel (and a merge of partial sums) recognises.
+__device__ __forceinline__ void poison_scalars_if_failed(const HibagModelView &M, const HibagBatchView &B, int s)
+{
+	if (__hip_atomic_load(B.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != B.epoch) return;
+	const size_t P = (size_t)M.n_cell;
+	for (int q = 0; q < 3; q++) B.part[(P + q) * B.n_pad + s] = __builtin_nan("");
+}
+
 // ---------------------------------------------------------------------------
 // k_accum (pass 2): for one tile of allele-pair cells and 64 samples, go through the classifiers in order and do
 //     S[p] += (cell * (1/total)) * w          (src/LibHLA.cpp:1828 then :1497-1507)
@@ -1317,6 +1366,9 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 
 	// the item's sums, or -- parked -- what the workgroup behind continues from
 	for (int j = 0; j < ncell; j++) B.part[(size_t)(p0 + j) * B.n_pad + s] = acc[j][lane];
+	// The workgroup that ends tile 0 of its sample groups also forms their ensemble scalars (k_scalars' loop, classifiers in
+	// order): one kernel and its launch gap less on the step.
+	if (tile == 0 && ce == C) ensemble_scalars(M, B, s, nullptr);
 	}
 	if (ce < C) handover_post(flag, B.epoch, (uint32_t)ce, B.drop_post == 2 && blockIdx.x == 8 * n_whole);
 }
@@ -1493,48 +1545,14 @@ __global__ void k_vote_tally(HibagModelView M, HibagBatchView B, const int *__re
 }
 
 // ---------------------------------------------------------------------------
-// k_scalars: per-sample ensemble scalars, classifiers in order:
-//   part[P]   = sum of weights   (_Sum_Weight, src/LibHLA.cpp:1505; for the
-//               majority vote the number of classifiers that produced a call)
-//   part[P+1] = sum_matching = sum_c total_c * w_c        (:2458)
-//   part[P+2] = num_matching = sum_c w_c                  (:2459)
+// k_scalars: the per-sample ensemble scalars (ensemble_scalars above) where pass 2 is not k_accum -- the majority vote and
+// models whose pass 2 only reads stored sums (k_accum_cells); k_accum's tile-0 workgroups form them themselves.
 __global__ void k_scalars(HibagModelView M, HibagBatchView B, const int *__restrict__ best_cell)
 {
 	const int s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= B.n_pad) return;
-	double sum_w = 0, sum_m = 0, num_m = 0;
-	constexpr int NB = 16;
-	for (int c0 = 0; c0 < M.n_classifier; c0 += NB) {
-		// sixteen classifiers' loads in flight, then the sums in classifier order (one thread per sample:
-		// with dependent loads this kernel would be pure memory latency)
-		double wv[NB], tv[NB];
-		int bv[NB];
-#pragma unroll
-		for (int j = 0; j < NB; j++) {
-			const bool in = c0 + j < M.n_classifier;
-			const size_t at = (size_t)(in ? c0 + j : c0) * B.n_pad + s;
-			wv[j] = in ? B.cw[at] : 0.0;
-			tv[j] = B.tot[at];
-			bv[j] = best_cell ? best_cell[at] : 0;
-		}
-#pragma unroll
-		for (int j = 0; j < NB; j++) {
-			const double w = wv[j];
-			if (!(w > 0)) continue;
-			sum_m += tv[j] * w;
-			num_m += w;
-			if (best_cell) { if (bv[j] >= 0) sum_w += 1.0; }
-			else sum_w += w;
-		}
-	}
-	// A hand-over of this batch failed (see handover_wait): its sums are not to be trusted.  The weight sum is never NaN
-	// otherwise, so NaN here is the in-band mark every k_finish_* kernel (and a merge of partial sums) recognises.
-	if (__hip_atomic_load(B.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == B.epoch)
-		sum_w = sum_m = num_m = __builtin_nan("");
-	const size_t P = (size_t)M.n_cell;
-	B.part[(P + 0) * B.n_pad + s] = sum_w;
-	B.part[(P + 1) * B.n_pad + s] = sum_m;
-	B.part[(P + 2) * B.n_pad + s] = num_m;
+	ensemble_scalars(M, B, s, best_cell);
+	poison_scalars_if_failed(M, B, s);
 }
 
 // k_nan_cells: the NaN terms of the structurally empty cells for the (sample, classifier) pairs pass 1 listed
@@ -1544,6 +1562,8 @@ __global__ void k_scalars(HibagModelView M, HibagBatchView B, const int *__restr
 // classifier looked at.  (k_accum_cells, store_cells == 1, does this itself.)
 __global__ __launch_bounds__(64) void k_nan_cells(HibagModelView M, HibagBatchView B)
 {
+	// (also the kernel behind k_accum that marks a batch whose hand-overs failed: k_accum forms the scalars itself)
+	if ((int)(blockIdx.x * 64 + threadIdx.x) < B.n_pad) poison_scalars_if_failed(M, B, blockIdx.x * 64 + threadIdx.x);
 	const uint32_t count = __hip_atomic_load(B.err_dev + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	if (count == 0) return;
 	if (count <= HIBAG_NAN_CAP) {
@@ -1866,9 +1886,13 @@ void hibag_launch_vote(const HibagModelView &M, const HibagBatchView &B, int *d_
 
 void hibag_launch_scalars(const HibagModelView &M, const HibagBatchView &B, const int *d_best_cell, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_scalars, grid1(B.n_pad, 64), dim3(64), 0, st, M, B, d_best_cell);
-	if (!d_best_cell && M.store_cells != 1 && M.n_classifier > 0)
+	if (!d_best_cell && M.store_cells != 1 && M.n_classifier > 0 && M.n_tile > 0) {
+		// pass 2 was k_accum: its tile-0 workgroups have written the scalars; what is left is the rare NaN work and the mark
+		// of a failed hand-over
 		hipLaunchKernelGGL(k_nan_cells, dim3((unsigned)std::max(M.n_tile, B.n_pad / 64)), dim3(64), 0, st, M, B);
+		return;
+	}
+	hipLaunchKernelGGL(k_scalars, grid1(B.n_pad, 64), dim3(64), 0, st, M, B, d_best_cell);
 }
 
 void hibag_launch_finish(const HibagModelView &M, const HibagBatchView &B, double *d_part,
