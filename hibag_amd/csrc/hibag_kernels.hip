@@ -13,9 +13,9 @@
 // Two engines compute the distance d of a pair (bit-identical results):
 //   matrix engine 8 d = A . B over 2k+1 positions (h1+h2 against the genotype's signs, h1&h2 against
 //                 [g = 1], an offset term): a small GEMM of 32 records x 64 samples per block --
-//                 up to 28 SNPs on the FP4 matrix path (v_mfma_scale_f32_32x32x64_f8f6f4, e2m1 operands: all 64 K
+//                 up to 30 SNPs on the FP4 matrix path (v_mfma_scale_f32_32x32x64_f8f6f4, e2m1 operands: all 64 K
 //                 positions in one instruction per sample half; block scales of 2^-73 make the f32 result the
-//                 denormal 8 d * 2^-149, whose bit pattern IS the integer 8 d), 29..32 SNPs on
+//                 denormal 8 d * 2^-149, whose bit pattern IS the integer 8 d), 31..32 SNPs on
 //                 v_mfma_i32_32x32x32_i8 (two K blocks) -- plus 16 v_permlane32_swap to give every lane its own
 //                 sample's column.  The records are generated: each lane gathers its pair's two haplotype
 //                 entries (nibble / byte images + frequency factors) from an O(H) table through a 4-byte index
@@ -28,10 +28,9 @@
 //
 // The normalisation 1/sum of a classifier's posterior needs all of its cells,
 // and 64 samples x P cells do not fit on chip, so the pair loop runs twice:
-// pass 1 (k_total) produces the in-order total per (sample, classifier), pass 2
-// (k_accum) recomputes each cell, scales it and adds it to the ensemble sum of its
-// tile of cells, held in LDS.  Recomputing is cheaper than moving 8*P bytes per
-// (sample, classifier) through HBM (DESIGN.md "Why two passes").
+// pass 1 (k_total) produces the in-order total per (sample, classifier) and stores the sums of the cells with many
+// pairs, pass 2 (k_accum) evaluates the other cells again (or reads the stored sums back), scales each cell and adds it to
+// the ensemble sum of its tile of cells, held in LDS (DESIGN.md "Why two passes").
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no FMA fusion: the
 // reference multiplies and adds with separate roundings).
