@@ -799,7 +799,7 @@ int finalize_model(hibag_hip_model *m)
 					(uint32_t)bt_row[c],
 					srow,
 					(uint32_t)jp, (uint32_t)(jp >> 32),
-					(uint32_t)(jps & 0xFFFFu), 0u};
+					(uint32_t)jps, 0u};
 				ehdr.insert(ehdr.end(), h, h + 8);
 				jp = closes >= 16 ? 0 : jp >> (4 * closes);
 				jps >>= 4 * nsb;

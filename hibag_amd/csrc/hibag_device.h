@@ -75,7 +75,9 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 #define HIBAG_PLIST_DWORDS 32
 #define HIBAG_PLIST_END 0x80000000u
 #define HIBAG_PLIST_STORE 0x40000000u        // with END: pass 1 stores this cell's sum for pass 2 to read back
-#define HIBAG_STORED_PER_VISIT 4             // mode 2: stored cells per (classifier, tile) -- what k_accum keeps in registers
+#ifndef HIBAG_STORED_PER_VISIT
+#define HIBAG_STORED_PER_VISIT 8             // mode 2: stored cells per block of pass 2 (and per (classifier, tile) visit of a classifier it evaluates) -- what k_accum keeps in registers; at most 8
+#endif
 // Matrix-engine variants (HibagModelView::engine[c]; 0 = VALU engine) and their haplotype-table entries:
 //   FP4  (up to 30 SNPs; 33 .. 112 in several K steps, below)  v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands: one instruction per sample half covers all
 //                         K = 64 positions.  Entry = { N[16], A[16], ff, f }: 12 dwords.  N and A both have nibble s = 2 (the code of 1.0)
@@ -195,7 +197,7 @@ struct HibagModelView {
 	// E-stream: what pass 2 (k_accum) reads when it evaluates pairs again (store_cells != 1).  Per tile the blocks of
 	// classifier 0, 1, 2 ... that have anything for the tile, back to back -- pair slots in `plist` (32 per block, as in the
 	// pass-1 lists), one 8-dword header per block in `ehdr`:
-	//   [0] classifier | SNPs << 18 | stored sums of this block (0..4) << 25     [1] dword offset of the classifier's haplotype table
+	//   [0] classifier | SNPs << 18 | stored sums of this block (0..HIBAG_STORED_PER_VISIT) << 25     [1] dword offset of the classifier's haplotype table
 	//   [2] first B-operand row     [3] first stored-sum row (model-wide numbering, HibagBatchView::cells)
 	//   [4], [5] tile rows of the cells that CLOSE in this block, 4 bits each, in closing order
 	//   [6] tile rows of the stored sums, 4 bits each

@@ -988,7 +988,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagMod
 			// (a store issued where the cell closes; parking the sums in LDS and sending them a block later, so that
 			// the vmcnt waits of the look-ahead gathers never include a young store, measured 10 % slower)
 			auto fin = [&](double v, bool stored) {
+#ifdef HIBAG_STORE_PLAIN      // (variant: write-back stores instead of streaming ones)
+				if (STORE && stored) { rows[(size_t)row * HIBAG_WAVE + lane] = v; row++; }
+#else
 				if (STORE && stored) { __builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++; }
+#endif
 				total += v;
 				asm("" : "+v"(total));                    // keeps the cell end a scalar branch
 			};
@@ -1264,7 +1268,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			const int sc = (int)((H.h0 & 0xFFFFu) * s_stride);
 			w = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_cw, vo_s, sc, 0));
 			inv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_inv, vo_s, sc, 0));
-			const int ns = (int)(H.h0 >> 25) & 7;
+			const int ns = (int)(H.h0 >> 25) & 15;
 			if (ns > 0) {
 				const int sr = (int)(H.srow * (uint32_t)(HIBAG_WAVE * 8));
 #pragma unroll
@@ -1306,7 +1310,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			for (int d = 0; d < 4; d++) arow[d] = lane >= 32 ? (e1[d] & e2[d]) : (e1[d] + e2[d]);
 			// the sums pass 1 stored for this block's classifier:   S[p] += (cell * (1/total)) * w
 			{
-				const int ns = (int)(Hc.h0 >> 25) & 7;
+				const int ns = (int)(Hc.h0 >> 25) & 15;
 				if (any && ns > 0) {
 					uint32_t jps = Hc.jps;
 #pragma unroll
