@@ -452,8 +452,8 @@ def other_configs(K):
                                     "call_accuracy_vs_truth": float(np.mean(best == want)),
                                     "what": "the reference's own GPU hook, TypeGPUExtProc.predict_avg_prob: ONE sample per call "
                                             "(src/LibHLA.cpp:2433-2441), genotypes packed by the host beforehand; upload of 100 "
-                                            "TGenotype + weights, the kernels with one live lane, download of the posterior, a "
-                                            "synchronisation -- latency-bound by construction, the batched entry is the product"}
+                                            "TGenotype + weights, the per-sample kernels (thread = allele-pair cell), download of the "
+                                            "posterior, a synchronisation -- latency-bound by construction, the batched entry is the product"}
     except Exception as e:
         res["plugin_per_sample"] = {"error": repr(e)}
     try:

@@ -200,8 +200,6 @@ struct hibag_hip_model {
 	StagedStreams staged;                  // the host-pointer entries' slice pipeline (created on first use)
 	PinBuf pin_geno, pin_out;              // its pinned staging buffers (two slices each)
 	bool staged_ready = false;
-	// plugin staging
-	DevBuf ws_tgeno, ws_weight;
 	// PLINK BED payload + SNP map of hibag_hip_predict_bed
 	DevBuf ws_bed, ws_bedidx;
 
@@ -222,7 +220,7 @@ struct hibag_hip_model {
 		if (side.join) (void)hipEventDestroy(side.join);
 		if (side.stream) (void)hipStreamDestroy(side.stream);
 		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_cells, &ws_sync, &ws_err, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
-		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_tgeno, &ws_weight, &ws_bed, &ws_bedidx})
+		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_bed, &ws_bedidx})
 			b->release();
 	}
 };
@@ -602,7 +600,7 @@ int finalize_model(hibag_hip_model *m)
 		}
 	}
 	{
-		// nothing pass 2 could evaluate (no one-step FP4 classifier, e.g. the per-sample plugin path): read everything back
+		// nothing pass 2 could evaluate (no one-step FP4 classifier, e.g. HIBAG_ENGINE=valu): read everything back
 		bool any_eval = false;
 		for (int c = 0; c < C; c++) any_eval |= pass2_evaluates(c);
 		if (m->store_mode == 2 && !any_eval) m->store_mode = 1;
@@ -1104,7 +1102,7 @@ int check_predict_args(hibag_hip_model *m, const void *geno, int n_samp, int vot
 	if (n_samp > 0 && !geno) return fail(HIBAG_HIP_EINVAL, "geno is NULL");
 	if ((H1 == nullptr) != (H2 == nullptr)) return fail(HIBAG_HIP_EINVAL, "H1 and H2 must be given together");
 	if (!m->have_snpidx)
-		return fail(HIBAG_HIP_ESTATE, "model was built without SNP indices (plugin path): raw genotypes cannot be packed");
+		return fail(HIBAG_HIP_ESTATE, "model was built without SNP indices: raw genotypes cannot be packed");
 	return 0;
 }
 
@@ -1900,86 +1898,12 @@ int hibag_hip_reset_timing(hibag_hip_model *m)
 
 namespace {
 
-hibag_hip_model *g_plugin_model = nullptr;
-thread_local char g_plugin_msg[600];
-
-[[noreturn]] void plugin_throw(const char *what)
-{
-	snprintf(g_plugin_msg, sizeof(g_plugin_msg), "HIBAG HIP plugin: %s: %s", what, hibag_hip_last_error());
-	throw (const char *)g_plugin_msg;
-}
-
-void plugin_predict_done()
-{
-	hibag_hip_model_free(g_plugin_model);
-	g_plugin_model = nullptr;
-}
-
-void plugin_predict_init(int n_hla, int n_classifier, const PluginHaplotype *const p_haplo[],
-	const int n_haplo[], const int n_snp[])
-{
-	plugin_predict_done();
-	hibag_hip_model *m = hibag_hip_model_new(n_hla, 0);
-	if (!m) plugin_throw("predict_init");
-	for (int c = 0; c < n_classifier; c++) {
-		const int H = n_haplo[c];
-		std::vector<double> freq(H);
-		std::vector<int32_t> hla(H);
-		std::vector<uint64_t> bits((size_t)H * 2);
-		for (int i = 0; i < H; i++) {
-			freq[i] = p_haplo[c][i].freq;
-			hla[i] = p_haplo[c][i].aux.hla_allele;       // filled by SetHaploAux_GPU, src/LibHLA.cpp:565-578
-			bits[2 * (size_t)i] = (uint64_t)p_haplo[c][i].packed[0];
-			bits[2 * (size_t)i + 1] = (uint64_t)p_haplo[c][i].packed[1];
-		}
-		if (hibag_hip_model_add_classifier_packed(m, n_snp[c], nullptr, H, freq.data(), hla.data(), bits.data())) {
-			hibag_hip_model_free(m);
-			plugin_throw("predict_init");
-		}
-	}
-	m->use_mfma = false;      // one live lane per call: the per-sample path packs masks only (k_unpack_tgeno)
-	if (hibag_hip_model_finalize(m)) { hibag_hip_model_free(m); plugin_throw("predict_init"); }
-	g_plugin_model = m;
-}
-
-int plugin_avg_prob(hibag_hip_model *m, const PluginGenotype geno[], const double weight[],
-	double out_prob[], double out_match[])
-{
-	std::lock_guard<std::mutex> g(m->lock);
-	HIP_TRY(hipSetDevice(m->device));
-	const int C = m->view.n_classifier;
-	const size_t P = (size_t)m->view.n_cell;
-	HibagBatchView B;
-	if (int rc = make_batch(m, 1, false, B)) return rc;
-	if (int rc = m->ws_tgeno.reserve((size_t)std::max(C, 1) * sizeof(PluginGenotype))) return rc;
-	if (int rc = m->ws_weight.reserve((size_t)std::max(C, 1) * sizeof(double))) return rc;
-	if (int rc = m->ws_out.reserve((P + 1) * sizeof(double))) return rc;
-	hipStream_t st = 0;
-	HIP_TRY(hipMemcpyAsync(m->ws_tgeno.p, geno, (size_t)C * sizeof(PluginGenotype), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(m->ws_weight.p, weight, (size_t)C * sizeof(double), hipMemcpyHostToDevice, st));
-	hibag_launch_unpack_tgeno(m->view, B, m->ws_tgeno.as<uint64_t>(), m->ws_weight.as<double>(), st);
-	run_core(m, B, 1, m->ws_part.as<double>(), st);
-	double *d_out = m->ws_out.as<double>();
-	hibag_launch_finish(m->view, B, B.part, nullptr, nullptr, nullptr, d_out + P, nullptr, d_out, st);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(out_prob, d_out, P * sizeof(double), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(out_match, d_out + P, sizeof(double), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	if (take_fault(m)) return fail(HIBAG_HIP_EHANDOVER, "a hand-over between workgroups failed");   // (a one-sample launch is never cut: cannot happen)
-	return 0;
-}
-
-void plugin_predict_avg_prob(const PluginGenotype geno[], const double weight[],
-	double out_prob[], double out_match[])
-{
-	if (!g_plugin_model) { fail(HIBAG_HIP_ESTATE, "predict_init was not called"); plugin_throw("predict_avg_prob"); }
-	if (plugin_avg_prob(g_plugin_model, geno, weight, out_prob, out_match)) plugin_throw("predict_avg_prob");
-}
-
+// The predict entries live in hibag_sample.hip (a per-sample form of the path: lane = allele-pair cell), the build entries in
+// hibag_build.hip.  One model and one training state per process at a time, like the reference's single staging buffer.
 const PluginTable g_plugin_table = {
 	hibag_build_init, hibag_build_done, hibag_build_set_bootstrap, hibag_build_haplomatch,
 	hibag_build_set_haplo_geno, hibag_build_acc_oob, hibag_build_acc_ib,
-	plugin_predict_init, plugin_predict_done, plugin_predict_avg_prob,
+	hibag_sample_init, hibag_sample_done, hibag_sample_avg_prob,
 };
 
 } // namespace

@@ -10,7 +10,7 @@
 //    For pass 2 the posterior cells are grouped in TILES of up to HIBAG_TILE consecutive
 //    cells with about equal work.
 //
-//    VALU-engine classifiers (more than 112 SNPs; every classifier of the per-sample plugin path)
+//    VALU-engine classifiers (more than 112 SNPs)
 //    get the nest flattened into a PAIR STREAM, one record per haplotype pair, fetched with scalar loads:
 //        W[nwp]  the 3k-bit string  H1 | H2 << k | ~(H1^H2) << 2k   (k = #SNPs)
 //        prod    the frequency factor, rounded as the reference rounds it:

@@ -15,8 +15,6 @@ void hibag_launch_pack_bed(const HibagModelView &M, const HibagBatchView &B, con
 	size_t stride, int samp0, const int32_t *d_snp_row, const int32_t *d_flip, uint8_t *d_codes, hipStream_t st);
 void hibag_launch_bed_geno(const uint8_t *d_bed, int mode, size_t stride, int n_samp, int n_save,
 	const int32_t *d_sel, int32_t *d_geno, hipStream_t st);
-void hibag_launch_unpack_tgeno(const HibagModelView &M, const HibagBatchView &B, const uint64_t *d_tgeno,
-	const double *d_weight, hipStream_t st);
 // `side`: a second stream and two events of the caller's, for the kernel that runs beside pass 1 where the model has
 // FP4 classifiers of several K steps (fork behind what is already on `st`, join before anything that follows)
 struct HibagSideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };

@@ -22,7 +22,8 @@
 //                 pair.  33..112 SNPs: FP4 again, 28 SNPs per K step, chained through the accumulator.  All real classifiers; the default.
 //   VALU engine   d = sum_w popc((W[w] ^ T'[w]) & M'[w]): v_bitop3_b32 + v_bcnt_u32_b32 per 32-bit
 //                 word of the stored 3k-bit pair string (W uniform in SGPRs, T'/M' the lane's genotype
-//                 masks); classifiers with more than 112 SNPs and the per-sample plugin path.
+//                 masks); classifiers with more than 112 SNPs.  (The per-sample plugin route has kernels of its own:
+//                 hibag_sample.hip.)
 // In both, what the contract fixes stays on the vector ALU, per lane and in the reference's order:
 //     cell += prod * TAB[d]          ds_read_b64 (table in LDS), v_mul_f64, v_add_f64
 //
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 		}
 	}
 	} else {
-		// VALU engine (more than 112 SNPs, or the plugin path): one pass over the k <= 128 SNPs builds the
+		// VALU engine (more than 112 SNPs): one pass over the k <= 128 SNPs builds the
 		// three k-bit fields [g == 2], [g in {0, 2}], [g == 1] in LDS (four words each per lane); the 3k-bit
 		// strings are then put together word by word with wave-uniform bit offsets.
 		uint32_t (*fld)[4][HIBAG_WAVE] = pack_s[threadIdx.x >> 6];          // [field][word][lane]
@@ -768,42 +769,6 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 		}
 	}
 	B.cw[(size_t)c * B.n_pad + s] = (s < B.n_samp && den > 0) ? ((double)num / den) : 0.0;
-}
-
-// k_unpack_tgeno: plugin path (predict_avg_prob): the host already packed one
-// sample per classifier as TGenotype (48 bytes: int64 S1[2], S2[2], 16 bytes
-// of book-keeping, inst/include/LibHLA_ext.h:311-352) and computed the
-// weights.  One block per classifier; lane 0 carries the sample, lanes 1..63
-// are padding (all missing, weight 0).
-__global__ void k_unpack_tgeno(HibagModelView M, HibagBatchView B,
-	const uint64_t *__restrict__ tgeno, const double *__restrict__ weight)
-{
-	const int c = blockIdx.x;
-	const int lane = threadIdx.x;
-	if (c == 0 && lane == 0) B.err_dev[2] = 0;            // (as k_pack: the batch's list for k_nan_cells starts empty)
-	const int k = M.n_snp_c[c];
-	const int nwp = M.nwp[c];
-	const int row0 = M.mask_row[c];
-	const uint64_t *g = tgeno + (size_t)c * 6;
-	int comp = 0, i = 0;
-	for (int m = 0; m < nwp; m++) {
-		uint32_t xw = 0, mw = 0;
-		if (lane == 0) {
-			for (int q = 0; q < 32 && comp < 3 && k > 0; q++) {
-				const uint32_t s1 = (uint32_t)(g[i >> 6] >> (i & 63)) & 1u;
-				const uint32_t s2 = (uint32_t)(g[2 + (i >> 6)] >> (i & 63)) & 1u;
-				const uint32_t bit = 1u << q;
-				if (comp < 2) {
-					if (s1 == s2) mw |= bit;           // g = 0 or 2
-					if (s1 & s2) xw |= bit;            // g = 2
-				} else if (s1 & ~s2 & 1u) mw |= bit;   // g = 1
-				if (++i == k) { i = 0; comp++; }
-			}
-		}
-		B.masks[(size_t)(row0 + m) * B.n_pad + lane] = xw;
-		B.masks[(size_t)(row0 + nwp + m) * B.n_pad + lane] = mw;
-	}
-	B.cw[(size_t)c * B.n_pad + lane] = (lane == 0) ? weight[c] : 0.0;
 }
 
 // ---------------------------------------------------------------------------
@@ -1758,13 +1723,6 @@ void hibag_launch_bed_geno(const uint8_t *d_bed, int mode, size_t stride, int n_
 	if (n_samp <= 0 || n_save <= 0) return;
 	hipLaunchKernelGGL(k_bed_geno, dim3((n_samp + 63) / 64, (n_save + 63) / 64), dim3(256), 0, st, d_bed, mode, stride,
 		n_samp, n_save, d_sel, d_geno);
-}
-
-void hibag_launch_unpack_tgeno(const HibagModelView &M, const HibagBatchView &B, const uint64_t *d_tgeno,
-	const double *d_weight, hipStream_t st)
-{
-	if (M.n_classifier == 0) return;
-	hipLaunchKernelGGL(k_unpack_tgeno, dim3(M.n_classifier), dim3(HIBAG_WAVE), 0, st, M, B, d_tgeno, d_weight);
 }
 
 // resident workgroups of a kernel on the current device (0 = unknown)

@@ -31,6 +31,11 @@ struct PluginTable {                // TypeGPUExtProc, LibHLA_ext.h:358-388
 	void (*predict_avg_prob)(const PluginGenotype[], const double[], double[], double[]);
 };
 
+// per-sample prediction entries (hibag_sample.hip): predict_init / predict_avg_prob / predict_done
+void hibag_sample_init(int n_hla, int n_classifier, const PluginHaplotype *const p_haplo[], const int n_haplo[], const int n_snp[]);
+void hibag_sample_avg_prob(const PluginGenotype geno[], const double weight[], double out_prob[], double out_match[]);
+void hibag_sample_done();
+
 // training-side entries (hibag_build.hip); failures throw `const char *` like the
 // predict entries (the host's CORE_CATCH turns that into an R error, src/HIBAG.cpp:41-60)
 void hibag_build_init(int n_hla, int n_sample);

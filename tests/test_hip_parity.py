@@ -432,3 +432,44 @@ def test_classifier_without_haplotypes(hib, oracle, k_empty):
         want = oracle.predict(oracle.flatten(model), G, vote_method=vote)
         got = hib.hlaModelFromObj(model).predict_raw(G, vote, want_dosage=True, want_prob=True)
         assert_same(got, want)
+
+
+def test_plugin_per_sample_route_every_width_and_edge(hib, oracle):
+    """The per-sample kernels behind predict_avg_prob (hibag_sample.hip: thread = allele-pair cell) through
+    hibag_amd.plugin.PluginHost, which plays the host's part (src/LibHLA.cpp:2418-2441): classifiers of 1 .. 128 SNPs (the
+    32-bit and the two-word distance), a classifier without haplotypes, samples with missing SNPs, an all-missing sample,
+    an underflowing total -- every posterior and matching value bit-equal to the oracle."""
+    from hibag_amd import synth
+    from hibag_amd.plugin import PluginHost
+    ks = [1, 5, 24, 31, 32, 33, 40, 63, 64, 65, 100, 127, 128]
+    model, founders, af = synth.make_model("hla-a-small", seed=41, n_classifier=len(ks), n_snp=160, snp_counts=ks, wide_classifier=False)
+    model.classifiers.insert(2, hib.Classifier(snpidx=np.arange(7), freq=np.zeros(0), hla=np.zeros(0, np.int32), haplo=[]))
+    G, _ = synth.make_samples(founders, af, 40, seed=42, miss=0.05)
+    G[3, :] = hib.NA_INTEGER
+    G[4, :7] = hib.NA_INTEGER                      # does not use the empty classifier
+    want = oracle.predict(oracle.flatten(model), G, vote_method=1)
+    host = PluginHost(model)
+    geno, wt = host.pack(G)
+    prob = np.zeros(model.n_cell); match = np.zeros(1)
+    for i in range(len(G)):
+        host.avg_prob(geno[i], wt[i], prob, match)
+        assert np.array_equal(prob, want["postprob"][i], equal_nan=True), i
+        assert match[0] == want["matching"][i] or (np.isnan(match[0]) and np.isnan(want["matching"][i])), i
+    host.close()
+    # total == 0 -> 1/total = inf -> NaN through the empty cells as well
+    k = 100
+    far = hib.Classifier(np.arange(k), [0.5, 0.5], [0, 1], ["1" * k, "1" * k])
+    near = hib.Classifier(np.arange(4), [0.3, 0.3, 0.4], [0, 1, 2], ["0000", "0101", "1111"])
+    model = hib.HlaAttrBagObj(0, k, ["a", "b", "c"], [near, far])
+    G = np.zeros((3, k), np.int32)
+    G[1, 40:] = hib.NA_INTEGER
+    G[2, :] = hib.NA_INTEGER
+    want = oracle.predict(oracle.flatten(model), G)
+    host = PluginHost(model)
+    geno, wt = host.pack(G)
+    prob = np.zeros(model.n_cell); match = np.zeros(1)
+    for i in range(len(G)):
+        host.avg_prob(geno[i], wt[i], prob, match)
+        assert np.array_equal(prob, want["postprob"][i], equal_nan=True), i
+        assert match[0] == want["matching"][i] or (np.isnan(match[0]) and np.isnan(want["matching"][i])), i
+    host.close()
