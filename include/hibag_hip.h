@@ -168,7 +168,7 @@ int hibag_hip_predict_mapped_device(hibag_hip_model *m, const int32_t *d_geno, i
  *     (CORE_TRY / CORE_CATCH, src/HIBAG.cpp:41-60; the RAII try_final_* guards, src/LibHLA.cpp:2307-2315);
  *   - from the first such fault on the model launches WITHOUT hand-overs (every work item undivided), so the
  *     caller's second attempt -- clear the status, call again, same process -- cannot fail the same way.
- * The host-pointer entries (hibag_hip_predict, _mapped, _bed, _multi, the plugin table) do all of that themselves:
+ * The host-pointer entries (hibag_hip_predict, _mapped, _bed, _multi) do all of that themselves:
  * they see the fault when they synchronise, run the call again without hand-overs and return the repaired result
  * with code 0; hibag_hip_model_handover_faults() counts how often that (or a sticky fault) happened.
  *
@@ -330,6 +330,9 @@ int hibag_hip_reset_timing(hibag_hip_model *m);
  * to HIBAG_NewClassifiers as its last argument (src/HIBAG.cpp:601-602); see
  * INTEGRATION.md.  Failures inside these void entries throw `const char *`, which
  * the host's CORE_CATCH turns into an R error (src/HIBAG.cpp:41-60).
+ * The predict entries are called once per SAMPLE by the host; they run kernels of their own that
+ * take their parallelism from the model instead of a batch (thread = allele-pair cell; no work items
+ * are cut, so the launch status above does not apply to them) -- about 0.1 ms per call.
  * The table serves ONE model and ONE training state per process at a time, on the device
  * selected with hibag_hip_set_device by the calling thread: predict_init replaces the model of
  * the previous predict_init, build_init the previous build state -- the same restriction as the
