@@ -1093,7 +1093,7 @@ __device__ __forceinline__ void poison_scalars_if_failed(const HibagModelView &M
 // (HibagModelView::store_cells); both arrive here as ONE STREAM OF BLOCKS per tile (hibag_device.h, "E-stream"): the
 // blocks of classifier 0, 1, 2 ... that have anything for the tile, each block 32 pair slots plus a 32-byte header that
 // names the block's classifier (-> weight and 1/total rows), its operand row and haplotype table, the tile rows its
-// cells close into and up to four stored sums to add.  Round 2 walked (classifier, tile) "visits" -- mostly one short
+// cells close into and up to eight stored sums to add.  Round 2 walked (classifier, tile) "visits" -- mostly one short
 // block each -- with a scalar prologue per visit (record, descriptors, engine dispatch) and nothing of the next visit in
 // flight while the current one ran: 0.73 us of SIMD time per visit against 0.35 us of instructions.  As a stream the loop
 // body is one block, and at its top EVERYTHING of block b + 1 is requested -- haplotype entries, B operand, weight,
