@@ -552,7 +552,9 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 		std::vector<double> lossv(m, 0.0);
 		// (Fitting in two halves, the first being scored while the second is fitted -- hibag_build_eval_launch / _collect have
 		// two slots for that -- was measured and dropped: the fits of a step differ so much in length that each half lasts
-		// about as long as the whole, 0.58 ms against 0.37 per step; profiles/r03_cfg5_notes.txt.)
+		// about as long as the whole, 0.58 ms against 0.37 per step.  Sending the first 16 candidates off as soon as they are
+		// fitted while helper threads fit the last two was measured too: no gain, the second launch and read-back cost what the
+		// overlap saves; profiles/r03_cfg5_notes.txt.)
 		const int half = m;
 		struct Part { std::vector<HibagBuildCandidate> bc; std::vector<std::vector<int32_t>> cols; std::vector<int> which; } part[2];
 		auto fit = [&](int lo, int hi) {
