@@ -493,19 +493,23 @@ int finalize_model(hibag_hip_model *m)
 			auto entry = [&](double ff, int i, double f) {
 				uint32_t w[12 + 4 * (HIBAG_FP4_MAX_STEPS - 1)] = {0};
 				int n = 0;
-				if (fp4 && steps == 1) {       // two nibble images: nibble s = 2 (the e2m1 code of 1.0) where bit s is set ...
+				if (fp4 && steps == 1) {       // two nibble images, both ADDED by the kernel (K layout in hibag_device.h):
+					// the "sum" image has nibble s = 2 (the e2m1 code of 1.0) where bit s is set, the "pair" image the code 3 (1.5) --
+					// two of them make the code 6 (4.0), so the sum of two pair images is w = 0 / 1.5 / 4 for 0 / 1 / 2 set bits
 					const uint32_t bits = window(i, 0);
-					for (int sb = 0; sb < 32; sb++) w[sb >> 3] |= ((bits >> sb) & 1u) << (4 * (sb & 7) + 1);
-					for (int d = 0; d < 4; d++) w[4 + d] = w[d];
+					for (int sb = 0; sb < 32; sb++) {
+						w[sb >> 3] |= ((bits >> sb) & 1u) << (4 * (sb & 7) + 1);
+						w[4 + (sb >> 3)] |= (((bits >> sb) & 1u) * 3u) << (4 * (sb & 7));
+					}
 					if (i >= 0) {
-						// ... plus the A-row constants of the offset digits at nibbles k, k + 1 (K layout in hibag_device.h): the "sum"
-						// image carries half of each (codes 1 and 3: 0.5 + 0.5 = 1, 1.5 + 1.5 = 3 + 3 = code 6 = 4), the "AND" image
-						// the codes 6, 6 themselves.  (Not the padding entry: its rows must stay zero.)
+						// ... plus the A-row constants of the offset digits at nibbles k, k + 1: each image carries half of each (sum
+						// image: codes 1 and 3, 0.5 + 0.5 = 1 and 3 + 3 = code 6 = 4; pair image: 3 and 3 -> 4, 4).  (Not the padding
+						// entry: its rows must stay zero.)
 						const int ks = k.n_snp;
 						for (int q = 0; q < 2; q++) {
 							const int nib = ks + q;
 							w[nib >> 3] |= (q == 0 ? 1u : 3u) << (4 * (nib & 7));
-							w[4 + (nib >> 3)] |= 6u << (4 * (nib & 7));
+							w[4 + (nib >> 3)] |= 3u << (4 * (nib & 7));
 						}
 					}
 					n = 8;

@@ -80,11 +80,12 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 #endif
 // Matrix-engine variants (HibagModelView::engine[c]; 0 = VALU engine) and their haplotype-table entries:
 //   FP4  (up to 30 SNPs; 33 .. 112 in several K steps, below)  v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands: one instruction per sample half covers all
-//                         K = 64 positions.  Entry = { N[16], A[16], ff, f }: 12 dwords.  N and A both have nibble s = 2 (the code of 1.0)
-//                         where bit s is set; N ("sum" image, fetched by lanes 0..31) has the codes 1, 3 (0.5, 1.5) at nibbles k, k+1 --
-//                         two of them add up to the A-row constants 1 and 4 of the lower K half --, A ("AND" image, lanes 32..63)
-//                         the codes 6, 6 (4, 4), which survive the AND: the offset digits' constants cost no instruction.
-//                         (Several K steps: { N[16], ff, f, N'[16] ... }, 8 + 4 (steps - 1) dwords, constants added by the kernel.)
+//                         K = 64 positions.  Entry = { N[16], W[16], ff, f }: 12 dwords.  N ("sum" image, fetched by lanes 0..31) has nibble
+//                         s = 2 (the code of 1.0) where bit s is set and the codes 1, 3 (0.5, 1.5) at nibbles k, k+1 -- two of them add up
+//                         to the A-row constants 1 and 4 of the lower K half; W ("pair" image, lanes 32..63) has the code 3 (1.5) where
+//                         bit s is set and at nibbles k, k+1 -- two of them add up to the code 6 (4.0).  The A row of EVERY lane is the
+//                         plain sum of its two images: neither the AND nor the offset digits' constants cost an instruction.
+//                         (Several K steps: { N[16], ff, f, N'[16] ... }, 8 + 4 (steps - 1) dwords; AND and constants made by the kernel.)
 //   I8   (31 SNPs), I8S (32 SNPs)  v_mfma_i32_32x32x32_i8, two K blocks.  Entry = { E[32] (byte s = bit s), ff, f }: 12 dwords
 #define HIBAG_ENGINE_VALU 0
 #define HIBAG_ENGINE_FP4 1
@@ -115,8 +116,11 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 //                                                                   starts the accumulators instead: HibagBatchView::bias)
 // FP4 (K positions = nibbles; the lower K half [0, 32) of B is scaled by 2^-73, the upper one by 2^-72, A by 2^-73, so
 // that the f32 result is the DENORMAL number 8 d * 2^-149, whose bit pattern is the integer 8 d):
-//   [0, k)          A: h1_s + h2_s           B: +1 / -1 / -1 / 0
-//   [32, 32 + k)    A: h1_s & h2_s           B: [g == 1]          (counts twice through the scale)
+//   [0, k)          A: S = h1_s + h2_s       B: +1 / -4 / -1 / 0  for g = 0 / 1 / 2 / missing
+//   [32, 32 + k)    A: w(S) = 0 / 1.5 / 4    B: [g == 1]          (counts twice through the scale)
+//                   -- h1 & h2 = w - 1.5 S, so 2 (h1 & h2) [g == 1] - S [g == 1] = 2 w [g == 1] - 4 S [g == 1]: the sum of two
+//                   "pair" images (code 3 + 3 = 6) stands in for the AND, and g = 1 costs -4 instead of -1 in the lower half
+//                   (classifiers of several K steps keep A: h1 & h2 against B: -1)
 //   k, k + 1        A: 1, 4                  B: offset & 3, (offset >> 2) & 3      (the values 0 .. 3: all e2m1 numbers)
 //   32 + k, + 1     A: 4, 4                  B: offset bit 4 * 2, bit 5 * 4        (count twice; offset <= 2 k <= 60)
 // so one K step holds up to 30 SNPs (round 2 spent six positions on the offset: 28).

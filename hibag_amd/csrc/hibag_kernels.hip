@@ -232,9 +232,9 @@ __device__ __forceinline__ v4i fp4_offset_term(int k, int lane)
 // e1, e2 = this lane's 16 bytes of the two haplotypes' images of record (lane % 32):
 //   I8 / I8S  bytes 16 (lane / 32) .. + 15 of the byte images; K block 0 = e1 + e2, K block 1 = e1 & e2; the value 8
 //             at K position 31 (byte 15 of the upper K half of block 0) meets the sample's offset term
-//   FP4       the whole nibble image (32 nibbles of code 0 / 2); lanes 0..31 carry e1 + e2 (codes 0 / 2 / 4 = 0, 1, 2),
-//             lanes 32..63 e1 & e2, each plus its constant nibbles `cterm`; the f32 result is the denormal 8 d * 2^-149,
-//             i.e. its bits are the integer 8 d
+//   FP4       one K step: this lane's nibble image (lanes 0..31 the sum image, lanes 32..63 the pair image), A = e1 + e2;
+//             several K steps: the one nibble image (codes 0 / 2), lanes 0..31 carry e1 + e2, lanes 32..63 e1 & e2, each plus
+//             its constant nibbles `cterm`; the f32 result is the denormal 8 d * 2^-149, i.e. its bits are the integer 8 d
 // One K step of the FP4 distance: d_n += A x B_n for the two sample halves, A built from this lane's images.
 __device__ __forceinline__ void fp4_step(const v4i &e1, const v4i &e2, int lane, const v4i &cterm, const v4i &b0v, const v4i &b1v,
 	v16f &d0, v16f &d1)
@@ -262,15 +262,15 @@ __device__ __forceinline__ void block_mfma(const v4i &e1, const v4i &e2, int lan
 {
 	const bool upper = lane >= 32;
 	if (ENG == HIBAG_ENGINE_FP4) {
-		// one K step: each lane has fetched ITS image of the two haplotypes -- lanes 0..31 the one whose nibbles add up to the
-		// A row of the lower K half (the offset digits' constants 1, 4 as 0.5 + 0.5, 1.5 + 1.5), lanes 32..63 the one whose
-		// AND is the row of the upper half (constants 4, 4) -- so the row is one instruction per dword
+		// one K step: each lane has fetched ITS image of the two haplotypes -- lanes 0..31 the "sum" image, whose nibbles add up
+		// to the A row of the lower K half (h1 + h2; the offset digits' constants 1, 4 as 0.5 + 0.5, 1.5 + 1.5), lanes 32..63 the
+		// "pair" image, whose nibbles add up to w = 0 / 1.5 / 4 (constants 4, 4) -- so the row is ONE add per dword for all lanes
 		v16f d0, d1;
 #pragma unroll
 		for (int r = 0; r < 16; r++) { d0[r] = 0.0f; d1[r] = 0.0f; }
 		v4i a;
 #pragma unroll
-		for (int d = 0; d < 4; d++) a[d] = upper ? (e1[d] & e2[d]) : (e1[d] + e2[d]);
+		for (int d = 0; d < 4; d++) a[d] = e1[d] + e2[d];
 		const v8i a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
 		const v8i b0 = {T.b[0][0][0], T.b[0][0][1], T.b[0][0][2], T.b[0][0][3], 0, 0, 0, 0};
 		const v8i b1 = {T.b[1][0][0], T.b[1][0][1], T.b[1][0][2], T.b[1][0][3], 0, 0, 0, 0};
@@ -324,14 +324,24 @@ __device__ __forceinline__ void block_own_sample(v16i &D0, v16i &D1, int n_valid
 // an even number of records, so only odd positions can close one).  Per group of
 // G records: G table look-ups (per-lane LDS gathers) and the G frequency factors
 // (G / 2 wave-uniform 16-byte LDS reads, broadcast to all lanes) are in flight before
-// the first wait.  `stage` = this wavefront's copy of the block's factors in LDS.
+// the first wait.  `stage` = LDS byte address of this wavefront's copy of the block's factors.
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 // G = records whose table look-ups and factors are in flight together: 4 in both passes (against 8: 12 registers
 // less -- in pass 1 that is a fifth wavefront per SIMD, -3 %; pass 2, whose visits are mostly one short block since it
 // reads the sums of the large cells from memory, needs the registers for those sums).
+typedef __attribute__((address_space(3))) double LdsDouble;
+typedef __attribute__((address_space(3))) f64x2 LdsDouble2;
+// the wavefront's staging buffer as an LDS byte address held in a vector register (the pointer itself is wave-uniform, and
+// the compiler would move it from its scalar register into a vector one for every group of reads)
+__device__ __forceinline__ uint32_t stage_address(double *stage)
+{
+	uint32_t a = (uint32_t)(uintptr_t)(LdsDouble *)stage;
+	asm volatile("" : "+v"(a));
+	return a;
+}
 template <int G, class Fin>
-__device__ __forceinline__ void block_accumulate(const double *stage, uint32_t endmask, uint32_t storemask, int n_valid,
+__device__ __forceinline__ void block_accumulate(uint32_t stage, uint32_t endmask, uint32_t storemask, int n_valid,
 	const v16i &D0, const v16i &D1, double &cell, const double *tab_s, Fin &&fin)
 {
 #pragma unroll
@@ -344,7 +354,7 @@ __device__ __forceinline__ void block_accumulate(const double *stage, uint32_t e
 #ifdef HIBAG_ABL_NOFAC
 			pv[q] = f64x2{1.0 + g, 2.0 + q};
 #else
-			pv[q] = *reinterpret_cast<const f64x2 *>(stage + G * g + 2 * q);
+			pv[q] = *(const LdsDouble2 *)(uintptr_t)(stage + 8u * (uint32_t)(G * g + 2 * q));
 #endif
 		}
 #pragma unroll
@@ -365,9 +375,8 @@ __device__ __forceinline__ void block_accumulate(const double *stage, uint32_t e
 	}
 }
 
-// LDS staging area of one wavefront: two buffers of 32 factors
+// LDS staging area of one wavefront: 32 factors
 #define STAGE_DOUBLES 32
-#define STAGE_BYTES (2 * STAGE_DOUBLES * 8)
 
 // The parts of a haplotype-table entry {image, ff, f} through a raw buffer; `vo` = the entry's byte offset
 // (+ this lane's offset into the image for the image loads); FO = byte offset of ff inside an entry.
@@ -430,6 +439,9 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 	const __amdgpu_buffer_rsrc_t pl = __builtin_amdgcn_make_buffer_rsrc((void *)(M.plist + at), 0,
 		left > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left, 0x00020000);
 	uint32_t soff = 0;
+	// (one staging buffer is enough: a wavefront's LDS operations execute in order, so the factors of block b + 1 are written
+	// after the last read of block b's)
+	const uint32_t sa = stage_address(stage);
 	if (cur.at != at) {                              // nothing usable fetched: slot words of blocks 0 and 1
 		cur.idx = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff, 0);
 		cur.idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + BB, 0);
@@ -441,7 +453,6 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 	v4i e1 = load_hap_image(hp, o1), e2 = load_hap_image(hp, o2);
 	double ff = load_hap_factor<FO>(hp, o1, 0), f2 = load_hap_factor<FO>(hp, o2, 1);
 	for (int b = 0; b < nblk; b++) {
-		double *buf = stage + (b & 1) * STAGE_DOUBLES;
 		// this block's records: images and the factor ff[i1] * f[i2]
 		const v4i a1 = e1, a2 = e2;
 		const double prod = ff * f2;
@@ -458,7 +469,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 		ff = load_hap_factor<FO>(hp, o1, 0); f2 = load_hap_factor<FO>(hp, o2, 1);
 		idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + 2 * BB, 0);
 		if (n_valid > 0) {
-			if (lane < 32) buf[lane] = prod;
+			if (lane < 32) *(LdsDouble *)(uintptr_t)(sa + 8u * (uint32_t)lane) = prod;
 			v16i D0, D1;
 			if (FP4W) {
 				// K step 0 like a one-step classifier, then the further steps: their images and B operands are fetched here
@@ -481,7 +492,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 				block_mfma<ENG>(a1, a2, lane, cterm, T, D0, D1);
 			}
 			block_own_sample(D0, D1, n_valid);
-			block_accumulate<G>(buf, endmask, storemask, n_valid, D0, D1, cell, tab_s, fin);
+			block_accumulate<G>(sa, endmask, storemask, n_valid, D0, D1, cell, tab_s, fin);
 		}
 		soff += BB;
 	}
@@ -693,7 +704,8 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
 					const uint32_t z8 = (Z >> (8 * q)) & 0xFFu, n8 = (neg >> (8 * q)) & 0xFFu, e8 = (E >> (8 * q)) & 0xFFu;
-					a[q] = h == 0 ? (expand_bits8_nibbles(z8 | n8) << 1) | (expand_bits8_nibbles(n8) << 3)
+					// (one K step: the upper half of A is w = 0 / 1.5 / 4, not the AND, so g = 1 counts -1 - 3 = -4 = code 0xE here)
+					a[q] = h == 0 ? (expand_bits8_nibbles(z8 | n8) << 1) | (expand_bits8_nibbles(n8) << 3) | (steps == 1 ? expand_bits8_nibbles(e8) << 2 : 0u)
 					              : expand_bits8_nibbles(e8) << 1;
 				}
 				// the offset (<= 60) in four digits: (offset & 3) and ((offset >> 2) & 3) as the values 0 / 1 / 2 / 3 (e2m1 codes
@@ -904,7 +916,7 @@ template <bool STORE>
 __global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagModelView M, HibagBatchView B, int gx, int n_whole, int rest, int stride, int K)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
-	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
+	__shared__ double stage_s[BLOCK_WAVES][STAGE_DOUBLES];
 	int li = blockIdx.x, k = 0;
 	if (li >= n_whole) {
 		const int jj = li - n_whole;
@@ -992,7 +1004,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagMod
 __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total_wide(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
-	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
+	__shared__ double stage_s[BLOCK_WAVES][STAGE_DOUBLES];
 	stage_table(M, tab_s);
 	const int *__restrict__ seg = M.wide_seg + 4 * blockIdx.y;
 	const int c = seg[0];
@@ -1132,7 +1144,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double acc_s[ACCUM_WAVES][HIBAG_TILE][HIBAG_WAVE];
-	__shared__ double stage_s[ACCUM_WAVES][2 * STAGE_DOUBLES];
+	__shared__ double stage_s[ACCUM_WAVES][STAGE_DOUBLES];
 
 	// Work item = (XCD, four sample groups, one tile); the four wavefronts of a workgroup take the four groups.
 	// They read the same blocks and the same haplotype-table entries at about the same time, so those
@@ -1205,7 +1217,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		const int vo_i = (lane & 31) * 4, vo_h = (lane & 7) * 4;
 		const int vo_bt = (group * HIBAG_WAVE + lane) * 16, vo_s = s * 8, vo_sv = lane * 8;
 		const uint32_t bt_stride = (uint32_t)B.n_pad * 16u, s_stride = (uint32_t)B.n_pad * 8u;      // bytes per operand row / per classifier's row
-		double *stage = stage_s[wave];
+		const uint32_t sa = stage_address(stage_s[wave]);
 		constexpr uint32_t ES = 4u * HIBAG_ENGINE_HAP_DWORDS(HIBAG_ENGINE_FP4);      // bytes per table entry: sum image, AND image, ff, f
 		const uint32_t img = (uint32_t)(lane >> 5) * 16u;     // lanes 0..31 fetch the "sum" image of their haplotypes, lanes 32..63 the "AND" image
 		constexpr int NS = HIBAG_STORED_PER_VISIT;
@@ -1255,7 +1267,6 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		double cell = 0;
 		uint32_t soff = 0;                            // byte offset of block b's slot words
 		for (int b = bb; b < be; b++) {
-			double *buf = stage + (b & 1) * STAGE_DOUBLES;
 			// ---- block b: what was requested a block ago has arrived
 			const EHeader Hn = read_header(hv_n);
 			const double w_c = w, inv_c = inv;
@@ -1272,7 +1283,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			// this block's A operand row: the two images' sum (lower K half) or AND (upper K half)
 			v4i arow;
 #pragma unroll
-			for (int d = 0; d < 4; d++) arow[d] = lane >= 32 ? (e1[d] & e2[d]) : (e1[d] + e2[d]);
+			for (int d = 0; d < 4; d++) arow[d] = e1[d] + e2[d];      // sum image / pair image: one add either way
 			// the sums pass 1 stored for this block's classifier:   S[p] += (cell * (1/total)) * w
 			{
 				const int ns = (int)(Hc.h0 >> 25) & 15;
@@ -1298,7 +1309,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			// into the registers they have just read
 			v16i D0, D1;
 			if (eval) {
-				if (lane < 32) buf[lane] = prod;
+				if (lane < 32) *(LdsDouble *)(uintptr_t)(sa + 8u * (uint32_t)lane) = prod;
 				v16f d0, d1;
 #pragma unroll
 				for (int r = 0; r < 16; r++) { d0[r] = 0.0f; d1[r] = 0.0f; }
@@ -1325,7 +1336,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 					__hip_atomic_fetch_add(&acc[(int)(jpack & 15)][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					jpack >>= 4;
 				};
-				block_accumulate<4>(buf, endmask, 0u, n_valid, D0, D1, cell, tab_s, fin);
+				block_accumulate<4>(sa, endmask, 0u, n_valid, D0, D1, cell, tab_s, fin);
 			}
 			Hc = Hn;
 			soff += 4 * HIBAG_PLIST_DWORDS;
@@ -1459,7 +1470,7 @@ __device__ __forceinline__ int classifier_best(const HibagModelView &M, const Hi
 __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_vote_best(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
-	__shared__ double stage_s[BLOCK_WAVES][2 * STAGE_DOUBLES];
+	__shared__ double stage_s[BLOCK_WAVES][STAGE_DOUBLES];
 	stage_table(M, tab_s);
 	const int c = M.c_order[blockIdx.y];
 	const int group = blockIdx.x * BLOCK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
