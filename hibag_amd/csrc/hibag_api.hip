@@ -172,7 +172,7 @@ struct hibag_hip_model {
 	double tab[HIBAG_TAB_N];
 
 	// device model
-	DevBuf d_int, d_stream, d_tile, d_tab, d_blk;
+	DevBuf d_int, d_stream, d_tile, d_tab, d_blk, d_pfac, d_phdr;
 	HibagModelView view{};
 	int mask_rows = 0, bt_rows = 0, cell_rows = 0;
 	size_t stream_bytes = 0;
@@ -219,7 +219,7 @@ struct hibag_hip_model {
 		if (side.fork) (void)hipEventDestroy(side.fork);
 		if (side.join) (void)hipEventDestroy(side.join);
 		if (side.stream) (void)hipStreamDestroy(side.stream);
-		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &ws_bt, &ws_bias, &ws_cells, &ws_sync, &ws_err, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
+		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &d_pfac, &d_phdr, &ws_bt, &ws_bias, &ws_cells, &ws_sync, &ws_err, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
 		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_bed, &ws_bedidx})
 			b->release();
 	}
@@ -755,6 +755,8 @@ int finalize_model(hibag_hip_model *m)
 	// (t, 1), ... follow each other, which is the order a pass-2 wavefront reads them in; then, per
 	// classifier, all cells back to back for pass 1 (no block left half empty at a tile boundary).
 	std::vector<uint32_t> plist;
+	struct SlotRange { size_t first, n; int c; };
+	std::vector<SlotRange> slot_ranges;          // which classifier's haplotype table the slots of plist[first, first + n) index
 	std::vector<uint64_t> blk_off(std::max(C, 1), 0), seg_off((size_t)std::max(C, 1) * n_tile, 0);
 	std::vector<uint32_t> seg_nblk((size_t)std::max(C, 1) * n_tile, 0);
 	long long dbg_b1 = 0, dbg_b2 = 0, dbg_seg = 0;
@@ -780,6 +782,7 @@ int finalize_model(hibag_hip_model *m)
 			if (pass2_evaluates(c) && tile_nlist[ct] > 0)
 				nb = append_pair_blocks(starts[c].data(), nh, tile_h1[t], tile_h2[t], tile_p0[t], tile_n[t],
 					(uint32_t)m->cls[c].freq.size(), plist, nullptr, store_mode == 2 ? stored[c].data() : nullptr);
+			if (nb > 0) slot_ranges.push_back({first, plist.size() - first, c});
 			const int ns = (int)tile_nstored[ct];
 			const int nvb = std::max(nb, (ns + HIBAG_STORED_PER_VISIT - 1) / HIBAG_STORED_PER_VISIT);
 			for (int b = nb; b < nvb; b++) plist.insert(plist.end(), HIBAG_PLIST_DWORDS, 0u);     // padding slots: entry 0 of the zero entry's "table"
@@ -848,12 +851,14 @@ int finalize_model(hibag_hip_model *m)
 				h1 = nh1; h2 = nh2;
 			}
 			cls_nblk[c] = (int)((plist.size() - blk_off[c]) / HIBAG_PLIST_DWORDS);
+			slot_ranges.push_back({(size_t)blk_off[c], plist.size() - (size_t)blk_off[c], c});
 			dbg_b1 += cls_nblk[c];
 			for (int b = 0; b < cls_nblk[c] && store_mode; b++) blk_close.push_back(0);     // (keeps the block numbering; not used for these)
 			continue;
 		}
 		cls_nblk[c] = append_pair_blocks(starts[c].data(), nh, 0, 0, 0, P, (uint32_t)m->cls[c].freq.size(), plist,
 			store_mode ? stored[c].data() : nullptr, nullptr);
+		slot_ranges.push_back({(size_t)blk_off[c], plist.size() - (size_t)blk_off[c], c});
 		dbg_b1 += cls_nblk[c];
 		uint32_t closed = 0;
 		for (int b = 0; b < cls_nblk[c] && store_mode; b++) {      // stored cells closed before block b
@@ -868,6 +873,32 @@ int finalize_model(hibag_hip_model *m)
 			"pair lists %.1f MB, haplotype table %.1f KB, VALU-engine stream %.1f MB\n",
 			C, n_tile, (long long)m->pair_evals, dbg_b1, dbg_b2, dbg_seg, plist.size() * 4e-6, hap.size() * 4e-3, stream.size() * 4e-6);
 	plist.insert(plist.end(), 4 * HIBAG_PLIST_DWORDS, 0u);   // look-ahead slack of the block walker
+	// What the kernels take from a block through the SCALAR cache (hibag_device.h): the frequency factor of every slot --
+	// ff[i1] * f[i2], the one rounded multiplication of src/LibHLA.cpp:1786-1813, made here once instead of by every wavefront
+	// that walks the list -- and a header {cell ends, stored cell ends, slots worth evaluating}.
+	std::vector<double> pfac(plist.size(), 0.0);
+	for (const SlotRange &r : slot_ranges) {
+		const std::vector<double> &freq = m->cls[r.c].freq;
+		const uint32_t H = (uint32_t)freq.size();
+		// table entries (above): [0, H) = {2 f, f}, H = the padding entry {0, 0}, H + 1 + i = {f, f} (first of a diagonal pair)
+		auto ff_of = [&](uint32_t e) { return e < H ? 2 * freq[e] : e == H ? 0.0 : freq[e - H - 1]; };
+		auto f_of = [&](uint32_t e) { return e < H ? freq[e] : e == H ? 0.0 : freq[e - H - 1]; };
+		for (size_t i = r.first; i < r.first + r.n; i++) pfac[i] = ff_of(plist[i] & 0xFFFFu) * f_of((plist[i] >> 16) & 0x3FFFu);
+	}
+	std::vector<uint32_t> phdr(plist.size() / HIBAG_PLIST_DWORDS * 4, 0u);
+	for (size_t b = 0; b < plist.size() / HIBAG_PLIST_DWORDS; b++) {
+		uint32_t ends = 0, stores = 0, live = 0;
+		for (int i = 0; i < HIBAG_PLIST_DWORDS; i++) {
+			const uint32_t w = plist[b * HIBAG_PLIST_DWORDS + i];
+			if (w & HIBAG_PLIST_END) ends |= 1u << i;
+			if (w >= (HIBAG_PLIST_END | HIBAG_PLIST_STORE)) stores |= 1u << i;
+			if (pfac[b * HIBAG_PLIST_DWORDS + i] != 0.0) live |= 1u << i;      // (a zero factor adds +0.0: skipping it is exact)
+		}
+		live |= ends;
+		int n_valid = 0;
+		while (n_valid < 32 && (live >> n_valid)) n_valid++;
+		phdr[4 * b] = ends; phdr[4 * b + 1] = stores; phdr[4 * b + 2] = (uint32_t)n_valid;
+	}
 	// per (classifier, tile) record of pass 2 (one s_load_dwordx8)
 	std::vector<uint32_t> ctile((size_t)std::max(C, 1) * n_tile * 8 + 8, 0);
 	for (int c = 0; c < C; c++)
@@ -939,6 +970,10 @@ int finalize_model(hibag_hip_model *m)
 		HIP_TRY(hipMemcpy(tbase + tb_wsoff, wseg_off.data(), wseg_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	if (int rc = m->d_blk.reserve(plist.size() * sizeof(uint32_t))) return rc;
 	HIP_TRY(hipMemcpy(m->d_blk.p, plist.data(), plist.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	if (int rc = m->d_pfac.reserve(pfac.size() * sizeof(double))) return rc;
+	HIP_TRY(hipMemcpy(m->d_pfac.p, pfac.data(), pfac.size() * sizeof(double), hipMemcpyHostToDevice));
+	if (int rc = m->d_phdr.reserve(phdr.size() * sizeof(uint32_t))) return rc;
+	HIP_TRY(hipMemcpy(m->d_phdr.p, phdr.data(), phdr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(m->d_tab.p, m->tab, sizeof(m->tab), hipMemcpyHostToDevice));
 
 	HibagModelView &V = m->view;
@@ -992,6 +1027,8 @@ int finalize_model(hibag_hip_model *m)
 	if (store_mode != 1 && (uint64_t)cell_row[C] >= (1ull << 23))      // (k_accum: a stored row's byte offset within a sample group in 32 bits)
 		return fail(HIBAG_HIP_EINVAL, "the model stores too many cell sums per sample (%d) for the second pass", cell_row[C]);
 	V.plist = m->d_blk.as<uint32_t>();
+	V.pfac = m->d_pfac.as<double>();
+	V.phdr = m->d_phdr.as<uint32_t>();
 	V.plist_dwords = plist.size();
 	m->bt_rows = bt_rows;
 	V.stream = m->d_stream.as<uint32_t>();

@@ -181,6 +181,10 @@ struct HibagModelView {
 	const int *cls_nblk;         // [C] blocks in that list
 	const uint32_t *plist;       // pair lists: blocks of HIBAG_PLIST_DWORDS dwords
 	uint64_t plist_dwords;       // total size (a raw buffer is rebased per classifier / tile segment: no 4 GB limit)
+	// per slot of plist its frequency factor ff[i1] * f[i2] (the rounded product of src/LibHLA.cpp:1786-1813), and per block
+	// {end-of-cell mask, stored-cell mask, slots worth evaluating, 0}: both wave-uniform, read through the scalar cache
+	const double *pfac;          // [plist_dwords]
+	const uint32_t *phdr;        // [plist_dwords / 32][4]
 	const uint32_t *ctile;       // [C][n_tile][8]: everything pass 2 needs per (classifier, tile) in one s_load_dwordx8:
 	                             // {engine | k << 2 | #listed cells << 8 | (K steps - 1) << 13 | bt_row << 16    (k: SNPs of the LAST K step), dword offset of the first haplotype-table entry,
 	                             //  pair list dword offset lo/hi, #blocks, first stored row | #stored cells << 27, row list lo/hi}

@@ -53,8 +53,14 @@
 #define BLOCK_WAVES 4                       // wavefronts per workgroup (each on its own work item)
 #endif
 #define BLOCK_THREADS (BLOCK_WAVES * HIBAG_WAVE)
+#ifndef TOTAL_G
+#define TOTAL_G 8                           // records of pass 1 whose look-ups are in flight together (and whose factors arrive in one scalar load)
+#endif
 #ifndef HIBAG_TOT_OCC
 #define HIBAG_TOT_OCC 5                     // workgroups per CU pass 1 is compiled for (96 VGPRs; 4 -> 128: measured slower)
+#endif
+#ifndef ACCUM_G
+#define ACCUM_G 4                           // the same for pass 2
 #endif
 #ifndef ACCUM_WAVES
 #define ACCUM_WAVES 4                       // wavefronts per workgroup of pass 2 (sample groups that share a tile's lists in L1)
@@ -321,42 +327,30 @@ __device__ __forceinline__ void block_own_sample(v16i &D0, v16i &D1, int n_valid
 
 // cell += prod_i * TAB[d_i] for the first n_valid records of a block, in order;
 // `fin(cell, stored)` at every record that closes a cell (end mask, store mask; cells are padded to
-// an even number of records, so only odd positions can close one).  Per group of
-// G records: G table look-ups (per-lane LDS gathers) and the G frequency factors
-// (G / 2 wave-uniform 16-byte LDS reads, broadcast to all lanes) are in flight before
-// the first wait.  `stage` = LDS byte address of this wavefront's copy of the block's factors.
+// an even number of records, so only odd positions can close one).
+// The factors prod_i are wave-uniform: they come from HibagModelView::pfac through the SCALAR cache, G at a time
+// (one s_load), and multiply as scalar-register operands -- no LDS traffic, no vector register, no instruction to
+// make them.  `fac` = the block's 32 factors, `F` = the first G of them, requested by the caller at the top of the
+// block.  Scalar loads share the lgkmcnt counter with the table look-ups and return out of order, so the wait for a
+// group's look-ups also waits for every scalar load in flight: the NEXT group's factors are therefore requested
+// right behind that wait (the first product), and have this group's arithmetic and the next group's look-ups to arrive.
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x8 __attribute__((ext_vector_type(8)));
+template <int G> struct FactorGroup;
+template <> struct FactorGroup<4> { typedef f64x4 type; };
+template <> struct FactorGroup<8> { typedef f64x8 type; };
 
-// G = records whose table look-ups and factors are in flight together: 4 in both passes (against 8: 12 registers
-// less -- in pass 1 that is a fifth wavefront per SIMD, -3 %; pass 2, whose visits are mostly one short block since it
-// reads the sums of the large cells from memory, needs the registers for those sums).
-typedef __attribute__((address_space(3))) double LdsDouble;
-typedef __attribute__((address_space(3))) f64x2 LdsDouble2;
-// the wavefront's staging buffer as an LDS byte address held in a vector register (the pointer itself is wave-uniform, and
-// the compiler would move it from its scalar register into a vector one for every group of reads)
-__device__ __forceinline__ uint32_t stage_address(double *stage)
-{
-	uint32_t a = (uint32_t)(uintptr_t)(LdsDouble *)stage;
-	asm volatile("" : "+v"(a));
-	return a;
-}
+// G = records whose table look-ups are in flight together
 template <int G, class Fin>
-__device__ __forceinline__ void block_accumulate(uint32_t stage, uint32_t endmask, uint32_t storemask, int n_valid,
+__device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename FactorGroup<G>::type F, uint32_t endmask, uint32_t storemask, int n_valid,
 	const v16i &D0, const v16i &D1, double &cell, const double *tab_s, Fin &&fin)
 {
+	typedef typename FactorGroup<G>::type FG;
 #pragma unroll
 	for (int g = 0; g < 32 / G; g++) {
 		if (G * g >= n_valid) break;
-		f64x2 pv[G / 2];
 		double t[G];
-#pragma unroll
-		for (int q = 0; q < G / 2; q++) {
-#ifdef HIBAG_ABL_NOFAC
-			pv[q] = f64x2{1.0 + g, 2.0 + q};
-#else
-			pv[q] = *(const LdsDouble2 *)(uintptr_t)(stage + 8u * (uint32_t)(G * g + 2 * q));
-#endif
-		}
 #pragma unroll
 		for (int q = 0; q < G; q++) {         // D = 8*d: already the byte offset into the table
 			const int i = G * g + q;          // record i = 8 m + r  ->  r < 4 ? D0[4 m + r] : D1[4 m + r - 4]
@@ -367,29 +361,30 @@ __device__ __forceinline__ void block_accumulate(uint32_t stage, uint32_t endmas
 			t[q] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab_s) + off);
 #endif
 		}
+		const double x0 = F[0] * t[0];
+		__builtin_amdgcn_sched_barrier(0);
+		FG Fn = F;
+		if (g + 1 < 32 / G) Fn = *(ConstPtr<FG>)(fac + G * (g + 1));
+		__builtin_amdgcn_sched_barrier(0);
+		cell += x0;
 #pragma unroll
-		for (int q = 0; q < G; q++) {
-			cell += pv[q >> 1][q & 1] * t[q];
+		for (int q = 1; q < G; q++) {
+			cell += F[q] * t[q];
 			if ((q & 1) && (endmask & (1u << (G * g + q)))) { fin(cell, (storemask & (1u << (G * g + q))) != 0); cell = 0; }
 		}
+		F = Fn;
 	}
 }
 
-// LDS staging area of one wavefront: 32 factors
-#define STAGE_DOUBLES 32
+// (the LDS staging area of round 2 -- the factors parked by lanes 0..31 and read back as broadcasts -- is gone)
 
-// The parts of a haplotype-table entry {image, ff, f} through a raw buffer; `vo` = the entry's byte offset
-// (+ this lane's offset into the image for the image loads); FO = byte offset of ff inside an entry.
+// The image part of a haplotype-table entry {image(s), ff, f} through a raw buffer; `vo` = the entry's byte offset + this
+// lane's offset into the image.  (ff and f stay in the entry for the per-sample route, hibag_sample.hip; the walks below
+// take the product ff * f of a pair from HibagModelView::pfac.)
 __device__ __forceinline__ v4i load_hap_image(__amdgpu_buffer_rsrc_t hp, uint32_t vo)
 {
 	const auto v = __builtin_amdgcn_raw_buffer_load_b128(hp, (int)vo, 0, 0);
 	return v4i{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
-}
-template <int FO>
-__device__ __forceinline__ double load_hap_factor(__amdgpu_buffer_rsrc_t hp, uint32_t vo, int second)
-{
-	return __builtin_bit_cast(double, second ? __builtin_amdgcn_raw_buffer_load_b64(hp, (int)vo, FO + 8, 0)
-	                                         : __builtin_amdgcn_raw_buffer_load_b64(hp, (int)vo, FO, 0));
 }
 
 // What a walk has already fetched of the list behind its last block: the slot words of the next two
@@ -400,36 +395,36 @@ struct ListCursor {
 	uint32_t idx = 0, idx_n = 0;     // this lane's slot word of that block and of the one behind it
 };
 
-// Walk `nblk` consecutive blocks of a pair list starting at dword offset `at`; `cell` = the sum of the cell the
-// first record belongs to so far (0 at a cell boundary), on return that of the cell the walk ended in.
+// a block's header {end-of-cell mask, stored-cell mask, slots worth evaluating, 0} (HibagModelView::phdr)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Walk `nblk` consecutive blocks of a pair list starting at dword offset `at` (a multiple of 32); `cell` = the sum of the
+// cell the first record belongs to so far (0 at a cell boundary), on return that of the cell the walk ended in.
 //
-// Latency plan.  Nothing in this loop goes through the scalar cache: scalar loads
-// share the lgkmcnt counter with the LDS table look-ups and return out of order,
-// so every wait for table values would also wait for the scalar load just issued.
-// Everything travels as per-lane vector loads, software-pipelined over the blocks:
-//   at the top of block b   the haplotype entries of block b+1 are gathered (their slot words
+// Latency plan.  What differs from lane to lane travels as per-lane vector loads, software-pipelined over the blocks:
+//   at the top of block b   the haplotype images of block b+1 are gathered (their slot words
 //                           arrived during block b-1) and the slot words of block b+2 are requested,
 // so that a whole block's evaluation covers their latency.  Lane l (and l+32: the other K half of
-// the same row) turns its pair (i1, i2) into the A-operand row (byte-wise sum and AND of the two E
-// images) and the factor ff[i1] * f[i2] with one FP64 multiply; lanes 0..31 park the 32 factors in the
-// wavefront's LDS staging buffer, from where the accumulation reads them back as wave-uniform
-// (broadcast) 16-byte LDS reads, in order with the table look-ups.  The end-of-cell mask is the ballot
-// of the slots' end flags; the number of slots worth evaluating follows from the last slot that closes
-// a cell or has a non-zero factor (a zero factor adds +0.0: skipping it is exact).  The list is padded
-// so that the look-ahead stays in bounds.
+// the same row) turns its pair (i1, i2) into the A-operand row (the sum of its two images).
+// What is the same for all lanes -- the block's header and the records' frequency factors ff[i1] * f[i2], both made by
+// the host (hibag_api.hip finalize_model) -- comes through the scalar cache into scalar registers: the header of block
+// b+1 and the first factors of block b are requested at the top of block b, before the matrix instructions; the other
+// factors group by group inside block_accumulate (which explains how they avoid the table look-ups' waits).  The number
+// of slots worth evaluating follows from the last slot that closes a cell or has a non-zero factor (a zero factor adds
+// +0.0: skipping it is exact).  The lists are padded so that every look-ahead stays in bounds.
 template <int ENG, int G, class Fin>
 __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at, int nblk, int lane, ListCursor &cur,
-	__amdgpu_buffer_rsrc_t hp, int k, const LaneOperand &T, const WideSrc &wide, const double *tab_s, double *stage, double &cell, Fin &&fin)
+	__amdgpu_buffer_rsrc_t hp, int k, const LaneOperand &T, const WideSrc &wide, const double *tab_s, double &cell, Fin &&fin)
 {
 	if (nblk <= 0) return;
+	typedef typename FactorGroup<G>::type FG;
 	// FP4W: an FP4 classifier of `wide.nstep` K steps; `k` = SNPs of its LAST step, the others have HIBAG_FP4_STEP_SNPS
 	constexpr bool FP4W = ENG == HIBAG_ENGINE_FP4W;
 	const uint32_t ES = FP4W ? 4u * (uint32_t)HIBAG_FP4_ENTRY_DWORDS(wide.nstep)
 	                         : 4u * (uint32_t)HIBAG_ENGINE_HAP_DWORDS(ENG);   // bytes per table entry (one-step FP4 and int8: 48)
-	constexpr int FO = FP4W ? 16 : 32;                                        // ff behind the image(s)
 	const int vo_i = (lane & 31) * 4;                // this lane's slot inside a block
 	// this lane's 16 bytes of an entry: the K half's bytes (int8), the K half's nibble image (one-step FP4: the "sum" image
-	// for lanes 0..31, the "AND" image for lanes 32..63), the one nibble image (FP4 of several steps)
+	// for lanes 0..31, the "pair" image for lanes 32..63), the one nibble image (FP4 of several steps)
 	const uint32_t img = FP4W ? 0u : (uint32_t)(lane >> 5) * 16u;
 	const v4i cterm = FP4W ? fp4_offset_term(HIBAG_FP4_STEP_SNPS, lane) : v4i{0, 0, 0, 0};   // (of K step 0)
 	const uint32_t BB = 4 * HIBAG_PLIST_DWORDS;      // bytes per block
@@ -438,38 +433,45 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 	const uint64_t left = (M.plist_dwords - at) * 4;
 	const __amdgpu_buffer_rsrc_t pl = __builtin_amdgcn_make_buffer_rsrc((void *)(M.plist + at), 0,
 		left > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left, 0x00020000);
+	ConstPtr<double> fac = as_const(M.pfac) + at;                            // this segment's factors and headers
+	ConstPtr<u32x4> hdr = (ConstPtr<u32x4>)(as_const(M.phdr) + at / HIBAG_PLIST_DWORDS * 4);
 	uint32_t soff = 0;
-	// (one staging buffer is enough: a wavefront's LDS operations execute in order, so the factors of block b + 1 are written
-	// after the last read of block b's)
-	const uint32_t sa = stage_address(stage);
 	if (cur.at != at) {                              // nothing usable fetched: slot words of blocks 0 and 1
 		cur.idx = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff, 0);
 		cur.idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + BB, 0);
 	}
 	uint32_t idx_c = cur.idx, idx_n = cur.idx_n;
-	// One address per haplotype: entry * size + this lane's offset into the image(s).  The factors are read FO / FO + 8
-	// bytes behind it, which is right for lanes 0..31 (image offset 0) -- the only ones whose factors are used.
+	// One address per haplotype: entry * size + this lane's offset into the image(s)
 	uint32_t o1 = (idx_c & 0xFFFFu) * ES + img, o2 = ((idx_c >> 16) & 0x3FFFu) * ES + img;
 	v4i e1 = load_hap_image(hp, o1), e2 = load_hap_image(hp, o2);
-	double ff = load_hap_factor<FO>(hp, o1, 0), f2 = load_hap_factor<FO>(hp, o2, 1);
+	u32x4 H_n = hdr[0];
+	FG F_n = *(ConstPtr<FG>)fac;
 	for (int b = 0; b < nblk; b++) {
-		// this block's records: images and the factor ff[i1] * f[i2]
-		const v4i a1 = e1, a2 = e2;
-		const double prod = ff * f2;
-		const uint32_t endmask = (uint32_t)__ballot((idx_c & HIBAG_PLIST_END) != 0);          // lanes 32..63 mirror 0..31
-		// (only pass 1 looks at it; STORE comes with END only, so both flags set = the two top bits set)
-		const uint32_t storemask = (uint32_t)__ballot(idx_c >= (HIBAG_PLIST_END | HIBAG_PLIST_STORE));
-		const uint32_t live = endmask | (uint32_t)__ballot(prod != 0.0);                      // low half: lanes 0..31
-		const int n_valid = live ? 32 - __builtin_clz(live) : 0;
+		// this block's records: header, first factors, images
+		const u32x4 H = H_n;
+		const FG F = F_n;
+		v4i a1 = e1, a2 = e2;
+		if (ENG == HIBAG_ENGINE_FP4) {
+			// one K step: the A row is made right away, so that the images' registers are free for the next block's loads
+			// (otherwise the loop ends in eight register moves)
+			a1 = e1 + e2; a2 = v4i{0, 0, 0, 0};
+			asm volatile("" : "+v"(a1));
+		}
+		const uint32_t endmask = H[0], storemask = H[1];
+		const int n_valid = (int)H[2];
 		const uint32_t ob1 = o1, ob2 = o2;           // (FP4W: where this block's entries are, for their further images)
-		// look-ahead: entries of block b+1, slot words of block b+2
+		// (the header is waited for HERE, before the next scalar loads are issued: a wait behind them would be for them too)
+		asm volatile("" :: "s"(n_valid));
+		__builtin_amdgcn_sched_barrier(0);
+		// look-ahead: header and first factors of block b+1 (carried around the loop: requested inside the branch below they
+		// would be waited for at once); entries of block b+1, slot words of block b+2
+		H_n = hdr[b + 1];
+		F_n = *(ConstPtr<FG>)(fac + (size_t)(b + 1) * HIBAG_PLIST_DWORDS);
 		idx_c = idx_n;
 		o1 = (idx_c & 0xFFFFu) * ES + img; o2 = ((idx_c >> 16) & 0x3FFFu) * ES + img;
 		e1 = load_hap_image(hp, o1); e2 = load_hap_image(hp, o2);
-		ff = load_hap_factor<FO>(hp, o1, 0); f2 = load_hap_factor<FO>(hp, o2, 1);
 		idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + 2 * BB, 0);
 		if (n_valid > 0) {
-			if (lane < 32) *(LdsDouble *)(uintptr_t)(sa + 8u * (uint32_t)lane) = prod;
 			v16i D0, D1;
 			if (FP4W) {
 				// K step 0 like a one-step classifier, then the further steps: their images and B operands are fetched here
@@ -492,7 +494,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 				block_mfma<ENG>(a1, a2, lane, cterm, T, D0, D1);
 			}
 			block_own_sample(D0, D1, n_valid);
-			block_accumulate<G>(sa, endmask, storemask, n_valid, D0, D1, cell, tab_s, fin);
+			block_accumulate<G>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, tab_s, fin);
 		}
 		soff += BB;
 	}
@@ -916,7 +918,6 @@ template <bool STORE>
 __global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagModelView M, HibagBatchView B, int gx, int n_whole, int rest, int stride, int K)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
-	__shared__ double stage_s[BLOCK_WAVES][STAGE_DOUBLES];
 	int li = blockIdx.x, k = 0;
 	if (li >= n_whole) {
 		const int jj = li - n_whole;
@@ -975,8 +976,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagMod
 			};
 #define CALL(E) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, lane, T);                                       \
 			ListCursor cur;                                                                                                \
-			walk_blocks<E, 4>(M, M.blk_off[c] + (uint64_t)b0 * HIBAG_PLIST_DWORDS, b1 - b0, lane, cur,                 \
-				hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c], T, WideSrc(), tab_s, stage_s[wave], cell, fin); }
+			walk_blocks<E, TOTAL_G>(M, M.blk_off[c] + (uint64_t)b0 * HIBAG_PLIST_DWORDS, b1 - b0, lane, cur,                 \
+				hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c], T, WideSrc(), tab_s, cell, fin); }
 			HIBAG_DISPATCH_ENGINE(nkb, CALL)
 #undef CALL
 			if (!last) { B.tot[at] = total; B.inv[at] = cell; }
@@ -1004,7 +1005,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagMod
 __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total_wide(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
-	__shared__ double stage_s[BLOCK_WAVES][STAGE_DOUBLES];
 	stage_table(M, tab_s);
 	const int *__restrict__ seg = M.wide_seg + 4 * blockIdx.y;
 	const int c = seg[0];
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total_wide(HibagModelView 
 	load_operand_row<HIBAG_ENGINE_FP4W>(B, M.bt_row[c], c, group, lane, T);
 	ListCursor cur;
 	walk_blocks<HIBAG_ENGINE_FP4W, 4>(M, M.wide_seg_off[blockIdx.y], seg[2], lane, cur, hap_rsrc(M, M.hap_off[c]),
-		M.n_snp_c[c] - HIBAG_FP4_STEP_SNPS * (wide.nstep - 1), T, wide, tab_s, stage_s[wave], cell, fin);
+		M.n_snp_c[c] - HIBAG_FP4_STEP_SNPS * (wide.nstep - 1), T, wide, tab_s, cell, fin);
 }
 
 // k_total_scan: the in-order total of a split classifier from its stored cell sums; thread = sample.
@@ -1144,7 +1144,6 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double acc_s[ACCUM_WAVES][HIBAG_TILE][HIBAG_WAVE];
-	__shared__ double stage_s[ACCUM_WAVES][STAGE_DOUBLES];
 
 	// Work item = (XCD, four sample groups, one tile); the four wavefronts of a workgroup take the four groups.
 	// They read the same blocks and the same haplotype-table entries at about the same time, so those
@@ -1206,6 +1205,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		const __amdgpu_buffer_rsrc_t ph = __builtin_amdgcn_make_buffer_rsrc((void *)(M.ehdr + blk0 * 8), 0,
 			left_h > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left_h, 0x00020000);
 		const __amdgpu_buffer_rsrc_t hp = hap_rsrc(M, 0);      // the whole haplotype table; a block's classifier enters as the scalar offset
+		ConstPtr<double> fac = as_const(M.pfac) + blk0 * HIBAG_PLIST_DWORDS;                 // the slots' frequency factors
+		ConstPtr<u32x4> phdr = (ConstPtr<u32x4>)(as_const(M.phdr) + blk0 * 4);               // the blocks' {end mask, -, slots worth evaluating, -}
+		u32x4 PH_n = phdr[0];
+		typedef FactorGroup<ACCUM_G>::type AFG;
+		AFG F_n = *(ConstPtr<AFG>)fac;
 		// the batch's operand / weight / 1/total rows and this group's stored sums as raw buffers too: a row is then a scalar
 		// offset (classifier or row number times the row size, SALU) added to one constant per-lane offset -- no 64-bit address
 		// arithmetic on the vector ALU.  (hibag_api.hip batch_limit keeps every one of these arrays below 4 GB.)
@@ -1217,7 +1221,6 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		const int vo_i = (lane & 31) * 4, vo_h = (lane & 7) * 4;
 		const int vo_bt = (group * HIBAG_WAVE + lane) * 16, vo_s = s * 8, vo_sv = lane * 8;
 		const uint32_t bt_stride = (uint32_t)B.n_pad * 16u, s_stride = (uint32_t)B.n_pad * 8u;      // bytes per operand row / per classifier's row
-		const uint32_t sa = stage_address(stage_s[wave]);
 		constexpr uint32_t ES = 4u * HIBAG_ENGINE_HAP_DWORDS(HIBAG_ENGINE_FP4);      // bytes per table entry: sum image, AND image, ff, f
 		const uint32_t img = (uint32_t)(lane >> 5) * 16u;     // lanes 0..31 fetch the "sum" image of their haplotypes, lanes 32..63 the "AND" image
 		constexpr int NS = HIBAG_STORED_PER_VISIT;
@@ -1230,7 +1233,6 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 
 		// everything block b needs, requested a block ahead
 		v4i e1, e2;                                   // the lane's images of its haplotype pair
-		double ff, f2;                                // the pair's frequency factors (used by lanes 0..31)
 		v4i t0, t1;                                   // the B operand (two sample halves)
 		double w, inv, sv[NS];
 		auto request = [&](uint32_t idx, const EHeader &H) {
@@ -1240,8 +1242,6 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			const auto i2 = __builtin_amdgcn_raw_buffer_load_b128(hp, (int)o2, so, 0);
 			e1 = v4i{(int)i1[0], (int)i1[1], (int)i1[2], (int)i1[3]};
 			e2 = v4i{(int)i2[0], (int)i2[1], (int)i2[2], (int)i2[3]};
-			ff = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(hp, (int)o1, so + 32, 0));
-			f2 = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(hp, (int)o2, so + 40, 0));
 			const int sc = (int)((H.h0 & 0xFFFFu) * s_stride);
 			w = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_cw, vo_s, sc, 0));
 			inv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_inv, vo_s, sc, 0));
@@ -1275,11 +1275,24 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			// inactive lanes (weight 0) must keep their sums: with 1/total replaced by 0 their term is
 			// (cell * 0) * 0 = +0 and a + 0 == a, which spares a select per closed cell
 			const double inv_e = active ? inv_c : 0.0;
-			const double prod = ff * f2;                  // the record's frequency factor, rounded like the reference's (src/LibHLA.cpp:1786-1813)
-			const uint32_t endmask = (uint32_t)__ballot((idx_c & HIBAG_PLIST_END) != 0);          // lanes 32..63 mirror 0..31
-			const uint32_t live = endmask | (uint32_t)__ballot(prod != 0.0);
-			const int n_valid = live ? 32 - __builtin_clz(live) : 0;
+			// the block's header and its first factors through the scalar cache (walk_blocks; the header of block b + 1 is
+			// requested here too: it is first looked at a block later)
+			const u32x4 PH = PH_n;
+			asm volatile("" :: "s"(PH[2]));               // (waited for before the next scalar loads are issued)
+			__builtin_amdgcn_sched_barrier(0);
+			PH_n = phdr[b - bb + 1];
+			const uint32_t endmask = PH[0];
+			const int n_valid = (int)PH[2];
 			const bool eval = any && n_valid > 0;
+			const AFG F = F_n;
+			F_n = *(ConstPtr<AFG>)(fac + (size_t)(b - bb + 1) * HIBAG_PLIST_DWORDS);
+			// The other three 64-byte lines of block b + 1's factors are touched a block ahead, so that the scalar loads of its
+			// later groups hit the scalar cache (-5 % on the kernel; pass 1, whose groups are twice as long, gains nothing):
+			// one dword each into registers nobody reads, held until the wait at the end of this block because the compiler
+			// does not know that these loads are in flight.
+			uint32_t tch0, tch1, tch2;
+			asm volatile("s_load_dword %0, %3, 0x40\n\ts_load_dword %1, %3, 0x80\n\ts_load_dword %2, %3, 0xc0"
+				: "=&s"(tch0), "=&s"(tch1), "=&s"(tch2) : "s"(fac + (size_t)(b - bb + 1) * HIBAG_PLIST_DWORDS));
 			// this block's A operand row: the two images' sum (lower K half) or AND (upper K half)
 			v4i arow;
 #pragma unroll
@@ -1309,7 +1322,6 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			// into the registers they have just read
 			v16i D0, D1;
 			if (eval) {
-				if (lane < 32) *(LdsDouble *)(uintptr_t)(sa + 8u * (uint32_t)lane) = prod;
 				v16f d0, d1;
 #pragma unroll
 				for (int r = 0; r < 16; r++) { d0[r] = 0.0f; d1[r] = 0.0f; }
@@ -1336,8 +1348,9 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 					__hip_atomic_fetch_add(&acc[(int)(jpack & 15)][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					jpack >>= 4;
 				};
-				block_accumulate<4>(sa, endmask, 0u, n_valid, D0, D1, cell, tab_s, fin);
+				block_accumulate<ACCUM_G>(fac + (size_t)(b - bb) * HIBAG_PLIST_DWORDS, F, endmask, 0u, n_valid, D0, D1, cell, tab_s, fin);
 			}
+			asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(tch0), "s"(tch1), "s"(tch2));
 			Hc = Hn;
 			soff += 4 * HIBAG_PLIST_DWORDS;
 		}
@@ -1470,7 +1483,6 @@ __device__ __forceinline__ int classifier_best(const HibagModelView &M, const Hi
 __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_vote_best(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
-	__shared__ double stage_s[BLOCK_WAVES][STAGE_DOUBLES];
 	stage_table(M, tab_s);
 	const int c = M.c_order[blockIdx.y];
 	const int group = blockIdx.x * BLOCK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1498,7 +1510,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_vote_best(HibagModelView M
 		ListCursor cur;                                                                                                \
 		double cell = 0;                                                                                               \
 		walk_blocks<E, 4>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), k_last,         \
-			T, wide, tab_s, stage_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)], cell, fin); }
+			T, wide, tab_s, cell, fin); }
 		HIBAG_DISPATCH_ENGINE_WIDE(nkb, wide.nstep, CALL)
 #undef CALL
 		bp = best_i < 0 ? -1 : (int)M.cls_cell[M.cls_off[c] + best_i];
