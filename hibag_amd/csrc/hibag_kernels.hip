@@ -1128,12 +1128,11 @@ struct EHeader {
 	uint32_t jps;       // tile rows of the stored sums
 };
 
-__device__ __forceinline__ EHeader read_header(uint32_t hv)      // lanes 0..7 hold the header's dwords
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ EHeader read_header(u32x8 hv)         // the header's dwords, one scalar load
 {
 	EHeader H;
-	H.h0 = __builtin_amdgcn_readlane(hv, 0); H.hap = __builtin_amdgcn_readlane(hv, 1); H.bt = __builtin_amdgcn_readlane(hv, 2);
-	H.srow = __builtin_amdgcn_readlane(hv, 3); H.jp_lo = __builtin_amdgcn_readlane(hv, 4); H.jp_hi = __builtin_amdgcn_readlane(hv, 5);
-	H.jps = __builtin_amdgcn_readlane(hv, 6);
+	H.h0 = hv[0]; H.hap = hv[1]; H.bt = hv[2]; H.srow = hv[3]; H.jp_lo = hv[4]; H.jp_hi = hv[5]; H.jps = hv[6];
 	return H;
 }
 
@@ -1197,13 +1196,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 #else
 	if (bb < be) {
 #endif
-		// the tile's blocks [bb, be): slot words and headers as raw buffers rebased at block bb (no 4 GB limit on the stream)
+		// the tile's blocks [bb, be): the slot words as a raw buffer rebased at block bb (no 4 GB limit on the stream)
 		const uint64_t blk0 = as_const(M.etile_blk0)[tile] + (uint64_t)bb;
-		const uint64_t left_s = (M.plist_dwords - blk0 * HIBAG_PLIST_DWORDS) * 4, left_h = (M.estream_blocks - blk0) * 32;
+		const uint64_t left_s = (M.plist_dwords - blk0 * HIBAG_PLIST_DWORDS) * 4;
 		const __amdgpu_buffer_rsrc_t pl = __builtin_amdgcn_make_buffer_rsrc((void *)(M.plist + blk0 * HIBAG_PLIST_DWORDS), 0,
 			left_s > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left_s, 0x00020000);
-		const __amdgpu_buffer_rsrc_t ph = __builtin_amdgcn_make_buffer_rsrc((void *)(M.ehdr + blk0 * 8), 0,
-			left_h > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left_h, 0x00020000);
 		const __amdgpu_buffer_rsrc_t hp = hap_rsrc(M, 0);      // the whole haplotype table; a block's classifier enters as the scalar offset
 		ConstPtr<double> fac = as_const(M.pfac) + blk0 * HIBAG_PLIST_DWORDS;                 // the slots' frequency factors
 		ConstPtr<u32x4> phdr = (ConstPtr<u32x4>)(as_const(M.phdr) + blk0 * 4);               // the blocks' {end mask, -, slots worth evaluating, -}
@@ -1218,7 +1215,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		const __amdgpu_buffer_rsrc_t r_inv = __builtin_amdgcn_make_buffer_rsrc((void *)B.inv, 0, (int)0xFFFFFFF0u, 0x00020000);
 		const __amdgpu_buffer_rsrc_t r_sv = __builtin_amdgcn_make_buffer_rsrc(
 			(void *)(B.cells + (size_t)group * (size_t)as_const(M.cell_row)[C] * HIBAG_WAVE), 0, (int)0xFFFFFFF0u, 0x00020000);
-		const int vo_i = (lane & 31) * 4, vo_h = (lane & 7) * 4;
+		const int vo_i = (lane & 31) * 4;
 		const int vo_bt = (group * HIBAG_WAVE + lane) * 16, vo_s = s * 8, vo_sv = lane * 8;
 		const uint32_t bt_stride = (uint32_t)B.n_pad * 16u, s_stride = (uint32_t)B.n_pad * 8u;      // bytes per operand row / per classifier's row
 		constexpr uint32_t ES = 4u * HIBAG_ENGINE_HAP_DWORDS(HIBAG_ENGINE_FP4);      // bytes per table entry: sum image, AND image, ff, f
@@ -1226,10 +1223,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		constexpr int NS = HIBAG_STORED_PER_VISIT;
 
 		uint32_t idx_c = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, 0, 0);
-		uint32_t hv_c = __builtin_amdgcn_raw_buffer_load_b32(ph, vo_h, 0, 0);
 		uint32_t idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, 4 * HIBAG_PLIST_DWORDS, 0);
-		uint32_t hv_n = __builtin_amdgcn_raw_buffer_load_b32(ph, vo_h, 32, 0);
-		EHeader Hc = read_header(hv_c);
+		ConstPtr<u32x8> eh = (ConstPtr<u32x8>)(as_const(M.ehdr) + blk0 * 8);                  // the blocks' 8-dword headers (scalar loads)
+		const u32x8 hv_0 = eh[0];
+		EHeader Hc = read_header(hv_0);
+		u32x8 hv_n = eh[1];
 
 		// everything block b needs, requested a block ahead
 		v4i e1, e2;                                   // the lane's images of its haplotype pair
@@ -1316,7 +1314,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			idx_c = idx_n;
 			request(idx_c, Hn);
 			idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + 2 * 4 * HIBAG_PLIST_DWORDS, 0);
-			hv_n = __builtin_amdgcn_raw_buffer_load_b32(ph, vo_h, (soff >> 2) + 64, 0);
+			hv_n = eh[b - bb + 2];
 			__builtin_amdgcn_sched_barrier(0);
 			// ---- block b: distances on the matrix pipe; behind the two instructions the next block's B operand is requested
 			// into the registers they have just read
