@@ -281,8 +281,12 @@ __device__ __forceinline__ void block_mfma(const v4i &e1, const v4i &e2, int lan
 		const v8i b0 = {T.b[0][0][0], T.b[0][0][1], T.b[0][0][2], T.b[0][0][3], 0, 0, 0, 0};
 		const v8i b1 = {T.b[1][0][0], T.b[1][0][1], T.b[1][0][2], T.b[1][0][3], 0, 0, 0, 0};
 		const int sb = upper ? HIBAG_FP4_SCALE_B_HI : HIBAG_FP4_SCALE_B_LO;
+#ifdef HIBAG_ABL_NOMFMA
+		d0[0] = __builtin_bit_cast(float, (a8[0] ^ b0[0]) & 0xF8); d1[0] = __builtin_bit_cast(float, (a8[1] ^ b1[1] ^ sb) & 0xF8);
+#else
 		d0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, d0, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sb);
 		d1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, d1, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sb);
+#endif
 		acc0 = __builtin_bit_cast(v16i, d0);
 		acc1 = __builtin_bit_cast(v16i, d1);
 		return;
@@ -317,6 +321,9 @@ __device__ __forceinline__ void block_own_sample(v16i &D0, v16i &D1, int n_valid
 #pragma unroll
 	for (int g = 0; g < 4; g++) {
 		if (8 * g >= n_valid) break;
+#ifdef HIBAG_ABL_NOSWAP
+		continue;
+#endif
 #pragma unroll
 		for (int r = 4 * g; r < 4 * g + 4; r++) {
 			const auto sw = __builtin_amdgcn_permlane32_swap(D0[r], D1[r], false, false);
@@ -457,7 +464,11 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 			a1 = e1 + e2; a2 = v4i{0, 0, 0, 0};
 			asm volatile("" : "+v"(a1));
 		}
+#ifdef HIBAG_ABL_NOEND
+		const uint32_t endmask = 0, storemask = 0;
+#else
 		const uint32_t endmask = H[0], storemask = H[1];
+#endif
 		const int n_valid = (int)H[2];
 		const uint32_t ob1 = o1, ob2 = o2;           // (FP4W: where this block's entries are, for their further images)
 		// (the header is waited for HERE, before the next scalar loads are issued: a wait behind them would be for them too)
@@ -965,6 +976,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagMod
 			const int lane = threadIdx.x & 63;
 			// (a store issued where the cell closes; parking the sums in LDS and sending them a block later, so that
 			// the vmcnt waits of the look-ahead gathers never include a young store, measured 10 % slower)
+			// (stores through a raw buffer with the row as a scalar offset -- no 64-bit address on the vector ALU -- measured 2 % slower)
 			auto fin = [&](double v, bool stored) {
 #ifdef HIBAG_STORE_PLAIN      // (variant: write-back stores instead of streaming ones)
 				if (STORE && stored) { rows[(size_t)row * HIBAG_WAVE + lane] = v; row++; }
