@@ -1253,9 +1253,17 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			e1 = v4i{(int)i1[0], (int)i1[1], (int)i1[2], (int)i1[3]};
 			e2 = v4i{(int)i2[0], (int)i2[1], (int)i2[2], (int)i2[3]};
 			const int sc = (int)((H.h0 & 0xFFFFu) * s_stride);
+#ifdef HIBAG_ABL2_NOWINV
+			w = 1.0 + sc; inv = 2.0 + sc;
+#else
 			w = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_cw, vo_s, sc, 0));
 			inv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_inv, vo_s, sc, 0));
+#endif
+#ifdef HIBAG_ABL2_NOSV
+			const int ns = 0;
+#else
 			const int ns = (int)(H.h0 >> 25) & 15;
+#endif
 			if (ns > 0) {
 				const int sr = (int)(H.srow * (uint32_t)(HIBAG_WAVE * 8));
 #pragma unroll
@@ -1293,7 +1301,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			PH_n = phdr[b - bb + 1];
 			const uint32_t endmask = PH[0];
 			const int n_valid = (int)PH[2];
+#ifdef HIBAG_ABL2_NOEVAL
+			const bool eval = false;
+#else
 			const bool eval = any && n_valid > 0;
+#endif
 			const AFG F = F_n;
 			F_n = *(ConstPtr<AFG>)(fac + (size_t)(b - bb + 1) * HIBAG_PLIST_DWORDS);
 			// The other three 64-byte lines of block b + 1's factors are touched a block ahead, so that the scalar loads of its
@@ -1309,7 +1321,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			for (int d = 0; d < 4; d++) arow[d] = e1[d] + e2[d];      // sum image / pair image: one add either way
 			// the sums pass 1 stored for this block's classifier:   S[p] += (cell * (1/total)) * w
 			{
+#ifdef HIBAG_ABL2_NOSV
+				const int ns = 0;
+#else
 				const int ns = (int)(Hc.h0 >> 25) & 15;
+#endif
 				if (any && ns > 0) {
 					uint32_t jps = Hc.jps;
 #pragma unroll
