@@ -473,3 +473,29 @@ def test_plugin_per_sample_route_every_width_and_edge(hib, oracle):
         assert np.array_equal(prob, want["postprob"][i], equal_nan=True), i
         assert match[0] == want["matching"][i] or (np.isnan(match[0]) and np.isnan(want["matching"][i])), i
     host.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 14, 15, 29, 30, 31, 32])
+def test_extreme_genotypes_and_zero_frequencies(hib, oracle, k):
+    """The corners of the matrix engine's K layout (hibag_device.h): every SNP heterozygous with both haplotypes carrying
+    the allele (the largest w = 4 terms against the -4 terms of the lower K half), every SNP homozygous for the other
+    allele (offset 2k: all four offset digits in use at k = 30), all missing; and haplotypes of frequency exactly zero,
+    whose pairs have the factor 0 the host writes into the per-slot factor array (the block headers' count of slots
+    worth evaluating ends at the last slot with a non-zero factor or a closing cell)."""
+    rng = np.random.default_rng(500 + k)
+    pats = ["1" * k, "0" * k, ("10" * k)[:k], ("01" * k)[:k]] + ["".join(rng.choice(["0", "1"], k)) for _ in range(9)]
+    H = len(pats)
+    hla = np.sort(rng.integers(0, 4, H)).astype(np.int32)
+    freq = rng.uniform(0.01, 1.0, H)
+    freq[[2, 5, H - 1]] = 0.0                                              # (incl. the last haplotype: trailing zero factors)
+    n_snp = k + 3
+    cl = [hib.Classifier(snpidx=np.arange(k) + j, freq=np.roll(freq, j), hla=hla, haplo=pats) for j in range(3)]
+    model = hib.HlaAttrBagObj(n_samp=0, n_snp=n_snp, hla_allele=["a", "b", "c", "d"], classifiers=cl)
+    rows = [np.full(n_snp, v, np.int32) for v in (0, 1, 2, hib.NA_INTEGER)]
+    rows += [rng.choice(np.array([0, 1, 2], np.int32), n_snp) for _ in range(60)]
+    G = np.stack(rows).astype(np.int32)
+    m = hib.hlaModelFromObj(model)
+    for vote in (1, 2):
+        want = oracle.predict(oracle.flatten(model), G, vote_method=vote)
+        got = m.predict_raw(G, vote, want_dosage=True, want_prob=True)
+        assert_same(got, want)
