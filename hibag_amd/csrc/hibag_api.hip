@@ -870,8 +870,9 @@ int finalize_model(hibag_hip_model *m)
 	(void)valu_pairs;
 	if (getenv("HIBAG_DEBUG_MODEL"))
 		fprintf(stderr, "[hibag model] %d classifiers, %d tiles, pairs %lld; blocks of 32: pass 1 %lld, pass 2 %lld in %lld (classifier, tile) segments; "
-			"pair lists %.1f MB, haplotype table %.1f KB, VALU-engine stream %.1f MB\n",
-			C, n_tile, (long long)m->pair_evals, dbg_b1, dbg_b2, dbg_seg, plist.size() * 4e-6, hap.size() * 4e-3, stream.size() * 4e-6);
+			"pair lists %.1f MB + factors %.1f MB + block headers %.1f MB, haplotype table %.1f KB, VALU-engine stream %.1f MB\n",
+			C, n_tile, (long long)m->pair_evals, dbg_b1, dbg_b2, dbg_seg, plist.size() * 4e-6, plist.size() * 8e-6, plist.size() / 32 * 16e-6,
+			hap.size() * 4e-3, stream.size() * 4e-6);
 	plist.insert(plist.end(), 4 * HIBAG_PLIST_DWORDS, 0u);   // look-ahead slack of the block walker
 	// What the kernels take from a block through the SCALAR cache (hibag_device.h): the frequency factor of every slot --
 	// ff[i1] * f[i2], the one rounded multiplication of src/LibHLA.cpp:1786-1813, made here once instead of by every wavefront
