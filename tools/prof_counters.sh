@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$1; shift; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 i=0
 for ctrs in "$@"; do i=$((i+1))
-  timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $out/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $out/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras $BENCH_ARGS > $out/p$i.log 2>&1
 done
 cd $R && python3 - "$out" <<'PY'
 import csv,glob,collections,sys
