@@ -231,7 +231,7 @@ def main():
                   "k_accum": {"ms": round(ms2, 4), "simd_ns_per_wave_pair": round(ns2, 2), "frac": round(floor_ns / ns2, 4),
                               "stored_cells_read_gb": round(stored * 8.0 * n_pad / 1e9, 3)},
                   "constants": K,
-                  "note": "the binding ceiling is SIMD issue (and, equally loaded, the LDS), not HBM: per evaluated pair one FP64 mul "
+                  "note": "the binding ceiling is SIMD issue, not HBM: per evaluated pair one FP64 mul "
                           "+ one FP64 add in the reference's order plus its share of the MFMAs, which serialise with FP64 on a SIMD "
                           "(constants: raw tools/ubench_* logs under profiles/, DESIGN.md section 5).  Pass 2 evaluates only the pairs "
                           "of the cells with few pairs (the others' sums come from pass 1 through HBM), so its time is mostly per-cell "
