@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total_wide(HibagModelView 
 	LaneOperand T;
 	load_operand_row<HIBAG_ENGINE_FP4W>(B, M.bt_row[c], c, group, lane, T);
 	ListCursor cur;
-	walk_blocks<HIBAG_ENGINE_FP4W, 4>(M, M.wide_seg_off[blockIdx.y], seg[2], lane, cur, hap_rsrc(M, M.hap_off[c]),
+	walk_blocks<HIBAG_ENGINE_FP4W, TOTAL_G>(M, M.wide_seg_off[blockIdx.y], seg[2], lane, cur, hap_rsrc(M, M.hap_off[c]),
 		M.n_snp_c[c] - HIBAG_FP4_STEP_SNPS * (wide.nstep - 1), T, wide, tab_s, cell, fin);
 }
 
@@ -1535,7 +1535,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_vote_best(HibagModelView M
 #define CALL(E) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, threadIdx.x & 63, T);                           \
 		ListCursor cur;                                                                                                \
 		double cell = 0;                                                                                               \
-		walk_blocks<E, 4>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), k_last,         \
+		walk_blocks<E, TOTAL_G>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), k_last,         \
 			T, wide, tab_s, cell, fin); }
 		HIBAG_DISPATCH_ENGINE_WIDE(nkb, wide.nstep, CALL)
 #undef CALL
