@@ -62,6 +62,7 @@
 #ifndef ACCUM_G
 #define ACCUM_G 4                           // the same for pass 2
 #endif
+#define ACCUM_TAB_N 64
 #ifndef ACCUM_WAVES
 #define ACCUM_WAVES 4                       // wavefronts per workgroup of pass 2 (sample groups that share a tile's lists in L1)
 #endif
@@ -553,9 +554,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t hap_rsrc(const HibagModelView 
 	default: { CALL(12); } break;          \
 	}
 
-__device__ __forceinline__ void stage_table(const HibagModelView &M, double *tab_s)
+__device__ __forceinline__ void stage_table(const HibagModelView &M, double *tab_s, int n = HIBAG_TAB_N)
 {
-	for (int i = threadIdx.x; i < HIBAG_TAB_N; i += blockDim.x) tab_s[i] = M.tab[i];
+	for (int i = threadIdx.x; i < n; i += blockDim.x) tab_s[i] = M.tab[i];
 	__syncthreads();
 }
 
@@ -1153,7 +1154,8 @@ __device__ __forceinline__ EHeader read_header(u32x8 hv)         // the header's
 #endif
 __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(HibagModelView M, HibagBatchView B, int n_whole, int K)
 {
-	__shared__ double tab_s[HIBAG_TAB_N];
+	// (pass 2 evaluates one-step FP4 classifiers only: distances up to 2 * 30, the first 64 table entries)
+	__shared__ double tab_s[ACCUM_TAB_N];
 	__shared__ double acc_s[ACCUM_WAVES][HIBAG_TILE][HIBAG_WAVE];
 
 	// Work item = (XCD, four sample groups, one tile); the four wavefronts of a workgroup take the four groups.
@@ -1180,7 +1182,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		if (k < K - 1) ce = chunk_bound(cum, C, (total * (uint64_t)(k + 1) + K - 1) / K);
 		if (cb >= ce) return;                         // (fewer classifiers than chunks)
 	}
-	stage_table(M, tab_s);
+	stage_table(M, tab_s, ACCUM_TAB_N);
 	const int jq = item / M.n_tile, tile = item - jq * M.n_tile;
 	const int group = (jq * ACCUM_WAVES + wave) * 8 + xcd;
 	unsigned long long *flag = B.sync + (size_t)xcd * n_item_x + item;
