@@ -467,6 +467,8 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 		}
 #ifdef HIBAG_ABL_NOEND
 		const uint32_t endmask = 0, storemask = 0;
+#elif defined(HIBAG_ABL_NOSTORE)
+		const uint32_t endmask = H[0], storemask = 0;
 #else
 		const uint32_t endmask = H[0], storemask = H[1];
 #endif
