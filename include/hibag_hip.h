@@ -198,7 +198,7 @@ int hibag_hip_model_engine(const hibag_hip_model *m, int classifier, int *engine
  *
  * The reference spreads a cohort over the workers of a `parallel` cluster: contiguous sample slices, every worker
  * holding the whole model, results concatenated (R/HIBAG.R:764-808).  Here a "worker" is a device:
- *   hibag_hip_model_replicate  a finalized copy of `m` on `device` (the model takes about 12 bytes per listed haplotype pair -- 14 MB for the benchmark model; every device holds all of it)
+ *   hibag_hip_model_replicate  a finalized copy of `m` on `device` (the model takes about 12 bytes per listed haplotype pair -- 11 MB for the benchmark model; every device holds all of it)
  *   hibag_hip_predict_multi    hibag_hip_predict over `n_models` replicas at once: one host thread per replica, each
  *                              takes the contiguous slice hibag_hip_multi_slice gives it and writes its part of every
  *                              output in place.  Samples are independent (src/LibHLA.cpp:2362-2411): no collective, and
