@@ -398,7 +398,18 @@ void prepare_haplotypes(T &t, const HapList &cur, HapList &next)
 
 // PrepareNewSNP, :1127-1183.  `pl` / `next` are the caller's working copies: candidates of one
 // growth step are fitted concurrently, each on its own copy.
-bool prepare_new_snp(const T &t, int snp, const HapList &cur, HapList &next, PairSet &pls)
+// One candidate SNP's fit: CAlg_EM::PrepareNewSNP (DoubleHaplosInitFreq, :444-459, and the pair flags, :1133-1183) followed by
+// ExpectationMaximization (:1185-1255) on the in-bag samples' haplotype pairs `t.pl`, which index the doubled list `next`.
+// The reference flags the pairs compatible with the new SNP's genotype and walks all pairs in every iteration; here the
+// compatible ones are copied once into compact arrays (the indices, then the pair frequencies) and the frequencies live in
+// two plain vectors -- the same additions and multiplications in the same order (per sample its pairs in list order, per
+// haplotype the pairs in sample order), without a copy of the whole pair set per candidate, without a branch per pair and
+// iteration, and with a third of the memory traffic.  Returns false where the reference skips the SNP (monomorphic in the bag).
+struct FitScratch {
+	std::vector<int> h1, h2, off;
+	std::vector<double> gfreq, old_freq, new_freq, log_buf;
+};
+bool fit_new_snp(const T &t, int snp, const HapList &cur, HapList &next, FitScratch &S)
 {
 	int allele_cnt = 0, valid_cnt = 0;
 	for (int i : t.inbag) {
@@ -408,58 +419,59 @@ bool prepare_new_snp(const T &t, int snp, const HapList &cur, HapList &next, Pai
 	}
 	if (allele_cnt == 0 || allele_cnt == valid_cnt) return false;
 	const double afreq = (double)allele_cnt / valid_cnt, p0 = 1 - afreq, p1 = afreq;   // DoubleHaplosInitFreq, :444-459
+	const size_t nh = next.list.size();
+	S.new_freq.resize(nh); S.old_freq.resize(nh);
 	for (size_t i = 0; i < cur.list.size(); i++) {
-		next.list[2 * i].freq = p0 * cur.list[i].freq + EM_INIT_VAL_FRAC;
-		next.list[2 * i + 1].freq = p1 * cur.list[i].freq + EM_INIT_VAL_FRAC;
+		S.new_freq[2 * i] = p0 * cur.list[i].freq + EM_INIT_VAL_FRAC;
+		S.new_freq[2 * i + 1] = p1 * cur.list[i].freq + EM_INIT_VAL_FRAC;
 	}
+	// the pairs compatible with the sample's genotype at the new SNP (every pair where it is missing)
+	const PairSet &pls = t.pl;
+	const size_t num = pls.size();
 	const int idx_new = next.n_snp - 1;
-	for (size_t i = 0; i < pls.size(); i++) {
+	S.off.resize(num + 1);
+	S.h1.clear(); S.h2.clear();
+	for (size_t i = 0; i < num; i++) {
+		S.off[i] = (int)S.h1.size();
 		const int geno = t.geno[(size_t)pls.samp[i] * t.n_snp + snp];
+		const bool typed = 0 <= geno && geno <= 2;
 		for (int j = pls.off[i]; j < pls.off[i + 1]; j++) {
-			HapPair &p = pls.p[j];
-			p.flag = (0 <= geno && geno <= 2) ?
-				(get_allele(next.list[p.h1], idx_new) + get_allele(next.list[p.h2], idx_new) == geno) : true;
+			const HapPair &p = pls.p[j];
+			if (!typed || get_allele(next.list[p.h1], idx_new) + get_allele(next.list[p.h2], idx_new) == geno) {
+				S.h1.push_back(p.h1); S.h2.push_back(p.h2);
+			}
 		}
 	}
-	return true;
-}
+	S.off[num] = (int)S.h1.size();
+	S.gfreq.resize(S.h1.size());
+	if (S.log_buf.size() < num) S.log_buf.resize(num);
+	const int *const H1 = S.h1.data(), *const H2 = S.h2.data();
+	double *const G = S.gfreq.data(), *const oldf = S.old_freq.data(), *const newf = S.new_freq.data();
 
-void expectation_maximization(const T &t, HapList &next, PairSet &pls, std::vector<double> &log_buf)   // :1185-1255
-{
 	const int total = t.n_samp;
 	const double em_reltol = std::sqrt(DBL_EPSILON);                    // :102
 	double conv_tol = 0, loglik = -1e+30;
-	const size_t num = pls.size();
-	if (log_buf.size() < num) log_buf.resize(num);
 	for (int iter = 0; iter <= EM_MAX_ITER; iter++) {
 		const double old_loglik = loglik;
-		for (size_t i = 0; i < next.list.size(); i++) { next.old_freq[i] = next.list[i].freq; next.list[i].freq = 0; }
-		HapPair *const P = pls.p.data();
+		for (size_t i = 0; i < nh; i++) { oldf[i] = newf[i]; newf[i] = 0; }
 		for (size_t i = 0; i < num; i++) {
-			const int j0 = pls.off[i], j1 = pls.off[i + 1];
+			const int j0 = S.off[i], j1 = S.off[i + 1];
 			double psum = 0;
 			for (int j = j0; j < j1; j++) {
-				HapPair &p = P[j];
-				if (p.flag) {
-					p.gfreq = (p.h1 != p.h2) ? (2 * next.old_freq[p.h1] * next.old_freq[p.h2])
-					                         : (next.old_freq[p.h1] * next.old_freq[p.h2]);
-					psum += p.gfreq;
-				}
+				G[j] = (H1[j] != H2[j]) ? (2 * oldf[H1[j]] * oldf[H2[j]]) : (oldf[H1[j]] * oldf[H2[j]]);
+				psum += G[j];
 			}
-			log_buf[i] = pls.boot[i] * std::log(psum);
+			S.log_buf[i] = pls.boot[i] * std::log(psum);
 			psum = pls.boot[i] / psum;
-			for (int j = j0; j < j1; j++) if (P[j].flag) P[j].gfreq *= psum;
+			for (int j = j0; j < j1; j++) G[j] *= psum;
 		}
 		loglik = 0;
 		for (size_t i = 0; i < num; i++) {
-			loglik += log_buf[i];
-			for (int j = pls.off[i]; j < pls.off[i + 1]; j++) {
-				const HapPair &p = P[j];
-				if (p.flag) { next.list[p.h1].freq += p.gfreq; next.list[p.h2].freq += p.gfreq; }
-			}
+			loglik += S.log_buf[i];
+			for (int j = S.off[i]; j < S.off[i + 1]; j++) { newf[H1[j]] += G[j]; newf[H2[j]] += G[j]; }
 		}
 		const double scale = 0.5 / total;
-		for (PluginHaplotype &h : next.list) h.freq *= scale;
+		for (size_t i = 0; i < nh; i++) newf[i] *= scale;
 		if (iter > 0) {
 			if (std::fabs(loglik - old_loglik) <= conv_tol) break;
 		} else {
@@ -467,6 +479,8 @@ void expectation_maximization(const T &t, HapList &next, PairSet &pls, std::vect
 			if (conv_tol < 0) conv_tol = 0;
 		}
 	}
+	for (size_t i = 0; i < nh; i++) next.list[i].freq = newf[i];
+	return true;
 }
 
 void erase_double_haplos(const HapList &in, double rare_prob, HapList &out)   // EraseDoubleHaplos, :461-515
@@ -562,12 +576,10 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 			std::atomic<int> next_i(lo);
 			auto work = [&]() {
 				HapList nx;
-				PairSet pls;
-				std::vector<double> log_buf;
+				FitScratch scratch;
 				for (int i; (i = next_i.fetch_add(1)) < hi;) {
-					nx = next; pls = t.pl;
-					if (!prepare_new_snp(t, vs.at(i), out_haplo, nx, pls)) continue;
-					expectation_maximization(t, nx, pls, log_buf);
+					nx = next;
+					if (!fit_new_snp(t, vs.at(i), out_haplo, nx, scratch)) continue;
 					erase_double_haplos(nx, rare_prob, cand[i]);
 					set_aux(cand[i]);                                   // _Init_EvalAcc, :1913-1929
 					valid[i] = 1;
