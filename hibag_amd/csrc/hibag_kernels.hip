@@ -11,21 +11,23 @@
 // the numeric path.
 //
 // Two engines compute the distance d of a pair (bit-identical results):
-//   matrix engine 8 d = A . B over 2k+1 positions (h1+h2 against the genotype's signs, h1&h2 against
-//                 [g = 1], an offset term): a small GEMM of 32 records x 64 samples per block --
+//   matrix engine 8 d = A . B over 2k+1 positions (h1+h2 against the genotype's signs, h1&h2 -- on the FP4 path a stand-in
+//                 for it that is a plain sum of two images -- against [g = 1], an offset term): a small GEMM of 32 records
+//                 x 64 samples per block --
 //                 up to 30 SNPs on the FP4 matrix path (v_mfma_scale_f32_32x32x64_f8f6f4, e2m1 operands: all 64 K
 //                 positions in one instruction per sample half; block scales of 2^-73 make the f32 result the
 //                 denormal 8 d * 2^-149, whose bit pattern IS the integer 8 d), 31..32 SNPs on
 //                 v_mfma_i32_32x32x32_i8 (two K blocks) -- plus 16 v_permlane32_swap to give every lane its own
 //                 sample's column.  The records are generated: each lane gathers its pair's two haplotype
-//                 entries (nibble / byte images + frequency factors) from an O(H) table through a 4-byte index
-//                 pair.  33..112 SNPs: FP4 again, 28 SNPs per K step, chained through the accumulator.  All real classifiers; the default.
+//                 images (nibbles / bytes) from an O(H) table through a 4-byte index pair; what is the same for all lanes
+//                 -- the pair's frequency factor, the block's end-of-cell masks -- comes through the scalar cache into
+//                 scalar registers.  33..112 SNPs: FP4 again, 28 SNPs per K step, chained through the accumulator.  All real classifiers; the default.
 //   VALU engine   d = sum_w popc((W[w] ^ T'[w]) & M'[w]): v_bitop3_b32 + v_bcnt_u32_b32 per 32-bit
 //                 word of the stored 3k-bit pair string (W uniform in SGPRs, T'/M' the lane's genotype
 //                 masks); classifiers with more than 112 SNPs.  (The per-sample plugin route has kernels of its own:
 //                 hibag_sample.hip.)
 // In both, what the contract fixes stays on the vector ALU, per lane and in the reference's order:
-//     cell += prod * TAB[d]          ds_read_b64 (table in LDS), v_mul_f64, v_add_f64
+//     cell += prod * TAB[d]          ds_read_b64 (table in LDS), v_mul_f64 (prod a scalar-register operand), v_add_f64
 //
 // The normalisation 1/sum of a classifier's posterior needs all of its cells,
 // and 64 samples x P cells do not fit on chip, so the pair loop runs twice:
