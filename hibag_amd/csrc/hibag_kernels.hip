@@ -64,7 +64,8 @@
 #ifndef ACCUM_G
 #define ACCUM_G 4                           // the same for pass 2
 #endif
-#define ACCUM_TAB_N 64
+#define ACCUM_TAB_N 64                      // table entries pass 2 stages: it evaluates one-step FP4 classifiers only
+static_assert(2 * HIBAG_FP4_MAX_SNPS + 1 <= ACCUM_TAB_N, "pass 2's table must cover every distance of a one-step FP4 classifier");
 #ifndef ACCUM_WAVES
 #define ACCUM_WAVES 4                       // wavefronts per workgroup of pass 2 (sample groups that share a tile's lists in L1)
 #endif
