@@ -1797,11 +1797,12 @@ static int resident_blocks(F kernel, int threads)
 // worse); items of several thousand blocks (the DRB1 shape: 3,900) take 8 - 16 (-4 % against 4): one chunk per
 // `blocks_per_item` / 256, between 4 and 12.
 // `forced` = HibagBatchView::tail_k: 1 after a failed hand-over on the model (its launches then have no hand-overs at all).
-static int tail_chunks(int forced, long long blocks_per_item = 0)
+// (Pass 2, whose items are a tile's ~85 short blocks: 2 chunks -- 0.522-0.527 ms against 0.532 with 4, same box, three runs each.)
+static int tail_chunks(int forced, long long blocks_per_item = 0, int at_least = 4)
 {
 	if (forced > 0) return forced;
 	static const int k = getenv("HIBAG_TAIL_K") ? std::max(1, std::min(64, atoi(getenv("HIBAG_TAIL_K")))) : 0;
-	return k ? k : (int)std::max(4ll, std::min(12ll, blocks_per_item / 256));
+	return k ? k : (int)std::max<long long>(at_least, std::min(12ll, blocks_per_item / 256));
 }
 
 // Resident workgroups of the chunked kernels on the current device; the model keeps them (HibagModelView::slots_*), so
@@ -1885,8 +1886,8 @@ void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStr
 	const int slots = M.slots_accum;
 	const unsigned nx = n / 8, sx = (unsigned)slots / 8;
 	unsigned n_whole = nx, K = 1;
-	if (tail_chunks(B.tail_k) > 1 && sx > 0 && nx > sx) {
-		K = (unsigned)tail_chunks(B.tail_k);
+	if (tail_chunks(B.tail_k, 0, 2) > 1 && sx > 0 && nx > sx) {
+		K = (unsigned)tail_chunks(B.tail_k, 0, 2);
 		n_whole = nx - (nx % sx + sx);
 	}
 	hipLaunchKernelGGL(k_accum, dim3(8 * (n_whole + K * (nx - n_whole))), dim3(ACCUM_WAVES * HIBAG_WAVE), 0, st, M, B, (int)n_whole, (int)K);
