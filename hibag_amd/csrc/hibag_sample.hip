@@ -6,7 +6,7 @@
 //
 //   k_one_cells   thread = one non-empty allele-pair cell of one classifier: the cell's haplotype pairs in the
 //                 reference's order, d = hamm_d on the packed words, sum += (2 f1 f2) * TAB[d]   (src/LibHLA.cpp:1776-1821)
-//   k_one_total   thread = classifier: its cells added in posterior order -> total, 1/total      (:1823-1829)
+//   k_one_total   wavefront = classifier: its cells added in posterior order by lane 0 -> total, 1/total      (:1823-1829)
 //   k_one_accum   thread = posterior cell p: S[p] += (cell * (1/total)) * w over the classifiers in order, normalised by
 //                 the sum of weights (:1497-1518, :2448-2480); thread 0 also forms the matching value
 //
@@ -26,7 +26,7 @@ int hibag_selected_device();      // hibag_api.hip
 
 namespace {
 
-struct OneCell { int c, a0, a1, b0, b1, k; };         // classifier, haplotype ranges (absolute indices) of the two alleles, SNPs of the classifier
+struct OneCell { int c, a0, a1, b0, b1, k, p, pad; };  // classifier, haplotype ranges (absolute indices) of the two alleles, SNPs of the classifier, posterior cell
 
 struct OneView {
 	int n_hla, n_cell, n_classifier, n_cells_total;
@@ -35,12 +35,12 @@ struct OneView {
 	const OneCell *cells;        // [n_cells_total] the non-empty cells, classifier after classifier, posterior order inside
 	const int *cell_off;         // [C + 1] first cell of each classifier
 	const int *hap_off;          // [C + 1] first haplotype of each classifier
-	const int *cellpos;          // [C][P] index of (classifier, posterior cell) in `cells`, -1 = structurally empty
 	const double *tab;           // [257]
 	// per call
 	const uint64_t *geno;        // [C][6] TGenotype: S1[2], S2[2], 16 bytes of book-keeping
 	const double *weight;        // [C]
-	double *cellv;               // [n_cells_total]
+	double *cellv;               // [n_cells_total] the cell sums, classifier after classifier (k_one_total adds them in order)
+	double *dense;               // [C][P] the same sums by posterior cell; the structurally empty cells stay +0.0 for ever (k_one_accum)
 	double *tot, *inv;           // [C]
 	double *out;                 // [P + 1]: the averaged posterior, then the matching value
 };
@@ -164,39 +164,49 @@ __global__ __launch_bounds__(256) void k_one_cells(OneView V)
 	// pre-fills them so, src/LibHLA.cpp:672-673)
 	const uint64_t ka = q.k >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << q.k) - 1), kb = q.k >= 128 ? ~(uint64_t)0 : (q.k <= 64 ? 0 : (((uint64_t)1 << (q.k - 64)) - 1));
 	const uint64_t s1a = g[0] & ka, s1b = g[1] & kb, s2a = g[2] | ~ka, s2b = g[3] | ~kb;
+	double v;
 	if (q.k <= 32)
-		V.cellv[t] = staged ? one_cell32(q, bits_s, freq_s, base, (uint32_t)s1a, (uint32_t)s2a, tab_s)
-		                    : one_cell32(q, V.bits, V.freq, 0, (uint32_t)s1a, (uint32_t)s2a, tab_s);
+		v = staged ? one_cell32(q, bits_s, freq_s, base, (uint32_t)s1a, (uint32_t)s2a, tab_s)
+		           : one_cell32(q, V.bits, V.freq, 0, (uint32_t)s1a, (uint32_t)s2a, tab_s);
 	else
-		V.cellv[t] = staged ? one_cell<true>(q, bits_s, freq_s, base, s1a, s1b, s2a, s2b, tab_s)
-		                    : one_cell<false>(q, V.bits, V.freq, 0, s1a, s1b, s2a, s2b, tab_s);
+		v = staged ? one_cell<true>(q, bits_s, freq_s, base, s1a, s1b, s2a, s2b, tab_s)
+		           : one_cell<false>(q, V.bits, V.freq, 0, s1a, s1b, s2a, s2b, tab_s);
+	V.cellv[t] = v;
+	V.dense[(size_t)q.c * V.n_cell + q.p] = v;
 }
 
-__global__ void k_one_total(OneView V)
+// One wavefront per classifier: the lanes fetch its cell sums 1,024 at a time into LDS (coalesced), lane 0 adds them in cell
+// order from there, sixteen values per LDS round trip -- a single thread reading memory directly took 16 us for the ~600 cells
+// of a classifier of the benchmark model, most of it the latency of ten rounds of loads.
+#define ONE_TOTAL_CHUNK 1024
+__global__ __launch_bounds__(64) void k_one_total(OneView V)
 {
-	const int c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= V.n_classifier) return;
-	if (!(V.weight[c] > 0)) { V.tot[c] = 0; V.inv[c] = 0; return; }
+	__shared__ double v_s[ONE_TOTAL_CHUNK];
+	const int c = blockIdx.x;
+	if (!(V.weight[c] > 0)) { if (threadIdx.x == 0) { V.tot[c] = 0; V.inv[c] = 0; } return; }
 	const int i0 = V.cell_off[c], i1 = V.cell_off[c + 1];
 	double total = 0;
-	int i = i0;
-	for (; i + 64 <= i1; i += 64) {                       // sixty-four loads in flight, added in cell order
-		double v[64];
+	for (int base = i0; base < i1; base += ONE_TOTAL_CHUNK) {
+		const int n = min(ONE_TOTAL_CHUNK, i1 - base);
+		for (int i = threadIdx.x; i < ONE_TOTAL_CHUNK; i += 64) v_s[i] = i < n ? V.cellv[base + i] : 0.0;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			int i = 0;
+			for (; i + 16 <= n; i += 16) {
+				double v[16];
 #pragma unroll
-		for (int j = 0; j < 64; j++) v[j] = V.cellv[i + j];
+				for (int j = 0; j < 16; j++) v[j] = v_s[i + j];
 #pragma unroll
-		for (int j = 0; j < 64; j++) total += v[j];
+				for (int j = 0; j < 16; j++) total += v[j];
+			}
+			for (; i < n; i++) total += v_s[i];
+		}
+		__syncthreads();
 	}
-	for (; i + 8 <= i1; i += 8) {
-		double v[8];
-#pragma unroll
-		for (int j = 0; j < 8; j++) v[j] = V.cellv[i + j];
-#pragma unroll
-		for (int j = 0; j < 8; j++) total += v[j];
+	if (threadIdx.x == 0) {
+		V.tot[c] = total;
+		V.inv[c] = 1 / total;                             // src/LibHLA.cpp:1827 (inf when total == 0)
 	}
-	for (; i < i1; i++) total += V.cellv[i];
-	V.tot[c] = total;
-	V.inv[c] = 1 / total;                                 // src/LibHLA.cpp:1827 (inf when total == 0)
 }
 
 __global__ __launch_bounds__(256) void k_one_accum(OneView V)
@@ -215,26 +225,25 @@ __global__ __launch_bounds__(256) void k_one_accum(OneView V)
 		V.out[V.n_cell] = sum_m / num_m;
 		return;
 	}
+	// Thirty-two classifiers' values in flight (coalesced: consecutive threads, consecutive cells), added in classifier order.
+	// A structurally empty cell reads +0.0 and adds (0 * inv) * w: +0.0 -- nothing -- for a finite 1/total, and NaN where the
+	// total is 0 or so small that 1/total overflows, which is what the reference's loop produces there (0 * inf).
 	double S = 0, sum_w = 0;
-	constexpr int NB = 16;
-	for (int c0 = 0; c0 < C; c0 += NB) {                  // sixteen classifiers' look-ups in flight, added in classifier order
-		int pos[NB];
+	constexpr int NB = 32;
+	for (int c0 = 0; c0 < C; c0 += NB) {
 		double w[NB], inv[NB], v[NB];
 #pragma unroll
 		for (int j = 0; j < NB; j++) {
 			const int c = c0 + j < C ? c0 + j : C - 1;
-			pos[j] = V.cellpos[(size_t)c * V.n_cell + p];
 			w[j] = c0 + j < C ? V.weight[c] : 0.0;
 			inv[j] = V.inv[c];
+			v[j] = V.dense[(size_t)c * V.n_cell + p];
 		}
-#pragma unroll
-		for (int j = 0; j < NB; j++) v[j] = V.cellv[pos[j] >= 0 ? pos[j] : 0];
 #pragma unroll
 		for (int j = 0; j < NB; j++) {
 			if (!(w[j] > 0)) continue;                    // AddProbToSum skips the classifier (:1497-1507)
 			sum_w += w[j];
-			if (pos[j] >= 0) S += (v[j] * inv[j]) * w[j];
-			else if (!(fabs(inv[j]) <= 1.79769313486231570815e+308)) S += (0.0 * inv[j]) * w[j];   // 0 * inf = NaN, like the reference
+			S += (v[j] * inv[j]) * w[j];
 		}
 	}
 	V.out[p] = sum_w > 0 ? S * (1.0 / sum_w) : S;         // NormalizeSumPostProb (:1509-1518)
@@ -282,7 +291,7 @@ void hibag_sample_init(int n_hla, int n_classifier, const PluginHaplotype *const
 	std::vector<uint64_t> bits;
 	std::vector<double> freq;
 	std::vector<OneCell> cells;
-	std::vector<int> cell_off(C + 1, 0), hap_off(C + 1, 0), cellpos((size_t)std::max(C, 1) * P, -1);
+	std::vector<int> cell_off(C + 1, 0), hap_off(C + 1, 0);
 	for (int c = 0; c < C; c++) {
 		const int H = n_haplo[c], k = n_snp[c];
 		if (H < 0 || k < 0 || k > 128) one_throw("predict_init: invalid classifier");
@@ -307,8 +316,7 @@ void hibag_sample_init(int n_hla, int n_classifier, const PluginHaplotype *const
 		for (int h1 = 0; h1 < n_hla; h1++)
 			for (int h2 = h1; h2 < n_hla; h2++, p++) {
 				if (st[h1] == st[h1 + 1] || st[h2] == st[h2 + 1]) continue;
-				cellpos[(size_t)c * P + p] = (int)cells.size();
-				cells.push_back(OneCell{c, base + st[h1], base + st[h1 + 1], base + st[h2], base + st[h2 + 1], k});
+				cells.push_back(OneCell{c, base + st[h1], base + st[h1 + 1], base + st[h2], base + st[h2 + 1], k, p, 0});
 			}
 	}
 	cell_off[C] = (int)cells.size();
@@ -322,20 +330,21 @@ void hibag_sample_init(int n_hla, int n_classifier, const PluginHaplotype *const
 	size_t o = 0;
 	auto take = [&](size_t bytes) { const size_t at = o; o = (o + std::max<size_t>(bytes, 8) + 63) & ~(size_t)63; return at; };
 	const size_t o_bits = take(bits.size() * 8), o_freq = take(freq.size() * 8), o_cells = take(cells.size() * sizeof(OneCell)),
-		o_off = take(cell_off.size() * 4), o_hoff = take(hap_off.size() * 4), o_pos = take(cellpos.size() * 4), o_tab = take(sizeof(tab));
+		o_off = take(cell_off.size() * 4), o_hoff = take(hap_off.size() * 4), o_tab = take(sizeof(tab));
 	ONE_OK(hipMalloc(&g1.d_model, o), "hipMalloc(model)");
 	char *d = (char *)g1.d_model;
 	auto put = [&](size_t at, const void *src, size_t bytes) { if (bytes) ONE_OK(hipMemcpy(d + at, src, bytes, hipMemcpyHostToDevice), "copy model"); };
 	put(o_bits, bits.data(), bits.size() * 8); put(o_freq, freq.data(), freq.size() * 8);
 	put(o_cells, cells.data(), cells.size() * sizeof(OneCell)); put(o_off, cell_off.data(), cell_off.size() * 4);
 	put(o_hoff, hap_off.data(), hap_off.size() * 4);
-	put(o_pos, cellpos.data(), cellpos.size() * 4); put(o_tab, tab, sizeof(tab));
+	put(o_tab, tab, sizeof(tab));
 	// per-call arena: [genotypes | weights] in, [posterior, matching] out, then scratch
 	size_t oc = 0;
 	auto takec = [&](size_t bytes) { const size_t at = oc; oc = (oc + std::max<size_t>(bytes, 8) + 63) & ~(size_t)63; return at; };
 	const size_t c_geno = takec((size_t)C * sizeof(PluginGenotype)), c_w = takec((size_t)C * 8);
 	g1.call_in = oc;
-	const size_t c_out = takec((size_t)(P + 1) * 8), c_cellv = takec(cells.size() * 8), c_tot = takec((size_t)C * 8), c_inv = takec((size_t)C * 8);
+	const size_t c_out = takec((size_t)(P + 1) * 8), c_cellv = takec(cells.size() * 8), c_tot = takec((size_t)C * 8), c_inv = takec((size_t)C * 8),
+		c_dense = takec((size_t)C * P * 8);            // (zeroed once, below: the empty cells are never written)
 	g1.call_bytes = oc;
 	ONE_OK(hipMalloc(&g1.d_call, oc), "hipMalloc(call)");
 	ONE_OK(hipMemset(g1.d_call, 0, oc), "hipMemset(call)");
@@ -344,9 +353,10 @@ void hibag_sample_init(int n_hla, int n_classifier, const PluginHaplotype *const
 	OneView &V = g1.V;
 	V.n_hla = n_hla; V.n_cell = P; V.n_classifier = C; V.n_cells_total = (int)cells.size();
 	V.bits = (const uint64_t *)(d + o_bits); V.freq = (const double *)(d + o_freq); V.cells = (const OneCell *)(d + o_cells);
-	V.cell_off = (const int *)(d + o_off); V.hap_off = (const int *)(d + o_hoff); V.cellpos = (const int *)(d + o_pos); V.tab = (const double *)(d + o_tab);
+	V.cell_off = (const int *)(d + o_off); V.hap_off = (const int *)(d + o_hoff); V.tab = (const double *)(d + o_tab);
 	V.geno = (const uint64_t *)(dc + c_geno); V.weight = (const double *)(dc + c_w);
 	V.out = (double *)(dc + c_out); V.cellv = (double *)(dc + c_cellv); V.tot = (double *)(dc + c_tot); V.inv = (double *)(dc + c_inv);
+	V.dense = (double *)(dc + c_dense);
 	g1.P = P; g1.C = C; g1.device = hibag_selected_device();
 	g1.active = true;
 }
@@ -365,7 +375,7 @@ void hibag_sample_avg_prob(const PluginGenotype geno[], const double weight[], d
 	if (C > 0) ONE_OK(hipMemcpyAsync(g1.d_call, h, g1.call_in, hipMemcpyHostToDevice, st), "copy genotypes");
 	const OneView &V = g1.V;
 	if (V.n_cells_total > 0) hipLaunchKernelGGL(k_one_cells, dim3((V.n_cells_total + 255) / 256), dim3(256), 0, st, V);
-	if (C > 0) hipLaunchKernelGGL(k_one_total, dim3((C + 63) / 64), dim3(64), 0, st, V);
+	if (C > 0) hipLaunchKernelGGL(k_one_total, dim3(C), dim3(64), 0, st, V);
 	hipLaunchKernelGGL(k_one_accum, dim3((P + 1 + 255) / 256), dim3(256), 0, st, V);
 	ONE_OK(hipGetLastError(), "launch");
 	double *h_out = (double *)(h + g1.call_in);
