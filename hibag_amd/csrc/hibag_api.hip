@@ -1283,8 +1283,12 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 	const size_t o_h1 = 0, o_h2 = o_h1 + (size_t)slice * 4, o_mp = (o_h2 + (size_t)slice * 4 + 7) / 8 * 8,
 		o_mt = o_mp + (size_t)slice * 8, o_ds = o_mt + (size_t)slice * 8, o_pp = o_ds + (size_t)slice * nh * 8,
 		out_bytes = (o_pp + (postprob ? (size_t)slice * P * 8 : 0) + 255) / 256 * 256;
-	const int n_slice = (n_samp + slice - 1) / slice;
-	const bool piped = n_slice > 1;
+	// A pipelined run starts with a shorter slice: what nothing overlaps with is the staging and upload of the FIRST slice,
+	// and a third of a slice costs the kernels less (their last rounds are emptier) than the wait it saves.
+	const bool piped = n_samp > slice;
+	static const int first_env = getenv("HIBAG_STAGED_FIRST") ? atoi(getenv("HIBAG_STAGED_FIRST")) : 0;     // (diagnostic)
+	const int first = piped ? std::max(64, std::min(slice, (first_env > 0 ? first_env : slice / 3) / 64 * 64)) : slice;
+	const int n_slice = piped ? 1 + (n_samp - first + slice - 1) / slice : 1;
 	const int nbuf = piped ? 2 : 1;
 	if (!bed)
 		if (int rc = m->ws_geno.reserve(geno_bytes * nbuf)) return rc;
@@ -1298,7 +1302,10 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 		if (!bed) if (int rc = m->pin_geno.reserve(geno_bytes * 2)) return rc;
 		if (int rc = m->pin_out.reserve(out_bytes * 2)) return rc;
 	}
-	auto slice_of = [&](int i, int &s0, int &n) { s0 = i * slice; n = std::min(slice, n_samp - s0); };
+	auto slice_of = [&](int i, int &s0, int &n) {
+		if (i == 0) { s0 = 0; n = std::min(first, n_samp); }
+		else { s0 = first + (i - 1) * slice; n = std::min(slice, n_samp - s0); }
+	};
 	auto upload = [&](int i) -> int {
 		if (bed) return 0;
 		int s0, n; slice_of(i, s0, n);
