@@ -73,7 +73,8 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 #define HIBAG_CHUNK_DWORDS(nwp) (HIBAG_CHUNK * ((nwp) + 2))
 // dwords of one 32-slot block of a pair list (matrix-core engine)
 #define HIBAG_PLIST_DWORDS 32
-#define HIBAG_PLIST_END 0x80000000u
+// slot flags (the kernels take them from the block headers, HibagModelView::phdr; the host builds the headers from the words)
+#define HIBAG_PLIST_END 0x80000000u          // the slot closes a cell
 #define HIBAG_PLIST_STORE 0x40000000u        // with END: pass 1 stores this cell's sum for pass 2 to read back
 #ifndef HIBAG_STORED_PER_VISIT
 #define HIBAG_STORED_PER_VISIT 8             // mode 2: stored cells per block of pass 2 (and per (classifier, tile) visit of a classifier it evaluates) -- what k_accum keeps in registers; at most 8
