@@ -1317,11 +1317,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			F_n = *(ConstPtr<AFG>)(fac + (size_t)(b - bb + 1) * HIBAG_PLIST_DWORDS);
 			// The other three 64-byte lines of block b + 1's factors are touched a block ahead, so that the scalar loads of its
 			// later groups hit the scalar cache (-5 % on the kernel; pass 1, whose groups are twice as long, gains nothing):
-			// one dword each into registers nobody reads, held until the wait at the end of this block because the compiler
-			// does not know that these loads are in flight.
-			uint32_t tch0, tch1, tch2;
-			asm volatile("s_load_dword %0, %3, 0x40\n\ts_load_dword %1, %3, 0x80\n\ts_load_dword %2, %3, 0xc0"
-				: "=&s"(tch0), "=&s"(tch1), "=&s"(tch2) : "s"(fac + (size_t)(b - bb + 1) * HIBAG_PLIST_DWORDS));
+			// one dword each, volatile so that the loads stay HERE, "used" at the end of this block (the compiler waits for them
+			// there, where they are long done; and it knows about them, should it ever have to spill their registers).
+			typedef const volatile __attribute__((address_space(4))) uint32_t *TouchPtr;
+			const TouchPtr touch = (TouchPtr)(uintptr_t)(fac + (size_t)(b - bb + 1) * HIBAG_PLIST_DWORDS);
+			const uint32_t tch0 = touch[16], tch1 = touch[32], tch2 = touch[48];
 			// this block's A operand row: the two images' sum (lower K half) or AND (upper K half)
 			v4i arow;
 #pragma unroll
@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 				};
 				block_accumulate<ACCUM_G>(fac + (size_t)(b - bb) * HIBAG_PLIST_DWORDS, F, endmask, 0u, n_valid, D0, D1, cell, tab_s, fin);
 			}
-			asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(tch0), "s"(tch1), "s"(tch2));
+			asm volatile("" :: "s"(tch0), "s"(tch1), "s"(tch2));
 			Hc = Hn;
 			soff += 4 * HIBAG_PLIST_DWORDS;
 		}
