@@ -1014,7 +1014,7 @@ int finalize_model(hibag_hip_model *m)
 	V.p1_blocks = dbg_b1;
 	V.cell_row = base + o_crow;
 	V.store_cells = store_mode;
-	hibag_query_slots(&V.slots_total[0], &V.slots_total[1], &V.slots_accum);
+	hibag_query_slots(V.slots_total, &V.slots_accum);
 	{
 		// A chunk waits for the chunk before it, which was dispatched a whole round earlier; in the worst case the chunks of
 		// an item run one after the other, so the wait is bounded by the item's own length.  One poll lasts ~1 us (s_sleep +

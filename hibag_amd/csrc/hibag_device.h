@@ -217,9 +217,9 @@ struct HibagModelView {
 	const uint32_t *etile_cstart;   // [n_tile][C + 1] block, counted from the tile's first, where classifier c's blocks begin:
 	                             // where a chunked work item is cut (hibag_kernels.hip "hand-overs"), and the item's length
 
-	// resident workgroups of k_total<false>, k_total<true> and k_accum on the model's device (0 = unknown), queried when
-	// the model is finalized (hibag_query_slots)
-	int slots_total[2], slots_accum;
+	// resident workgroups of k_total<STORE, occupancy> ([2 * STORE + (six per CU)]) and of k_accum on the model's device
+	// (0 = unknown), queried when the model is finalized (hibag_query_slots)
+	int slots_total[4], slots_accum;
 };
 
 struct HibagBatchView {

@@ -19,8 +19,9 @@ void hibag_launch_bed_geno(const uint8_t *d_bed, int mode, size_t stride, int n_
 // FP4 classifiers of several K steps (fork behind what is already on `st`, join before anything that follows)
 struct HibagSideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st, const HibagSideStream &side);
-// resident workgroups of k_total<false>, k_total<true>, k_accum on the current device (0 = unknown)
-void hibag_query_slots(int *total_plain, int *total_store, int *accum);
+// resident workgroups of k_total<STORE, occupancy> -- [0] <false, 5>, [1] <false, 6>, [2] <true, 5>, [3] <true, 6> -- and of
+// k_accum on the current device (0 = unknown)
+void hibag_query_slots(int total[4], int *accum);
 void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStream_t st);
 void hibag_launch_vote(const HibagModelView &M, const HibagBatchView &B, int *d_best_cell, hipStream_t st);
 void hibag_launch_scalars(const HibagModelView &M, const HibagBatchView &B, const int *d_best_cell, hipStream_t st);

@@ -58,8 +58,16 @@
 #ifndef TOTAL_G
 #define TOTAL_G 8                           // records of pass 1 whose look-ups are in flight together (and whose factors arrive in one scalar load)
 #endif
+// Workgroups per CU pass 1 is compiled for, twice: 5 (96 VGPRs) and 6 (80 VGPRs: the FP4 block loop still fits, the int8 and
+// VALU-engine loops spill a little).  Six wavefronts per SIMD are 1.5 - 4 % faster once a pass is two rounds of resident
+// workgroups or more (10,000 samples of the HLA-B shape: 0.80 -> 0.775 ms; 8,192 of DRB1: 14.1 -> 13.6 ms), and slower below that,
+// where a pass lasts as long as its longest work item, which six wavefronts sharing a SIMD stretch (4,096 samples of DRB1:
+// 7.1 -> 7.9 ms): the launcher chooses by the number of work items (hibag_launch_total).  (4 -> 128 VGPRs: measured slower.)
 #ifndef HIBAG_TOT_OCC
-#define HIBAG_TOT_OCC 5                     // workgroups per CU pass 1 is compiled for (96 VGPRs; 4 -> 128: measured slower)
+#define HIBAG_TOT_OCC 5
+#endif
+#ifndef HIBAG_TOT_OCC_MANY
+#define HIBAG_TOT_OCC_MANY 6
 #endif
 #ifndef ACCUM_G
 #define ACCUM_G 4                           // the same for pass 2
@@ -931,8 +939,8 @@ __device__ __forceinline__ int chunk_bound(const uint32_t *__restrict__ cum, int
 // parked in the classifier's tot / inv rows.
 // STORE: every cell sum goes to HibagBatchView::cells for pass 2 to read back (models whose pass 2 streams, see
 // k_accum_cells); otherwise only a split VALU-engine classifier stores its cells (for k_total_scan).
-template <bool STORE>
-__global__ __launch_bounds__(BLOCK_THREADS, HIBAG_TOT_OCC) void k_total(HibagModelView M, HibagBatchView B, int gx, int n_whole, int rest, int stride, int K)
+template <bool STORE, int OCC>
+__global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, HibagBatchView B, int gx, int n_whole, int rest, int stride, int K)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	int li = blockIdx.x, k = 0;
@@ -1807,10 +1815,13 @@ static int tail_chunks(int forced, long long blocks_per_item = 0, int at_least =
 
 // Resident workgroups of the chunked kernels on the current device; the model keeps them (HibagModelView::slots_*), so
 // that models on different devices, and the two instantiations of k_total, each get their own figure.
-void hibag_query_slots(int *total_plain, int *total_store, int *accum)
+void hibag_query_slots(int total[4], int *accum)
 {
-	*total_plain = resident_blocks(k_total<false>, BLOCK_THREADS);
-	*total_store = resident_blocks(k_total<true>, BLOCK_THREADS);
+	// [STORE][many]: k_total<false, 5>, <false, 6>, <true, 5>, <true, 6>
+	total[0] = resident_blocks(k_total<false, HIBAG_TOT_OCC>, BLOCK_THREADS);
+	total[1] = resident_blocks(k_total<false, HIBAG_TOT_OCC_MANY>, BLOCK_THREADS);
+	total[2] = resident_blocks(k_total<true, HIBAG_TOT_OCC>, BLOCK_THREADS);
+	total[3] = resident_blocks(k_total<true, HIBAG_TOT_OCC_MANY>, BLOCK_THREADS);
 	*accum = resident_blocks(k_accum, ACCUM_WAVES * HIBAG_WAVE);
 }
 
@@ -1848,8 +1859,12 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 	V.n_item = split ? M.n_item_split : M.n_item_whole;
 	if (!split) V.n_split = 0;
 	// more items than resident workgroups: the last, incomplete round and the full round before it go in K chunks each
-	const int slots = M.slots_total[M.store_cells ? 1 : 0];
 	const unsigned n = gx * (unsigned)V.n_item;
+	// two rounds of the denser build's resident workgroups or more: six workgroups per CU, otherwise five (above)
+	static const int occ_env = getenv("HIBAG_TOT_OCC") ? atoi(getenv("HIBAG_TOT_OCC")) : 0;      // (diagnostic: 5 or 6)
+	const int slots_many = M.slots_total[(M.store_cells ? 2 : 0) + 1];
+	const bool many = occ_env ? occ_env == HIBAG_TOT_OCC_MANY : (slots_many > 0 && n >= 2u * (unsigned)slots_many);
+	const int slots = M.slots_total[(M.store_cells ? 2 : 0) + (many ? 1 : 0)];
 	unsigned n_whole = n, rest = 0, stride = 8, K = 1;
 	const int k_pass1 = tail_chunks(B.tail_k, M.p1_blocks / std::max(M.n_classifier, 1));
 	if (k_pass1 > 1 && slots > 0 && n > (unsigned)slots) {
@@ -1859,10 +1874,13 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 		stride = (rest + 7) / 8 * 8;
 	}
 	const dim3 grid(n_whole + (rest ? K * stride : 0));
-	if (M.store_cells)
-		hipLaunchKernelGGL(k_total<true>, grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
-	else
-		hipLaunchKernelGGL(k_total<false>, grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
+	if (M.store_cells) {
+		if (many) hipLaunchKernelGGL((k_total<true, HIBAG_TOT_OCC_MANY>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
+		else hipLaunchKernelGGL((k_total<true, HIBAG_TOT_OCC>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
+	} else {
+		if (many) hipLaunchKernelGGL((k_total<false, HIBAG_TOT_OCC_MANY>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
+		else hipLaunchKernelGGL((k_total<false, HIBAG_TOT_OCC>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
+	}
 	if (split)
 		hipLaunchKernelGGL(k_total_scan, dim3(B.n_pad / 64, V.n_split), dim3(64), 0, st, V, B);
 	if (wide && side.stream) (void)hipStreamWaitEvent(st, side.join, 0);
