@@ -499,6 +499,22 @@ def other_configs(K):
         else:
             floor2, ach2 = issue_floor(obj, acc_ms, n4, K, m)
             res["cfg4_hla_drb1"].update({"pass2": "evaluates every haplotype pair again", "k_accum_issue_frac": round(floor2 / ach2, 4)})
+        # the same model on twice the batch: at 4,096 samples pass 1 is 1,600 work items on ~1,300 resident workgroups, i.e.
+        # as long as its longest item; from two rounds on the denser build of pass 1 takes over
+        n8 = 2 * n4
+        G8, _ = synth.make_samples(founders, af, n8)
+        dg8 = torch.from_numpy(G8).to(dev)
+        o8 = [torch.empty(n8, dtype=torch.int32, device=dev), torch.empty(n8, dtype=torch.int32, device=dev),
+              torch.empty(n8, dtype=torch.float64, device=dev), torch.empty(n8, dtype=torch.float64, device=dev),
+              torch.empty((n8, obj.n_hla), dtype=torch.float64, device=dev)]
+        run8 = lambda: m.predict_device(dg8.data_ptr(), n8, 1, *[x.data_ptr() for x in o8], None, stream=st)
+        run8(); torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(2):
+            run8()
+        torch.cuda.synchronize(dev)
+        dt8 = (time.perf_counter() - t) / 2
+        res["cfg4_hla_drb1"]["at_twice_the_batch"] = {"samples": n8, "samples_per_s": n8 / dt8, "ms_per_step": dt8 * 1e3}
         m.close()
     except Exception as e:                       # an extra must not take the metric line down
         res["cfg4_hla_drb1"] = {"error": repr(e)}
