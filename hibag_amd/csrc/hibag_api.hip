@@ -1187,6 +1187,15 @@ int workspace_leave(hibag_hip_model *m, hipStream_t st)
 	return 0;
 }
 
+// Records ws_done when a device-pointer entry returns -- also on its error paths, once anything has been enqueued.
+struct WorkspaceGuard {
+	hibag_hip_model *m;
+	hipStream_t st;
+	bool enqueued = false, left = false;
+	int leave() { left = true; return workspace_leave(m, st); }
+	~WorkspaceGuard() { if (enqueued && !left && m->ws_done) { (void)hipEventRecord(m->ws_done, st); m->ws_pending = true; } }
+};
+
 // Where a batch's genotypes come from: the int32 matrix, or a PLINK BED payload.
 struct PackSource {
 	const int32_t *d_geno = nullptr;       // [n_samp][row_len]
@@ -1205,12 +1214,16 @@ int predict_device_locked(hibag_hip_model *m, const PackSource &src, int n_samp,
 {
 	HIP_TRY(hipSetDevice(m->device));
 	if (int rc = workspace_enter(m, st)) return rc;
+	// Whatever way this call ends, work it has enqueued still uses the shared workspace: the next call on another stream
+	// must be chained behind it (an error in a later batch used to skip the record).
+	WorkspaceGuard guard{m, st};
 	const int lim = batch_limit(m);
 	const size_t P = (size_t)m->view.n_cell;
 	for (int s0 = 0; s0 < n_samp; s0 += lim) {
 		const int n = std::min(lim, n_samp - s0);
 		HibagBatchView B;
 		if (int rc = make_batch(m, n, vote_method == 2, B)) return rc;
+		guard.enqueued = true;
 		m->timer.begin(HIBAG_HIP_K_PACK, st);
 		if (src.d_bed)
 			hibag_launch_pack_bed(m->view, B, src.d_bed, src.mode, src.stride, src.samp0 + s0, src.d_row, src.d_flip,
@@ -1229,7 +1242,7 @@ int predict_device_locked(hibag_hip_model *m, const PackSource &src, int n_samp,
 		m->timer.end(st);
 	}
 	HIP_TRY(hipGetLastError());
-	return workspace_leave(m, st);
+	return guard.leave();
 }
 
 // Host-pointer driver.  The cohort is cut into slices (bounded workspace, bounded genotype staging); consecutive slices
@@ -1276,6 +1289,9 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 	const PackSource *map = nullptr, bool is_retry = false)
 {
 	// `map`: geno is the cohort's own matrix (map->row_len SNPs per sample); map->d_col / d_flip sit on the device
+	// A device-pointer launch still running on another stream may yet fail a hand-over: wait for it, so that its fault
+	// becomes the model's sticky status (its caller's to see) instead of being taken for this call's own and repaired away.
+	if (m->ws_pending && m->ws_done && !is_retry) HIP_TRY(hipEventSynchronize(m->ws_done));
 	if (int rc = sticky_fault(m)) return rc;
 	const size_t P = (size_t)m->view.n_cell, nh = (size_t)m->n_hla, S = map ? (size_t)map->row_len : (size_t)m->n_snp;
 	const int slice = staged_slice(m, n_samp, bed ? 1 : S);
@@ -1683,26 +1699,42 @@ int hibag_hip_predict_multi(hibag_hip_model *const *models, int n_models, const 
 	}
 	if (n_samp == 0) return 0;
 	const size_t S = (size_t)models[0]->n_snp, nh = (size_t)models[0]->n_hla, P = nh * (nh + 1) / 2;
-	std::vector<int> rc(n_models, 0);
-	std::vector<std::string> msg(n_models);
+	// One host thread per replica: each drives its own device through the ordinary host-pointer entry on its slice of the
+	// cohort and writes its slice of every output in place -- samples are independent (src/LibHLA.cpp:2362-2411), nothing is
+	// merged.  The first non-empty slice runs on the calling thread.  No C++ exception leaves this function (thread
+	// creation and the vectors below can throw): threads already started are joined, the call fails with ENOMEM.
 	std::vector<std::thread> th;
-	// one host thread per replica: each drives its own device through the ordinary host-pointer entry on its slice of the
-	// cohort and writes its slice of every output in place -- samples are independent (src/LibHLA.cpp:2362-2411), nothing is merged
-	for (int i = 0; i < n_models; i++) {
-		int first = 0, count = 0;
-		(void)hibag_hip_multi_slice(n_samp, n_models, i, &first, &count);
-		if (count == 0) continue;
-		th.emplace_back([=, &rc, &msg]() {
+	int code = 0, who = -1;
+	std::string text;
+	try {
+		std::vector<int> rc(n_models, 0);
+		std::vector<std::string> msg(n_models);
+		auto run = [&](int i, int first, int count) {
 			rc[i] = hibag_hip_predict(models[i], geno + (size_t)first * S, count, vote_method,
 				H1 ? H1 + first : nullptr, H2 ? H2 + first : nullptr, max_prob ? max_prob + first : nullptr,
 				matching ? matching + first : nullptr, dosage ? dosage + (size_t)first * nh : nullptr,
 				postprob ? postprob + (size_t)first * P : nullptr);
-			if (rc[i]) msg[i] = hibag_hip_last_error();
-		});
+			if (rc[i]) { try { msg[i] = hibag_hip_last_error(); } catch (...) {} }
+		};
+		int mine = -1, mine_first = 0, mine_count = 0;
+		th.reserve(n_models);
+		for (int i = 0; i < n_models; i++) {
+			int first = 0, count = 0;
+			(void)hibag_hip_multi_slice(n_samp, n_models, i, &first, &count);
+			if (count == 0) continue;
+			if (mine < 0) { mine = i; mine_first = first; mine_count = count; continue; }
+			th.emplace_back(run, i, first, count);
+		}
+		if (mine >= 0) run(mine, mine_first, mine_count);
+		for (auto &t : th) t.join();
+		th.clear();
+		for (int i = 0; i < n_models && !code; i++)
+			if (rc[i]) { code = rc[i]; who = i; text = msg[i]; }
+	} catch (...) {
+		for (auto &t : th) if (t.joinable()) t.join();
+		return fail(HIBAG_HIP_ENOMEM, "hibag_hip_predict_multi: could not start a host thread per replica");
 	}
-	for (auto &t : th) t.join();
-	for (int i = 0; i < n_models; i++)
-		if (rc[i]) return fail(rc[i], "replica %d (device %d): %s", i, models[i]->device, msg[i].c_str());
+	if (code) return fail(code, "replica %d (device %d): %s", who, models[who]->device, text.c_str());
 	return 0;
 }
 

@@ -513,10 +513,13 @@ void erase_double_haplos(const HapList &in, double rare_prob, HapList &out)   //
 	for (PluginHaplotype &h : out.list) h.freq *= scale;
 }
 
-// CPUs this process may use: affinity mask capped by the cgroup quota; HIBAG_TRAIN_THREADS overrides
+// Host threads a trainer fits candidate SNPs on: the CPUs this process may use (affinity mask capped by the cgroup quota)
+// divided by the ranks that share the host -- one process per GPU under torch.distributed.run, which exports
+// LOCAL_WORLD_SIZE: eight trainers that each started one thread per CPU would oversubscribe the host eight times.
+// HIBAG_TRAIN_THREADS overrides; hibag_hip_trainer_set_threads() sets it per trainer.
 int usable_threads()
 {
-	if (const char *e = getenv("HIBAG_TRAIN_THREADS")) return std::max(1, atoi(e));
+	if (const char *e = getenv("HIBAG_TRAIN_THREADS")) return std::max(1, std::min(atoi(e), 256));
 	int n = (int)std::thread::hardware_concurrency();
 	cpu_set_t set;
 	if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
@@ -527,7 +530,9 @@ int usable_threads()
 			n = std::min(n, std::max(1, (int)((atol(quota) + period / 2) / period)));
 		fclose(f);
 	}
-	return std::max(1, std::min(n, 64));
+	int ranks = 1;
+	if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
+	return std::max(1, std::min(n / ranks, 64));
 }
 
 const char *date_text()
@@ -734,6 +739,17 @@ hibag_hip_trainer *hibag_hip_trainer_new(int n_snp, int n_samp, const int32_t *s
 }
 
 void hibag_hip_trainer_free(hibag_hip_trainer *t) { delete t; }
+
+int hibag_hip_trainer_set_threads(hibag_hip_trainer *t, int n_threads)
+{
+	if (!t) return hibag_fail(HIBAG_HIP_EINVAL, "trainer is NULL");
+	std::lock_guard<std::mutex> g(t->lock);
+	const int n = n_threads > 0 ? std::min(n_threads, 256) : usable_threads();
+	if (n != t->n_threads) { t->pool.reset(); t->n_threads = n; }      // (the helpers are started by the next training call)
+	return 0;
+}
+
+int hibag_hip_trainer_threads(const hibag_hip_trainer *t) { return t ? t->n_threads : 0; }
 
 int hibag_hip_trainer_set_seed(hibag_hip_trainer *t, uint32_t seed)
 {

@@ -162,6 +162,14 @@ class _Trainer:
         except Exception:
             pass
 
+    def set_threads(self, n_threads: int):
+        """Host threads for the EM fits (``nthread`` of ``hlaAttrBagging``); <= 0 restores the default."""
+        _lib.check(_lib.lib().hibag_hip_trainer_set_threads(self._h, int(n_threads)))
+
+    @property
+    def threads(self) -> int:
+        return int(_lib.lib().hibag_hip_trainer_threads(self._h))
+
     def set_seed(self, seed: int):
         _lib.check(_lib.lib().hibag_hip_trainer_set_seed(self._h, C.c_uint32(int(seed) & 0xFFFFFFFF)))
 
@@ -206,11 +214,12 @@ def _row_mean_half(g: np.ndarray) -> np.ndarray:
 
 def hlaAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,
                    mtry: Union[str, float, int] = "sqrt", prune: bool = True, na_rm: bool = True,
-                   mono_rm: bool = True, maf: float = float("nan"), nthread: int = 1, verbose: bool = True,
+                   mono_rm: bool = True, maf: float = float("nan"), nthread: Optional[int] = None, verbose: bool = True,
                    verbose_detail: bool = False, rng: Optional[RRandom] = None, grow=None,
                    device: Optional[int] = None) -> HlaAttrBagClass:
-    """``hlaAttrBagging`` (``R/HIBAG.R:48-275``).  ``nthread`` is accepted for signature
-    compatibility (the scoring runs on the device).  ``rng`` defaults to the module's
+    """``hlaAttrBagging`` (``R/HIBAG.R:48-275``).  ``nthread``: host threads for the EM fits of a growth step
+    (the scoring runs on the device); ``None`` = the library's default, the usable CPUs divided by the ranks
+    sharing the host (``hibag_hip_trainer_set_threads``).  ``rng`` defaults to the module's
     R-compatible stream (see :func:`set_seed`).  ``grow`` (internal) replaces the single-device
     call of the native driver, see :func:`hlaParallelAttrBagging`.  ``device`` (extension): the HIP
     device that trains and holds the returned model (default: the thread's current selection)."""
@@ -297,6 +306,8 @@ def hlaAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,
         tr = _Trainer(np.ascontiguousarray(geno.T), H1, H2, len(HUA))
         try:
             tr.set_rng(_R if rng is None else rng)
+            if nthread is not None:
+                tr.set_threads(int(nthread))
             tr.new_classifiers(nclassifier, m, prune, verbose, verbose_detail)
             classifiers = tr.classifiers()
         finally:

@@ -275,6 +275,15 @@ hibag_hip_trainer *hibag_hip_trainer_new(int n_snp, int n_samp, const int32_t *s
 	const int32_t *H1, const int32_t *H2);
 void hibag_hip_trainer_free(hibag_hip_trainer *t);
 
+/* Host threads the trainer fits the candidate SNPs of a growth step on (the EM of
+ * CAlg_EM::ExpectationMaximization, src/LibHLA.cpp:1185-1255, runs on the host: its log() must be the
+ * host libm's for bit equality with stored models).  Default: the CPUs the process may use (affinity
+ * mask, cgroup quota) divided by LOCAL_WORLD_SIZE, so that the ranks of one node -- one process per GPU --
+ * share the host instead of oversubscribing it; HIBAG_TRAIN_THREADS overrides the default, n_threads <= 0
+ * restores it.  The counterpart of HIBAG_NewClassifiers' `nthread` (src/HIBAG.cpp:599-634). */
+int hibag_hip_trainer_set_threads(hibag_hip_trainer *t, int n_threads);
+int hibag_hip_trainer_threads(const hibag_hip_trainer *t);
+
 /* Source of the uniform draws the reference takes from R's unif_rand()
  * (src/LibHLA.cpp:120-126; bootstrap :2236, SNP sampling :957).  An R binding
  * passes a trampoline to unif_rand between GetRNGstate()/PutRNGstate()
