@@ -993,6 +993,9 @@ int finalize_model(hibag_hip_model *m)
 	V.n_item_split = (int)item.size() / 4; V.n_item_whole = (int)item_whole.size() / 4; V.n_split = (int)split_cls.size();
 	V.item_split = base + o_item; V.item_whole = base + o_itemw; V.item = V.item_whole; V.n_item = V.n_item_whole;
 	V.split_row = base + o_srow; V.split_cls = base + o_scls;
+	V.all_fp4 = 1;
+	for (int c = 0; c < C; c++)
+		if (n_step[c] == 1 && !(engine[c] == HIBAG_ENGINE_FP4)) V.all_fp4 = 0;      // (classifiers of several K steps are not work items of k_total)
 	V.n_wide = (int)wide_cls.size(); V.wide_cls = base + o_wide;
 	V.n_wide_seg = (int)wseg.size() / 4; V.wide_seg = base + o_wseg; V.wide_seg_off = (const uint64_t *)(tbase + tb_wsoff);
 	if (V.n_wide > 0 && !m->side.stream) {

@@ -156,6 +156,7 @@ struct HibagModelView {
 	// several items that store their cell sums (split_row[c] >= 0: the classifier is split,
 	// -1 = not split); k_total_scan then adds them in order.
 	int n_item, n_split;
+	int all_fp4;                 // every pass-1 work item is a one-step FP4 classifier (k_total's denser build carries that loop only)
 	const int *item;             // [n_item][4]: the launcher points this at the split or the whole list
 	int n_item_whole, n_item_split;
 	const int *item_whole, *item_split;

@@ -58,8 +58,9 @@
 #ifndef TOTAL_G
 #define TOTAL_G 8                           // records of pass 1 whose look-ups are in flight together (and whose factors arrive in one scalar load)
 #endif
-// Workgroups per CU pass 1 is compiled for, twice: 5 (96 VGPRs) and 6 (80 VGPRs: the FP4 block loop still fits, the int8 and
-// VALU-engine loops spill a little).  Six wavefronts per SIMD are 1.5 - 4 % faster once a pass is two rounds of resident
+// Workgroups per CU pass 1 is compiled for, twice: 5 (96 VGPRs: every engine) and 6 (80 VGPRs: the one-step FP4 block loop
+// fits, the int8 and VALU-engine loops would spill, so that build carries the FP4 loop alone and serves models whose work
+// items are all one-step FP4 classifiers -- k_total's FP4ONLY; no kernel of the path has a private segment).  Six wavefronts per SIMD are 1.5 - 4 % faster once a pass is two rounds of resident
 // workgroups or more (10,000 samples of the HLA-B shape: 0.80 -> 0.775 ms; 8,192 of DRB1: 14.1 -> 13.6 ms), and slower below that,
 // where a pass lasts as long as its longest work item, which six wavefronts sharing a SIMD stretch (4,096 samples of DRB1:
 // 7.1 -> 7.9 ms): the launcher chooses by the number of work items (hibag_launch_total).  (4 -> 128 VGPRs: measured slower.)
@@ -390,6 +391,46 @@ __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename 
 		for (int q = 1; q < G; q++) {
 			cell += F[q] * t[q];
 			if ((q & 1) && (endmask & (1u << (G * g + q)))) { fin(cell, (storemask & (1u << (G * g + q))) != 0); cell = 0; }
+		}
+		F = Fn;
+	}
+}
+
+// The same with the table look-ups of group g + 1 requested BEFORE group g is added up (pass 2: four wavefronts per SIMD,
+// each of which otherwise sits out an LDS round trip per group of four records).  Look-ups and scalar loads share
+// lgkmcnt, and a pending scalar load turns every wait into lgkmcnt(0): so per group ONE wait -- for this group's
+// look-ups and factors, both requested a group ago -- and behind it the next group's look-ups and factors.
+template <int G, class Fin>
+__device__ __forceinline__ void block_accumulate_ahead(ConstPtr<double> fac, typename FactorGroup<G>::type F, uint32_t endmask, int n_valid,
+	const v16i &D0, const v16i &D1, double &cell, const double *tab_s, Fin &&fin)
+{
+	typedef typename FactorGroup<G>::type FG;
+	auto look_up = [&](int g, double (&t)[G]) {
+#pragma unroll
+		for (int q = 0; q < G; q++) {
+			const int i = G * g + q;
+			const int off = (i & 7) < 4 ? D0[4 * (i >> 3) + (i & 3)] : D1[4 * (i >> 3) + (i & 3)];
+			t[q] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab_s) + off);
+		}
+	};
+	double t[32 / G + 1][G];
+	look_up(0, t[0]);
+#pragma unroll
+	for (int g = 0; g < 32 / G; g++) {
+		if (G * g >= n_valid) break;
+		const double x0 = F[0] * t[g][0];
+		__builtin_amdgcn_sched_barrier(0);
+		FG Fn = F;
+		if (g + 1 < 32 / G) {
+			Fn = *(ConstPtr<FG>)(fac + G * (g + 1));
+			if (G * (g + 1) < n_valid) look_up(g + 1, t[g + 1]);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		cell += x0;
+#pragma unroll
+		for (int q = 1; q < G; q++) {
+			cell += F[q] * t[g][q];
+			if ((q & 1) && (endmask & (1u << (G * g + q)))) { fin(cell, false); cell = 0; }
 		}
 		F = Fn;
 	}
@@ -939,7 +980,9 @@ __device__ __forceinline__ int chunk_bound(const uint32_t *__restrict__ cum, int
 // parked in the classifier's tot / inv rows.
 // STORE: every cell sum goes to HibagBatchView::cells for pass 2 to read back (models whose pass 2 streams, see
 // k_accum_cells); otherwise only a split VALU-engine classifier stores its cells (for k_total_scan).
-template <bool STORE, int OCC>
+// FP4ONLY: every work item is a one-step FP4 classifier (HibagModelView::all_fp4) -- the build for six workgroups per CU
+// carries that loop alone: at 80 registers the int8 and VALU-engine loops would spill, the FP4 loop does not.
+template <bool STORE, int OCC, bool FP4ONLY>
 __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, HibagBatchView B, int gx, int n_whole, int rest, int stride, int K)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
@@ -952,7 +995,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, 
 	}
 	const int *__restrict__ item = M.item + 4 * (li / gx);
 	const int c = item[0];
-	const int nkb = M.engine[c];                      // matrix-engine variant, 0 = VALU engine
+	const int nkb = FP4ONLY ? HIBAG_ENGINE_FP4 : M.engine[c];      // matrix-engine variant, 0 = VALU engine
 	// blocks [b0, b1) of the classifier's list
 	int b0 = 0, b1 = nkb > 0 ? M.cls_nblk[c] : 0;
 	const bool chunked = blockIdx.x >= n_whole && nkb > 0;
@@ -1004,10 +1047,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, 
 			ListCursor cur;                                                                                                \
 			walk_blocks<E, TOTAL_G>(M, M.blk_off[c] + (uint64_t)b0 * HIBAG_PLIST_DWORDS, b1 - b0, lane, cur,                 \
 				hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c], T, WideSrc(), tab_s, cell, fin); }
-			HIBAG_DISPATCH_ENGINE(nkb, CALL)
+			if (FP4ONLY) { CALL(HIBAG_ENGINE_FP4) } else { HIBAG_DISPATCH_ENGINE(nkb, CALL) }
 #undef CALL
 			if (!last) { B.tot[at] = total; B.inv[at] = cell; }
-		} else {
+		} else if (!FP4ONLY) {
 #define CALL(N) total = classifier_total<N>(M, B, c, s, item[1], item[2], item[3], rows, tab_s)
 			HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
 #undef CALL
@@ -1280,7 +1323,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			const int ns = (int)(H.h0 >> 25) & 15;
 #endif
 			if (ns > 0) {
+#ifdef HIBAG_ABL2_SVHOT       // (timing ablation: every stored sum read from the group's first rows -- cache hits instead of HBM)
+				const int sr = (int)((H.srow & 7u) * (uint32_t)(HIBAG_WAVE * 8));
+#else
 				const int sr = (int)(H.srow * (uint32_t)(HIBAG_WAVE * 8));
+#endif
 #pragma unroll
 				for (int i = 0; i < NS; i++) {
 					if (i >= ns) break;
@@ -1389,7 +1436,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 					__hip_atomic_fetch_add(&acc[(int)(jpack & 15)][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					jpack >>= 4;
 				};
+#ifdef HIBAG_ACCUM_AHEAD
+				block_accumulate_ahead<ACCUM_G>(fac + (size_t)(b - bb) * HIBAG_PLIST_DWORDS, F, endmask, n_valid, D0, D1, cell, tab_s, fin);
+#else
 				block_accumulate<ACCUM_G>(fac + (size_t)(b - bb) * HIBAG_PLIST_DWORDS, F, endmask, 0u, n_valid, D0, D1, cell, tab_s, fin);
+#endif
 			}
 			asm volatile("" :: "s"(tch0), "s"(tch1), "s"(tch2));
 			Hc = Hn;
@@ -1524,11 +1575,15 @@ __device__ __forceinline__ int classifier_best(const HibagModelView &M, const Hi
 #ifndef VOTE_OCC
 #define VOTE_OCC 5                          // workgroups per CU the majority-vote walk is compiled for (4: 3.5 % slower, 6: 5 % slower)
 #endif
-__global__ __launch_bounds__(BLOCK_THREADS, VOTE_OCC) void k_vote_best(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
+// WIDE: the instance for FP4 classifiers of several K steps (their walk needs more registers than five workgroups per CU
+// leave: a kernel of their own, like k_total_wide); the other instance skips them, and vice versa.
+template <bool WIDE>
+__global__ __launch_bounds__(BLOCK_THREADS, WIDE ? 4 : VOTE_OCC) void k_vote_best(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
-	stage_table(M, tab_s);
 	const int c = M.c_order[blockIdx.y];
+	if ((M.n_step[c] > 1) != WIDE) return;
+	stage_table(M, tab_s);
 	const int group = blockIdx.x * BLOCK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (group * HIBAG_WAVE >= B.n_pad) return;
 	const int s = group * HIBAG_WAVE + (threadIdx.x & 63);
@@ -1555,14 +1610,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, VOTE_OCC) void k_vote_best(HibagMode
 		double cell = 0;                                                                                               \
 		walk_blocks<E, TOTAL_G>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), k_last,         \
 			T, wide, tab_s, cell, fin); }
-		HIBAG_DISPATCH_ENGINE_WIDE(nkb, wide.nstep, CALL)
+		if (WIDE) { CALL(HIBAG_ENGINE_FP4W) } else { HIBAG_DISPATCH_ENGINE(nkb, CALL) }
 #undef CALL
 		bp = best_i < 0 ? -1 : (int)M.cls_cell[M.cls_off[c] + best_i];
-	} else {
+	} else if (!WIDE) {
 #define CALL(N) bp = classifier_best<N>(M, B, c, s, inv, tab_s)
 		HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
 #undef CALL
-	}
+	} else bp = -1;
 	best_cell[at] = active ? bp : -1;
 }
 
@@ -1821,10 +1876,10 @@ static int tail_chunks(int forced, long long blocks_per_item = 0, int at_least =
 void hibag_query_slots(int total[4], int *accum)
 {
 	// [STORE][many]: k_total<false, 5>, <false, 6>, <true, 5>, <true, 6>
-	total[0] = resident_blocks(k_total<false, HIBAG_TOT_OCC>, BLOCK_THREADS);
-	total[1] = resident_blocks(k_total<false, HIBAG_TOT_OCC_MANY>, BLOCK_THREADS);
-	total[2] = resident_blocks(k_total<true, HIBAG_TOT_OCC>, BLOCK_THREADS);
-	total[3] = resident_blocks(k_total<true, HIBAG_TOT_OCC_MANY>, BLOCK_THREADS);
+	total[0] = resident_blocks(k_total<false, HIBAG_TOT_OCC, false>, BLOCK_THREADS);
+	total[1] = resident_blocks(k_total<false, HIBAG_TOT_OCC_MANY, true>, BLOCK_THREADS);
+	total[2] = resident_blocks(k_total<true, HIBAG_TOT_OCC, false>, BLOCK_THREADS);
+	total[3] = resident_blocks(k_total<true, HIBAG_TOT_OCC_MANY, true>, BLOCK_THREADS);
 	*accum = resident_blocks(k_accum, ACCUM_WAVES * HIBAG_WAVE);
 }
 
@@ -1866,7 +1921,8 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 	// two rounds of the denser build's resident workgroups or more: six workgroups per CU, otherwise five (above)
 	static const int occ_env = getenv("HIBAG_TOT_OCC") ? atoi(getenv("HIBAG_TOT_OCC")) : 0;      // (diagnostic: 5 or 6)
 	const int slots_many = M.slots_total[(M.store_cells ? 2 : 0) + 1];
-	const bool many = occ_env ? occ_env == HIBAG_TOT_OCC_MANY : (slots_many > 0 && n >= 2u * (unsigned)slots_many);
+	// (the denser build holds the one-step FP4 loop only: models with other work items always take the general one)
+	const bool many = M.all_fp4 && !split && (occ_env ? occ_env == HIBAG_TOT_OCC_MANY : (slots_many > 0 && n >= 2u * (unsigned)slots_many));
 	const int slots = M.slots_total[(M.store_cells ? 2 : 0) + (many ? 1 : 0)];
 	unsigned n_whole = n, rest = 0, stride = 8, K = 1;
 	const int k_pass1 = tail_chunks(B.tail_k, M.p1_blocks / std::max(M.n_classifier, 1));
@@ -1878,11 +1934,11 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 	}
 	const dim3 grid(n_whole + (rest ? K * stride : 0));
 	if (M.store_cells) {
-		if (many) hipLaunchKernelGGL((k_total<true, HIBAG_TOT_OCC_MANY>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
-		else hipLaunchKernelGGL((k_total<true, HIBAG_TOT_OCC>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
+		if (many) hipLaunchKernelGGL((k_total<true, HIBAG_TOT_OCC_MANY, true>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
+		else hipLaunchKernelGGL((k_total<true, HIBAG_TOT_OCC, false>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
 	} else {
-		if (many) hipLaunchKernelGGL((k_total<false, HIBAG_TOT_OCC_MANY>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
-		else hipLaunchKernelGGL((k_total<false, HIBAG_TOT_OCC>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
+		if (many) hipLaunchKernelGGL((k_total<false, HIBAG_TOT_OCC_MANY, true>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
+		else hipLaunchKernelGGL((k_total<false, HIBAG_TOT_OCC, false>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
 	}
 	if (split)
 		hipLaunchKernelGGL(k_total_scan, dim3(B.n_pad / 64, V.n_split), dim3(64), 0, st, V, B);
@@ -1918,7 +1974,8 @@ void hibag_launch_vote(const HibagModelView &M, const HibagBatchView &B, int *d_
 {
 	if (M.n_classifier > 0) {
 		const unsigned gx = (unsigned)((B.n_pad / HIBAG_WAVE + BLOCK_WAVES - 1) / BLOCK_WAVES);
-		hipLaunchKernelGGL(k_vote_best, dim3(gx, M.n_classifier), dim3(BLOCK_THREADS), 0, st, M, B, d_best_cell);
+		hipLaunchKernelGGL(k_vote_best<false>, dim3(gx, M.n_classifier), dim3(BLOCK_THREADS), 0, st, M, B, d_best_cell);
+		if (M.n_wide > 0) hipLaunchKernelGGL(k_vote_best<true>, dim3(gx, M.n_classifier), dim3(BLOCK_THREADS), 0, st, M, B, d_best_cell);
 	}
 	hipLaunchKernelGGL(k_vote_tally, grid1(B.n_pad, 64), dim3(64), 0, st, M, B, (const int *)d_best_cell);
 }

@@ -13,6 +13,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k(int iters, const double *gtab, unsigned *out)
 {
 	__shared__ double tab[512];
+	__shared__ double rows[4][8][64];                                   // (KIND 10..12: accumulator rows, conflict-free: lane * 8 bytes)
 	for (int i = threadIdx.x; i < 512; i += 256) tab[i] = gtab[i & 63] + i;
 	__syncthreads();
 	const unsigned lane = threadIdx.x & 63;
@@ -66,6 +67,18 @@ __global__ __launch_bounds__(256) void k(int iters, const double *gtab, unsigned
 				: "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7) : "v"(a), "v"(v));
 			u += x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
 		}
+		if (KIND == 10 || KIND == 11) {   // 8 x ds_add_f64 (no return) / ds_write_b64 into eight 512-byte rows of this wavefront
+			const unsigned a = (unsigned)(size_t)&rows[threadIdx.x >> 6][0][lane];
+			const double x = 1.0 + lane;
+			if (KIND == 10)
+				asm volatile("ds_add_f64 %0, %1\n ds_add_f64 %0, %1 offset:512\n ds_add_f64 %0, %1 offset:1024\n ds_add_f64 %0, %1 offset:1536\n"
+					"ds_add_f64 %0, %1 offset:2048\n ds_add_f64 %0, %1 offset:2560\n ds_add_f64 %0, %1 offset:3072\n ds_add_f64 %0, %1 offset:3584\n s_waitcnt lgkmcnt(0)"
+					:: "v"(a), "v"(x) : "memory");
+			else
+				asm volatile("ds_write_b64 %0, %1\n ds_write_b64 %0, %1 offset:512\n ds_write_b64 %0, %1 offset:1024\n ds_write_b64 %0, %1 offset:1536\n"
+					"ds_write_b64 %0, %1 offset:2048\n ds_write_b64 %0, %1 offset:2560\n ds_write_b64 %0, %1 offset:3072\n ds_write_b64 %0, %1 offset:3584\n s_waitcnt lgkmcnt(0)"
+					:: "v"(a), "v"(x) : "memory");
+		}
 		if (KIND == 9) {     // reference: 8 x v_fma_f64 (FP64 FMA = the VALU's full-rate FP64 op)
 			asm volatile("v_fma_f64 %0, %0, %1, %1\n v_fma_f64 %0, %0, %1, %1\n v_fma_f64 %0, %0, %1, %1\n v_fma_f64 %0, %0, %1, %1\n"
 				"v_fma_f64 %0, %0, %1, %1\n v_fma_f64 %0, %0, %1, %1\n v_fma_f64 %0, %0, %1, %1\n v_fma_f64 %0, %0, %1, %1" : "+v"(acc) : "v"(1.0000001));
@@ -107,6 +120,8 @@ int main()
 	run<2>("ds_read_b128 broadcast (factors)", gtab, d_out, 8);
 	run<3>("ds_read_b128 lane*16", gtab, d_out, 8);
 	run<8>("ds_bpermute_b32", gtab, d_out, 8);
+	run<10>("ds_add_f64 lane*8 (accumulator rows)", gtab, d_out, 8);
+	run<11>("ds_write_b64 lane*8", gtab, d_out, 8);
 	run<5>("v_readlane_b32 (x2 = one factor)", gtab, d_out, 16);
 	run<6>("global_load_dwordx2 broadcast (L1 hit)", gtab, d_out, 8);
 	run<7>("global_load_dwordx2 gather 61 doubles (L1)", gtab, d_out, 8);
