@@ -34,6 +34,9 @@ EXPORTS = [
     "hibag_hip_model_status", "hibag_hip_model_clear_status", "hibag_hip_model_handover_faults",
     "hibag_hip_test_inject_handover_fault", "hibag_hip_model_engine", "hibag_hip_model_replicate",
     "hibag_hip_multi_slice", "hibag_hip_predict_multi", "hibag_hip_model_device",
+    "hibag_hip_shard_bounds", "hibag_hip_model_shard", "hibag_hip_model_batch_limit", "hibag_hip_shard_group_new",
+    "hibag_hip_shard_group_free", "hibag_hip_shard_group_ranks", "hibag_hip_shard_group_allreduces", "hibag_hip_rccl_version",
+    "hibag_hip_shard_group_predict", "hibag_hip_predict_multi_sharded",
 ]
 
 
@@ -122,6 +125,20 @@ def lib() -> C.CDLL:
     L.hibag_hip_model_replicate.restype = vp
     L.hibag_hip_multi_slice.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     L.hibag_hip_predict_multi.argtypes = [C.POINTER(vp), i32, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.hibag_hip_shard_bounds.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.hibag_hip_model_shard.argtypes = [vp, i32, i32, i32]
+    L.hibag_hip_model_shard.restype = vp
+    L.hibag_hip_model_batch_limit.argtypes = [vp]
+    L.hibag_hip_shard_group_new.argtypes = [C.POINTER(vp), i32]
+    L.hibag_hip_shard_group_new.restype = vp
+    L.hibag_hip_shard_group_free.argtypes = [vp]
+    L.hibag_hip_shard_group_free.restype = None
+    L.hibag_hip_shard_group_ranks.argtypes = [vp]
+    L.hibag_hip_shard_group_allreduces.argtypes = [vp]
+    L.hibag_hip_shard_group_allreduces.restype = i64
+    L.hibag_hip_rccl_version.restype = i32
+    L.hibag_hip_shard_group_predict.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.hibag_hip_predict_multi_sharded.argtypes = [C.POINTER(vp), i32, vp, i32, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -1680,6 +1680,37 @@ hibag_hip_model *hibag_hip_model_replicate(const hibag_hip_model *src, int devic
 	return m;
 }
 
+// A shard of a model for classifier-sharded prediction (hibag_shard.hip): classifiers [first, first + count) of `src`, order
+// kept, with the FULL model's per-SNP classifier counts (_GetSNPWeights, src/LibHLA.cpp:2484-2496), on `device`.
+hibag_hip_model *hibag_hip_model_shard(const hibag_hip_model *src, int shard, int n_shards, int device)
+{
+	if (!src) { fail(HIBAG_HIP_EINVAL, "model is NULL"); return nullptr; }
+	int first = 0, count = 0;
+	if (hibag_hip_shard_bounds((int)src->cls.size(), n_shards, shard, &first, &count)) return nullptr;
+	const int n = hibag_hip_device_count();
+	if (device < 0 || device >= n) { fail(HIBAG_HIP_ENODEV, "HIP device %d not available (%d visible)", device, n); return nullptr; }
+	hibag_hip_model *m = new (std::nothrow) hibag_hip_model;
+	if (!m) { fail(HIBAG_HIP_ENOMEM, "out of host memory"); return nullptr; }
+	try {
+		m->device = device;
+		m->n_hla = src->n_hla; m->n_snp = src->n_snp;
+		m->have_snpidx = src->have_snpidx; m->use_mfma = src->use_mfma; m->use_fp4 = src->use_fp4;
+		m->cls.assign(src->cls.begin() + first, src->cls.begin() + first + count);
+		if (!src->snp_weight_override.empty()) m->snp_weight_override = src->snp_weight_override;     // (a shard of a shard keeps the full model's counts)
+		else {
+			m->snp_weight_override.assign(std::max(src->n_snp, 1), 0);
+			for (const HostClassifier &k : src->cls)
+				for (int v : k.snpidx) m->snp_weight_override[v]++;
+		}
+		memcpy(m->tab, src->tab, sizeof(m->tab));
+	} catch (...) { delete m; fail(HIBAG_HIP_ENOMEM, "out of host memory"); return nullptr; }
+	if (src->finalized && hibag_hip_model_finalize(m)) { delete m; return nullptr; }
+	return m;
+}
+
+// samples per batch of the device-pointer entries that take ONE batch (hibag_hip_predict_partial_device); 0 = not finalized
+int hibag_hip_model_batch_limit(const hibag_hip_model *m) { return m && m->finalized ? batch_limit(m) : 0; }
+
 int hibag_hip_multi_slice(int n_samp, int n_models, int i, int *first, int *count)
 {
 	if (n_samp < 0 || n_models <= 0 || i < 0 || i >= n_models) return fail(HIBAG_HIP_EINVAL, "bad slice query (n_samp=%d, n_models=%d, i=%d)", n_samp, n_models, i);

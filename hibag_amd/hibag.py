@@ -157,6 +157,17 @@ class HlaAttrBagClass:
         r._h = C.c_void_p(h)
         return r
 
+    def shard(self, shard: int, n_shards: int, device: int) -> "HlaAttrBagClass":
+        """Classifiers ``hibag_hip_shard_bounds(C, n_shards, shard)`` of the model as a model of their own on ``device``,
+        with the full model's per-SNP classifier counts: ``hibag_hip_model_shard``."""
+        h = _lib.lib().hibag_hip_model_shard(self.handle, int(shard), int(n_shards), int(device))
+        if not h:
+            raise HibagHipError(-2, _lib.lib().hibag_hip_last_error().decode())
+        r = object.__new__(HlaAttrBagClass)
+        r.obj = self.obj                      # (alleles, SNPs: the full model's; the shard's classifiers live in the library)
+        r._h = C.c_void_p(h)
+        return r
+
     def mutation_table(self) -> np.ndarray:
         t = np.empty(257, np.float64)
         _lib.check(_lib.lib().hibag_hip_model_mutation_table(self.handle, _as_ptr(t)))
@@ -295,6 +306,62 @@ def predict_multi(models: Sequence[HlaAttrBagClass], genomat: np.ndarray, vote_m
         hs, len(models), _as_ptr(g), n, int(vote_method), _as_ptr(out["h1"]), _as_ptr(out["h2"]),
         _as_ptr(out["prob"]), _as_ptr(out["matching"]), _as_ptr(out.get("dosage")), _as_ptr(out.get("postprob"))))
     return out
+
+
+class ShardGroup:
+    """``hibag_hip_shard_group``: the shards of one model, each on its device, merged per batch by ONE RCCL all-reduce
+    issued by the library itself (``hibag_amd/csrc/hibag_shard.hip``).  ``devices``: one entry per shard (a device may
+    repeat: its shards are added up on it before the all-reduce)."""
+
+    def __init__(self, model: HlaAttrBagClass, devices: Sequence[int]):
+        if not devices:
+            raise ValueError("no devices given")
+        self.obj = model.obj
+        self.shards = [model.shard(i, len(devices), int(d)) for i, d in enumerate(devices)]
+        hs = (C.c_void_p * len(self.shards))(*[m.handle for m in self.shards])
+        h = _lib.lib().hibag_hip_shard_group_new(hs, len(self.shards))
+        if not h:
+            msg = _lib.lib().hibag_hip_last_error().decode()
+            for m in self.shards:
+                m.close()
+            raise HibagHipError(-2, msg)
+        self._h = C.c_void_p(h)
+
+    @property
+    def ranks(self) -> int:
+        return int(_lib.lib().hibag_hip_shard_group_ranks(self._h))
+
+    @property
+    def allreduces(self) -> int:
+        return int(_lib.lib().hibag_hip_shard_group_allreduces(self._h))
+
+    def predict_raw(self, genomat: np.ndarray, want_dosage: bool = True, want_prob: bool = False) -> dict:
+        g = np.ascontiguousarray(genomat, np.int32)
+        if g.ndim != 2 or g.shape[1] != self.obj.n_snp:
+            raise ValueError("genomat must be [n_samp, n.snp] int32")
+        n = g.shape[0]
+        out = dict(h1=np.zeros(n, np.int32), h2=np.zeros(n, np.int32), prob=np.zeros(n, np.float64), matching=np.zeros(n, np.float64))
+        if want_dosage:
+            out["dosage"] = np.zeros((n, self.obj.n_hla), np.float64)
+        if want_prob:
+            out["postprob"] = np.zeros((n, self.obj.n_cell), np.float64)
+        _lib.check(_lib.lib().hibag_hip_shard_group_predict(
+            self._h, _as_ptr(g), n, _as_ptr(out["h1"]), _as_ptr(out["h2"]), _as_ptr(out["prob"]), _as_ptr(out["matching"]),
+            _as_ptr(out.get("dosage")), _as_ptr(out.get("postprob"))))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            _lib.lib().hibag_hip_shard_group_free(self._h)
+            self._h = None
+            for m in self.shards:
+                m.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def hlaModelFromObj(obj: HlaAttrBagObj, device: Optional[int] = None) -> HlaAttrBagClass:

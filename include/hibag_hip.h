@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIBAG_HIP_ABI_VERSION 5   /* 2: + PLINK BED entries, training driver; 3: + hibag_hip_predict_mapped[_device]; 4: + hibag_hip_model_stored_cells;
+#define HIBAG_HIP_ABI_VERSION 6   /* 2: + PLINK BED entries, training driver; 3: + hibag_hip_predict_mapped[_device]; 4: + hibag_hip_model_stored_cells;
                                      5: + hibag_hip_model_status / _clear_status, hibag_hip_predict_multi, hibag_hip_model_replicate, hibag_hip_model_engine */
 
 /* error codes */
@@ -226,6 +226,39 @@ int hibag_hip_predict_partial_device(hibag_hip_model *m, const int32_t *d_geno,
 int hibag_hip_finish_device(hibag_hip_model *m, const double *d_partial, int n_samp,
 	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching,
 	double *d_dosage, double *d_postprob, void *stream);
+
+/* The same split driven from ONE process over the devices of a node, merged by RCCL (hibag_amd/csrc/hibag_shard.hip) --
+ * what an R / C++ host uses where the model is too large to replicate, or a batch too small to be worth slicing:
+ *   hibag_hip_shard_bounds      classifiers [*first, *first + *count) of shard `shard` of `n_shards` (sizes differ by at most one)
+ *   hibag_hip_model_shard       that run of `src`'s classifiers as a model of its own on `device`, built with the FULL
+ *                               model's per-SNP classifier counts; finalized if `src` is
+ *   hibag_hip_model_batch_limit samples one call of hibag_hip_predict_partial_device takes (0 = not finalized)
+ *   hibag_hip_shard_group_new   n shards of ONE model, each on its device: one RCCL rank per distinct device
+ *                               (ncclCommInitAll; shards sharing a device are added up on it first, in shard order),
+ *                               a stream and the batch buffers per rank.  RCCL (librccl.so.1) is loaded here, not before.
+ *   hibag_hip_shard_group_predict   CAttrBag_Model::PredictHLA with vote_method 1 (averaged posteriors) on host pointers, as
+ *                               hibag_hip_predict: per batch the genotypes go to every rank, every shard writes its
+ *                               un-normalised partial sums (the sum split is src/LibHLA.cpp:2448-2476 with :1497-1518),
+ *                               ONE ncclAllReduce(ncclDouble, ncclSum) of [P + 3][n_pad] doubles merges them over xGMI,
+ *                               rank 0 finishes.  Calls are identical to the unsharded run's and posteriors within 1e-10
+ *                               relative (the order of the classifiers' additions changes with the split).  A failed
+ *                               hand-over on any shard reaches every rank as NaN through the sum and the batch is run again.
+ *   hibag_hip_predict_multi_sharded   group_new + group_predict + group_free in one call (pays the communicator set-up each time)
+ *   hibag_hip_shard_group_ranks / _allreduces   RCCL ranks of the group, all-reduces it has issued;  hibag_hip_rccl_version: NCCL_VERSION_CODE of the loaded library, 0 = none
+ * The reference's own multi-worker branch (R/HIBAG.R:764-808) splits samples: that is hibag_hip_predict_multi above. */
+typedef struct hibag_hip_shard_group hibag_hip_shard_group;
+int hibag_hip_shard_bounds(int n_classifier, int n_shards, int shard, int *first, int *count);
+hibag_hip_model *hibag_hip_model_shard(const hibag_hip_model *src, int shard, int n_shards, int device);
+int hibag_hip_model_batch_limit(const hibag_hip_model *m);
+hibag_hip_shard_group *hibag_hip_shard_group_new(hibag_hip_model *const *shards, int n_shards);
+void hibag_hip_shard_group_free(hibag_hip_shard_group *g);
+int hibag_hip_shard_group_ranks(const hibag_hip_shard_group *g);
+int64_t hibag_hip_shard_group_allreduces(const hibag_hip_shard_group *g);
+int hibag_hip_rccl_version(void);
+int hibag_hip_shard_group_predict(hibag_hip_shard_group *g, const int32_t *geno, int n_samp,
+	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob);
+int hibag_hip_predict_multi_sharded(hibag_hip_model *const *shards, int n_shards, const int32_t *geno, int n_samp,
+	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob);
 
 /* ---- PLINK BED input: replaces HIBAG_BEDFlag + HIBAG_ConvBED --------------- */
 

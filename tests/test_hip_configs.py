@@ -34,6 +34,8 @@ def test_cfg3_100k_samples_eight_classifier_shards(hib, oracle):
     G[7, :] = hib.NA_INTEGER                              # one sample with every SNP missing -> NA call
     dev_model = hib.hlaModelFromObj(model)
     full = dev_model.predict_raw(G, 1, want_dosage=True, want_prob=True)     # more than one batch inside the library
+    # a failed hand-over would have been repaired silently by the host entry (at twice the time): it must not have happened
+    assert dev_model.handover_faults() == 0 and dev_model.status() == 0
     dev_model.close()
     ok = np.ones(n, bool); ok[7] = False
     assert np.mean((full["h1"][ok] == truth[ok, 0]) & (full["h2"][ok] == truth[ok, 1])) > 0.9
@@ -70,6 +72,7 @@ def test_cfg3_100k_samples_eight_classifier_shards(hib, oracle):
                                         full["postprob"][sl][fin][live])))
     assert worst <= 1e-10
     for _, _, m in shards:
+        assert m.handover_faults() == 0 and m.status() == 0
         m.close()
 
 
@@ -120,6 +123,7 @@ def test_device_entry_on_a_stream_of_the_callers(hib, oracle):
                              stream=st.cuda_stream)
             outs.append((dg, h1, h2, pr, mt, ds)); genos.append(G)
     st.synchronize()
+    assert m.status() == 0 and m.handover_faults() == 0
     flat = oracle.flatten(model)
     for G, (dg, h1, h2, pr, mt, ds) in zip(genos, outs):
         sub = np.arange(0, n, 25)
@@ -271,6 +275,9 @@ def test_predict_multi_two_replicas_on_one_device_equal_the_single_call(hib, ora
     assert np.array_equal(res1.prob, res2.prob, equal_nan=True) and np.array_equal(res1.dosage, res2.dosage, equal_nan=True)
     with pytest.raises(hib.HibagHipError):
         m.replicate(99)
+    # the host entries repair a failed hand-over themselves and return 0: only the counter would show it (as twice the time)
+    for r in (m, r0, r1):
+        assert r.handover_faults() == 0 and r.status() == 0
     for r in (r0, r1):
         r.close()
     m.close()

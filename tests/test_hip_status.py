@@ -147,9 +147,41 @@ def test_calls_on_two_streams_share_the_workspace_safely(hib, oracle):
         outs.append((Ga, device_call(m, torch, dev, Ga, s1)))
         outs.append((Gb, device_call(m, torch, dev, Gb, s2)))
     s1.synchronize(); s2.synchronize()
-    assert m.status() == 0
+    assert m.status() == 0 and m.handover_faults() == 0
     sub = np.arange(0, n, 250)
     for G, out in outs:
         want = oracle.predict(flat, G[sub], vote_method=1, want_prob=False, avx2=True, n_threads=8)
         same_as_oracle(out, sub, want)
     m.close()
+
+
+def test_two_models_run_concurrently_on_two_streams_without_a_fault(hib, oracle):
+    """Two DIFFERENT models (their own workspaces, flags and epochs) launched back to back on two streams, so that their
+    chunked work items share the device: the hand-over scheme rests on observed dispatch order (chunks of an item on one
+    XCD, first chunks dispatched before second chunks) -- with two grids in flight it must still hold: zero faults, and
+    both models' outputs bit-equal to the oracle.  (src/HIBAG.cpp:41-60: an entry never returns numbers it cannot vouch for.)"""
+    import torch
+    from hibag_amd import synth
+    dev = torch.device("cuda", 0)
+    ma_obj, fa, afa = synth.make_model("hla-b")
+    mb_obj, fb, afb = synth.make_model("hla-b", seed=synth.DEFAULT_SEED + 5, n_classifier=60, wide_classifier=False)
+    ma, mb = hib.hlaModelFromObj(ma_obj), hib.hlaModelFromObj(mb_obj)
+    n = N
+    Ga, _ = synth.make_samples(fa, afa, n, seed=601)
+    Gb, _ = synth.make_samples(fb, afb, n, seed=602)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize(dev)
+    outs = []
+    for rep in range(4):
+        outs.append((ma_obj, Ga, device_call(ma, torch, dev, Ga, s1)))
+        outs.append((mb_obj, Gb, device_call(mb, torch, dev, Gb, s2)))
+    s1.synchronize(); s2.synchronize()
+    assert ma.status() == 0 and mb.status() == 0
+    assert ma.handover_faults() == 0 and mb.handover_faults() == 0
+    sub = np.arange(0, n, 417)[:24]
+    want = {}
+    for obj, G, out in outs:
+        if id(obj) not in want:
+            want[id(obj)] = oracle.predict(oracle.flatten(obj), G[sub], vote_method=1, want_prob=False, avx2=True, n_threads=8)
+        same_as_oracle(out, sub, want[id(obj)])
+    ma.close(); mb.close()

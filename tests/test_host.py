@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.hibag_hip_abi_version() == 5
+    assert L.hibag_hip_abi_version() == 6
 
 
 def test_no_cpu_fallback_in_product():
@@ -278,3 +278,23 @@ def test_status_entries_reject_bad_arguments_without_a_gpu():
     assert L.hibag_hip_model_engine(m, 0, C.byref(e), C.byref(k)) == -4          # not finalized
     assert L.hibag_hip_model_status(m) in (0, -2)                                # no launches; -2 where there is no device
     L.hibag_hip_model_free(m)
+
+
+def test_classifier_shard_bounds_cover_the_model_in_order():
+    """hibag_hip_shard_bounds (host logic of the RCCL-merged route): contiguous, ordered, sizes within one of each other --
+    the same split hibag_amd.dist.shard_bounds makes for the one-process-per-GPU route."""
+    import ctypes as C
+    from hibag_amd import _lib
+    from hibag_amd.dist import shard_bounds
+    L = _lib.lib()
+    for n, w in ((100, 8), (7, 3), (3, 8), (0, 2), (1, 1)):
+        at = 0
+        for r in range(w):
+            f, c = C.c_int(-1), C.c_int(-1)
+            assert L.hibag_hip_shard_bounds(n, w, r, C.byref(f), C.byref(c)) == 0
+            assert (f.value, f.value + c.value) == shard_bounds(n, w, r)
+            assert f.value == at
+            at += c.value
+        assert at == n
+    assert L.hibag_hip_shard_bounds(10, 0, 0, None, None) != 0 and L.hibag_hip_shard_bounds(10, 2, 2, None, None) != 0
+    assert L.hibag_hip_shard_group_new(None, 0) is None          # (no GPU needed to be refused)
