@@ -7,16 +7,21 @@ Metric (BASELINE.json): hlaPredict() samples/sec (+ achieved HBM GB/s) on the
 10k-sample x 100-classifier HLA-B configuration.  A *step* is one pass of the
 hot path (CAttrBag_Model::PredictHLA, src/LibHLA.cpp:2317-2412, with the
 default outputs of type="response+dosage": calls, probability, matching,
-dosage) over one batch of 10,000 synthetic samples that already sit in HBM.
-With N > 1 every rank owns its own 10,000 samples (samples are independent, no
-data-path collective; weak scaling) -- one process per GPU, launched by
-torch.distributed.run, rendezvous over RCCL.
+dosage) over one batch of synthetic samples that already sit in HBM; `value`
+is device-resident (the PCIe-inclusive rate of the host-pointer entry is
+`host_inclusive`, SURVEY.md 8(d)'s protocol number).
+  N = 1   BASELINE config 2: 10,000 samples.
+  N > 1   BASELINE config 3: 100,000 samples split N ways (contiguous slices, samples are independent: no data-path
+          collective; strong scaling) -- one process per GPU, launched by torch.distributed.run, rendezvous over RCCL --
+          and, in the same line under "classifier_sharded", config 3's other reading: every rank a slice of the
+          CLASSIFIERS on all the samples, merged by one RCCL all-reduce of the partial posterior sums per 25,000 samples.
+          `--samples n` instead gives every rank its own n samples (weak scaling).
 
 Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
   roofline     : the dominant kernel against the HBM roof the metric names,
                  from HIP events recorded on the launch stream inside the timed
                  region (and, under "issue", the SIMD time per wavefront-pair
-                 against the measured FP64 + matrix-core issue floor, the ceiling
+                 against the FP64 + matrix-core issue floor measured in this process, the ceiling
                  that actually binds this path -- DESIGN.md section 5);
   cpu_baseline : the AVX2 + threads CPU port of the reference's kernel
                  (oracle/, kind "port") timed on this box's host cores on a
@@ -32,7 +37,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SAMPLES_PER_GPU = 10_000
+SAMPLES_PER_GPU = 10_000       # BASELINE config 2
+CFG3_SAMPLES = 100_000         # BASELINE config 3: the cohort N GPUs share
+CFG3_SLICE = 25_000            # ... and what one all-reduce of the classifier-sharded route merges
 SHAPE = "hla-b"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 # Issue floor used for the "issue" block (DESIGN.md "Rooflines"), measured on MI355X
@@ -46,11 +53,23 @@ UBENCH_FILE = os.path.join(ROOT, "profiles", "ubench_constants.json")   # parsed
 
 
 def issue_constants():
-    """FP64 / MFMA issue costs (ns per wave-instruction per SIMD) from the committed micro-benchmark
-    logs (profiles/ubench_constants.json, written by tools/parse_ubench.py from the raw outputs of
-    tools/ubench_mfma and tools/ubench_valu); the built-in values are the round-1 measurements."""
+    """FP64 / MFMA issue costs (ns per wave-instruction per SIMD) measured NOW on this process's device
+    (hibag_hip_measure_issue_costs, ~50 ms: boards differ by up to 10 % under an FP64 / matrix load); if the
+    measurement cannot run, the committed micro-benchmark logs of an earlier round (profiles/ubench_constants.json)."""
+    import ctypes as C
     c = {"fp64_op_ns": FP64_OP_NS, "mfma_i8_32x32x32_ns": MFMA_NS, "mfma_fp4_32x32x64_ns": 18.3, "mfma_fp64_overlap": None,
          "source": "built-in (round 1)"}
+    try:
+        from hibag_amd import _lib
+        v = [C.c_double(0) for _ in range(4)]
+        if _lib.lib().hibag_hip_measure_issue_costs(*[C.byref(x) for x in v]) == 0 and v[0].value > 0:
+            c.update({"fp64_op_ns": round(v[0].value, 3), "mfma_i8_32x32x32_ns": round(v[1].value, 2),
+                      "mfma_fp4_32x32x64_ns": round(v[2].value, 2),
+                      "mfma_fp64_overlap": {"frac_of_serial_sum": round(v[3].value, 3)},
+                      "source": "measured in this process (hibag_hip_measure_issue_costs: 8 wavefronts on every SIMD)"})
+            return c
+    except Exception:
+        pass
     try:
         d = json.load(open(UBENCH_FILE))
         c.update({k: d[k] for k in ("fp64_op_ns", "mfma_i8_32x32x32_ns", "mfma_fp4_32x32x64_ns", "mfma_fp64_overlap") if k in d})
@@ -60,12 +79,26 @@ def issue_constants():
     return c
 
 
+def issue_constants_file():
+    """The constants earlier rounds priced the floor with (profiles/ubench_constants.json, measured in round 2 on another
+    board): kept so that the fraction can be followed across rounds next to the one from this process's own measurement."""
+    c = {"fp64_op_ns": 2.2, "mfma_i8_32x32x32_ns": 16.1, "mfma_fp4_32x32x64_ns": 18.3}
+    try:
+        d = json.load(open(UBENCH_FILE))
+        c.update({k: d[k] for k in c if k in d})
+    except (OSError, ValueError):
+        pass
+    return c
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--samples", type=int, default=SAMPLES_PER_GPU, help="samples per GPU per step")
+    ap.add_argument("--samples", type=int, default=None,
+                    help="samples per GPU per step (weak scaling).  Default: 10,000 at one GPU (BASELINE config 2); with "
+                         "--gpus N > 1 the 100,000 samples of config 3 split N ways (strong scaling)")
     ap.add_argument("--shape", default=SHAPE)
     ap.add_argument("--prob", action="store_true", help="also return the full posterior matrix (type='response+prob')")
     ap.add_argument("--vote", choices=("prob", "majority"), default="prob", help="hlaPredict(vote=): averaged posteriors (default) or majority vote")
@@ -118,12 +151,29 @@ def main():
     hibag_amd._lib.check(hibag_amd._lib.lib().hibag_hip_set_device(local_rank))
     target = hibag_amd.hlaSetKernelTarget("hip")[0]
     model_obj, founders, afreq = synth.make_model(args.shape, wide_classifier=not args.no_wide)
-    n = args.samples
     by_classifier = args.shard == "classifiers"
     vote_method = 2 if args.vote == "majority" else 1
-    geno, truth = synth.make_samples(founders, afreq, n, seed=synth.DEFAULT_SEED + 1 + (0 if by_classifier else rank))
+    from hibag_amd import dist as hdist
+    # What the ranks share.  Default: one GPU -> config 2's 10,000 samples; N GPUs -> config 3's 100,000 samples, a
+    # contiguous slice per rank (strong scaling).  --samples n: every rank its own n samples (weak scaling).
+    strong = args.samples is None and world > 1
     if by_classifier:
-        from hibag_amd import dist as hdist
+        # every rank sees ALL the samples and holds a slice of the classifiers
+        n = args.samples if args.samples is not None else (CFG3_SAMPLES if world > 1 else SAMPLES_PER_GPU)
+        n_total = n
+        geno, truth = synth.make_samples(founders, afreq, n, seed=synth.DEFAULT_SEED + 1)
+    elif strong:
+        n_total = CFG3_SAMPLES
+        lo, hi = hdist.shard_bounds(n_total, world, rank)
+        n = hi - lo
+        geno_all, truth_all = synth.make_samples(founders, afreq, n_total, seed=synth.DEFAULT_SEED + 1)
+        geno, truth = np.ascontiguousarray(geno_all[lo:hi]), truth_all[lo:hi]
+    else:
+        n = args.samples if args.samples is not None else SAMPLES_PER_GPU
+        n_total = n * world
+        geno, truth = synth.make_samples(founders, afreq, n, seed=synth.DEFAULT_SEED + 1 + rank)
+    scaling = "strong" if (by_classifier or strong) else "weak"
+    if by_classifier:
         sub, sw = hdist.classifier_shard(model_obj, world, rank)
         model = hibag_amd.HlaAttrBagClass(sub, device=local_rank, snp_weight=sw)
     else:
@@ -139,21 +189,33 @@ def main():
     d_pp = torch.empty((n, P), dtype=torch.float64, device=dev) if args.prob else None
     stream = torch.cuda.current_stream(dev)
 
-    n_pad = (n + 63) // 64 * 64
-    d_part = torch.zeros((P + 3, n_pad), dtype=torch.float64, device=dev) if by_classifier else None
+    def sharded_step_fn(mdl, n_s, g, h1, h2, pr, mt, ds, pp):
+        """One step of the classifier-sharded route on n_s samples: per slice of <= CFG3_SLICE samples the partial ensemble
+        sums of this rank's classifiers -> ONE all-reduce -> arg-max / dosage (on every rank)."""
+        sl = min(CFG3_SLICE, mdl.batch_limit(), max(n_s, 1))
+        part = torch.zeros((P + 3, (sl + 63) // 64 * 64), dtype=torch.float64, device=dev)
 
-    def step():
-        if by_classifier:
-            # partial ensemble sums of this rank's classifiers -> ONE all-reduce -> arg-max / dosage on every rank
-            model.predict_partial_device(d_geno.data_ptr(), n, d_part.data_ptr(), stream=stream.cuda_stream)
-            if world > 1:
-                dist.all_reduce(d_part, op=dist.ReduceOp.SUM)
-            model.finish_device(d_part.data_ptr(), n, d_h1.data_ptr(), d_h2.data_ptr(), d_prob.data_ptr(), d_match.data_ptr(),
-                                d_dos.data_ptr(), None if d_pp is None else d_pp.data_ptr(), stream=stream.cuda_stream)
-            return
-        model.predict_device(d_geno.data_ptr(), n, vote_method, d_h1.data_ptr(), d_h2.data_ptr(), d_prob.data_ptr(),
-                             d_match.data_ptr(), d_dos.data_ptr(), None if d_pp is None else d_pp.data_ptr(),
-                             stream=stream.cuda_stream)
+        def run():
+            for s0 in range(0, n_s, sl):
+                k = min(sl, n_s - s0)
+                kp = (k + 63) // 64 * 64
+                view = part if kp == part.shape[1] else part[:, :kp].contiguous()     # (the entry wants rows of n_pad doubles)
+                mdl.predict_partial_device(g.data_ptr() + 4 * s0 * S, k, view.data_ptr(), stream=stream.cuda_stream)
+                if world > 1:
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM)
+                mdl.finish_device(view.data_ptr(), k, h1.data_ptr() + 4 * s0, h2.data_ptr() + 4 * s0, pr.data_ptr() + 8 * s0,
+                                  mt.data_ptr() + 8 * s0, ds.data_ptr() + 8 * s0 * n_hla,
+                                  None if pp is None else pp.data_ptr() + 8 * s0 * P, stream=stream.cuda_stream)
+        return run, int((P + 3) * ((sl + 63) // 64 * 64) * 8)
+
+    allreduce_bytes = None
+    if by_classifier:
+        step, allreduce_bytes = sharded_step_fn(model, n, d_geno, d_h1, d_h2, d_prob, d_match, d_dos, d_pp)
+    else:
+        def step():
+            model.predict_device(d_geno.data_ptr(), n, vote_method, d_h1.data_ptr(), d_h2.data_ptr(), d_prob.data_ptr(),
+                                 d_match.data_ptr(), d_dos.data_ptr(), None if d_pp is None else d_pp.data_ptr(),
+                                 stream=stream.cuda_stream)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -161,30 +223,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    model.set_timing(True)
-    model.reset_timing()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    timing = model.get_timing()
-    model.set_timing(False)
+    def timed(fn, warmup, steps, mdl):
+        for _ in range(warmup):
+            fn()
+        fence()
+        mdl.set_timing(True)
+        mdl.reset_timing()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        fence()
+        dt_ = time.perf_counter() - t0
+        tm = mdl.get_timing()
+        mdl.set_timing(False)
+        if world > 1:
+            t = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_, tm
 
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, timing = timed(step, args.warmup, args.steps, model)
+    faults = {"timed_model": int(model.handover_faults())}
 
     # sanity on the timed outputs: calls of samples drawn from the model
     h1 = d_h1.cpu().numpy(); h2 = d_h2.cpu().numpy()
     call_acc = float(np.mean((h1 == truth[:, 0]) & (h2 == truth[:, 1])))
 
-    total_samples = n * (1 if by_classifier else world) * args.steps
-    value = total_samples / dt
+    value = n_total * args.steps / dt
     pair_evals = model_obj.pair_evals_per_sample()
     pe_rank = sub.pair_evals_per_sample() if by_classifier else pair_evals      # what one rank's kernels evaluate
 
@@ -206,6 +271,7 @@ def main():
         except Exception:
             traffic = None
     K = issue_constants()
+    n_pad = (n + 63) // 64 * 64
     # SIMD issue: both passes together against the pairs they actually evaluate (pass 1 all of them; pass 2 those of
     # the cells whose sums pass 1 did not store), and each pass by itself
     ms1 = timing["total"][0] / max(timing["total"][1], 1)
@@ -231,46 +297,77 @@ def main():
                   "k_accum": {"ms": round(ms2, 4), "simd_ns_per_wave_pair": round(ns2, 2), "frac": round(floor_ns / ns2, 4),
                               "stored_cells_read_gb": round(stored * 8.0 * n_pad / 1e9, 3)},
                   "constants": K,
+                  "k_total_frac_with_round2_constants": round(issue_floor(obj_rank, ms1, n, issue_constants_file(), model)[0] /
+                                                              max(issue_floor(obj_rank, ms1, n, issue_constants_file(), model)[1], 1e-9), 4),
                   "note": "the binding ceiling is SIMD issue, not HBM: per evaluated pair one FP64 mul "
                           "+ one FP64 add in the reference's order plus its share of the MFMAs, which serialise with FP64 on a SIMD "
-                          "(constants: raw tools/ubench_* logs under profiles/, DESIGN.md section 5).  Pass 2 evaluates only the pairs "
+                          "(constants: measured in this process, see `constants.source`; DESIGN.md section 5).  Pass 2 evaluates only the pairs "
                           "of the cells with few pairs (the others' sums come from pass 1 through HBM), so its time is mostly per-cell "
                           "and per-(classifier, tile) work, not pair evaluation"},
         "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in timing.items()},
     }
 
-    # classifier-sharded mode: how far the merged posterior is from the unsharded (= sample-sharded) result
-    shard_check = None
-    if by_classifier:
+    def shard_check_of(mdl, n_s, g, G_host, calls):
+        """How far the classifier-sharded route's merged posterior is from the unsharded run (on at most 10,000 samples)."""
+        k = min(n_s, 10_000)
         full = hibag_amd.hlaModelFromObj(model_obj, device=local_rank)
-        ref = full.predict_raw(geno, 1, want_dosage=False, want_prob=True)
-        if d_pp is None:
-            d_pp2 = torch.empty((n, P), dtype=torch.float64, device=dev)
-            model.finish_device(d_part.data_ptr(), n, d_h1.data_ptr(), d_h2.data_ptr(), d_prob.data_ptr(), d_match.data_ptr(),
-                                d_dos.data_ptr(), d_pp2.data_ptr(), stream=stream.cuda_stream)
-            torch.cuda.synchronize(dev)
-        else:
-            d_pp2 = d_pp
-        got_pp = d_pp2.cpu().numpy()
-        denom = np.maximum(np.abs(ref["postprob"]), 1e-300)
-        live = ref["postprob"] > 1e-200            # below that both sides are sums of denormals
-        rel = float(np.max(np.abs(got_pp - ref["postprob"])[live] / denom[live])) if live.any() else 0.0
-        shard_check = {"max_rel_dev_posterior_vs_unsharded": rel,
-                       "calls_identical_to_unsharded": bool(np.array_equal(ref["h1"], h1) and np.array_equal(ref["h2"], h2)),
-                       "tolerance": 1e-10}
+        ref = full.predict_raw(G_host[:k], 1, want_dosage=False, want_prob=True)
         full.close()
+        o = [torch.empty(k, dtype=torch.int32, device=dev), torch.empty(k, dtype=torch.int32, device=dev),
+             torch.empty(k, dtype=torch.float64, device=dev), torch.empty(k, dtype=torch.float64, device=dev),
+             torch.empty((k, n_hla), dtype=torch.float64, device=dev), torch.empty((k, P), dtype=torch.float64, device=dev)]
+        run, _ = sharded_step_fn(mdl, k, g, *o)
+        run()
+        torch.cuda.synchronize(dev)
+        got_pp = o[5].cpu().numpy()
+        denom = np.maximum(np.abs(ref["postprob"]), 1e-300)
+        with np.errstate(invalid="ignore"):
+            live = ref["postprob"] > 1e-200        # below that both sides are sums of denormals (NaN rows: samples nobody can call)
+            rel = float(np.max(np.abs(got_pp - ref["postprob"])[live] / denom[live])) if live.any() else 0.0
+        nan_same = bool(np.array_equal(np.isnan(got_pp), np.isnan(ref["postprob"])))
+        return {"samples_checked": k, "nan_pattern_identical": nan_same, "max_rel_dev_posterior_vs_unsharded": rel,
+                "calls_identical_to_unsharded": bool(np.array_equal(ref["h1"], calls[0][:k]) and np.array_equal(ref["h2"], calls[1][:k])),
+                "tolerance": 1e-10}
+
+    # classifier-sharded mode: how far the merged posterior is from the unsharded (= sample-sharded) result
+    shard_check = shard_check_of(model, n, d_geno, geno, (h1, h2)) if by_classifier else None
+
+    # N > 1, default workload: config 3's other reading in the same line -- every rank a slice of the classifiers on ALL
+    # 100,000 samples, the partial posterior sums merged by one RCCL all-reduce per 25,000 samples
+    sharded_line = None
+    if strong and not args.no_extras and vote_method == 1:
+        sub2, sw2 = hdist.classifier_shard(model_obj, world, rank)
+        m2 = hibag_amd.HlaAttrBagClass(sub2, device=local_rank, snp_weight=sw2)
+        g2 = torch.from_numpy(geno_all).to(dev)
+        o2 = [torch.empty(n_total, dtype=torch.int32, device=dev), torch.empty(n_total, dtype=torch.int32, device=dev),
+              torch.empty(n_total, dtype=torch.float64, device=dev), torch.empty(n_total, dtype=torch.float64, device=dev),
+              torch.empty((n_total, n_hla), dtype=torch.float64, device=dev)]
+        run2, ar_bytes = sharded_step_fn(m2, n_total, g2, *o2, None)
+        k2 = max(1, min(args.steps, 5))
+        dt2, tm2 = timed(run2, 1, k2, m2)
+        c1, c2 = o2[0].cpu().numpy(), o2[1].cpu().numpy()
+        sharded_line = {"value": n_total * k2 / dt2, "unit": "samples/s", "ms_per_step": dt2 / k2 * 1e3, "steps": k2,
+                        "samples": n_total, "scaling": "strong",
+                        "parallelism": f"classifier-sharded x{world}: {len(sub2.classifiers)} of {len(model_obj.classifiers)} classifiers on this rank, "
+                                       f"one RCCL all-reduce of {ar_bytes} bytes per {CFG3_SLICE} samples",
+                        "allreduce_bytes_per_step": ar_bytes * ((n_total + CFG3_SLICE - 1) // CFG3_SLICE),
+                        "kernels_ms_per_step": {k: round(v[0] / k2, 4) for k, v in tm2.items()},
+                        "call_accuracy_vs_truth": float(np.mean((c1 == truth_all[:, 0]) & (c2 == truth_all[:, 1]))),
+                        "check": shard_check_of(m2, n_total, g2, geno_all, (c1, c2))}
+        faults["classifier_sharded_model"] = int(m2.handover_faults())
+        m2.close()
+        del g2, o2
 
     out = {
         "metric": "hlaPredict() samples/sec, 10k samples x 100-classifier HLA-B",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if by_classifier else "weak",
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"synthetic {args.shape} model ({n_hla} alleles, {len(model_obj.classifiers)} classifiers, "
-                               f"{S} SNPs, {pair_evals} haplotype-pair evaluations/sample), {n} samples per GPU per step, "
-                               f"type={'response+prob' if args.prob else 'response+dosage'}, vote={args.vote}",
-                   "samples_per_gpu": n,
-                   "parallelism": (f"classifier-sharded x{world} (one all-reduce of {P + 3} x {n_pad} doubles per step)"
-                                   if by_classifier else f"sample-sharded x{world} (no collective)"),
+        "config": {"workload": workload_text(args, model_obj, n, n_total, world, strong or by_classifier),
+                   "samples_per_gpu": n, "samples_per_step": n_total,
+                   "parallelism": (f"classifier-sharded x{world} ({len(sub.classifiers)} of {len(model_obj.classifiers)} classifiers on this rank; "
+                                   f"one RCCL all-reduce of {allreduce_bytes} bytes per {CFG3_SLICE} samples)"
+                                   if by_classifier else f"sample-sharded x{world} (contiguous slices, no collective)"),
                    "kernel_target": target,
                    "engine": os.environ.get("HIBAG_ENGINE", "mfma") + " (FP4 / int8 MFMA distances + FP64 VALU accumulation in reference order)"},
         "pair_evals_per_s": value * pair_evals,
@@ -280,6 +377,8 @@ def main():
     }
     if shard_check is not None:
         out["classifier_shard_check"] = shard_check
+    if sharded_line is not None:
+        out["classifier_sharded"] = sharded_line
 
     if rank == 0 and world == 1 and not args.no_extras and not by_classifier:
         # SURVEY.md 8(d) protocol: median of >= 10 individually timed repetitions; the device-resident step (what `value`
@@ -290,20 +389,35 @@ def main():
         out["protocol"]["device_resident_median_samples_per_s"] = n / out["protocol"]["device_resident_median_ms"] * 1e3
         out["host_inclusive"] = host_inclusive(model, geno, n)
         out["host_inclusive"]["frac_of_device_resident"] = out["host_inclusive"]["value"] / out["protocol"]["device_resident_median_samples_per_s"]
+        faults["host_inclusive"] = int(model.handover_faults()) - faults["timed_model"]
         if args.shape == SHAPE and n == SAMPLES_PER_GPU:
             out["host_inclusive_100k"] = host_inclusive_cohort(model, model_obj, founders, afreq, dev, 100_000)
+            faults["host_inclusive_100k"] = int(model.handover_faults()) - faults["timed_model"] - faults["host_inclusive"]
             model.close()
-            out["other_configs"] = other_configs(K)
+            out["other_configs"] = other_configs(K, faults)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and vote_method == 1:
         out["cpu_baseline"] = cpu_baseline(model_obj, geno, h1, h2)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
 
+    # hand-overs that failed (and were repaired or reported) in any model this run timed: a fault costs a repeated batch,
+    # so a non-zero count explains a slow line -- it must be 0
+    out["handover_faults"] = faults
+
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def workload_text(args, model_obj, n, n_total, world, shared):
+    what = (f"BASELINE config 3: {n_total} samples shared by {world} GPUs" if (shared and world > 1)
+            else "BASELINE config 2" if (n == SAMPLES_PER_GPU and world == 1) else f"{n} samples per GPU")
+    return (f"{what}: synthetic {args.shape} model ({model_obj.n_hla} alleles, {len(model_obj.classifiers)} classifiers, "
+            f"{model_obj.n_snp} SNPs, {model_obj.pair_evals_per_sample()} haplotype-pair evaluations/sample), {n} samples per GPU per step, "
+            f"type={'response+prob' if args.prob else 'response+dosage'}, vote={args.vote}; genotypes and outputs resident in HBM "
+            f"(transfers excluded: `host_inclusive` is the PCIe-inclusive rate of the host-pointer entry)")
 
 
 def issue_floor(obj, avg_ms, n, K, dev_model):
@@ -393,7 +507,7 @@ def m_pad(n):
     return (n + 63) // 64 * 64
 
 
-def other_configs(K):
+def other_configs(K, faults=None):
     """BASELINE configs 4 and 5 at reduced repetition (the metric's config is the main line): cfg4 = the
     HLA-DRB1 shape (500 haplotypes per classifier), cfg5 = hlaAttrBagging() at 1,000 samples x 300 SNPs."""
     import numpy as np
@@ -423,6 +537,7 @@ def other_configs(K):
             ms = median_ms(one, 10)
             acc = float(np.mean((h1.cpu().numpy() == truth[:, 0]) & (h2.cpu().numpy() == truth[:, 1])))
             res[name] = {"samples_per_s": n2 / ms * 1e3, "ms_per_step": ms, "repetitions": 10, "call_accuracy_vs_truth": acc,
+                         "handover_faults": int(m.handover_faults()),
                          "what": ("type='response+prob': also the posterior matrix, %d B per sample" % (8 * obj.n_cell)) if post is not None
                                  else "vote='majority' (k_vote_best + k_vote_tally instead of pass 2)"}
         m.close()
@@ -515,42 +630,139 @@ def other_configs(K):
         torch.cuda.synchronize(dev)
         dt8 = (time.perf_counter() - t) / 2
         res["cfg4_hla_drb1"]["at_twice_the_batch"] = {"samples": n8, "samples_per_s": n8 / dt8, "ms_per_step": dt8 * 1e3}
+        res["cfg4_hla_drb1"]["handover_faults"] = int(m.handover_faults())
         m.close()
+        # the same model on the host cores: the AVX2 + threads port of the reference's kernel on a bounded sample
+        from oracle import oracle as O
+        O.build()
+        cores, cores_note = usable_cores()
+        nc = 768
+        t = time.perf_counter()
+        ref = O.predict(O.flatten(obj), G[:nc], avx2=True, n_threads=cores, want_dosage=True, want_prob=False)
+        dtc = time.perf_counter() - t
+        res["cfg4_hla_drb1"]["cpu_baseline"] = {
+            "value": nc / dtc, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"the first {nc} samples of the timed batch ({dtc:.1f} s), same model, same outputs; AVX2 4-wide inner loop + "
+                      f"{cores} threads over samples ({cores_note})",
+            "calls_identical_to_gpu": bool(np.array_equal(ref["h1"], h1.cpu().numpy()[:nc]) and np.array_equal(ref["h2"], h2.cpu().numpy()[:nc]))}
+        res["cfg4_hla_drb1"]["speedup_vs_cpu_baseline"] = res["cfg4_hla_drb1"]["samples_per_s"] / res["cfg4_hla_drb1"]["cpu_baseline"]["value"]
     except Exception as e:                       # an extra must not take the metric line down
         res["cfg4_hla_drb1"] = {"error": repr(e)}
     try:
         mdl, founders, af = synth.make_model("hla-b", seed=9, n_snp=300, n_classifier=1, wide_classifier=False)
         G, truth = synth.make_samples(founders, af, 1000, seed=10)
         mtry = int(np.ceil(np.sqrt(300)))
-        tr = train._Trainer(G, truth[:, 0], truth[:, 1], mdl.n_hla)
-        tr.set_seed(100)
-        tr.new_classifiers(1, mtry, True, False, False)           # warm-up (allocations, first launches)
-        ncl = 100                                                 # BASELINE config 5: 100 individual classifiers
-        t = time.perf_counter()
-        tr.new_classifiers(ncl, mtry, True, False, False)
-        dt = (time.perf_counter() - t) / ncl
-        cls = tr.classifiers()[1:]
-        tr.close()
+
+        def train_rate(threads, ncl):
+            tr = train._Trainer(G, truth[:, 0], truth[:, 1], mdl.n_hla)
+            if threads:
+                tr.set_threads(threads)
+            used = tr.threads
+            tr.set_seed(100)
+            tr.new_classifiers(1, mtry, True, False, False)           # warm-up (allocations, first launches)
+            t = time.perf_counter()
+            tr.new_classifiers(ncl, mtry, True, False, False)
+            dt = (time.perf_counter() - t) / ncl
+            everything = tr.classifiers()
+            tr.close()
+            return dt, used, everything
+        ncl = 100                                                     # BASELINE config 5: 100 individual classifiers
+        dt, used, grown = train_rate(0, ncl)
+        cls = grown[1:]
         res["cfg5_training"] = {"s_per_classifier": dt, "classifiers_per_s": 1.0 / dt, "model_of_100_classifiers_s": dt * ncl,
-                                "n_samp": 1000, "n_snp": 300,
+                                "threads": used, "n_samp": 1000, "n_snp": 300,
                                 "n_hla": mdl.n_hla, "mtry": mtry, "classifiers_timed": ncl,
                                 "mean_snps": float(np.mean([len(c.snpidx) for c in cls])),
                                 "mean_haplo": float(np.mean([len(c.freq) for c in cls]))}
+        # What a rank gets of the host when eight of them share it (usable CPUs / 8, the default under LOCAL_WORLD_SIZE=8),
+        # and the 8-rank rate that projects to: classifiers are independent, every rank grows its share (no collective on
+        # the compute path), so the model of 100 takes ceil(100 / 8) classifiers' time at that thread count.
+        cores, _ = usable_cores()
+        per_rank = max(1, cores // 8)
+        dt8, used8, _ = train_rate(per_rank, 24)
+        res["cfg5_training"]["at_one_eighth_of_the_host"] = {
+            "threads": used8, "s_per_classifier": dt8, "slowdown_vs_all_cores": dt8 / dt, "classifiers_timed": 24,
+            "projected_8_ranks": {"classifiers_per_s": 8.0 / dt8, "model_of_100_classifiers_s": -(-ncl // 8) * dt8,
+                                  "speedup_vs_one_rank_with_all_cores": (dt * ncl) / (-(-ncl // 8) * dt8),
+                                  "what": "eight ranks of one node, each a trainer on its own GPU with 1/8 of the host's usable CPUs "
+                                          "(hibag_hip_trainer_set_threads; the default under LOCAL_WORLD_SIZE=8); projected from the "
+                                          "one-GPU measurement at that thread count, no 8-GPU node was available to the build"}}
+        # the oracle's one-core restatement of the reference's training driver on the same data, same random stream
+        from oracle import oracle as O
+        O.build()
+        t = time.perf_counter()
+        oc = O.train(G, truth[:, 0], truth[:, 1], mdl.n_hla, 2, mtry, True, 100)
+        dto = (time.perf_counter() - t) / 2
+        same = all(np.array_equal(a.snpidx, b["snpidx"]) and np.array_equal(a.freq, b["freq"]) and a.haplo == b["haplo"]
+                   for a, b in zip(grown[:2], oc))
+        res["cfg5_training"]["cpu_baseline"] = {
+            "value": 1.0 / dto, "unit": "classifiers/s", "s_per_classifier": dto, "cores": 1, "kind": "port",
+            "sample": f"the first 2 classifiers of the same training run (seed 100, {dto * 2:.1f} s): oracle/hibag_oracle_train.c, the "
+                      "reference's driver restated for one core (its CPU kernels' nthread applies to prediction only)",
+            "classifiers_identical_to_gpu": bool(same)}
+        res["cfg5_training"]["speedup_vs_cpu_baseline"] = dto / dt
     except Exception as e:
-        res["cfg5_training"] = {"error": repr(e)}
+        res["cfg5_training"] = dict(res.get("cfg5_training", {}), error=repr(e))
+    # classifiers of 33 .. 112 SNPs only (FP4 in two to four K steps: k_total_wide + k_total_scan, every cell stored): the
+    # shape of tests/test_hip_parity.py::test_only_wide_classifiers at the benchmark's batch size
+    try:
+        ks = [33, 40, 56, 57, 84, 85, 100, 112] * 4
+        obj, founders, af = synth.make_model("hla-b", seed=31, n_classifier=len(ks), n_snp=150, snp_counts=ks, wide_classifier=False)
+        nw = SAMPLES_PER_GPU
+        G, truth = synth.make_samples(founders, af, nw, seed=32)
+        m = hibag_amd.hlaModelFromObj(obj)
+        dg = torch.from_numpy(G).to(dev)
+        o = [torch.empty(nw, dtype=torch.int32, device=dev), torch.empty(nw, dtype=torch.int32, device=dev),
+             torch.empty(nw, dtype=torch.float64, device=dev), torch.empty(nw, dtype=torch.float64, device=dev),
+             torch.empty((nw, obj.n_hla), dtype=torch.float64, device=dev)]
+        st = torch.cuda.current_stream(dev).cuda_stream
+        run = lambda: m.predict_device(dg.data_ptr(), nw, 1, *[x.data_ptr() for x in o], None, stream=st)
+        run(); torch.cuda.synchronize(dev)
+        m.set_timing(True); m.reset_timing()
+        steps = 5
+        t = time.perf_counter()
+        for _ in range(steps):
+            run()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t) / steps
+        tm = m.get_timing(); m.set_timing(False)
+        tot_ms = tm["total"][0] / max(tm["total"][1], 1)
+        floor, ach = issue_floor(obj, tot_ms, nw, K, m)
+        res["wide_classifiers"] = {"samples_per_s": nw / dt, "samples": nw, "ms_per_step": dt * 1e3,
+                                   "snps_per_classifier": ks[:8], "classifiers": len(ks),
+                                   "pair_evals_per_sample": obj.pair_evals_per_sample(),
+                                   "kernels_ms_per_step": {k: round(v[0] / steps, 3) for k, v in tm.items()},
+                                   "pass1_frac_of_multi_step_fp4_floor": round(floor / ach, 4),
+                                   "handover_faults": int(m.handover_faults()),
+                                   "call_accuracy_vs_truth": float(np.mean((o[0].cpu().numpy() == truth[:, 0]) & (o[1].cpu().numpy() == truth[:, 1]))),
+                                   "what": "every classifier 33..112 SNPs: FP4 distances in two to four K steps chained through the accumulator; "
+                                           "pass 1 = k_total_wide + k_total_scan (the 'total' timer), every cell sum stored, pass 2 reads them back"}
+        m.close()
+    except Exception as e:
+        res["wide_classifiers"] = {"error": repr(e)}
+    if faults is not None:
+        for k, v in res.items():
+            if isinstance(v, dict) and "handover_faults" in v:
+                faults[k] = v["handover_faults"]
     return res
 
 
 def main_threads(args):
-    """`--launcher threads`: ONE process, one host thread per GPU, no torch.distributed: every thread drives its own replica
-    of the model (hibag_hip_model_replicate) through the device entry of the C ABI on its own 10,000 resident samples --
-    what an R / C++ host does with a node's GPUs.  Timing as in the ranks mode: a barrier over
-    the threads and a device synchronisation on both sides of exactly K steps, the slowest thread's time."""
+    """`--launcher threads`: ONE process, no torch.distributed -- what an R / C++ host does with a node's GPUs through the
+    C ABI (INTEGRATION.md sections B and C).
+      --shard samples (default)   one host thread and one replica of the model per GPU (hibag_hip_model_replicate), each on
+                                  its slice of config 3's 100,000 samples (or its own `--samples` n) through the device
+                                  entry; a barrier over the threads and a device synchronisation on both sides of exactly K
+                                  steps, the slowest thread's time
+      --shard classifiers         hibag_hip_model_shard + hibag_hip_shard_group_predict: every device a slice of the
+                                  classifiers, the partial posterior sums merged by the ONE ncclAllReduce per batch that
+                                  libhibag_hip.so issues itself; host pointers in and out, so transfers are inside the time."""
     import threading
     import numpy as np
     import torch
     import hibag_amd
     from hibag_amd import synth
+    from hibag_amd import dist as hdist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: hibag_amd has no CPU fallback")
     n_dev = torch.cuda.device_count()
@@ -558,18 +770,71 @@ def main_threads(args):
     devices = [i % n_dev for i in range(N)]          # (more replicas than devices: several on one, for a dry run on a 1-GPU box)
     target = hibag_amd.hlaSetKernelTarget("hip")[0]
     model_obj, founders, afreq = synth.make_model(args.shape, wide_classifier=not args.no_wide)
-    n = args.samples
     vote_method = 2 if args.vote == "majority" else 1
+    strong = args.samples is None and N > 1
+    n_total = CFG3_SAMPLES if strong else (args.samples if args.samples is not None else SAMPLES_PER_GPU) * (1 if args.shard == "classifiers" else N)
+    pair_evals = model_obj.pair_evals_per_sample()
     first = hibag_amd.hlaModelFromObj(model_obj, device=devices[0])
+
+    if args.shard == "classifiers":
+        from hibag_amd.hibag import ShardGroup
+        n = n_total
+        geno, truth = synth.make_samples(founders, afreq, n, seed=synth.DEFAULT_SEED + 1)
+        grp = ShardGroup(first, devices)
+        for _ in range(max(1, min(args.warmup, 2))):
+            got = grp.predict_raw(geno, want_dosage=True)
+        steps = max(1, min(args.steps, 10))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            got = grp.predict_raw(geno, want_dosage=True)
+        dt = time.perf_counter() - t0
+        ref = first.predict_raw(geno[:10_000], 1, want_dosage=False, want_prob=False)
+        out = {
+            "metric": "hlaPredict() samples/sec, 10k samples x 100-classifier HLA-B",
+            "value": n * steps / dt, "unit": "samples/s", "n_gpus": N, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": workload_text(args, model_obj, n, n, N, True).replace(
+                           "genotypes and outputs resident in HBM (transfers excluded: `host_inclusive` is the PCIe-inclusive rate of the host-pointer entry)",
+                           "HOST pointers in and out (upload of the genotypes to every rank and download of the outputs are inside the time)"),
+                       "samples_per_step": n,
+                       "parallelism": f"classifier-sharded x{N} inside libhibag_hip.so: {len(grp.shards)} shards on devices {devices}, "
+                                      f"{grp.ranks} RCCL rank(s), one ncclAllReduce per batch of the library's choosing",
+                       "kernel_target": target,
+                       "launcher": "threads: one process, the calling thread drives every device (hibag_hip_shard_group_predict)"},
+            "pair_evals_per_s": n * steps / dt * pair_evals,
+            "call_accuracy_vs_truth": float(np.mean((got["h1"] == truth[:, 0]) & (got["h2"] == truth[:, 1]))),
+            "rccl_ranks": grp.ranks, "rccl_allreduces": grp.allreduces,
+            "rccl_version_code": int(hibag_amd._lib.lib().hibag_hip_rccl_version()),
+            "classifier_shard_check": {"calls_identical_to_unsharded": bool(np.array_equal(ref["h1"], got["h1"][:10_000]) and
+                                                                            np.array_equal(ref["h2"], got["h2"][:10_000])),
+                                       "max_rel_dev_prob_vs_unsharded": float(np.nanmax(np.abs(got["prob"][:10_000] - ref["prob"]) /
+                                                                                        np.maximum(np.abs(ref["prob"]), 1e-300))),
+                                       "tolerance": 1e-10},
+            "handover_faults": {"shards": int(sum(m.handover_faults() for m in grp.shards))},
+        }
+        print(json.dumps(out), flush=True)
+        grp.close(); first.close()
+        return
+
     models = [first] + [first.replicate(d) for d in devices[1:]]
+    geno_all = truth_all = None
+    if strong:
+        geno_all, truth_all = synth.make_samples(founders, afreq, n_total, seed=synth.DEFAULT_SEED + 1)
     bar = threading.Barrier(N)
-    times, accs, errs = [0.0] * N, [0.0] * N, []
+    times, accs, errs, sizes = [0.0] * N, [0.0] * N, [], [0] * N
 
     def worker(r):
         try:
             dev = torch.device("cuda", devices[r])
             torch.cuda.set_device(dev)
-            geno, truth = synth.make_samples(founders, afreq, n, seed=synth.DEFAULT_SEED + 1 + r)
+            if strong:
+                lo, hi = hdist.shard_bounds(n_total, N, r)
+                geno, truth = np.ascontiguousarray(geno_all[lo:hi]), truth_all[lo:hi]
+            else:
+                geno, truth = synth.make_samples(founders, afreq, n_total // N, seed=synth.DEFAULT_SEED + 1 + r)
+            n = len(geno)
+            sizes[r] = n
             m = models[r]
             dg = torch.from_numpy(geno).to(dev)
             h1 = torch.empty(n, dtype=torch.int32, device=dev); h2 = torch.empty_like(h1)
@@ -602,22 +867,22 @@ def main_threads(args):
     if errs:
         sys.exit("bench.py --launcher threads: " + "; ".join(errs))
     dt = max(times)
-    pair_evals = model_obj.pair_evals_per_sample()
+    total = sum(sizes)
     out = {
         "metric": "hlaPredict() samples/sec, 10k samples x 100-classifier HLA-B",
-        "value": n * N * args.steps / dt, "unit": "samples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": f"synthetic {args.shape} model ({model_obj.n_hla} alleles, {len(model_obj.classifiers)} classifiers, "
-                               f"{model_obj.n_snp} SNPs, {pair_evals} haplotype-pair evaluations/sample), {n} samples per GPU per step, "
-                               f"type=response+dosage, vote={args.vote}",
-                   "samples_per_gpu": n, "parallelism": f"sample-sharded x{N} (no collective)", "kernel_target": target,
+        "value": total * args.steps / dt, "unit": "samples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": workload_text(args, model_obj, sizes[0], total, N, strong),
+                   "samples_per_gpu": sizes[0], "samples_per_step": total,
+                   "parallelism": f"sample-sharded x{N} (contiguous slices, no collective)", "kernel_target": target,
                    "launcher": f"threads: one process, one host thread and one model replica per GPU through the C ABI "
                                f"(devices {devices})"},
-        "pair_evals_per_s": n * N * args.steps / dt * pair_evals,
+        "pair_evals_per_s": total * args.steps / dt * pair_evals,
         "call_accuracy_vs_truth": float(np.mean(accs)), "rccl_ranks": None,
+        "handover_faults": {"replicas": int(sum(m.handover_faults() for m in models))},
     }
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     for m in models[1:]:
         m.close()
     first.close()

@@ -36,7 +36,7 @@ EXPORTS = [
     "hibag_hip_multi_slice", "hibag_hip_predict_multi", "hibag_hip_model_device",
     "hibag_hip_shard_bounds", "hibag_hip_model_shard", "hibag_hip_model_batch_limit", "hibag_hip_shard_group_new",
     "hibag_hip_shard_group_free", "hibag_hip_shard_group_ranks", "hibag_hip_shard_group_allreduces", "hibag_hip_rccl_version",
-    "hibag_hip_shard_group_predict", "hibag_hip_predict_multi_sharded",
+    "hibag_hip_shard_group_predict", "hibag_hip_predict_multi_sharded", "hibag_hip_measure_issue_costs",
 ]
 
 
@@ -139,6 +139,7 @@ def lib() -> C.CDLL:
     L.hibag_hip_rccl_version.restype = i32
     L.hibag_hip_shard_group_predict.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.hibag_hip_predict_multi_sharded.argtypes = [C.POINTER(vp), i32, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.hibag_hip_measure_issue_costs.argtypes = [C.POINTER(dbl)] * 4
     _lib = L
     return L
 

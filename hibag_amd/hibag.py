@@ -263,6 +263,10 @@ class HlaAttrBagClass:
             self.handle, p(d_geno), int(n_samp), int(vote_method), p(d_h1), p(d_h2), p(d_prob), p(d_matching),
             p(d_dosage), p(d_postprob), p(stream)))
 
+    def batch_limit(self) -> int:
+        """Samples one call of the partial entry takes (``hibag_hip_model_batch_limit``)."""
+        return int(_lib.lib().hibag_hip_model_batch_limit(self.handle))
+
     def predict_partial_device(self, d_geno, n_samp: int, d_partial, stream=None):
         def p(x):
             return None if x is None else C.c_void_p(int(x))

@@ -359,6 +359,14 @@ int hibag_hip_set_timing(hibag_hip_model *m, int enabled);
 int hibag_hip_get_timing(hibag_hip_model *m, int k, double *ms_total, int64_t *launches);
 int hibag_hip_reset_timing(hibag_hip_model *m);
 
+/* The instruction costs the kernels' issue floor is priced with, measured on the calling thread's
+ * current device in about 50 ms: ns per wave64 instruction per SIMD with 8 wavefronts on every SIMD, for FP64 mul / add
+ * (the one multiplication and one addition per haplotype pair of src/LibHLA.cpp:1786-1813 are the irreducible part of a
+ * pass), v_mfma_i32_32x32x32_i8 and v_mfma_scale_f32_32x32x64_f8f6f4 (FP4 operands), and the time of a half / half mix of
+ * FP64 and int8-MFMA wavefronts as a fraction of the serial sum (1 = the matrix pipe does not hide behind FP64 work).
+ * Any pointer may be NULL.  Measurement only: nothing in the library reads these numbers. */
+int hibag_hip_measure_issue_costs(double *fp64_op_ns, double *mfma_i8_ns, double *mfma_fp4_ns, double *mix_frac_of_serial);
+
 /* ---- HIBAG plugin table (per-sample, drop-in for an unmodified HIBAG) ---- */
 
 /* Returns a pointer to a static struct laid out exactly like
