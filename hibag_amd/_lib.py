@@ -37,6 +37,7 @@ EXPORTS = [
     "hibag_hip_shard_bounds", "hibag_hip_model_shard", "hibag_hip_model_batch_limit", "hibag_hip_shard_group_new",
     "hibag_hip_shard_group_free", "hibag_hip_shard_group_ranks", "hibag_hip_shard_group_allreduces", "hibag_hip_rccl_version",
     "hibag_hip_shard_group_predict", "hibag_hip_predict_multi_sharded", "hibag_hip_measure_issue_costs",
+    "hibag_hip_test_time_avg_prob",
 ]
 
 
@@ -140,6 +141,7 @@ def lib() -> C.CDLL:
     L.hibag_hip_shard_group_predict.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.hibag_hip_predict_multi_sharded.argtypes = [C.POINTER(vp), i32, vp, i32, vp, vp, vp, vp, vp, vp]
     L.hibag_hip_measure_issue_costs.argtypes = [C.POINTER(dbl)] * 4
+    L.hibag_hip_test_time_avg_prob.argtypes = [vp, vp, i32, i32, i32, vp, vp, C.POINTER(dbl)]
     _lib = L
     return L
 

@@ -2024,3 +2024,33 @@ const PluginTable g_plugin_table = {
 } // namespace
 
 extern "C" const void *hibag_hip_gpu_ext_proc(void) { return &g_plugin_table; }
+
+// The loop an unmodified HIBAG runs around predict_avg_prob (src/LibHLA.cpp:2362-2411 with :2433-2441), in C like the host's: for
+// every sample one call through the table with its packed genotypes and weights, then BestGuessEnsemble's scan of the posterior
+// (:1549-1566: first strict maximum in cell order, -1 when nothing is positive).  Measurement and tests: the time of the n_samp
+// calls as a compiled host sees them (no interpreter between the calls), and the per-sample best cell to check them with.
+extern "C" int hibag_hip_test_time_avg_prob(const void *geno, const double *weight, int n_samp, int n_classifier, int n_cell,
+	int32_t *best_cell, double *matching, double *seconds)
+{
+	if (!geno || !weight || n_samp < 0 || n_classifier < 0 || n_cell <= 0) return fail(HIBAG_HIP_EINVAL, "bad arguments");
+	std::vector<double> prob;
+	try { prob.assign((size_t)n_cell, 0.0); } catch (...) { return fail(HIBAG_HIP_ENOMEM, "out of host memory"); }
+	const PluginGenotype *g = (const PluginGenotype *)geno;
+	double match = 0;
+	const auto t0 = std::chrono::steady_clock::now();
+	try {
+		for (int i = 0; i < n_samp; i++) {
+			g_plugin_table.predict_avg_prob(g + (size_t)i * n_classifier, weight + (size_t)i * n_classifier, prob.data(), &match);
+			double best = 0;
+			int cell = -1;
+			for (int p = 0; p < n_cell; p++)
+				if (best < prob[p]) { best = prob[p]; cell = p; }
+			if (best_cell) best_cell[i] = cell;
+			if (matching) matching[i] = match;
+		}
+	} catch (const char *msg) {
+		return fail(HIBAG_HIP_ENODEV, "%s", msg);
+	}
+	if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	return 0;
+}

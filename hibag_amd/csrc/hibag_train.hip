@@ -41,6 +41,7 @@
 
 #include "../../include/hibag_hip.h"
 #include "hibag_plugin.h"
+#include "hibag_pool.h"
 
 int hibag_fail(int code, const char *fmt, ...);       // hibag_api.hip: sets the thread's last error
 int hibag_selected_device();                          // hibag_api.hip: the thread's hibag_hip_set_device() choice
@@ -156,72 +157,6 @@ struct Sampling {
 		const int n = (int)a.size();
 		for (int i = n - 1; i >= n - m_try; i--)
 			if (a[i] < 0) a.erase(a.begin() + i);
-	}
-};
-
-// Persistent helper threads for the per-step fits: a growth step lasts about a millisecond, so
-// creating threads per step would cost as much as the work.
-class Pool {
-	std::vector<std::thread> th;
-	std::mutex m;
-	std::condition_variable wake, done;
-	std::function<void()> job;
-	unsigned long gen = 0;
-	int pending = 0;
-	bool stop = false;
-	std::exception_ptr failed;                  // first exception of a job, rethrown by run() on the caller
-	void note_failure()
-	{
-		std::lock_guard<std::mutex> lk(m);
-		if (!failed) failed = std::current_exception();
-	}
-public:
-	explicit Pool(int n_helpers)
-	{
-		for (int i = 0; i < n_helpers; i++)
-			th.emplace_back([this] {
-				unsigned long seen = 0;
-				for (;;) {
-					std::function<void()> f;
-					{
-						std::unique_lock<std::mutex> lk(m);
-						wake.wait(lk, [&] { return stop || gen != seen; });
-						if (stop) return;
-						seen = gen;
-						f = job;
-					}
-					try { f(); } catch (...) { note_failure(); }     // never let an exception leave the thread
-					{
-						std::lock_guard<std::mutex> lk(m);
-						if (--pending == 0) done.notify_one();
-					}
-				}
-			});
-	}
-	~Pool()
-	{
-		{ std::lock_guard<std::mutex> lk(m); stop = true; }
-		wake.notify_all();
-		for (std::thread &t : th) t.join();
-	}
-	// runs f on every helper and on the caller; returns when all are done
-	void run(const std::function<void()> &f)
-	{
-		{
-			std::lock_guard<std::mutex> lk(m);
-			job = f; gen++; pending = (int)th.size();
-		}
-		wake.notify_all();
-		try { f(); } catch (...) { note_failure(); }
-		// always wait for the helpers: they use objects on the caller's stack
-		std::unique_lock<std::mutex> lk(m);
-		done.wait(lk, [&] { return pending == 0; });
-		if (failed) {
-			std::exception_ptr e = failed;
-			failed = nullptr;
-			lk.unlock();
-			std::rethrow_exception(e);
-		}
 	}
 };
 

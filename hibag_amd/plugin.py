@@ -99,6 +99,20 @@ class PluginHost:
         self.table.predict_avg_prob(geno_row.ctypes.data_as(C.POINTER(TGenotype)), wt_row.ctypes.data_as(C.POINTER(C.c_double)),
                                     out_prob.ctypes.data_as(C.POINTER(C.c_double)), out_match.ctypes.data_as(C.POINTER(C.c_double)))
 
+    def avg_prob_loop(self, geno: np.ndarray, wt: np.ndarray):
+        """The host's per-sample loop in C (``hibag_hip_test_time_avg_prob``): ``predict_avg_prob`` for every row of
+        ``geno`` / ``wt`` followed by the arg-max scan -- no interpreter between the calls, which is how a compiled host
+        sees the route.  Returns (best posterior cell per sample, matching per sample, seconds)."""
+        g = np.ascontiguousarray(geno, np.uint64)
+        w = np.ascontiguousarray(wt, np.float64)
+        n, nC = w.shape
+        best = np.zeros(n, np.int32); match = np.zeros(n, np.float64)
+        sec = C.c_double(0)
+        _lib.check(_lib.lib().hibag_hip_test_time_avg_prob(g.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), n, nC,
+                                                           self.obj.n_cell, best.ctypes.data_as(C.c_void_p),
+                                                           match.ctypes.data_as(C.c_void_p), C.byref(sec)))
+        return best, match, sec.value
+
     def close(self):
         if getattr(self, "_open", False):
             self.table.predict_done()

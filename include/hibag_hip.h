@@ -390,6 +390,14 @@ int hibag_hip_measure_issue_costs(double *fp64_op_ns, double *mfma_i8_ns, double
  * call with nthread = 1. */
 const void *hibag_hip_gpu_ext_proc(void);
 
+/* The loop an unmodified HIBAG runs around predict_avg_prob (src/LibHLA.cpp:2362-2411, :2433-2441), compiled like the host's:
+ * n_samp calls through the table -- geno: TGenotype [n_samp][n_classifier] (48 bytes each), weight [n_samp][n_classifier] --
+ * each followed by BestGuessEnsemble's scan (:1549-1566).  Returns the elapsed time of the loop in *seconds, the winning
+ * posterior cell (-1: none) and the matching value per sample.  predict_init must have been called.  For measurements
+ * (bench.py: what the zero-change route costs a compiled host, no interpreter between the calls) and tests. */
+int hibag_hip_test_time_avg_prob(const void *geno, const double *weight, int n_samp, int n_classifier, int n_cell,
+	int32_t *best_cell, double *matching, double *seconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,8 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libhibag_oracle.so")
+# HIBAG_ORACLE_LIBRARY selects another build of the oracle (the sanitizer builds of oracle/Makefile, tools/run_sanitizers.sh)
+_LIB_PATH = os.environ.get("HIBAG_ORACLE_LIBRARY") or os.path.join(_HERE, "libhibag_oracle.so")
 NA_INTEGER = -2147483648
 
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -33,7 +34,7 @@ def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in ("hibag_oracle.c", "hibag_oracle_avx2.c", "hibag_oracle_train.c", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
-    if force or stale:
+    if (force or stale) and not os.environ.get("HIBAG_ORACLE_LIBRARY"):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
 

@@ -23,4 +23,4 @@ PY
 python3 /tmp/plugin_run.py
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 /tmp/plugin_run.py > $out/log.txt 2>&1
-f=$(ls $out/*/*kernel_stats.csv | head -1); cp $f $R/gpurun_out/r03_plugin_kernel_stats.csv; cut -d, -f1-4 $f | head -6
+f=$(ls $out/*/*kernel_stats.csv | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/r04_plugin_kernel_stats.csv && cut -d, -f1-4 "$f" | head -6
