@@ -657,8 +657,9 @@ def other_configs(K, faults=None):
         G, truth = synth.make_samples(founders, af, 1000, seed=10)
         mtry = int(np.ceil(np.sqrt(300)))
 
-        def train_rate(threads, ncl):
+        def train_rate(threads, ncl, em="auto"):
             tr = train._Trainer(G, truth[:, 0], truth[:, 1], mdl.n_hla)
+            tr.set_em_mode(em)
             if threads:
                 tr.set_threads(threads)
             used = tr.threads
@@ -684,8 +685,12 @@ def other_configs(K, faults=None):
         cores, _ = usable_cores()
         per_rank = max(1, cores // 8)
         dt8, used8, _ = train_rate(per_rank, 24)
+        dt8h, _, _ = train_rate(per_rank, 24, "host")
+        res["cfg5_training"]["em_fits"] = ("host threads (more than two of them: the faster place)" if used > 2 else "device (hibag_em.hip)")
         res["cfg5_training"]["at_one_eighth_of_the_host"] = {
             "threads": used8, "s_per_classifier": dt8, "slowdown_vs_all_cores": dt8 / dt, "classifiers_timed": 24,
+            "em_fits": "device (two host threads or fewer: hibag_em.hip, workgroup = candidate)" if used8 <= 2 else "host threads",
+            "s_per_classifier_with_the_fits_on_the_host_threads": dt8h,
             "projected_8_ranks": {"classifiers_per_s": 8.0 / dt8, "model_of_100_classifiers_s": -(-ncl // 8) * dt8,
                                   "speedup_vs_one_rank_with_all_cores": (dt * ncl) / (-(-ncl // 8) * dt8),
                                   "what": "eight ranks of one node, each a trainer on its own GPU with 1/8 of the host's usable CPUs "

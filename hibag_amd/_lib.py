@@ -30,7 +30,7 @@ EXPORTS = [
     "hibag_hip_gpu_ext_proc", "hibag_hip_bed_flag", "hibag_hip_conv_bed", "hibag_hip_predict_bed", "hibag_hip_predict_mapped", "hibag_hip_predict_mapped_device",
     "hibag_hip_trainer_new", "hibag_hip_trainer_free", "hibag_hip_trainer_set_rng", "hibag_hip_trainer_set_seed",
     "hibag_hip_trainer_new_classifiers", "hibag_hip_trainer_n_classifier", "hibag_hip_trainer_classifier_dims",
-    "hibag_hip_trainer_classifier_get", "hibag_hip_trainer_set_threads", "hibag_hip_trainer_threads",
+    "hibag_hip_trainer_classifier_get", "hibag_hip_trainer_set_threads", "hibag_hip_trainer_threads", "hibag_hip_trainer_set_em_mode",
     "hibag_hip_model_status", "hibag_hip_model_clear_status", "hibag_hip_model_handover_faults",
     "hibag_hip_test_inject_handover_fault", "hibag_hip_model_engine", "hibag_hip_model_replicate",
     "hibag_hip_multi_slice", "hibag_hip_predict_multi", "hibag_hip_model_device",
@@ -109,6 +109,7 @@ def lib() -> C.CDLL:
     L.hibag_hip_trainer_n_classifier.argtypes = [vp]
     L.hibag_hip_trainer_set_threads.argtypes = [vp, i32]
     L.hibag_hip_trainer_threads.argtypes = [vp]
+    L.hibag_hip_trainer_set_em_mode.argtypes = [vp, i32]
     L.hibag_hip_trainer_classifier_dims.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.hibag_hip_trainer_classifier_get.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.POINTER(dbl)]
     L.hibag_hip_bed_flag.argtypes = [C.c_char_p]

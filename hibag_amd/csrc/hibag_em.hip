@@ -1,0 +1,391 @@
+// hibag_em.hip -- the EM haplotype-frequency fit of a growth step's candidate SNPs on the device.
+//
+// CAlg_EM::PrepareNewSNP + ExpectationMaximization (src/LibHLA.cpp:1127-1255) once per candidate SNP: the in-bag samples'
+// haplotype pairs (CAlg_EM::PrepareHaplotypes, :1002-1125) index the DOUBLED haplotype list (DoubleHaplos, :416-442:
+// entry 2i carries allele 0 of the new SNP, 2i + 1 allele 1), a pair is compatible with a sample's genotype g at the new
+// SNP iff (h1 & 1) + (h2 & 1) == g (every pair where it is missing), and the iteration
+//     E   G_j = (h1 != h2 ? (2 f[h1]) f[h2] : f[h1] f[h2]);  psum_i = sum_j G_j;  loglik += boot_i log(psum_i);  G_j *= boot_i / psum_i
+//     M   f'[h] = (sum of the G_j of the pairs that contain h, in pair order, a homozygous pair twice) * (0.5 / n_samp)
+// runs until |loglik - loglik_before| <= sqrt(eps) (|loglik_0| + sqrt(eps)), at most 500 times.
+//
+// Until round 4 the host fitted the candidates on a thread per CPU (hibag_train.hip fit_new_snp; it still does where this
+// file says it must): with eight ranks on one node's cores -- two threads each on the pool's boxes -- the fit was 1.6 x
+// slower and the longest part of a growth step.  Here: workgroup = candidate, the growth step's pair set and the
+// candidate's state in LDS, and an iteration in barrier-separated phases (k_em_fit below): thread = pair for the products,
+// thread = sample for its psum in list order (an incompatible pair's G is +0.0, and x + (+0.0) is x bit for bit -- no sum
+// here can be -0.0 -- so nothing downstream needs the compatibility test again), thread = haplotype for the M step (the G of
+// its pairs, a transposed list built once per growth step, in pair order), and one thread that does nothing but the
+// samples' terms in sample order.  Every sum is formed by one thread in the host's order with the host's operations
+// (-ffp-contract=off), so the fitted frequencies are bit-identical to the host's.
+//
+// What it buys (profiles/r04_cfg5_notes.txt): the fit no longer depends on the host's cores -- 0.7 ms per growth step
+// whatever the rank's share of them, against 0.28 ms on 16 host threads and 0.8 ms on two.  It is a latency-bound kernel
+// (the slowest candidate of a step takes 60 iterations of ~11 us: dependent FP64 additions at 12 cycles each and
+// per-lane LDS gathers with bank conflicts), so the trainer uses it where a rank has two host threads or fewer
+// (hibag_hip_trainer_set_em_mode) and the host threads otherwise.
+//
+// The ONE thing the device cannot reproduce bit for bit is log(): the host's is glibc's, the device's ocml's, both good to
+// about an ulp and not identical.  loglik only ever decides WHEN the iteration stops, so the device decides with a margin:
+// with B >= |loglik_device - loglik_host| (a bound from the logs' ulp errors and the length of the sum, computed beside the
+// sum), the test |dL| <= tol is settled whenever |dL| is further than the accumulated bounds from tol -- then host and
+// device agree for certain -- and where it is not (a band eight orders of magnitude narrower than tol) the candidate is
+// handed back to the host, which fits it with its own log().  Stored models are reproduced bit for bit
+// (tests/test_hip_train_driver.py, tests/test_hip_configs.py) with the host idle.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
+#include <vector>
+#include "hibag_em.h"
+
+namespace {
+
+#define EM_THREADS 1024
+#define EM_MAX_ITER 500                     // src/LibHLA.cpp:98
+#define EM_INIT_VAL_FRAC 0.001              // :100
+#define EM_LDS_BYTES (156 * 1024)           // a growth step's pair set and a candidate's state live in LDS (a CU has 160 KB); larger steps go to the host
+
+struct EmView {
+	int n_ib, n_pair, n_hap, n_samp_total;  // in-bag samples, their pairs, doubled haplotypes, all samples (the M step's 0.5 / total)
+	int n_ent;                              // entries of hent (padding included)
+	const uint32_t *pw;                     // [n_pair] h1 | h2 << 14
+	const int *off;                         // [n_ib + 1]
+	const int *boot;                        // [n_ib]
+	const int *hoff;                        // [n_hap + 1] transposed lists: the pairs that contain haplotype h ...
+	const uint32_t *hent;                   // ... in pair order, a homozygous pair twice: BYTE offsets into G, every list padded to a multiple of 4 entries with n_pair * 8 (a slot that holds +0.0); hoff counts entries incl. padding
+	const double *cur_freq;                 // [n_hap / 2]
+	// per candidate
+	const int8_t *geno;                     // [n_cand][n_ib] genotype of the in-bag samples at the candidate SNP: 0, 1, 2, 3 = missing
+	const double *afreq;                    // [n_cand] allele frequency in the bag (DoubleHaplosInitFreq, :444-459)
+	double *out_freq;                       // [n_cand][n_hap]
+	int *status;                            // [n_cand] 1 = fitted, 2 = the host must fit it; [n_cand + c]: iterations
+};
+
+// LDS layout of k_em_fit (bytes), shared by the kernel and the host's size check
+struct EmLayout {
+	size_t oldf, newf, G, lterm, rs, pw, off, bt, hoff, hent, ps, total;
+	__host__ __device__ EmLayout(int n_ib, int n_pair, int n_hap)
+	{
+		size_t o = 0;
+		auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 7) & ~(size_t)7; return at; };
+		oldf = take((size_t)n_hap * 8); newf = take((size_t)n_hap * 8); G = take((size_t)(n_pair + 1) * 8 + 8); lterm = take((size_t)n_ib * 16); rs = take((size_t)n_ib * 8);
+		pw = take((size_t)n_pair * 4); off = take((size_t)(n_ib + 1) * 4); bt = take((size_t)n_ib * 4); hoff = take((size_t)(n_hap + 1) * 4);
+		hent = take(((size_t)2 * n_pair + 4 * (size_t)n_hap) * 4 + 16); ps = take((size_t)n_pair * 2);
+		total = o;
+	}
+};
+
+// Workgroup = candidate.  An iteration is three barrier-separated phases of about a microsecond each --
+//   A  thread = pair:       G_j = (h1 != h2 ? (2 f[h1]) f[h2] : f[h1] f[h2]), +0.0 for a pair the sample's genotype rules out
+//   B  thread = sample:     psum = its G in list order;  term = boot log(psum);  its compatible G *= boot / psum
+//   C  thread = haplotype:  f'[h] = (its pairs' G in pair order) * (0.5 / n)
+// -- and the one long serial chain, loglik = the samples' terms in sample order (632 dependent additions: three
+// microseconds), runs BESIDE them on a thread that does nothing else: a third of the chain in each phase of the NEXT
+// iteration (the terms are double-buffered).  So the stopping test of iteration k is known at the end of iteration k + 1; a
+// fit that stops at k returns the frequencies it had then -- oldf, which iteration k + 1 only read.
+__global__ __launch_bounds__(EM_THREADS) void k_em_fit(EmView V)
+{
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	__shared__ int verdict_s;                                         // of the iteration before: 0 = go on, 1 = converged, 2 = cannot tell (host)
+	__shared__ unsigned long long tmax_s[2];                          // largest |term| of an iteration (bits of a non-negative double), by parity
+	const EmLayout L(V.n_ib, V.n_pair, V.n_hap);
+	double *oldf = (double *)(lds + L.oldf), *newf = (double *)(lds + L.newf), *G = (double *)(lds + L.G), *lterm = (double *)(lds + L.lterm);
+	uint32_t *pw = (uint32_t *)(lds + L.pw);                          // h1 | h2 << 14 | genotype of the pair's sample << 28
+	int *off = (int *)(lds + L.off), *bt = (int *)(lds + L.bt), *hoff = (int *)(lds + L.hoff);
+	uint32_t *hent = (uint32_t *)((((uintptr_t)(lds + L.hent)) + 15) & ~(uintptr_t)15);
+	uint16_t *ps = (uint16_t *)(lds + L.ps);                          // the sample of each pair
+	double *rs = (double *)(lds + L.rs);                              // boot_i / psum_i
+	const int tid = threadIdx.x, c = blockIdx.x, n_ib = V.n_ib, n_pair = V.n_pair, n_hap = V.n_hap;
+	const bool summer = tid == EM_THREADS - 1;                        // the thread of the loglik chain (no other work)
+	const int nw = EM_THREADS - 1;                                    // worker threads
+	// the growth step's pair set (the same for every candidate) and this candidate's genotypes: once into LDS
+	for (int e = tid; e < V.n_ent; e += EM_THREADS) hent[e] = V.hent[e];
+	if (tid == 0) G[n_pair] = 0.0;                                   // what the lists' padding entries point at
+	for (int i = tid; i <= n_ib; i += EM_THREADS) off[i] = V.off[i];
+	for (int i = tid; i < n_ib; i += EM_THREADS) bt[i] = V.boot[i];
+	for (int h = tid; h <= n_hap; h += EM_THREADS) hoff[h] = V.hoff[h];
+	const double p1 = V.afreq[c], p0 = 1 - p1;                        // :447-448
+	for (int h = tid; h < n_hap; h += EM_THREADS)                     // DoubleHaplosInitFreq, :444-459
+		newf[h] = ((h & 1) ? p1 : p0) * V.cur_freq[h >> 1] + EM_INIT_VAL_FRAC;
+	for (int i = tid; i < n_ib; i += EM_THREADS) {
+		const uint32_t g = (uint32_t)(V.geno[(size_t)c * n_ib + i] & 3);
+		for (int j = V.off[i]; j < V.off[i + 1]; j++) { pw[j] = V.pw[j] | (g << 28); ps[j] = (uint16_t)i; }
+	}
+	const double em_reltol = 1.4901161193847656e-08;                  // sqrt(DBL_EPSILON), :102
+	const double scale = 0.5 / V.n_samp_total;
+	// the summer's state: the chain of iteration (iter - 1)'s terms, its loglik history, the tolerance.  The chain is cut in
+	// four pieces, one per phase of the next iteration, about as long as the phases are (A 12 %, B 22 %, B' 6 %, C 60 %).
+	double chain = 0, conv_tol = 0, tol_bound = 0, loglik_prev = -1e+30, bound_prev = 0;
+	const int cut[5] = {0, (n_ib * 12 + 99) / 100, (n_ib * 34 + 99) / 100, (n_ib * 40 + 99) / 100, n_ib};
+	auto sum_part = [&](const double *t, int part) {                  // terms [cut[part], cut[part + 1]) in order, sixteen reads in flight
+		const int hi = min(n_ib, cut[part + 1]);
+		int i = min(n_ib, cut[part]);
+		for (; i + 16 <= hi; i += 16) {
+			double v[16];
+#pragma unroll
+			for (int u = 0; u < 16; u++) v[u] = t[i + u];
+#pragma unroll
+			for (int u = 0; u < 16; u++) chain += v[u];
+		}
+		for (; i < hi; i++) chain += t[i];
+	};
+	int iter = 0, stopped = 0;
+	if (tid == 0) verdict_s = 0;
+
+	for (; iter <= EM_MAX_ITER; iter++) {
+		__syncthreads();
+		for (int h = tid; h < n_hap; h += EM_THREADS) oldf[h] = newf[h];
+		const double *t_prev = lterm + (size_t)((iter + 1) & 1) * n_ib;   // the terms of iteration iter - 1
+		double *t_cur = lterm + (size_t)(iter & 1) * n_ib;
+		if (summer) chain = 0;
+		if (tid == 0) tmax_s[iter & 1] = 0;
+		__syncthreads();
+		// ---- A
+		if (summer) { if (iter > 0) sum_part(t_prev, 0); }
+		else
+			for (int j0 = tid; j0 < n_pair; j0 += 4 * nw) {            // four pairs per turn: their look-ups in flight together
+				uint32_t w[4];
+				double fa[4], fb[4];
+#pragma unroll
+				for (int u = 0; u < 4; u++) w[u] = pw[min(j0 + u * nw, n_pair - 1)];
+#pragma unroll
+				for (int u = 0; u < 4; u++) { fa[u] = oldf[w[u] & 0x3FFFu]; fb[u] = oldf[(w[u] >> 14) & 0x3FFFu]; }
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const int j = j0 + u * nw;
+					if (j >= n_pair) break;
+					const int a = (int)(w[u] & 0x3FFFu), b = (int)((w[u] >> 14) & 0x3FFFu), g = (int)(w[u] >> 28);
+					double x = 0;
+					if (g > 2 || (a & 1) + (b & 1) == g) x = a != b ? (2 * fa[u]) * fb[u] : fa[u] * fb[u];
+					G[j] = x;
+				}
+			}
+		__syncthreads();
+		// ---- B: a sample's psum in list order (sixteen reads in flight), its term, its scaling factor
+		unsigned long long my_max = 0;
+		if (summer) { if (iter > 0) sum_part(t_prev, 1); }
+		else
+			for (int i = tid; i < n_ib; i += nw) {
+				const int j0 = off[i], j1 = off[i + 1], b_i = bt[i];
+				double psum = 0;
+				int j = j0;
+				for (; j + 16 <= j1; j += 16) {
+					double v[16];
+#pragma unroll
+					for (int u = 0; u < 16; u++) v[u] = G[j + u];
+#pragma unroll
+					for (int u = 0; u < 16; u++) psum += v[u];
+				}
+				for (; j < j1; j++) psum += G[j];
+				const double term = b_i * log(psum);
+				t_cur[i] = term;
+				rs[i] = b_i / psum;
+				my_max = max(my_max, (unsigned long long)__double_as_longlong(fabs(term)));     // (bits of a non-negative double: NaN / inf sort above every number)
+			}
+		for (int d = 32; d > 0; d >>= 1) my_max = max(my_max, (unsigned long long)__shfl_xor((long long)my_max, d));
+		if ((tid & 63) == 0 && my_max) atomicMax(&tmax_s[iter & 1], my_max);
+		__syncthreads();
+		// ---- B': thread = pair again: the compatible G *= boot / psum (an incompatible pair stays +0.0 whatever the factor is)
+		if (summer) { if (iter > 0) sum_part(t_prev, 2); }
+		else
+			for (int j0 = tid; j0 < n_pair; j0 += 4 * nw) {
+				uint32_t w[4];
+				double r[4], x[4];
+#pragma unroll
+				for (int u = 0; u < 4; u++) { const int j = min(j0 + u * nw, n_pair - 1); w[u] = pw[j]; r[u] = rs[ps[j]]; x[u] = G[j]; }
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const int j = j0 + u * nw;
+					if (j >= n_pair) break;
+					const int g = (int)(w[u] >> 28);
+					if (g > 2 || (int)((w[u] & 1u) + ((w[u] >> 14) & 1u)) == g) G[j] = x[u] * r[u];
+				}
+			}
+		__syncthreads();
+		// ---- C
+		if (summer) {
+			if (iter > 0) {
+				sum_part(t_prev, 3);
+				// the stopping test of iteration iter - 1 (:1247-1254), with a margin for the device's log():
+				// |loglik here - loglik on the host| <= (n + 4) 2^-52 (sum of the terms' magnitudes) for logs within 2 ulp of each
+				// other; the sum bounded by n times the largest, and the whole taken eight times as wide
+				const double tmax = __longlong_as_double((long long)tmax_s[(iter + 1) & 1]);
+				const double loglik = chain, bound = 16.0 * 1.1102230246251565e-16 * (double)(n_ib + 4) * ((double)n_ib * tmax);
+				int verdict = 0;
+				if (iter > 1) {
+					const double d = fabs(loglik - loglik_prev), slack = bound + bound_prev + tol_bound;
+					if (d + slack <= conv_tol) verdict = 1;           // the host's test succeeds for certain
+					else if (!(d - slack > conv_tol)) verdict = 2;    // too close to call (or not a number): the host's own log() decides
+				} else {
+					conv_tol = em_reltol * (fabs(loglik) + em_reltol);
+					if (conv_tol < 0) conv_tol = 0;
+					tol_bound = em_reltol * bound;
+					if (!(fabs(loglik) <= DBL_MAX)) verdict = 2;
+				}
+				loglik_prev = loglik; bound_prev = bound;
+				verdict_s = verdict;
+			}
+		} else
+			for (int h = tid; h < n_hap; h += nw) {
+				const int e0 = hoff[h], e1 = hoff[h + 1];                 // (multiples of 4: the lists are padded with a +0.0 slot)
+				const char *Gb = (const char *)G;
+				const uint32_t pad_off = (uint32_t)n_pair * 8u;
+				double s = 0;
+				// batches of 8 entries, software-pipelined: while a batch is added (the only ordered part), the next batch's G
+				// values and the one after's offsets are on their way
+				auto idx = [&](int e, uint4 (&q)[2]) {
+#pragma unroll
+					for (int u = 0; u < 2; u++) q[u] = e + 4 * u < e1 ? *(const uint4 *)(hent + e + 4 * u) : uint4{pad_off, pad_off, pad_off, pad_off};
+				};
+				auto gat = [&](const uint4 (&q)[2], double (&t)[8]) {
+#pragma unroll
+					for (int u = 0; u < 2; u++) {
+						t[4 * u] = *(const double *)(Gb + q[u].x); t[4 * u + 1] = *(const double *)(Gb + q[u].y);
+						t[4 * u + 2] = *(const double *)(Gb + q[u].z); t[4 * u + 3] = *(const double *)(Gb + q[u].w);
+					}
+				};
+				uint4 q0[2], q1[2];
+				double ta[8], tb[8];
+				idx(e0, q0); gat(q0, ta); idx(e0 + 8, q1);
+				for (int e = e0; e < e1; e += 16) {
+					gat(q1, tb); idx(e + 16, q0);
+#pragma unroll
+					for (int u = 0; u < 8; u++) s += ta[u];               // (entries behind the list's end are the +0.0 slot: s + 0.0 is s)
+					if (e + 8 >= e1) break;
+					gat(q0, ta); idx(e + 24, q1);
+#pragma unroll
+					for (int u = 0; u < 8; u++) s += tb[u];
+				}
+				newf[h] = s * scale;
+			}
+		__syncthreads();
+		if (verdict_s) { stopped = 1; break; }                        // iteration iter - 1 was the last: its frequencies are in oldf
+	}
+	__syncthreads();
+	const double *res = stopped ? oldf : newf;
+	for (int h = tid; h < n_hap; h += EM_THREADS) V.out_freq[(size_t)c * n_hap + h] = res[h];
+	if (tid == 0) {
+		V.status[c] = verdict_s == 2 ? 2 : 1;                         // (500 iterations without convergence end the host's loop too)
+		V.status[gridDim.x + c] = stopped ? iter - 1 : iter;
+	}
+}
+
+struct EmState {
+	int device = -1;
+	void *d = nullptr, *h = nullptr;        // one device arena, one pinned staging area (upload, then download behind it)
+	size_t cap_d = 0, cap_h = 0;
+	hipStream_t st = nullptr;
+};
+EmState g_em;
+thread_local char g_em_msg[300];
+
+[[noreturn]] void em_throw(const char *what, hipError_t e)
+{
+	snprintf(g_em_msg, sizeof(g_em_msg), "HIBAG HIP trainer: %s: %s", what, hipGetErrorString(e));
+	throw (const char *)g_em_msg;
+}
+#define EM_OK(expr, what) do { hipError_t e_ = (expr); if (e_ != hipSuccess) em_throw(what, e_); } while (0)
+
+double em_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+} // namespace
+
+double g_em_prof[3] = {0, 0, 0};            // seconds in hibag_em_fit_batch: staging the upload, copy + kernel + copy back (waited for), total
+
+void hibag_em_release()
+{
+	if (g_em.st) { (void)hipStreamSynchronize(g_em.st); (void)hipStreamDestroy(g_em.st); }
+	if (g_em.d) (void)hipFree(g_em.d);
+	if (g_em.h) (void)hipHostFree(g_em.h);
+	g_em = EmState();
+}
+
+// Fits `n_cand` candidates on the current device; see hibag_em.h.
+void hibag_em_fit_batch(const HibagEmPairs &P, const int8_t *const geno[], const double afreq[], int n_cand, double *out_freq, int *status, int *iters)
+{
+	if (n_cand <= 0) return;
+	const double t_in = em_now();
+	int dev = 0;
+	EM_OK(hipGetDevice(&dev), "hipGetDevice");
+	if (g_em.device != dev) { hibag_em_release(); g_em.device = dev; }
+	if (!g_em.st) EM_OK(hipStreamCreateWithFlags(&g_em.st, hipStreamNonBlocking), "hipStreamCreate");
+	const size_t np = (size_t)P.n_pair, nib = (size_t)P.n_ib, nh = (size_t)P.n_hap, nc = (size_t)n_cand;
+	const EmLayout L(P.n_ib, P.n_pair, P.n_hap);
+	static bool lds_set = false;
+	if (!lds_set) {
+		EM_OK(hipFuncSetAttribute((const void *)k_em_fit, hipFuncAttributeMaxDynamicSharedMemorySize, EM_LDS_BYTES), "hipFuncSetAttribute");
+		lds_set = true;
+	}
+	// upload area (one copy), then the results (one copy back)
+	size_t o = 0;
+	auto take = [&](size_t bytes) { const size_t at = o; o = (o + std::max<size_t>(bytes, 8) + 63) & ~(size_t)63; return at; };
+	const size_t o_pw = take(np * 4), o_off = take((nib + 1) * 4), o_boot = take(nib * 4), o_hoff = take((nh + 1) * 4),
+		o_hent = take((2 * np + 4 * nh) * 4), o_cur = take(nh / 2 * 8), o_geno = take(nc * nib), o_af = take(nc * 8);
+	const size_t up_bytes = o;
+	const size_t o_out = take(nc * nh * 8), o_stat = take(2 * nc * 4);
+	const size_t down_bytes = o - o_out;
+	if (o > g_em.cap_d) {
+		EM_OK(hipStreamSynchronize(g_em.st), "hipStreamSynchronize");
+		if (g_em.d) (void)hipFree(g_em.d);
+		g_em.d = nullptr; g_em.cap_d = 0;
+		EM_OK(hipMalloc(&g_em.d, o + o / 2), "hipMalloc(EM arena)");
+		g_em.cap_d = o + o / 2;
+	}
+	if (o > g_em.cap_h) {
+		if (g_em.h) (void)hipHostFree(g_em.h);
+		g_em.h = nullptr; g_em.cap_h = 0;
+		EM_OK(hipHostMalloc(&g_em.h, o + o / 2, hipHostMallocDefault), "hipHostMalloc(EM staging)");
+		g_em.cap_h = o + o / 2;
+	}
+	char *h = (char *)g_em.h, *d = (char *)g_em.d;
+	size_t n_ent = 0;
+	{
+		uint32_t *pw = (uint32_t *)(h + o_pw);
+		for (size_t j = 0; j < np; j++) pw[j] = (uint32_t)P.h1[j] | ((uint32_t)P.h2[j] << 14);
+		// the transposed lists as byte offsets into G, each padded to a multiple of four entries with the +0.0 slot behind G
+		uint32_t *he = (uint32_t *)(h + o_hent);
+		int *ho = (int *)(h + o_hoff);
+		size_t e = 0;
+		for (size_t q = 0; q < nh; q++) {
+			ho[q] = (int)e;
+			for (int k = P.hoff[q]; k < P.hoff[q + 1]; k++) he[e++] = (uint32_t)P.hent[k] * 8u;
+			while (e & 3) he[e++] = (uint32_t)np * 8u;
+		}
+		ho[nh] = (int)e;
+		n_ent = e;
+	}
+	memcpy(h + o_off, P.off, (nib + 1) * 4); memcpy(h + o_boot, P.boot, nib * 4);
+	memcpy(h + o_cur, P.cur_freq, nh / 2 * 8);
+	for (size_t c = 0; c < nc; c++) memcpy(h + o_geno + c * nib, geno[c], nib);
+	memcpy(h + o_af, afreq, nc * 8);
+	const double t_up = em_now();
+	EM_OK(hipMemcpyAsync(d, h, up_bytes, hipMemcpyHostToDevice, g_em.st), "copy pairs");
+	EmView V;
+	V.n_ib = P.n_ib; V.n_pair = P.n_pair; V.n_hap = P.n_hap; V.n_samp_total = P.n_samp_total;
+	V.pw = (const uint32_t *)(d + o_pw); V.off = (const int *)(d + o_off); V.boot = (const int *)(d + o_boot);
+	V.hoff = (const int *)(d + o_hoff); V.hent = (const uint32_t *)(d + o_hent); V.n_ent = (int)n_ent; V.cur_freq = (const double *)(d + o_cur);
+	V.geno = (const int8_t *)(d + o_geno); V.afreq = (const double *)(d + o_af);
+	V.out_freq = (double *)(d + o_out); V.status = (int *)(d + o_stat);
+	hipLaunchKernelGGL(k_em_fit, dim3(n_cand), dim3(EM_THREADS), L.total, g_em.st, V);
+	EM_OK(hipGetLastError(), "launch");
+	EM_OK(hipMemcpyAsync(h + o_out, d + o_out, down_bytes, hipMemcpyDeviceToHost, g_em.st), "read frequencies");
+	EM_OK(hipStreamSynchronize(g_em.st), "EM fit");
+	const double t_done = em_now();
+	memcpy(out_freq, h + o_out, nc * nh * 8);
+	const int *st = (const int *)(h + o_stat);
+	for (size_t c = 0; c < nc; c++) { status[c] = st[c]; if (iters) iters[c] = st[nc + c]; }
+	g_em_prof[0] += t_up - t_in; g_em_prof[1] += t_done - t_up; g_em_prof[2] += em_now() - t_in;
+}
+
+// does a growth step of these dimensions fit the device kernel (its LDS, 16-bit indices)?
+bool hibag_em_fits(int n_ib, int n_pair, int n_hap)
+{
+	return n_hap <= 16384 && n_pair <= 65535 && n_ib > 0 && n_ib <= 65535 && EmLayout(n_ib, n_pair, n_hap).total + 64 <= EM_LDS_BYTES;
+}
+

@@ -42,10 +42,12 @@
 #include "../../include/hibag_hip.h"
 #include "hibag_plugin.h"
 #include "hibag_pool.h"
+#include "hibag_em.h"
 
 int hibag_fail(int code, const char *fmt, ...);       // hibag_api.hip: sets the thread's last error
 int hibag_selected_device();                          // hibag_api.hip: the thread's hibag_hip_set_device() choice
 extern double g_batch_prof[6];                        // hibag_build.hip
+extern double g_em_prof[3];                           // hibag_em.hip
 
 namespace {
 
@@ -178,6 +180,7 @@ struct hibag_hip_trainer {
 	std::vector<int> inbag, outbag;
 	PairSet pl;
 	int n_threads = 1;                          // host threads that fit candidate SNPs concurrently
+	int em_mode = 0;                            // where the EM fits run: 0 = by the thread count, 1 = host threads, 2 = device (hibag_em.hip)
 	std::unique_ptr<Pool> pool;                 // n_threads - 1 helpers, created by the first training call
 
 	double unif() { return unif_fn ? unif_fn(unif_ctx) : rng.unif(); }
@@ -199,6 +202,7 @@ struct Profile {
 	static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 };
 Profile g_prof;
+long long g_em_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // candidates fitted on the device, of them handed back to the host, device iterations; growth steps' pairs (sum, max), longest transposed list
 struct Tick {
 	int k; double t0;
 	explicit Tick(int k_) : k(k_), t0(Profile::now()) {}
@@ -511,6 +515,68 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 		// overlap saves; profiles/r03_cfg5_notes.txt.)
 		const int half = m;
 		struct Part { std::vector<HibagBuildCandidate> bc; std::vector<std::vector<int32_t>> cols; std::vector<int> which; } part[2];
+		// The fits: on the device (hibag_em.hip, workgroup = candidate), except the candidates whose stopping test the device's
+		// log() cannot decide the way the host's would -- a handful per model -- and where the rank has host threads to spare all of them:
+		// those go to the host threads below, as every fit did until round 4.
+		// (the device fit does not depend on the host's cores but is the slower one from about three host threads on:
+		// hibag_em.hip; HIBAG_TRAIN_EM=host|device and hibag_hip_trainer_set_em_mode override the choice by thread count)
+		static const int em_env = !getenv("HIBAG_TRAIN_EM") ? 0 : !strcmp(getenv("HIBAG_TRAIN_EM"), "host") ? 1 : !strcmp(getenv("HIBAG_TRAIN_EM"), "device") ? 2 : 0;
+		const int em_mode = t.em_mode ? t.em_mode : em_env;
+		const bool em_host = em_mode == 1 || (em_mode == 0 && t.n_threads > 2);
+		std::vector<char> on_host(m, 1);
+		if (!em_host && hibag_em_fits((int)t.pl.size(), (int)t.pl.p.size(), (int)next.list.size())) {
+			Tick tk(1);
+			const PairSet &pls = t.pl;
+			const int n_ib = (int)pls.size(), n_pair = (int)pls.p.size(), n_hap = (int)next.list.size();
+			std::vector<int> ph1(n_pair), ph2(n_pair), hoff(n_hap + 1, 0), hent(2 * (size_t)n_pair);
+			for (int j = 0; j < n_pair; j++) { ph1[j] = pls.p[j].h1; ph2[j] = pls.p[j].h2; hoff[ph1[j] + 1]++; hoff[ph2[j] + 1]++; }
+			for (int h = 0; h < n_hap; h++) hoff[h + 1] += hoff[h];
+			{
+				std::vector<int> at(hoff.begin(), hoff.end() - 1);
+				for (int j = 0; j < n_pair; j++) { hent[at[ph1[j]]++] = j; hent[at[ph2[j]]++] = j; }      // (pair order; (h, h) twice)
+			}
+			g_em_stats[3] += n_pair; g_em_stats[4] = std::max<long long>(g_em_stats[4], n_pair);
+			for (int h = 0; h < n_hap; h++) g_em_stats[5] = std::max<long long>(g_em_stats[5], hoff[h + 1] - hoff[h]);
+			for (int k = 0; k < n_ib; k++) g_em_stats[7] = std::max<long long>(g_em_stats[7], pls.off[k + 1] - pls.off[k]);
+			std::vector<double> curf(out_haplo.list.size());
+			for (size_t i = 0; i < curf.size(); i++) curf[i] = out_haplo.list[i].freq;
+			// the reference skips a SNP that is monomorphic in the bag (:1140-1143)
+			std::vector<int> which;
+			std::vector<double> af;
+			std::vector<std::vector<int8_t>> gcol;
+			for (int i = 0; i < m; i++) {
+				const int snp = vs.at(i);
+				int allele_cnt = 0, valid_cnt = 0;
+				std::vector<int8_t> col(n_ib);
+				for (int k = 0; k < n_ib; k++) {
+					const int g = t.geno[(size_t)pls.samp[k] * t.n_snp + snp];
+					const bool typed = 0 <= g && g <= 2;
+					col[k] = typed ? (int8_t)g : (int8_t)3;
+					if (typed) { allele_cnt += g * pls.boot[k]; valid_cnt += 2 * pls.boot[k]; }
+				}
+				if (allele_cnt == 0 || allele_cnt == valid_cnt) { on_host[i] = 0; continue; }       // (not fitted at all: valid stays 0)
+				which.push_back(i); af.push_back((double)allele_cnt / valid_cnt); gcol.push_back(std::move(col));
+			}
+			if (!which.empty()) {
+				HibagEmPairs P{n_ib, n_pair, n_hap, t.n_samp, ph1.data(), ph2.data(), pls.off.data(), pls.boot.data(), hoff.data(), hent.data(), curf.data()};
+				std::vector<const int8_t *> gp;
+				for (auto &c : gcol) gp.push_back(c.data());
+				std::vector<double> freq((size_t)which.size() * n_hap);
+				std::vector<int> status(which.size()), iters(which.size());
+				hibag_em_fit_batch(P, gp.data(), af.data(), (int)which.size(), freq.data(), status.data(), iters.data());
+				g_em_stats[6] += *std::max_element(iters.begin(), iters.end());
+				for (size_t w = 0; w < which.size(); w++) {
+					const int i = which[w];
+					g_em_stats[0]++; g_em_stats[2] += iters[w];
+					if (status[w] != 1) { g_em_stats[1]++; continue; }                                  // (stays on_host)
+					HapList nx = next;
+					for (int h = 0; h < n_hap; h++) nx.list[h].freq = freq[w * n_hap + h];
+					erase_double_haplos(nx, rare_prob, cand[i]);
+					set_aux(cand[i]);                                   // _Init_EvalAcc, :1913-1929
+					valid[i] = 1; on_host[i] = 0;
+				}
+			}
+		}
 		auto fit = [&](int lo, int hi) {
 			Tick tk(1);
 			std::atomic<int> next_i(lo);
@@ -518,6 +584,7 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 				HapList nx;
 				FitScratch scratch;
 				for (int i; (i = next_i.fetch_add(1)) < hi;) {
+					if (!on_host[i]) continue;
 					nx = next;
 					if (!fit_new_snp(t, vs.at(i), out_haplo, nx, scratch)) continue;
 					erase_double_haplos(nx, rare_prob, cand[i]);
@@ -686,6 +753,15 @@ int hibag_hip_trainer_set_threads(hibag_hip_trainer *t, int n_threads)
 
 int hibag_hip_trainer_threads(const hibag_hip_trainer *t) { return t ? t->n_threads : 0; }
 
+int hibag_hip_trainer_set_em_mode(hibag_hip_trainer *t, int mode)
+{
+	if (!t) return hibag_fail(HIBAG_HIP_EINVAL, "trainer is NULL");
+	if (mode < 0 || mode > 2) return hibag_fail(HIBAG_HIP_EINVAL, "EM mode must be 0 (automatic), 1 (host threads) or 2 (device)");
+	std::lock_guard<std::mutex> g(t->lock);
+	t->em_mode = mode;
+	return 0;
+}
+
 int hibag_hip_trainer_set_seed(hibag_hip_trainer *t, uint32_t seed)
 {
 	if (!t) return hibag_fail(HIBAG_HIP_EINVAL, "trainer is NULL");
@@ -715,9 +791,16 @@ int hibag_hip_trainer_new_classifiers(hibag_hip_trainer *t, int nclassifier, int
 	try {
 		if (!t->pool && t->n_threads > 1) t->pool.reset(new Pool(t->n_threads - 1));
 		g_prof = Profile();
+		for (long long &v : g_em_stats) v = 0;
+		for (double &v : g_em_prof) v = 0;
 		for (double &v : g_batch_prof) v = 0;
 		const double t0 = Profile::now();
 		build_classifiers(*t, nclassifier, mtry, prune != 0, verbose != 0 || verbose_detail != 0, verbose_detail != 0);
+		if (getenv("HIBAG_TRAIN_PROFILE"))
+			fprintf(stderr, "[hibag train] EM fits on the device: %lld candidates, %lld handed back to the host's log(), %.1f iterations each; "
+				"pairs per growth step: mean %.0f, max %lld; longest list of a haplotype %lld; in the batch call %.3f s (staging %.3f, copy + kernel + copy %.3f); the slowest candidate of a step: %.1f iterations; most pairs of one sample %lld\n",
+				g_em_stats[0], g_em_stats[1], g_em_stats[0] ? (double)g_em_stats[2] / g_em_stats[0] : 0.0,
+				g_prof.t[7] > 0 ? (double)g_em_stats[3] / g_prof.t[7] : 0.0, g_em_stats[4], g_em_stats[5], g_em_prof[2], g_em_prof[0], g_em_prof[1], g_prof.t[7] > 0 ? (double)g_em_stats[6] / g_prof.t[7] : 0.0, g_em_stats[7]);
 		if (getenv("HIBAG_TRAIN_PROFILE"))
 			fprintf(stderr, "[hibag train] total %.3f s: pair lists (device) %.3f, EM (host) %.3f, scoring (device) %.3f "
 				"[pack %.3f (staging %.3f, allocation %.3f), copy+kernels %.3f, read-back %.3f, reductions %.3f], compare + accept %.3f, select %.3f; search() %.3f, %d growth steps\n",

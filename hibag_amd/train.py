@@ -166,6 +166,10 @@ class _Trainer:
         """Host threads for the EM fits (``nthread`` of ``hlaAttrBagging``); <= 0 restores the default."""
         _lib.check(_lib.lib().hibag_hip_trainer_set_threads(self._h, int(n_threads)))
 
+    def set_em_mode(self, mode: str):
+        """Where the EM fits run: "auto" (the device where the trainer has two host threads or fewer), "host", "device"."""
+        _lib.check(_lib.lib().hibag_hip_trainer_set_em_mode(self._h, {"auto": 0, "host": 1, "device": 2}[mode]))
+
     @property
     def threads(self) -> int:
         return int(_lib.lib().hibag_hip_trainer_threads(self._h))

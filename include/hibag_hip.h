@@ -316,6 +316,11 @@ void hibag_hip_trainer_free(hibag_hip_trainer *t);
  * restores it.  The counterpart of HIBAG_NewClassifiers' `nthread` (src/HIBAG.cpp:599-634). */
 int hibag_hip_trainer_set_threads(hibag_hip_trainer *t, int n_threads);
 int hibag_hip_trainer_threads(const hibag_hip_trainer *t);
+/* Where the EM fits of a growth step's candidate SNPs run (CAlg_EM::ExpectationMaximization, src/LibHLA.cpp:1185-1255):
+ * 1 = on the trainer's host threads, 2 = on the device (hibag_amd/csrc/hibag_em.hip: workgroup = candidate, every sum in the
+ * host's order; the stopping test decided with a margin for the device's log(), candidates it cannot decide handed back to the
+ * host), 0 = automatic: the device where the trainer has two host threads or fewer.  Both give the same classifiers bit for bit. */
+int hibag_hip_trainer_set_em_mode(hibag_hip_trainer *t, int mode);
 
 /* Source of the uniform draws the reference takes from R's unif_rand()
  * (src/LibHLA.cpp:120-126; bootstrap :2236, SNP sampling :957).  An R binding

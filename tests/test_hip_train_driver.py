@@ -187,3 +187,51 @@ def test_training_runs_on_the_selected_device(hib, oracle):
     if n_dev > 1:
         assert abs(torch.cuda.mem_get_info(0)[0] - free_other) < (8 << 20)      # nothing landed on device 0
     assert L.hibag_hip_set_device(0) == 0
+
+
+@pytest.mark.parametrize("em", ["device", "host"])
+def test_both_em_routes_reproduce_the_stored_model(hib, hapmap_geno, hla_type_table, model_a, em):
+    """inst/extdata/ModelList.RData (set.seed(100), all 60 samples, 100 classifiers) re-trained with the EM fits forced onto the
+    device (hibag_amd/csrc/hibag_em.hip: every sum in the host's order, the stopping test decided with a margin for the
+    device's log() or handed back) and onto the host threads: every stored classifier bit for bit either way
+    (CAlg_EM::ExpectationMaximization, src/LibHLA.cpp:1185-1255)."""
+    from hibag_amd import train
+    G, h1, h2 = training_inputs(model_a, hapmap_geno, hla_type_table)
+    mtry = int(math.ceil(math.sqrt(G.shape[1])))
+    tr = train._Trainer(G, h1, h2, len(model_a.hla_allele))
+    tr.set_em_mode(em)
+    tr.set_seed(100)
+    tr.new_classifiers(len(model_a.classifiers), mtry, True, False, False)
+    got = tr.classifiers()
+    tr.close()
+    assert len(got) == len(model_a.classifiers)
+    for i, (g, w) in enumerate(zip(got, model_a.classifiers)):
+        assert_same_classifier(_as_dict(g), w, i)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_device_em_on_random_problems(hib, oracle, seed):
+    """The device EM on cohorts with missing genotypes, few samples, one to many alleles -- against the oracle."""
+    from hibag_amd import train
+    rng = np.random.default_rng(900 + seed)
+    n_hla = int(rng.integers(1, 12))
+    n_snp = int(rng.integers(6, 50))
+    n_samp = int(rng.integers(12, 160))
+    founders = (rng.random((n_hla, n_snp)) < rng.uniform(0.1, 0.9, n_snp)).astype(np.int32)
+    a = rng.integers(0, n_hla, (n_samp, 2))
+    G = (founders[a[:, 0]] + founders[a[:, 1]]).astype(np.int32)
+    G = np.where(rng.random(G.shape) < 0.05, (G + 1) % 3, G).astype(np.int32)
+    G[rng.random(G.shape) < rng.uniform(0, 0.2)] = hib.NA_INTEGER
+    mtry = int(rng.integers(1, n_snp + 1))
+    want = oracle.train(G, a[:, 0], a[:, 1], n_hla, nclassifier=3, mtry=mtry, prune=True, seed=70 + seed)
+    tr = train._Trainer(G, a[:, 0], a[:, 1], n_hla)
+    tr.set_em_mode("device")
+    tr.set_threads(1)
+    tr.set_seed(70 + seed)
+    tr.new_classifiers(3, mtry, True, False, False)
+    got = tr.classifiers()
+    tr.close()
+    for i, (g, w) in enumerate(zip(got, want)):
+        c = hib.Classifier(snpidx=w["snpidx"], freq=w["freq"], hla=w["hla"], haplo=w["haplo"], samp_num=w["samp_num"],
+                           outofbag_acc=w["acc"])
+        assert_same_classifier(_as_dict(g), c, i)

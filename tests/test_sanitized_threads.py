@@ -30,8 +30,8 @@ def test_trainer_thread_pool_harness(tmp_path):
     san = os.environ.get("HIBAG_POOL_TEST_SANITIZER", "")           # e.g. "thread" or "address,undefined"
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-pthread", "-I", os.path.join(ROOT, "hibag_amd", "csrc"),
            os.path.join(ROOT, "tests", "native", "pool_test.cpp"), "-o", exe] + ([f"-fsanitize={san}"] if san else [])
-    subprocess.check_call(cmd)
     env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}   # (a preloaded sanitizer runtime is for the Python process)
+    subprocess.check_call(cmd, env=env)
     p = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "pool_test OK" in p.stdout
