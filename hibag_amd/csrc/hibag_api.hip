@@ -821,7 +821,7 @@ int finalize_model(hibag_hip_model *m)
 	const uint64_t p1_base = plist.size();
 	std::vector<uint32_t> blk_close;
 	// segments of the classifiers with several K steps (k_total_wide): {classifier, first stored row, blocks} + list offset
-	std::vector<int> wseg;
+	std::vector<int> wseg, wide_scan;                   // wide_scan: the classifiers of several K steps whose total k_total_scan forms
 	std::vector<uint64_t> wseg_off;
 	for (int c = 0; c < C; c++) {
 		if (!mfma_nkb[c]) continue;
@@ -831,7 +831,12 @@ int finalize_model(hibag_hip_model *m)
 			// that different workgroups can walk them (their cell sums are stored, k_total_scan adds them in order);
 			// walked as one list (majority vote) the padding between the segments adds nothing.
 			// (pairs per segment: about what a typical one-step classifier of 5,000 pairs costs)
-			const long long seg_pairs = std::max<long long>(512, 6000 / n_step[c]);
+			// A model with many such classifiers has parallelism enough: then a classifier is ONE segment, its walk forms the
+			// in-order total itself (wide_seg[3] = 1) and k_total_scan -- a second pass over every stored sum, HBM-bound --
+			// is not needed for it.
+			const bool whole = (int)wide_cls.size() >= 8;
+			const long long seg_pairs = whole ? (1ll << 62) : std::max<long long>(512, 6000 / n_step[c]);
+			bool any_seg = false;
 			int p_lo = 0, h1_lo = 0, h2_lo = 0, row = 0, h1 = 0, h2 = 0;
 			long long acc_pairs = 0;
 			int rows_in_seg = 0;
@@ -844,12 +849,13 @@ int finalize_model(hibag_hip_model *m)
 					const size_t off = plist.size();
 					const int nb = append_pair_blocks(starts[c].data(), nh, h1_lo, h2_lo, p_lo, p + 1 - p_lo, (uint32_t)m->cls[c].freq.size(),
 						plist, stored[c].data(), nullptr);
-					if (nb > 0) { wseg.insert(wseg.end(), {c, row, nb, 0}); wseg_off.push_back(off); }
+					if (nb > 0) { wseg.insert(wseg.end(), {c, row, nb, whole ? 1 : 0}); wseg_off.push_back(off); any_seg = true; }
 					row += rows_in_seg; rows_in_seg = 0; acc_pairs = 0;
 					p_lo = p + 1; h1_lo = nh1; h2_lo = nh2;
 				}
 				h1 = nh1; h2 = nh2;
 			}
+			if (!whole || !any_seg) wide_scan.push_back(c);          // (a classifier without haplotypes has no segment: the scan writes its zero total)
 			cls_nblk[c] = (int)((plist.size() - blk_off[c]) / HIBAG_PLIST_DWORDS);
 			slot_ranges.push_back({(size_t)blk_off[c], plist.size() - (size_t)blk_off[c], c});
 			dbg_b1 += cls_nblk[c];
@@ -935,7 +941,7 @@ int finalize_model(hibag_hip_model *m)
 		o_snpw = put(snp_weight), o_mrow = put(mask_row), o_order = put(c_order), o_tp0 = put(tile_p0), o_tn = put(tile_n),
 		o_coff = put(cls_off), o_cn = put(cls_n), o_nkb = put(mfma_nkb), o_nstep = put(n_step), o_btrow = put(bt_row), o_nblk = put(cls_nblk), o_hapoff = put(hap_off_i),
 		o_item = put(item), o_srow = put(split_row), o_scls = put(split_cls), o_itemw = put(item_whole), o_crow = put(cell_row),
-		o_wide = put(wide_cls), o_wseg = put(wseg);
+		o_wide = put(wide_cls), o_wseg = put(wseg), o_wscan = put(wide_scan);
 
 	if (int rc = m->d_int.reserve(arena.size() * sizeof(int))) return rc;
 	if (int rc = m->d_stream.reserve(stream.size() * sizeof(uint32_t))) return rc;
@@ -997,6 +1003,7 @@ int finalize_model(hibag_hip_model *m)
 	for (int c = 0; c < C; c++)
 		if (n_step[c] == 1 && !(engine[c] == HIBAG_ENGINE_FP4)) V.all_fp4 = 0;      // (classifiers of several K steps are not work items of k_total)
 	V.n_wide = (int)wide_cls.size(); V.wide_cls = base + o_wide;
+	V.n_wide_scan = (int)wide_scan.size(); V.wide_scan = base + o_wscan;
 	V.n_wide_seg = (int)wseg.size() / 4; V.wide_seg = base + o_wseg; V.wide_seg_off = (const uint64_t *)(tbase + tb_wsoff);
 	if (V.n_wide > 0 && !m->side.stream) {
 		HIP_TRY(hipStreamCreateWithFlags(&m->side.stream, hipStreamNonBlocking));

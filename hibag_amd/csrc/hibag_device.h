@@ -172,8 +172,10 @@ struct HibagModelView {
 	const int *n_step;           // [C] K steps of the FP4 engine (1 up to 28 SNPs; HIBAG_FP4_STEPS), 1 for the others
 	int n_wide;                  // classifiers with n_step > 1: pass 1 in k_total_wide, not among the work items; all their cells stored
 	const int *wide_cls;         // [n_wide]
+	int n_wide_scan;             // ... of them the ones whose in-order total k_total_scan forms from the stored sums (cut into several segments)
+	const int *wide_scan;        // [n_wide_scan]
 	int n_wide_seg;              // their pair lists in segments of whole cells (one workgroup each per group quad):
-	const int *wide_seg;         // [n_wide_seg][4] {classifier, first stored row, blocks, 0}
+	const int *wide_seg;         // [n_wide_seg][4] {classifier, first stored row, blocks, 1 = the segment is the whole classifier: the walk forms the total}
 	const uint64_t *wide_seg_off; // [n_wide_seg] dword offset of the segment in plist
 	const int *bt_row;           // [C] first operand row of the classifier in HibagBatchView::bt
 	const uint32_t *hap;         // haplotype table (entry size by engine, see below)

@@ -1071,6 +1071,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, 
 // segments of whole cells (HibagModelView::wide_seg), one workgroup per segment and group quad; every cell sum is
 // stored (pass 2 reads them back whatever the model's other classifiers do) and k_total_scan adds them in order.
 // grid (group quads, segments).
+// WHOLE: every segment is a whole classifier (a model with many of them): the walk forms the in-order total itself.
+template <bool WHOLE>
 __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total_wide(HibagModelView M, HibagBatchView B)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
@@ -1082,16 +1084,26 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total_wide(HibagModelView 
 	if (group * HIBAG_WAVE >= B.n_pad) return;
 	const int s = group * HIBAG_WAVE + lane;
 	if (__ballot(B.cw[(size_t)c * B.n_pad + s] > 0) == 0) return;          // nobody needs this classifier (src/LibHLA.cpp:2451)
-	double cell = 0;
+	double cell = 0, total = 0;
 	double *__restrict__ rows = cell_rows(M, B, c, group);
 	int row = seg[1];
-	auto fin = [&](double v, bool) { __builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++; };
+	auto fin = [&](double v, bool) {
+		__builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++;
+		if (WHOLE) { total += v; asm("" : "+v"(total)); }   // (the asm keeps the cell end a scalar branch)
+	};
 	const WideSrc wide = wide_src(B, M.bt_row[c], M.n_step[c], group);
 	LaneOperand T;
 	load_operand_row<HIBAG_ENGINE_FP4W>(B, M.bt_row[c], c, group, lane, T);
 	ListCursor cur;
 	walk_blocks<HIBAG_ENGINE_FP4W, TOTAL_G>(M, M.wide_seg_off[blockIdx.y], seg[2], lane, cur, hap_rsrc(M, M.hap_off[c]),
 		M.n_snp_c[c] - HIBAG_FP4_STEP_SNPS * (wide.nstep - 1), T, wide, tab_s, cell, fin);
+	if (WHOLE) {
+		const size_t at = (size_t)c * B.n_pad + s;
+		const double inv = 1 / total;                 // src/LibHLA.cpp:1827 (inf when total == 0)
+		B.tot[at] = total;
+		B.inv[at] = inv;
+		note_infinite_reciprocal(B, c, s, B.cw[at], inv);
+	}
 }
 
 // k_total_scan: the in-order total of a split classifier from its stored cell sums; thread = sample.
@@ -1578,7 +1590,7 @@ __device__ __forceinline__ int classifier_best(const HibagModelView &M, const Hi
 // WIDE: the instance for FP4 classifiers of several K steps (their walk needs more registers than five workgroups per CU
 // leave: a kernel of their own, like k_total_wide); the other instance skips them, and vice versa.
 template <bool WIDE>
-__global__ __launch_bounds__(BLOCK_THREADS, WIDE ? 4 : VOTE_OCC) void k_vote_best(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
+__global__ __launch_bounds__(BLOCK_THREADS, WIDE ? 3 : VOTE_OCC) void k_vote_best(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	const int c = M.c_order[blockIdx.y];
@@ -1890,16 +1902,18 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 	if (wide) {
 		// the classifiers of several K steps: their own kernel, beside k_total (more registers than k_total's hot loop may have)
 		const unsigned gq = (unsigned)((B.n_pad / HIBAG_WAVE + BLOCK_WAVES - 1) / BLOCK_WAVES);
-		HibagModelView W = M;                         // k_total_scan over the classifiers of several K steps
-		W.split_cls = M.wide_cls;
+		HibagModelView W = M;                         // k_total_scan over the classifiers of several K steps that were cut into segments
+		W.split_cls = M.wide_scan;
 		const hipStream_t ws = side.stream ? side.stream : st;
 		if (side.stream) {
 			(void)hipEventRecord(side.fork, st);
 			(void)hipStreamWaitEvent(side.stream, side.fork, 0);
 		}
 		// (a classifier of several K steps without haplotypes has no segment: its total still has to be written)
-		if (M.n_wide_seg > 0) hipLaunchKernelGGL(k_total_wide, dim3(gq, M.n_wide_seg), dim3(BLOCK_THREADS), 0, ws, M, B);
-		hipLaunchKernelGGL(k_total_scan, dim3(B.n_pad / 64, M.n_wide), dim3(64), 0, ws, W, B);
+		// (segments are either all whole classifiers or none: hibag_api.hip finalize_model)
+		if (M.n_wide_seg > 0 && M.n_wide_scan < M.n_wide) hipLaunchKernelGGL(k_total_wide<true>, dim3(gq, M.n_wide_seg), dim3(BLOCK_THREADS), 0, ws, M, B);
+		else if (M.n_wide_seg > 0) hipLaunchKernelGGL(k_total_wide<false>, dim3(gq, M.n_wide_seg), dim3(BLOCK_THREADS), 0, ws, M, B);
+		if (M.n_wide_scan > 0) hipLaunchKernelGGL(k_total_scan, dim3(B.n_pad / 64, M.n_wide_scan), dim3(64), 0, ws, W, B);
 		if (side.stream) (void)hipEventRecord(side.join, side.stream);
 	}
 	if (M.n_item_whole == 0) {                        // (every classifier is one of those)

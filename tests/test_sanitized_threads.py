@@ -35,3 +35,17 @@ def test_trainer_thread_pool_harness(tmp_path):
     p = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "pool_test OK" in p.stdout
+
+
+def test_oracle_threads_harness(tmp_path):
+    """tests/native/oracle_threads_test.c (what tools/run_sanitizers.sh builds with -fsanitize=thread): the threaded AVX2 port
+    equals the scalar oracle at every thread count."""
+    exe = str(tmp_path / "oracle_threads_test")
+    san = os.environ.get("HIBAG_POOL_TEST_SANITIZER", "")
+    src = [os.path.join(ROOT, "tests", "native", "oracle_threads_test.c"), os.path.join(ROOT, "oracle", "hibag_oracle.c"),
+           os.path.join(ROOT, "oracle", "hibag_oracle_avx2.c")]
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    subprocess.check_call(["gcc", "-O1", "-g", "-ffp-contract=off", "-pthread"] + ([f"-fsanitize={san}"] if san else []) + src + ["-o", exe, "-lm"], env=env)
+    p = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "oracle_threads_test OK" in p.stdout or "skipped" in p.stdout
