@@ -505,6 +505,17 @@ def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, HlaBEDGeno, np.nd
     want_prob = type in ("prob", "response+prob")
     want_dosage = type != "response"
     devices = list(cl) if isinstance(cl, (list, tuple)) else None
+    if devices is not None:
+        # a device list: validated up front (an index out of range used to surface as ENODEV from deep inside replicate())
+        n_dev = int(_lib.lib().hibag_hip_device_count())
+        bad = [d for d in devices if not isinstance(d, (int, np.integer)) or isinstance(d, bool) or not (0 <= int(d) < n_dev)]
+        if not devices or bad:
+            raise ValueError(f"'cl' must be a non-empty list of HIP device indices below {n_dev}: {cl!r}")
+        if bed_plan is not None:
+            # the BED route decodes on ONE device (hibag_hip_predict_bed); silently ignoring the list would not be what
+            # the caller asked for
+            raise ValueError("hlaPredict(cl = [devices]) takes a genotype matrix or an hlaSNPGenoClass; for a lazily opened BED "
+                             "file (hlaBED2Geno(lazy=True)) predict on one device, or load the genotypes first (hlaBED2Geno())")
     if devices is not None and bed_plan is None:
         # several devices: the model-order matrix is built on the host (the model's few hundred columns of the
         # cohort), then sliced over the replicas

@@ -107,6 +107,9 @@ def test_predict_straight_from_bed_hapmap(hib, oracle, model_a, hapmap_geno, tmp
     got = hib.hlaPredict(m, lazy, type="response+prob", match_type="RefSNP", allele_check=False, verbose=False)
     assert np.array_equal(got.h1, want["h1"]) and np.array_equal(got.h2, want["h2"])
     assert np.array_equal(got.postprob.T, want["postprob"], equal_nan=True)
+    # a device list with a lazily opened BED file is refused, not silently ignored (the BED route decodes on one device)
+    with pytest.raises(ValueError, match="device"):
+        hib.hlaPredict(m, lazy, cl=[0], match_type="RefSNP", verbose=False)
 
 
 @pytest.mark.parametrize("mode", [0, 1])

@@ -273,6 +273,9 @@ def test_predict_multi_two_replicas_on_one_device_equal_the_single_call(hib, ora
     res2 = hib.hlaPredict(m, synth.as_snp_geno(model, G[:700]), cl=[0, 0], type="response+dosage", verbose=False)
     assert res1.allele1 == res2.allele1 and res1.allele2 == res2.allele2
     assert np.array_equal(res1.prob, res2.prob, equal_nan=True) and np.array_equal(res1.dosage, res2.dosage, equal_nan=True)
+    for bad in ([99], [], [0, -1], [0.5]):                     # device lists are validated up front
+        with pytest.raises(ValueError):
+            hib.hlaPredict(m, synth.as_snp_geno(model, G[:64]), cl=bad, verbose=False)
     with pytest.raises(hib.HibagHipError):
         m.replicate(99)
     # the host entries repair a failed hand-over themselves and return 0: only the counter would show it (as twice the time)
