@@ -475,6 +475,39 @@ def test_plugin_per_sample_route_every_width_and_edge(hib, oracle):
     host.close()
 
 
+def test_plugin_per_sample_route_beyond_one_round_of_workgroups_and_pairs(hib, oracle):
+    """k_one's corners (hibag_sample.hip): more classifiers than the device holds workgroups of it at once (every workgroup then
+    walks several, 300 of them), many alleles with few classifiers (more posterior cells per workgroup than one tile of the
+    ensemble phase takes), and classifiers whose pair lists need several rounds (150 haplotypes: 11,325 pairs > 8,192) -- the
+    compiled host loop (hibag_hip_test_time_avg_prob) and the per-call entry against the oracle, bit for bit."""
+    from hibag_amd import synth
+    from hibag_amd.plugin import PluginHost
+    cases = [dict(shape="hla-a-small", seed=51, n_classifier=300, n_snp=60),
+             dict(shape="hla-b", seed=52, n_classifier=3, n_snp=90, n_haplo=150, wide_classifier=False),
+             dict(shape="hla-drb1", seed=53, n_classifier=2, n_snp=64, n_haplo=260, wide_classifier=False)]
+    for kw in cases:
+        shape = kw.pop("shape")
+        model, founders, af = synth.make_model(shape, **kw)
+        G, _ = synth.make_samples(founders, af, 12, seed=kw["seed"] + 1, miss=0.04)
+        G[5, :] = hib.NA_INTEGER
+        want = oracle.predict(oracle.flatten(model), G, vote_method=1, avx2=True, n_threads=8)
+        host = PluginHost(model)
+        geno, wt = host.pack(G)
+        prob = np.zeros(model.n_cell); match = np.zeros(1)
+        for i in range(len(G)):
+            host.avg_prob(geno[i], wt[i], prob, match)
+            assert np.array_equal(prob, want["postprob"][i], equal_nan=True), (shape, i)
+            assert match[0] == want["matching"][i] or (np.isnan(match[0]) and np.isnan(want["matching"][i])), (shape, i)
+        best, mt, _ = host.avg_prob_loop(geno, wt)
+        nh = model.n_hla
+        cell = lambda a, b: b + a * (2 * nh - a - 1) // 2
+        for i in range(len(G)):
+            exp = -1 if want["h1"][i] == hib.NA_INTEGER else cell(int(want["h1"][i]), int(want["h2"][i]))
+            assert best[i] == exp, (shape, i)
+            assert mt[i] == want["matching"][i] or (np.isnan(mt[i]) and np.isnan(want["matching"][i])), (shape, i)
+        host.close()
+
+
 @pytest.mark.parametrize("k", [1, 2, 14, 15, 29, 30, 31, 32])
 def test_extreme_genotypes_and_zero_frequencies(hib, oracle, k):
     """The corners of the matrix engine's K layout (hibag_device.h): every SNP heterozygous with both haplotypes carrying
