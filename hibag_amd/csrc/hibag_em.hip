@@ -281,6 +281,7 @@ struct EmState {
 	void *d = nullptr, *h = nullptr;        // one device arena, one pinned staging area (upload, then download behind it)
 	size_t cap_d = 0, cap_h = 0;
 	hipStream_t st = nullptr;
+	bool lds_set = false;                   // k_em_fit may use EM_LDS_BYTES of dynamic LDS on this device
 };
 EmState g_em;
 thread_local char g_em_msg[300];
@@ -317,10 +318,9 @@ void hibag_em_fit_batch(const HibagEmPairs &P, const int8_t *const geno[], const
 	if (!g_em.st) EM_OK(hipStreamCreateWithFlags(&g_em.st, hipStreamNonBlocking), "hipStreamCreate");
 	const size_t np = (size_t)P.n_pair, nib = (size_t)P.n_ib, nh = (size_t)P.n_hap, nc = (size_t)n_cand;
 	const EmLayout L(P.n_ib, P.n_pair, P.n_hap);
-	static bool lds_set = false;
-	if (!lds_set) {
+	if (!g_em.lds_set) {                                              // (per device: the state is reset when the device changes)
 		EM_OK(hipFuncSetAttribute((const void *)k_em_fit, hipFuncAttributeMaxDynamicSharedMemorySize, EM_LDS_BYTES), "hipFuncSetAttribute");
-		lds_set = true;
+		g_em.lds_set = true;
 	}
 	// upload area (one copy), then the results (one copy back)
 	size_t o = 0;

@@ -1939,7 +1939,8 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 	const bool many = M.all_fp4 && !split && (occ_env ? occ_env == HIBAG_TOT_OCC_MANY : (slots_many > 0 && n >= 2u * (unsigned)slots_many));
 	const int slots = M.slots_total[(M.store_cells ? 2 : 0) + (many ? 1 : 0)];
 	unsigned n_whole = n, rest = 0, stride = 8, K = 1;
-	const int k_pass1 = tail_chunks(B.tail_k, M.p1_blocks / std::max(M.n_classifier, 1));
+	static const int k1_env = getenv("HIBAG_TAIL_K1") ? std::max(1, std::min(64, atoi(getenv("HIBAG_TAIL_K1")))) : 0;     // (diagnostic: pass 1 only)
+	const int k_pass1 = (k1_env && B.tail_k == 0) ? k1_env : tail_chunks(B.tail_k, M.p1_blocks / std::max(M.n_classifier, 1));
 	if (k_pass1 > 1 && slots > 0 && n > (unsigned)slots) {
 		K = (unsigned)k_pass1;
 		rest = n % (unsigned)slots + (unsigned)slots;

@@ -268,7 +268,10 @@ int hibag_hip_shard_group_predict(hibag_hip_shard_group *g, const int32_t *geno,
 		for (int attempt = 0; attempt < 2; attempt++) {
 			rc = run_batch(g, geno + (size_t)s0 * g->n_snp, n, H1 ? H1 + s0 : nullptr, H2 ? H2 + s0 : nullptr, max_prob ? max_prob + s0 : nullptr,
 				matching ? matching + s0 : nullptr, dosage ? dosage + (size_t)s0 * g->n_hla : nullptr, postprob ? postprob + (size_t)s0 * P : nullptr);
-			if (rc) break;
+			if (rc) {                                                  // nothing of a failed batch may still be running when the caller's buffers go away
+				for (Rank &r : g->ranks) { (void)hipSetDevice(r.device); (void)hipStreamSynchronize(r.st); }
+				break;
+			}
 			// a failed hand-over on any shard poisoned the merged sums of every rank: the shard now launches without
 			// hand-overs (sticky status cleared here), and the batch is run once more -- never returned as numbers
 			bool fault = false;
