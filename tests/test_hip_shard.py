@@ -113,3 +113,31 @@ def test_a_failed_handover_on_one_shard_is_repaired_not_returned(hib):
     for k in ("h1", "h2", "prob", "matching", "dosage"):
         assert np.array_equal(got[k], full[k], equal_nan=True), k
     grp.close(); m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--no-cpu-baseline"], ["--shard", "classifiers"]])
+def test_bench_two_rank_rehearsal_on_one_device(extra):
+    """`python bench.py --gpus 2` end to end on a one-GPU box: bench.py starts its own two ranks (torch.distributed.run), both
+    ranks share device 0 and the collectives go over gloo (HIBAG_BENCH_DRY_RANKS=1 -- RCCL refuses two ranks on one device).
+    What is checked is the orchestration the driver's 8-GPU run goes through: slice bounds, the classifier-sharded merge
+    against the unsharded posterior, the one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIBAG_BENCH_DRY_RANKS="1")
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, stdin=subprocess.DEVNULL)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["samples_per_step"] == 100_000
+    assert "dry_run" in d and d["rccl_ranks"] is None
+    assert d["call_accuracy_vs_truth"] > 0.99
+    chk = d["classifier_shard_check"] if "--shard" in extra else d["classifier_sharded"]["check"]
+    assert chk["calls_identical_to_unsharded"] and chk["nan_pattern_identical"]
+    assert chk["max_rel_dev_posterior_vs_unsharded"] < chk["tolerance"]
+    assert all(v == 0 for v in d["handover_faults"].values())
