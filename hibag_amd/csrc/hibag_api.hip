@@ -90,8 +90,12 @@ struct HostClassifier {
 };
 
 struct KernelTimer {
-	struct Pending { int k; hipEvent_t a, b; };
+	struct Pending { int k; hipEvent_t a, b; bool a_shared; };
 	bool enabled = false;
+	unsigned mask = 0xf;               // kernel classes that get events (bit k); the others run unobserved
+	bool open = false;                 // begin() recorded something that end() has to close
+	bool chainable = false;            // the last timer operation was an end() that recorded an event ...
+	hipStream_t chain_stream = nullptr; // ... on this stream
 	std::vector<Pending> pending;
 	std::vector<hipEvent_t> pool;
 	double ms[HIBAG_HIP_K_COUNT] = {0, 0, 0, 0};
@@ -104,17 +108,29 @@ struct KernelTimer {
 		(void)hipEventCreate(&e);
 		return e;
 	}
-	void begin(int k, hipStream_t st)
+	// `chain`: the caller has enqueued nothing on `st` since the end() before -- that end's event is this begin's too
+	// (an event record is a barrier packet of its own on the queue: five per batch instead of eight).
+	void begin(int k, hipStream_t st, bool chain = false)
 	{
-		if (!enabled) return;
-		Pending p{k, get(), get()};
-		(void)hipEventRecord(p.a, st);
+		open = false;
+		if (!enabled || !((mask >> k) & 1u)) { chainable = false; return; }
+		Pending p;
+		p.k = k;
+		p.a_shared = chain && chainable && chain_stream == st && !pending.empty();
+		p.a = p.a_shared ? pending.back().b : get();
+		p.b = get();
+		if (!p.a_shared) (void)hipEventRecord(p.a, st);
 		pending.push_back(p);
+		open = true;
+		chainable = false;
 	}
 	void end(hipStream_t st)
 	{
-		if (!enabled) return;
+		if (!open) return;
 		(void)hipEventRecord(pending.back().b, st);
+		open = false;
+		chainable = true;
+		chain_stream = st;
 	}
 	void resolve()
 	{
@@ -122,10 +138,14 @@ struct KernelTimer {
 			(void)hipEventSynchronize(p.b);
 			float t = 0;
 			if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { ms[p.k] += t; n[p.k]++; }
-			pool.push_back(p.a);
+		}
+		for (auto &p : pending) {
+			if (!p.a_shared) pool.push_back(p.a);
 			pool.push_back(p.b);
 		}
 		pending.clear();
+		chainable = false;
+		open = false;
 	}
 	void reset()
 	{
@@ -1129,10 +1149,10 @@ void run_core(hibag_hip_model *m, HibagBatchView &B, int vote_method, double *d_
 {
 	KernelTimer &T = m->timer;
 	B.part = d_part;
-	T.begin(HIBAG_HIP_K_TOTAL, st);
+	T.begin(HIBAG_HIP_K_TOTAL, st, true);      // (callers enqueue nothing between their pack and this)
 	hibag_launch_total(m->view, B, st, m->side);
 	T.end(st);
-	T.begin(HIBAG_HIP_K_ACCUM, st);
+	T.begin(HIBAG_HIP_K_ACCUM, st, true);
 	if (vote_method == 1) {
 		hibag_launch_accum(m->view, B, st);
 		hibag_launch_scalars(m->view, B, nullptr, st);
@@ -1243,7 +1263,7 @@ int predict_device_locked(hibag_hip_model *m, const PackSource &src, int n_samp,
 				src.d_col, src.d_flip, m->ws_codes.as<uint8_t>(), st);
 		m->timer.end(st);
 		run_core(m, B, vote_method, m->ws_part.as<double>(), st);
-		m->timer.begin(HIBAG_HIP_K_FINISH, st);
+		m->timer.begin(HIBAG_HIP_K_FINISH, st, true);
 		hibag_launch_finish(m->view, B, B.part,
 			d_H1 ? d_H1 + s0 : nullptr, d_H2 ? d_H2 + s0 : nullptr,
 			d_max_prob ? d_max_prob + s0 : nullptr, d_matching ? d_matching + s0 : nullptr,
@@ -1947,6 +1967,7 @@ int hibag_hip_set_timing(hibag_hip_model *m, int enabled)
 	(void)hipSetDevice(m->device);
 	m->timer.resolve();
 	m->timer.enabled = enabled != 0;
+	m->timer.mask = enabled > 1 ? ((unsigned)enabled >> 1) & 0xfu : 0xfu;     // 1: every kernel class; 2 * bits: only those
 	return 0;
 }
 

@@ -174,8 +174,15 @@ class HlaAttrBagClass:
         return t
 
     # --- timing of the kernels (HIP events on the launch stream) ---
-    def set_timing(self, enabled: bool = True):
-        _lib.check(_lib.lib().hibag_hip_set_timing(self.handle, int(bool(enabled))))
+    def set_timing(self, enabled=True):
+        """True / False: HIP events around every kernel class or none; a sequence of kernel names (``"total"``, ``"accum"``,
+        ``"pack"``, ``"finish"``): events around those only (``hibag_hip_set_timing``'s mask form)."""
+        if isinstance(enabled, (list, tuple, set, frozenset)):
+            ids = {v: k for k, v in _lib.KERNEL_NAMES.items()}
+            code = 2 * sum(1 << ids[name] for name in set(enabled))
+        else:
+            code = int(bool(enabled))
+        _lib.check(_lib.lib().hibag_hip_set_timing(self.handle, code))
 
     def reset_timing(self):
         _lib.check(_lib.lib().hibag_hip_reset_timing(self.handle))

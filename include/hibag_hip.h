@@ -357,7 +357,10 @@ int hibag_hip_trainer_classifier_get(const hibag_hip_trainer *t, int idx, int32_
 #define HIBAG_HIP_K_FINISH   3   /* arg-max, dosage, transposed posterior output */
 #define HIBAG_HIP_K_COUNT    4
 
-/* When enabled every kernel launch is bracketed by hipEvents on its stream. */
+/* enabled = 1: every kernel class is bracketed by hipEvents on its stream (classes that follow each other directly share
+ * the event between them: five records per batch).  enabled = 2 * mask, mask = OR of (1 << HIBAG_HIP_K_*): only those
+ * classes (an event record is a packet of its own on the queue and costs the step a few microseconds each: a caller that
+ * wants one kernel's duration out of a timed region asks for that kernel alone).  0: off. */
 int hibag_hip_set_timing(hibag_hip_model *m, int enabled);
 /* Resolves pending events (synchronises on them) and returns, for kernel `k`,
  * the summed duration in ms and the number of launches since the last reset. */
