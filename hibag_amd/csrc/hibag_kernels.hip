@@ -384,7 +384,9 @@ __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename 
 		const double x0 = F[0] * t[0];
 		__builtin_amdgcn_sched_barrier(0);
 		FG Fn = F;
+#ifndef HIBAG_ABL_NOFAC       // (timing ablation: every group multiplies by the block's first factors)
 		if (g + 1 < 32 / G) Fn = *(ConstPtr<FG>)(fac + G * (g + 1));
+#endif
 		__builtin_amdgcn_sched_barrier(0);
 		cell += x0;
 #pragma unroll
@@ -1088,7 +1090,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total_wide(HibagModelView 
 	double *__restrict__ rows = cell_rows(M, B, c, group);
 	int row = seg[1];
 	auto fin = [&](double v, bool) {
+#ifndef HIBAG_ABL_WIDE_NOSTORE       // (timing ablation)
 		__builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++;
+#endif
 		if (WHOLE) { total += v; asm("" : "+v"(total)); }   // (the asm keeps the cell end a scalar branch)
 	};
 	const WideSrc wide = wide_src(B, M.bt_row[c], M.n_step[c], group);

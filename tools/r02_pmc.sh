@@ -2,6 +2,7 @@
 # SQ / LDS / TCP counters of both passes for the current build (GPU box, via gpurun): outputs gpurun_out/$1/pmc_summary.txt
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/${1:-r02pmc}; rm -rf $out; mkdir -p $out
 ARGS="${BENCH_ARGS:---steps 2 --warmup 1 --no-cpu-baseline --no-extras}"
+PROG="${PMC_PROG:-$R/bench.py $ARGS}"      # PMC_PROG="$GRAFT_REPO_ROOT/tools/wide_bench.py": the counters of another workload
 cd /tmp && export TMPDIR=/tmp
 i=0
 for ctrs in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
@@ -9,7 +10,7 @@ for ctrs in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES 
             "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH" \
             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum" \
             "FETCH_SIZE" "WRITE_SIZE"; do i=$((i+1))
-  timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $out/p$i -- python3 $R/bench.py $ARGS > $out/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $out/p$i -- python3 $PROG > $out/p$i.log 2>&1 < /dev/null
 done
 cd $R && python3 - "$out" <<'PY'
 import csv,glob,collections,sys
