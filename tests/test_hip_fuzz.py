@@ -52,3 +52,95 @@ def test_random_models_in_every_pass2_mode(mode, oracle, monkeypatch):
                     bad.append((seed, vote, key))
                     break
     assert not bad, bad
+
+
+def _campaign_case(hib, rng, big):
+    """One random model + cohort of the wide campaign: classifiers of 1..128 SNPs (one-step FP4, int8, several-step FP4 and the
+    vector engine mixed in one model), up to 40 classifiers, up to 200 haplotypes each, frequencies over 300 decades in some,
+    cohorts up to 6,000 samples (`big`: 12,000+, where pass 1 cuts work items into chunks that hand over)."""
+    n_hla = int(rng.integers(1, 60))
+    n_snp = int(rng.integers(1, 200))
+    kmax = [8, 30, 32, 64, 112, 128][int(rng.integers(0, 6))]
+    n_cls = int(rng.integers(1, 41)) if not big else int(rng.integers(20, 60))
+    tiny = rng.random() < 0.2
+    cls = []
+    for _ in range(n_cls):
+        k = int(rng.integers(1, min(n_snp, kmax) + 1))
+        H = int(rng.integers(1, 200)) if not big else int(rng.integers(40, 120))
+        hla = np.sort(rng.integers(0, n_hla, H)).astype(np.int32)
+        freq = 10.0 ** rng.uniform(-300 if tiny else -5, 0, H)
+        if rng.random() < 0.1:
+            freq[rng.random(H) < 0.3] = 0.0
+        haplo = ["".join(rng.choice(["0", "1"], k)) for _ in range(H)]
+        cls.append(hib.Classifier(snpidx=rng.choice(n_snp, k, replace=False), freq=freq, hla=hla, haplo=haplo))
+    model = hib.HlaAttrBagObj(n_samp=0, n_snp=n_snp, hla_allele=[f"{i:02d}" for i in range(n_hla)], classifiers=cls)
+    n = int(rng.integers(12_000, 16_000)) if big else int(rng.choice([rng.integers(1, 70), rng.integers(1, 1500), rng.integers(1, 6000)]))
+    style = int(rng.integers(0, 3))
+    if style == 0:
+        G = rng.choice(np.array([0, 1, 2, hib.NA_INTEGER, -1, 3], np.int64), size=(n, n_snp), p=[.3, .3, .3, .04, .03, .03]).astype(np.int32)
+    else:
+        # samples made of two haplotypes of a random classifier each (so that somebody matches), 2 % missing
+        G = rng.integers(0, 3, size=(n, n_snp)).astype(np.int32)
+        for c0 in ([cls[int(rng.integers(0, n_cls))]] if style == 1 else cls[:: max(1, n_cls // 4)]):
+            H0 = np.array([[int(ch) for ch in h] for h in c0.haplo])
+            a, b = rng.integers(0, len(c0.haplo), n), rng.integers(0, len(c0.haplo), n)
+            G[:, np.asarray(c0.snpidx)] = H0[a] + H0[b]
+        G[rng.random(G.shape) < 0.02] = hib.NA_INTEGER
+    if rng.random() < 0.3:
+        G[int(rng.integers(0, n)), :] = hib.NA_INTEGER
+    return model, G
+
+
+def test_wide_campaign(oracle, monkeypatch):
+    """Time-boxed random campaign over a wider space than the test above (every engine, up to 40 classifiers, cohorts of
+    thousands, both votes, the per-sample plugin route on a few samples): HIBAG_FUZZ_SECONDS (default 20) of cases, each
+    bit-equal to the oracle.  HIBAG_FUZZ_SEED moves the window; a long run's summary is profiles/r04_fuzz_campaign.txt."""
+    import os
+    import time
+    import hibag_amd as hib
+    from hibag_amd import plugin
+    hib.hlaSetKernelTarget("hip")
+    budget = float(os.environ.get("HIBAG_FUZZ_SECONDS", "20"))
+    seed0 = int(os.environ.get("HIBAG_FUZZ_SEED", "90000"))
+    t_end = time.time() + budget
+    bad, done, samples, seed = [], 0, 0, seed0
+    while time.time() < t_end:
+        rng = np.random.default_rng(seed)
+        monkeypatch.setenv("HIBAG_STORE_PAIRS", str(int(rng.integers(0, 14))) if rng.random() < 0.5 else "")
+        if not os.environ.get("HIBAG_STORE_PAIRS"):
+            monkeypatch.delenv("HIBAG_STORE_PAIRS", raising=False)
+        model, G = _campaign_case(hib, rng, big=(seed % 25 == 24))
+        flat = oracle.flatten(model)
+        m = hib.hlaModelFromObj(model)
+        for vote in (1, 2):
+            got = m.predict_raw(G, vote, want_dosage=True, want_prob=True)
+            want = oracle.predict(flat, G, vote_method=vote, avx2=True, n_threads=8)
+            for key in ("h1", "h2", "prob", "matching", "dosage", "postprob"):
+                if not np.array_equal(got[key], want[key], equal_nan=True):
+                    bad.append((seed, vote, key, G.shape, len(model.classifiers)))
+                    break
+        if m.handover_faults():
+            bad.append((seed, "handover_faults", int(m.handover_faults())))
+        if seed % 5 == 0:
+            # the reference's per-sample hook on the first samples: the averaged posterior of vote = prob, un-normalised
+            sub = G[: min(len(G), 6)]
+            want = oracle.predict(flat, sub, vote_method=1, avx2=False)
+            host = plugin.PluginHost(model)
+            geno, wt = host.pack(sub)
+            prob = np.zeros(model.n_cell); match = np.zeros(1)
+            for i in range(len(sub)):
+                host.avg_prob(geno[i], wt[i], prob, match)
+                if not (np.array_equal(prob, want["postprob"][i], equal_nan=True) and
+                        (match[0] == want["matching"][i] or (np.isnan(match[0]) and np.isnan(want["matching"][i])))):
+                    bad.append((seed, "plugin", i))
+                    break
+            host.close()
+        m.close()
+        done += 1
+        samples += len(G)
+        seed += 1
+    print(f"wide campaign: {done} models (seeds {seed0}..{seed - 1}), {samples} samples, {len(bad)} mismatches")
+    if os.environ.get("HIBAG_FUZZ_REPORT"):
+        with open(os.environ["HIBAG_FUZZ_REPORT"], "a") as f:
+            f.write(f"seeds {seed0}..{seed - 1}: {done} models, {samples} samples, both votes, mismatches: {bad}\n")
+    assert not bad, bad
