@@ -235,3 +235,54 @@ def test_device_em_on_random_problems(hib, oracle, seed):
         c = hib.Classifier(snpidx=w["snpidx"], freq=w["freq"], hla=w["hla"], haplo=w["haplo"], samp_num=w["samp_num"],
                            outofbag_acc=w["acc"])
         assert_same_classifier(_as_dict(g), c, i)
+
+
+def test_training_campaign(hib, oracle):
+    """Time-boxed random campaign of the training driver against the oracle's trainer (HIBAG_FUZZ_SECONDS, default 15):
+    cohorts of 10..400 samples, 4..120 SNPs, 1..20 alleles, genotyping errors and up to 25 % missing, mtry and prune at
+    random, EM fits on the host threads (1..8) or on the device -- every classifier (SNPs, haplotypes, frequencies,
+    out-of-bag accuracy) bit for bit.  A long run's summary: profiles/r04_fuzz_campaign.txt."""
+    import os
+    import time
+    from hibag_amd import train
+    budget = float(os.environ.get("HIBAG_FUZZ_SECONDS", "15"))
+    seed0 = int(os.environ.get("HIBAG_FUZZ_SEED", "40000"))
+    t_end = time.time() + budget
+    seed, done, bad = seed0, 0, []
+    while time.time() < t_end:
+        rng = np.random.default_rng(seed)
+        n_hla = int(rng.integers(1, 21))
+        n_snp = int(rng.integers(4, 121))
+        n_samp = int(rng.choice([rng.integers(10, 60), rng.integers(10, 200), rng.integers(10, 401)]))
+        founders = (rng.random((n_hla, n_snp)) < rng.uniform(0.05, 0.95, n_snp)).astype(np.int32)
+        a = rng.integers(0, n_hla, (n_samp, 2))
+        G = (founders[a[:, 0]] + founders[a[:, 1]]).astype(np.int32)
+        G = np.where(rng.random(G.shape) < rng.uniform(0, 0.08), (G + 1) % 3, G).astype(np.int32)
+        G[rng.random(G.shape) < rng.uniform(0, 0.25)] = hib.NA_INTEGER
+        mtry = int(rng.integers(1, n_snp + 1))
+        prune = bool(rng.integers(0, 2))
+        em = ["host", "device"][int(rng.integers(0, 2))]
+        threads = int(rng.integers(1, 9))
+        want = oracle.train(G, a[:, 0], a[:, 1], n_hla, nclassifier=2, mtry=mtry, prune=prune, seed=seed)
+        tr = train._Trainer(G, a[:, 0], a[:, 1], n_hla)
+        tr.set_em_mode(em)
+        tr.set_threads(threads)
+        tr.set_seed(seed)
+        tr.new_classifiers(2, mtry, prune, False, False)
+        got = tr.classifiers()
+        tr.close()
+        try:
+            assert len(got) == len(want)
+            for i, (g, w) in enumerate(zip(got, want)):
+                c = hib.Classifier(snpidx=w["snpidx"], freq=w["freq"], hla=w["hla"], haplo=w["haplo"], samp_num=w["samp_num"],
+                                   outofbag_acc=w["acc"])
+                assert_same_classifier(_as_dict(g), c, i)
+        except AssertionError as e:
+            bad.append((seed, em, threads, str(e)[:120]))
+        done += 1
+        seed += 1
+    print(f"training campaign: {done} cohorts (seeds {seed0}..{seed - 1}), {len(bad)} mismatches")
+    if os.environ.get("HIBAG_FUZZ_REPORT"):
+        with open(os.environ["HIBAG_FUZZ_REPORT"], "a") as f:
+            f.write(f"training, seeds {seed0}..{seed - 1}: {done} cohorts x 2 classifiers, mismatches: {bad}\n")
+    assert not bad, bad
