@@ -821,7 +821,10 @@ int finalize_model(hibag_hip_model *m)
 				const uint32_t h[8] = {
 					(uint32_t)c | ((uint32_t)(slots ? n_snp_c[c] : 0) << 18) | ((uint32_t)nsb << 25),
 					slots ? hap_off[c] : zero_entry_dword,
-					(uint32_t)bt_row[c],
+					// (pass 2 requests the operand rows of every block it passes, also of blocks that only carry stored sums: a
+					// classifier of the vector engine has no rows -- bt_row[c] is then the NEXT classifier's first row, or one past
+					// the last row of the batch's array for the model's last classifiers: rows 0 and 1 instead)
+					(uint32_t)(HIBAG_ENGINE_ROWS(engine[c], n_snp_c[c]) > 0 ? bt_row[c] : 0),
 					srow,
 					(uint32_t)jp, (uint32_t)(jp >> 32),
 					(uint32_t)jps, 0u};
@@ -1100,7 +1103,8 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	if (int rc = m->ws_inv.reserve(C * n_pad * sizeof(double))) return rc;
 	if (int rc = m->ws_part.reserve((size_t)(m->view.n_cell + 3) * n_pad * sizeof(double))) return rc;
 	if (int rc = m->ws_codes.reserve((size_t)std::max(m->n_snp, 1) * n_pad)) return rc;
-	if (int rc = m->ws_bt.reserve((size_t)std::max(m->bt_rows, 1) * n_pad * sizeof(uint4))) return rc;
+	// (two rows more than the model has: k_accum reads rows bt and bt + 1 of every block header it passes, whatever the block holds)
+	if (int rc = m->ws_bt.reserve((size_t)(std::max(m->bt_rows, 1) + 2) * n_pad * sizeof(uint4))) return rc;
 	if (int rc = m->ws_bias.reserve(2 * C * n_pad * sizeof(int))) return rc;
 	if (int rc = m->ws_cells.reserve((size_t)std::max(m->cell_rows, 1) * n_pad * sizeof(double))) return rc;
 	if (need_best)
@@ -1145,22 +1149,36 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 
 // Passes 1 and 2 (+ majority-vote variant) and the ensemble scalars for a
 // batch whose planes / weights are already on the device.
+// HIBAG_DEBUG_SYNC=1: wait for the stream behind every stage and name it on stderr (which kernel a device fault belongs to)
+static void debug_stage(const char *what, hipStream_t st)
+{
+	static const bool on = getenv("HIBAG_DEBUG_SYNC") != nullptr;
+	if (!on) return;
+	const hipError_t e = hipStreamSynchronize(st);
+	fprintf(stderr, "[hibag stage] %s: %s\n", what, hipGetErrorString(e));
+	fflush(stderr);
+}
+
 void run_core(hibag_hip_model *m, HibagBatchView &B, int vote_method, double *d_part, hipStream_t st)
 {
 	KernelTimer &T = m->timer;
 	B.part = d_part;
+	debug_stage("pack", st);
 	T.begin(HIBAG_HIP_K_TOTAL, st, true);      // (callers enqueue nothing between their pack and this)
 	hibag_launch_total(m->view, B, st, m->side);
 	T.end(st);
+	debug_stage("pass 1", st);
 	T.begin(HIBAG_HIP_K_ACCUM, st, true);
 	if (vote_method == 1) {
 		hibag_launch_accum(m->view, B, st);
+		debug_stage("pass 2 (accumulate)", st);
 		hibag_launch_scalars(m->view, B, nullptr, st);
 	} else {
 		hibag_launch_vote(m->view, B, m->ws_best.as<int>(), st);
 		hibag_launch_scalars(m->view, B, m->ws_best.as<int>(), st);
 	}
 	T.end(st);
+	debug_stage("pass 2", st);
 }
 
 int check_predict_args(hibag_hip_model *m, const void *geno, int n_samp, int vote_method,

@@ -106,6 +106,9 @@ def test_wide_campaign(oracle, monkeypatch):
     bad, done, samples, seed = [], 0, 0, seed0
     while time.time() < t_end:
         rng = np.random.default_rng(seed)
+        if os.environ.get("HIBAG_FUZZ_LOG"):            # (the seed in flight, should the process die)
+            with open(os.environ["HIBAG_FUZZ_LOG"], "w") as f:
+                f.write(f"{seed}\n")
         monkeypatch.setenv("HIBAG_STORE_PAIRS", str(int(rng.integers(0, 14))) if rng.random() < 0.5 else "")
         if not os.environ.get("HIBAG_STORE_PAIRS"):
             monkeypatch.delenv("HIBAG_STORE_PAIRS", raising=False)
@@ -144,3 +147,31 @@ def test_wide_campaign(oracle, monkeypatch):
         with open(os.environ["HIBAG_FUZZ_REPORT"], "a") as f:
             f.write(f"seeds {seed0}..{seed - 1}: {done} models, {samples} samples, both votes, mismatches: {bad}\n")
     assert not bad, bad
+
+
+def test_campaign_case_with_vector_engine_classifiers_last(oracle, monkeypatch):
+    """Seed 202699 of the campaign above, found by it: 59 classifiers of up to 128 SNPs whose last ones run on the vector engine
+    (no B-operand rows), every non-empty cell stored (HIBAG_STORE_PAIRS=0), 12,251 samples = 192 sample groups.  Pass 2 requests
+    the operand rows named by every block header it passes, stored-sums-only blocks included; for those classifiers the header named
+    the row one past the end of the batch's operand array -- harmless while the over-read stayed inside the allocation's slack, a
+    device memory fault at this size.  (The headers now name row 0 and the array has two rows to spare.)"""
+    import hibag_amd as hib
+    hib.hlaSetKernelTarget("hip")
+    seed = 202699
+    rng = np.random.default_rng(seed)
+    sp = str(int(rng.integers(0, 14))) if rng.random() < 0.5 else ""
+    assert sp == "0"
+    monkeypatch.setenv("HIBAG_STORE_PAIRS", sp)
+    model, G = _campaign_case(hib, rng, big=True)
+    assert len(model.classifiers) == 59 and len(G) == 12251 and len(model.classifiers[-1].snpidx) == 120
+    m = hib.hlaModelFromObj(model)
+    assert m.stored_cells() > 0 and m.second_pass_pairs() > 0          # pass 2 = k_accum with stored sums
+    sub = np.concatenate([np.arange(0, len(G), 97), np.arange(len(G) - 70, len(G))])
+    flat = oracle.flatten(model)
+    for vote in (1, 2):
+        got = m.predict_raw(G, vote, want_dosage=True, want_prob=True)
+        want = oracle.predict(flat, G[sub], vote_method=vote, avx2=True, n_threads=8)
+        for key in ("h1", "h2", "prob", "matching", "dosage", "postprob"):
+            assert np.array_equal(got[key][sub], want[key], equal_nan=True), (vote, key)
+    assert m.handover_faults() == 0
+    m.close()
