@@ -175,3 +175,107 @@ def test_campaign_case_with_vector_engine_classifiers_last(oracle, monkeypatch):
             assert np.array_equal(got[key][sub], want[key], equal_nan=True), (vote, key)
     assert m.handover_faults() == 0
     m.close()
+
+
+def test_entry_points_campaign(monkeypatch, tmp_path):
+    """Time-boxed random campaign over the OTHER ways into the same kernels (HIBAG_FUZZ_SECONDS, default 15), each against
+    hibag_hip_predict on the model-order matrix (which the campaign above pins to the oracle): the cohort's own matrix with a
+    column map and flips (hibag_hip_predict_mapped), a PLINK BED file in either storage mode (hibag_hip_predict_bed), the device
+    entry on a caller's stream with device-resident data, replicas on the one device (hibag_hip_predict_multi), and classifier
+    shards merged by the library's RCCL all-reduce (identical calls, posteriors to 1e-10: the summation order differs)."""
+    import os
+    import time
+    import torch
+    import hibag_amd as hib
+    from conftest import write_bed
+    hib.hlaSetKernelTarget("hip")
+    NA = hib.NA_INTEGER
+    budget = float(os.environ.get("HIBAG_FUZZ_SECONDS", "15"))
+    seed0 = int(os.environ.get("HIBAG_FUZZ_SEED", "60000"))
+    t_end = time.time() + budget
+    seed, done, bad = seed0, 0, []
+    dev = torch.device("cuda", 0)
+    keys = ("h1", "h2", "prob", "matching", "dosage", "postprob")
+
+    def same(a, b):
+        return all(np.array_equal(a[k], b[k], equal_nan=True) for k in keys)
+
+    while time.time() < t_end:
+        rng = np.random.default_rng(seed)
+        if os.environ.get("HIBAG_FUZZ_LOG"):
+            with open(os.environ["HIBAG_FUZZ_LOG"], "w") as f:
+                f.write(f"{seed}\n")
+        monkeypatch.delenv("HIBAG_STORE_PAIRS", raising=False)
+        model, G = _campaign_case(hib, rng, big=False)
+        n, S = G.shape
+        vote = int(rng.integers(1, 3))
+        m = hib.hlaModelFromObj(model)
+        ref = m.predict_raw(G, vote, want_dosage=True, want_prob=True)
+        # -- the cohort's own matrix: model SNP k in column col[k] (or absent), reversed where flip[k]
+        n_extra = int(rng.integers(0, 12))
+        absent = rng.random(S) < 0.1
+        flip = rng.random(S) < 0.3
+        cols = rng.permutation(S + n_extra)[:S].astype(np.int32)
+        cohort = rng.integers(0, 3, size=(n, S + n_extra)).astype(np.int32)
+        valid = (G >= 0) & (G <= 2)
+        cohort[:, cols] = np.where(flip[None, :] & valid, 2 - G, G)
+        col = np.where(absent, -1, cols).astype(np.int32)
+        Gm = G.copy()
+        Gm[:, absent] = NA
+        want = m.predict_raw(Gm, vote, want_dosage=True, want_prob=True)
+        got = m.predict_mapped(cohort, col, flip, vote, want_dosage=True, want_prob=True)
+        if not same(got, want):
+            bad.append((seed, "mapped"))
+        # -- the same cohort as a BED file (values outside 0..2 are missing there as here)
+        if seed % 3 == 0:
+            mode = int(rng.integers(0, 2))
+            path = write_bed(str(tmp_path / f"c{seed}.bed"), cohort.T, mode)
+            got = m.predict_bed(path, n, S + n_extra, col, flip, vote, want_dosage=True, want_prob=True)
+            os.remove(path)
+            if not same(got, want):
+                bad.append((seed, "bed", mode))
+        # -- device entry on a stream of the caller's
+        if seed % 2 == 0:
+            st = torch.cuda.Stream(dev)
+            dg = torch.from_numpy(G).to(dev)
+            o = dict(h1=torch.zeros(n, dtype=torch.int32, device=dev), h2=torch.zeros(n, dtype=torch.int32, device=dev),
+                     prob=torch.zeros(n, dtype=torch.float64, device=dev), matching=torch.zeros(n, dtype=torch.float64, device=dev),
+                     dosage=torch.zeros((n, model.n_hla), dtype=torch.float64, device=dev),
+                     postprob=torch.zeros((n, model.n_cell), dtype=torch.float64, device=dev))
+            torch.cuda.synchronize(dev)
+            m.predict_device(dg.data_ptr(), n, vote, *[o[k].data_ptr() for k in keys], stream=st.cuda_stream)
+            st.synchronize()
+            if not same({k: o[k].cpu().numpy() for k in keys}, ref):
+                bad.append((seed, "device"))
+        # -- replicas on the one device
+        if seed % 4 == 1:
+            reps = [m] + [m.replicate(0) for _ in range(int(rng.integers(1, 4)))]
+            got = hib.hibag.predict_multi(reps, G, vote, want_dosage=True, want_prob=True)
+            for r in reps[1:]:
+                r.close()
+            if not same(got, ref):
+                bad.append((seed, "multi"))
+        # -- classifier shards merged by the library's all-reduce (vote = prob only)
+        if seed % 4 == 3 and len(model.classifiers) >= 2:
+            want1 = ref if vote == 1 else m.predict_raw(G, 1, want_dosage=True, want_prob=True)
+            grp = hib.hibag.ShardGroup(m, [0] * int(rng.integers(2, min(len(model.classifiers), 6) + 1)))
+            got = grp.predict_raw(G, want_dosage=True, want_prob=True)
+            grp.close()
+            ok = np.array_equal(got["h1"], want1["h1"]) and np.array_equal(got["h2"], want1["h2"])
+            with np.errstate(invalid="ignore", divide="ignore"):
+                fin = np.isfinite(want1["postprob"]) & (want1["postprob"] > 1e-200)
+                rel = np.abs(got["postprob"] - want1["postprob"])[fin] / want1["postprob"][fin]
+            ok = ok and (rel.size == 0 or float(rel.max()) < 1e-10)
+            ok = ok and np.array_equal(np.isnan(got["postprob"]), np.isnan(want1["postprob"]))
+            if not ok:
+                bad.append((seed, "shards"))
+        if m.handover_faults():
+            bad.append((seed, "handover_faults"))
+        m.close()
+        done += 1
+        seed += 1
+    print(f"entry-point campaign: {done} models (seeds {seed0}..{seed - 1}), {len(bad)} mismatches")
+    if os.environ.get("HIBAG_FUZZ_REPORT"):
+        with open(os.environ["HIBAG_FUZZ_REPORT"], "a") as f:
+            f.write(f"entry points, seeds {seed0}..{seed - 1}: {done} models, mismatches: {bad}\n")
+    assert not bad, bad
