@@ -102,6 +102,7 @@ def test_wide_campaign(oracle, monkeypatch):
     hib.hlaSetKernelTarget("hip")
     budget = float(os.environ.get("HIBAG_FUZZ_SECONDS", "20"))
     seed0 = int(os.environ.get("HIBAG_FUZZ_SEED", "90000"))
+    big_every = max(1, int(os.environ.get("HIBAG_FUZZ_BIG_EVERY", "25")))      # every n-th case is a cohort of 12,000-16,000 samples
     t_end = time.time() + budget
     bad, done, samples, seed = [], 0, 0, seed0
     while time.time() < t_end:
@@ -112,7 +113,7 @@ def test_wide_campaign(oracle, monkeypatch):
         monkeypatch.setenv("HIBAG_STORE_PAIRS", str(int(rng.integers(0, 14))) if rng.random() < 0.5 else "")
         if not os.environ.get("HIBAG_STORE_PAIRS"):
             monkeypatch.delenv("HIBAG_STORE_PAIRS", raising=False)
-        model, G = _campaign_case(hib, rng, big=(seed % 25 == 24))
+        model, G = _campaign_case(hib, rng, big=(seed % big_every == big_every - 1))
         flat = oracle.flatten(model)
         m = hib.hlaModelFromObj(model)
         for vote in (1, 2):
