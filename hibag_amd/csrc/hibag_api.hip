@@ -1143,6 +1143,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	B.cw = m->ws_cw.as<double>(); B.tot = m->ws_tot.as<double>(); B.inv = m->ws_inv.as<double>();
 	B.part = m->ws_part.as<double>();
 	B.bt = m->ws_bt.as<uint4>(); B.bias = m->ws_bias.as<int>();
+	B.bt_rows = std::max(m->bt_rows, 1) + 2;
 	B.cells = m->ws_cells.as<double>();
 	return 0;
 }

@@ -237,6 +237,7 @@ struct HibagBatchView {
 	// matrix-core engine: per classifier and sample group the B operand tiles
 	// (int8, MFMA lane layout; K layout above) and, for classifiers with 32 SNPs, the distance offsets
 	uint4 *bt;          // [(bt_row[c] + n * (rows / 2) + kb)][n_pad/64][64]
+	int bt_rows;        // rows of `bt` that exist (the model's + 2 spare): pass 2's buffer descriptor ends there
 	int *bias;          // [(2c + n)][n_pad/64][64]  8 * (2*#(g=2) + #(g=1)), written for 32-SNP classifiers only
 	// hand-over flags of chunked work items: (epoch << 32 | progress) per item; a new epoch per batch, so the
 	// flags are never cleared

@@ -1296,11 +1296,16 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		// the batch's operand / weight / 1/total rows and this group's stored sums as raw buffers too: a row is then a scalar
 		// offset (classifier or row number times the row size, SALU) added to one constant per-lane offset -- no 64-bit address
 		// arithmetic on the vector ALU.  (hibag_api.hip batch_limit keeps every one of these arrays below 4 GB.)
-		const __amdgpu_buffer_rsrc_t r_bt = __builtin_amdgcn_make_buffer_rsrc((void *)B.bt, 0, (int)0xFFFFFFF0u, 0x00020000);
-		const __amdgpu_buffer_rsrc_t r_cw = __builtin_amdgcn_make_buffer_rsrc((void *)B.cw, 0, (int)0xFFFFFFF0u, 0x00020000);
-		const __amdgpu_buffer_rsrc_t r_inv = __builtin_amdgcn_make_buffer_rsrc((void *)B.inv, 0, (int)0xFFFFFFF0u, 0x00020000);
+		// (every descriptor ends where its array ends: a request past it -- a look-ahead through a header that names more than
+		// exists -- reads zeros instead of faulting)
+		auto bytes32 = [](size_t n) { return n > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)(uint32_t)n; };
+		const size_t row_bytes = (size_t)B.n_pad * 8u;
+		const __amdgpu_buffer_rsrc_t r_bt = __builtin_amdgcn_make_buffer_rsrc((void *)B.bt, 0, bytes32((size_t)B.bt_rows * B.n_pad * 16u), 0x00020000);
+		const __amdgpu_buffer_rsrc_t r_cw = __builtin_amdgcn_make_buffer_rsrc((void *)B.cw, 0, bytes32((size_t)C * row_bytes), 0x00020000);
+		const __amdgpu_buffer_rsrc_t r_inv = __builtin_amdgcn_make_buffer_rsrc((void *)B.inv, 0, bytes32((size_t)C * row_bytes), 0x00020000);
 		const __amdgpu_buffer_rsrc_t r_sv = __builtin_amdgcn_make_buffer_rsrc(
-			(void *)(B.cells + (size_t)group * (size_t)as_const(M.cell_row)[C] * HIBAG_WAVE), 0, (int)0xFFFFFFF0u, 0x00020000);
+			(void *)(B.cells + (size_t)group * (size_t)as_const(M.cell_row)[C] * HIBAG_WAVE), 0,
+			bytes32((size_t)as_const(M.cell_row)[C] * HIBAG_WAVE * 8u), 0x00020000);
 		const int vo_i = (lane & 31) * 4;
 		const int vo_bt = (group * HIBAG_WAVE + lane) * 16, vo_s = s * 8, vo_sv = lane * 8;
 		const uint32_t bt_stride = (uint32_t)B.n_pad * 16u, s_stride = (uint32_t)B.n_pad * 8u;      // bytes per operand row / per classifier's row
