@@ -114,6 +114,12 @@ def test_wide_campaign(oracle, monkeypatch):
         if not os.environ.get("HIBAG_STORE_PAIRS"):
             monkeypatch.delenv("HIBAG_STORE_PAIRS", raising=False)
         model, G = _campaign_case(hib, rng, big=(seed % big_every == big_every - 1))
+        # (drawn after the case, so that a seed names the same model whatever is varied here) which cell sums pass 1 stores for
+        # pass 2 -- all / those of the big cells / none -- and, now and then, every classifier on the vector engine or on int8 MFMA
+        mode = ["", "", "stream", "hybrid", "recompute"][int(rng.integers(0, 5))]
+        monkeypatch.setenv("HIBAG_PASS2", mode) if mode else monkeypatch.delenv("HIBAG_PASS2", raising=False)
+        eng = ["valu", "i8", ""][min(int(rng.random() / 0.08), 2)]     # 8 % vector engine, 8 % int8 MFMA instead of FP4
+        monkeypatch.setenv("HIBAG_ENGINE", eng) if eng else monkeypatch.delenv("HIBAG_ENGINE", raising=False)
         flat = oracle.flatten(model)
         m = hib.hlaModelFromObj(model)
         for vote in (1, 2):
@@ -143,6 +149,8 @@ def test_wide_campaign(oracle, monkeypatch):
         done += 1
         samples += len(G)
         seed += 1
+    monkeypatch.delenv("HIBAG_PASS2", raising=False)
+    monkeypatch.delenv("HIBAG_ENGINE", raising=False)
     print(f"wide campaign: {done} models (seeds {seed0}..{seed - 1}), {samples} samples, {len(bad)} mismatches")
     if os.environ.get("HIBAG_FUZZ_REPORT"):
         with open(os.environ["HIBAG_FUZZ_REPORT"], "a") as f:
