@@ -284,3 +284,37 @@ def test_predict_multi_two_replicas_on_one_device_equal_the_single_call(hib, ora
     for r in (r0, r1):
         r.close()
     m.close()
+
+
+@pytest.mark.parametrize("n_haplo", [16383, 16384])
+def test_haplotype_count_at_the_matrix_engines_index_limit(hib, oracle, n_haplo):
+    """A classifier of 16,383 haplotypes is the largest the matrix engines take (a block's slot word holds the second
+    haplotype's table index in 14 bits, the first's in 16: hibag_api.hip finalize_model); one of 16,384 goes to the vector
+    engine whatever its SNP count.  134 million haplotype pairs per sample either way; beside it an ordinary classifier."""
+    rng = np.random.default_rng(n_haplo)
+    n_hla, k = 40, 20
+    founders = rng.integers(0, 2, (n_hla, k))
+    hla = np.sort(rng.integers(0, n_hla, n_haplo)).astype(np.int32)
+    bits = founders[hla] ^ (rng.random((n_haplo, k)) < 0.08)
+    haplo = ["".join("01"[b] for b in row) for row in bits]
+    freq = rng.dirichlet(np.full(n_haplo, 0.3)) + 1e-9
+    big = hib.Classifier(snpidx=np.arange(k), freq=freq, hla=hla, haplo=haplo)
+    small = hib.Classifier(snpidx=np.arange(3, 15), freq=[0.2, 0.3, 0.5], hla=[0, 5, 39], haplo=["0" * 12, "01" * 6, "1" * 12])
+    model = hib.HlaAttrBagObj(0, k, [f"{i:02d}" for i in range(n_hla)], [small, big])
+    n = 70
+    a, b = rng.integers(0, n_haplo, n), rng.integers(0, n_haplo, n)
+    G = (bits[a].astype(np.int32) + bits[b].astype(np.int32)).astype(np.int32)
+    G[rng.random(G.shape) < 0.03] = hib.NA_INTEGER
+    G[1, :] = hib.NA_INTEGER
+    m = hib.hlaModelFromObj(model)
+    kind = m.engine(1)
+    assert (kind[0] == "valu") == (n_haplo >= 16384), kind
+    sub = np.array([0, 1, 2, 63, 64, 69])
+    flat = oracle.flatten(model)
+    for vote in (1, 2):
+        got = m.predict_raw(G, vote, want_dosage=True, want_prob=True)
+        want = oracle.predict(flat, G[sub], vote_method=vote, avx2=True, n_threads=8)
+        for key in ("h1", "h2", "prob", "matching", "dosage", "postprob"):
+            assert np.array_equal(got[key][sub], want[key], equal_nan=True), (vote, key)
+    assert m.handover_faults() == 0
+    m.close()
