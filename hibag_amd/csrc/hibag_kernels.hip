@@ -1720,14 +1720,14 @@ __device__ __forceinline__ double normalised(double v, bool scale, double ff) { 
 // its segment in order, then the segments are merged in order with the same
 // strict comparison, which reproduces the sequential scan exactly.
 #define FIN_SEG 16
-__global__ __launch_bounds__(64 * FIN_SEG) void k_finish_call(HibagModelView M, HibagBatchView B,
+__device__ __forceinline__ void finish_call(const HibagModelView &M, const HibagBatchView &B, int group,
 	const double *__restrict__ part, int32_t *__restrict__ H1, int32_t *__restrict__ H2,
 	double *__restrict__ max_prob, double *__restrict__ matching)
 {
 	__shared__ double best_s[FIN_SEG][64];
 	__shared__ int cell_s[FIN_SEG][64];
 	const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
-	const int s = blockIdx.x * 64 + lane;
+	const int s = group * 64 + lane;
 	const int P = M.n_cell;
 	const size_t np = (size_t)B.n_pad;
 	const double sum_w = part[(size_t)P * np + s];
@@ -1771,17 +1771,22 @@ __global__ __launch_bounds__(64 * FIN_SEG) void k_finish_call(HibagModelView M, 
 	if (matching) matching[s] = part[(size_t)(P + 1) * np + s] / part[(size_t)(P + 2) * np + s];
 }
 
-// k_finish_dosage: expected allele dosage (src/LibHLA.cpp:2387-2402).  The
+__global__ __launch_bounds__(64 * FIN_SEG) void k_finish_call(HibagModelView M, HibagBatchView B,
+	const double *__restrict__ part, int32_t *__restrict__ H1, int32_t *__restrict__ H2,
+	double *__restrict__ max_prob, double *__restrict__ matching)
+{
+	finish_call(M, B, blockIdx.x, part, H1, H2, max_prob, matching);
+}
+
+// finish_dosage: expected allele dosage (src/LibHLA.cpp:2387-2402).  The
 // reference scatters each cell into d[h1] and d[h2] while scanning cells in
 // order; gathered per allele h that is  S[0,h], S[1,h], ..., then 2*S[h,h],
 // then S[h,h+1], ...  added in that order.  thread = (sample, allele).
-__global__ void k_finish_dosage(HibagModelView M, HibagBatchView B, const double *__restrict__ part,
-	double *__restrict__ dosage)
+__device__ __forceinline__ void finish_dosage(const HibagModelView &M, const HibagBatchView &B, int s, int h,
+	const double *__restrict__ part, double *__restrict__ dosage)
 {
-	const int s = blockIdx.x * blockDim.x + threadIdx.x;
-	const int h = blockIdx.y;
-	if (s >= B.n_samp) return;
 	const int n = M.n_hla;
+	if (s >= B.n_samp || h >= n) return;
 	const size_t np = (size_t)B.n_pad;
 	const double sum_w = part[(size_t)M.n_cell * np + s];
 	const bool scale = sum_w > 0;
@@ -1809,6 +1814,22 @@ __global__ void k_finish_dosage(HibagModelView M, HibagBatchView B, const double
 		d += g == h ? 2 * x : x;
 	}
 	dosage[(size_t)s * n + h] = sum_w != sum_w ? sum_w : d;      // (NaN weight sum: poisoned batch, see k_scalars)
+}
+
+// k_finish: the call and the dosage in ONE launch -- two independent readers of the ensemble sums, which as two kernels ran
+// one behind the other (20 + 33 us of the benchmark step's 1,340).  The first n_pad / 64 workgroups are k_finish_call's, the
+// others take 64 samples x FIN_SEG alleles each.
+__global__ __launch_bounds__(64 * FIN_SEG) void k_finish(HibagModelView M, HibagBatchView B,
+	const double *__restrict__ part, int32_t *__restrict__ H1, int32_t *__restrict__ H2,
+	double *__restrict__ max_prob, double *__restrict__ matching, double *__restrict__ dosage)
+{
+	const int n_group = B.n_pad / 64;
+	if ((int)blockIdx.x < n_group) {
+		finish_call(M, B, blockIdx.x, part, H1, H2, max_prob, matching);
+	} else {
+		const int j = (int)blockIdx.x - n_group;
+		finish_dosage(M, B, (j % n_group) * 64 + (int)(threadIdx.x & 63), (j / n_group) * FIN_SEG + (int)(threadIdx.x >> 6), part, dosage);
+	}
 }
 
 // k_finish_prob: posterior matrix out, [n_samp][P] sample-major
@@ -2019,11 +2040,14 @@ void hibag_launch_finish(const HibagModelView &M, const HibagBatchView &B, doubl
 	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching,
 	double *d_dosage, double *d_postprob, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_finish_call, dim3(B.n_pad / 64), dim3(64 * FIN_SEG), 0, st, M, B, (const double *)d_part,
-		d_H1, d_H2, d_max_prob, d_matching);
-	if (d_dosage)
-		hipLaunchKernelGGL(k_finish_dosage, dim3((B.n_pad + 63) / 64, M.n_hla), dim3(64), 0, st,
-			M, B, (const double *)d_part, d_dosage);
+	if (d_dosage) {
+		const unsigned n_group = (unsigned)(B.n_pad / 64);
+		hipLaunchKernelGGL(k_finish, dim3(n_group * (1u + (unsigned)((M.n_hla + FIN_SEG - 1) / FIN_SEG))), dim3(64 * FIN_SEG), 0, st,
+			M, B, (const double *)d_part, d_H1, d_H2, d_max_prob, d_matching, d_dosage);
+	} else {
+		hipLaunchKernelGGL(k_finish_call, dim3(B.n_pad / 64), dim3(64 * FIN_SEG), 0, st, M, B, (const double *)d_part,
+			d_H1, d_H2, d_max_prob, d_matching);
+	}
 	if (d_postprob)
 		hipLaunchKernelGGL(k_finish_prob, dim3(B.n_pad / 64, (M.n_cell + 63) / 64), dim3(256), 0, st,
 			M, B, (const double *)d_part, d_postprob);
