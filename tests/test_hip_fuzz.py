@@ -288,3 +288,69 @@ def test_entry_points_campaign(monkeypatch, tmp_path):
         with open(os.environ["HIBAG_FUZZ_REPORT"], "a") as f:
             f.write(f"entry points, seeds {seed0}..{seed - 1}: {done} models, mismatches: {bad}\n")
     assert not bad, bad
+
+
+def test_plugin_campaign(oracle):
+    """Time-boxed random campaign of the reference's per-sample GPU hook (TypeGPUExtProc.predict_init / predict_avg_prob /
+    predict_done through hibag_amd.plugin.PluginHost; hibag_sample.hip's one kernel per call): up to 150 classifiers (workgroup =
+    classifier), up to 110 alleles (6,105 cells: more than one round of 4,096 cells per workgroup), up to 250 haplotypes (31,375
+    pairs: several rounds of 8,192 pairs), 1..128 SNPs -- posterior and matching of every sample bit-equal to the oracle.
+    HIBAG_FUZZ_SECONDS (default 10)."""
+    import os
+    import time
+    import hibag_amd as hib
+    from hibag_amd import plugin
+    hib.hlaSetKernelTarget("hip")
+    budget = float(os.environ.get("HIBAG_FUZZ_SECONDS", "10"))
+    seed0 = int(os.environ.get("HIBAG_FUZZ_SEED", "80000"))
+    t_end = time.time() + budget
+    seed, done, bad = seed0, 0, []
+    while time.time() < t_end:
+        rng = np.random.default_rng(seed)
+        if os.environ.get("HIBAG_FUZZ_LOG"):
+            with open(os.environ["HIBAG_FUZZ_LOG"], "w") as f:
+                f.write(f"{seed}\n")
+        n_hla = int(rng.choice([rng.integers(1, 20), rng.integers(1, 60), rng.integers(60, 111)]))
+        n_snp = int(rng.integers(1, 200))
+        n_cls = int(rng.choice([rng.integers(1, 6), rng.integers(1, 40), rng.integers(40, 151)]))
+        hmax = int(rng.choice([8, 60, 250]))
+        kmax = [8, 30, 32, 64, 128][int(rng.integers(0, 5))]
+        tiny = rng.random() < 0.2
+        cls = []
+        for _ in range(n_cls):
+            k = int(rng.integers(1, min(n_snp, kmax) + 1))
+            H = int(rng.integers(0 if rng.random() < 0.03 else 1, hmax + 1))
+            hla = np.sort(rng.integers(0, n_hla, H)).astype(np.int32)
+            freq = 10.0 ** rng.uniform(-300 if tiny else -5, 0, H)
+            haplo = ["".join(rng.choice(["0", "1"], k)) for _ in range(H)]
+            cls.append(hib.Classifier(snpidx=rng.choice(n_snp, k, replace=False), freq=freq, hla=hla, haplo=haplo))
+        model = hib.HlaAttrBagObj(n_samp=0, n_snp=n_snp, hla_allele=[f"{i:03d}" for i in range(n_hla)], classifiers=cls)
+        n = 5
+        G = rng.integers(0, 3, size=(n, n_snp)).astype(np.int32)
+        live = [c for c in cls if len(c.freq)]
+        for i in range(n):
+            for c0 in live[:: max(1, len(live) // 3)]:
+                H0 = np.array([[int(ch) for ch in h] for h in c0.haplo])
+                a, b = rng.integers(0, len(c0.haplo), 2)
+                G[i, np.asarray(c0.snpidx)] = H0[a] + H0[b]
+        G[rng.random(G.shape) < 0.03] = hib.NA_INTEGER
+        if rng.random() < 0.3:
+            G[0, :] = hib.NA_INTEGER
+        want = oracle.predict(oracle.flatten(model), G, vote_method=1, avx2=True, n_threads=4)
+        host = plugin.PluginHost(model)
+        geno, wt = host.pack(G)
+        prob = np.zeros(model.n_cell); match = np.zeros(1)
+        for i in range(n):
+            host.avg_prob(geno[i], wt[i], prob, match)
+            if not (np.array_equal(prob, want["postprob"][i], equal_nan=True) and
+                    (match[0] == want["matching"][i] or (np.isnan(match[0]) and np.isnan(want["matching"][i])))):
+                bad.append((seed, i, n_hla, n_cls, hmax, kmax))
+                break
+        host.close()
+        done += 1
+        seed += 1
+    print(f"plugin campaign: {done} models (seeds {seed0}..{seed - 1}), {len(bad)} mismatches")
+    if os.environ.get("HIBAG_FUZZ_REPORT"):
+        with open(os.environ["HIBAG_FUZZ_REPORT"], "a") as f:
+            f.write(f"per-sample hook, seeds {seed0}..{seed - 1}: {done} models x 5 samples, mismatches: {bad}\n")
+    assert not bad, bad
