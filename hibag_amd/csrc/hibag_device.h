@@ -60,7 +60,9 @@
 #define HIBAG_WAVE 64
 #define HIBAG_TAB_N 257          // 2*128 + 1 distances (src/LibHLA.cpp:167)
 #ifndef HIBAG_TILE
-#define HIBAG_TILE 16            // allele-pair cells per tile (one LDS accumulator row each; at most 16)
+#define HIBAG_TILE 15            // allele-pair cells per tile (one LDS accumulator row each; at most 16).  Fifteen, not sixteen: pass 2's
+                                 // workgroup then needs 4 x 15 x 64 x 8 = 30,720 bytes of accumulators (+ 512 of table), and FIVE of
+                                 // them fit a CU's 160 KB instead of four (measured: k_accum -4 %, k_accum_cells -19 %)
 #endif
 #ifndef HIBAG_CHUNK
 #define HIBAG_CHUNK 4            // pair records per chunk
@@ -77,7 +79,9 @@ static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 #define HIBAG_PLIST_END 0x80000000u          // the slot closes a cell
 #define HIBAG_PLIST_STORE 0x40000000u        // with END: pass 1 stores this cell's sum for pass 2 to read back
 #ifndef HIBAG_STORED_PER_VISIT
-#define HIBAG_STORED_PER_VISIT 8             // mode 2: stored cells per block of pass 2 (and per (classifier, tile) visit of a classifier it evaluates) -- what k_accum keeps in registers; at most 8
+#define HIBAG_STORED_PER_VISIT 7             // mode 2: stored cells per block of pass 2 (and per (classifier, tile) visit of a classifier it evaluates) -- what k_accum
+                                             // keeps in registers; at most 8.  Seven: with eight k_accum needs 97 vector registers, one more than five
+                                             // wavefronts per SIMD leave it (96) -- four spilled; with seven it needs 95
 #endif
 // Matrix-engine variants (HibagModelView::engine[c]; 0 = VALU engine) and their haplotype-table entries:
 //   FP4  (up to 30 SNPs; 33 .. 112 in several K steps, below)  v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands: one instruction per sample half covers all

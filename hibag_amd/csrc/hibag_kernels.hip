@@ -1222,7 +1222,7 @@ __device__ __forceinline__ EHeader read_header(u32x8 hv)         // the header's
 }
 
 #ifndef ACCUM_OCC
-#define ACCUM_OCC 4                         // workgroups per CU pass 2 is compiled for
+#define ACCUM_OCC 5                         // workgroups per CU pass 2 is compiled for (LDS: HIBAG_TILE in hibag_device.h; registers: HIBAG_STORED_PER_VISIT)
 #endif
 __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(HibagModelView M, HibagBatchView B, int n_whole, int K)
 {
@@ -1482,12 +1482,16 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 // k_accum_cells (pass 2, cells read back): S[p] += (cell * (1/total)) * w over the classifiers in order
 // (src/LibHLA.cpp:1828 then :1497-1507) with the cell sums pass 1 stored -- 8 bytes per sample, classifier and
 // non-empty cell instead of a second evaluation of every haplotype pair; bound by HBM reads.
-// Wavefront = (tile of up to 16 cells, 64 samples), the tile's sums in registers; the four wavefronts of a
+// Wavefront = (tile of up to HIBAG_TILE cells, 64 samples), the tile's sums in LDS; the four wavefronts of a
 // workgroup take four tiles of one sample group (its weights and 1/totals then come from L1 for three of them), and a
 // group's workgroups all go to XCD group % 8, so those rows stay in one L2.
 #define CELLS_WAVES 4
-__global__ __launch_bounds__(CELLS_WAVES * HIBAG_WAVE, 4) void k_accum_cells(HibagModelView M, HibagBatchView B)
+#ifndef CELLS_OCC
+#define CELLS_OCC 4                         // workgroups per CU k_accum_cells is compiled for
+#endif
+__global__ __launch_bounds__(CELLS_WAVES * HIBAG_WAVE, CELLS_OCC) void k_accum_cells(HibagModelView M, HibagBatchView B)
 {
+	constexpr int CELLS_V = (HIBAG_TILE + 3) / 4 * 4;     // the cell sums of a visit in registers: requested four at a time
 	__shared__ double acc_s[CELLS_WAVES][HIBAG_TILE][HIBAG_WAVE];
 	const int n_group = B.n_pad / HIBAG_WAVE;
 	const int tq = (M.n_tile + CELLS_WAVES - 1) / CELLS_WAVES;
@@ -1518,7 +1522,7 @@ __global__ __launch_bounds__(CELLS_WAVES * HIBAG_WAVE, 4) void k_accum_cells(Hib
 	// request the tile's n non-empty cells of the classifier (rows k0 .. k0 + n - 1 of the group's cells), four at a time.
 	// (Also where pass 1 skipped the classifier because no sample of the group uses it: the rows then hold stale
 	// numbers, which `add` never looks at.)
-	auto fetch = [&](const Visit &x, double (&v)[HIBAG_TILE]) {
+	auto fetch = [&](const Visit &x, double (&v)[CELLS_V]) {
 		const int n = (int)((x.rec[0] >> 8) & 31u);
 		const double *__restrict__ rows = group_rows + (size_t)(x.rec[5] & 0x7FFFFFFu) * HIBAG_WAVE;
 #pragma unroll
@@ -1529,7 +1533,7 @@ __global__ __launch_bounds__(CELLS_WAVES * HIBAG_WAVE, 4) void k_accum_cells(Hib
 		}
 	};
 	// S[p] += (cell * (1/total)) * w for those cells, rows in the order of the tile's non-empty list
-	auto add = [&](int c, const Visit &x, const double (&v)[HIBAG_TILE]) {
+	auto add = [&](int c, const Visit &x, const double (&v)[CELLS_V]) {
 		const bool active = x.w > 0;
 		if (__ballot(active) == 0) return;           // nobody in the group uses the classifier (src/LibHLA.cpp:2451)
 		const bool poison = __ballot(active && !(fabs(x.inv) <= 1.79769313486231570815e+308)) != 0;
@@ -1552,7 +1556,7 @@ __global__ __launch_bounds__(CELLS_WAVES * HIBAG_WAVE, 4) void k_accum_cells(Hib
 	};
 
 	// two classifiers per turn: while classifier c is added, the cells of c + 1 and the records of c + 2 are in flight
-	double va[HIBAG_TILE], vb[HIBAG_TILE];
+	double va[CELLS_V], vb[CELLS_V];
 	Visit x0 = visit(0), x1 = visit(C > 1 ? 1 : 0);
 	fetch(x0, va);
 	for (int c = 0; c < C; c += 2) {
