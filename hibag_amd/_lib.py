@@ -37,7 +37,7 @@ EXPORTS = [
     "hibag_hip_shard_bounds", "hibag_hip_model_shard", "hibag_hip_model_batch_limit", "hibag_hip_shard_group_new",
     "hibag_hip_shard_group_free", "hibag_hip_shard_group_ranks", "hibag_hip_shard_group_allreduces", "hibag_hip_rccl_version",
     "hibag_hip_shard_group_predict", "hibag_hip_predict_multi_sharded", "hibag_hip_measure_issue_costs",
-    "hibag_hip_test_time_avg_prob",
+    "hibag_hip_test_time_avg_prob", "hibag_hip_test_read_diag", "hibag_hip_plugin_degraded_calls",
 ]
 
 
@@ -143,6 +143,9 @@ def lib() -> C.CDLL:
     L.hibag_hip_predict_multi_sharded.argtypes = [C.POINTER(vp), i32, vp, i32, vp, vp, vp, vp, vp, vp]
     L.hibag_hip_measure_issue_costs.argtypes = [C.POINTER(dbl)] * 4
     L.hibag_hip_test_time_avg_prob.argtypes = [vp, vp, i32, i32, i32, vp, vp, C.POINTER(dbl)]
+    if hasattr(L, "hibag_hip_test_read_diag"):          # (absent from older builds loaded through HIBAG_HIP_LIBRARY for A/B timings)
+        L.hibag_hip_test_read_diag.argtypes = [vp, vp, i32]
+        L.hibag_hip_plugin_degraded_calls.restype = i64
     _lib = L
     return L
 

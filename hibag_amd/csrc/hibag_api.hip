@@ -192,13 +192,13 @@ struct hibag_hip_model {
 	double tab[HIBAG_TAB_N];
 
 	// device model
-	DevBuf d_int, d_stream, d_tile, d_tab, d_blk, d_pfac, d_phdr;
+	DevBuf d_int, d_stream, d_tile, d_tab, d_blk, d_pfac, d_phdr, d_parow;
 	HibagModelView view{};
 	int mask_rows = 0, bt_rows = 0, cell_rows = 0;
 	size_t stream_bytes = 0;
 
 	// per-batch workspace (grow-only)
-	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias, ws_cells, ws_sync;
+	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_winv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias, ws_cells, ws_sync;
 	std::vector<int> engine_of, steps_of;  // per classifier: HIBAG_HIP_ENGINE_* and K steps, as finalized
 	int store_mode = 0;                    // which cell sums pass 1 stores for pass 2 (HibagModelView::store_cells)
 	int64_t second_pass_pairs = 0;         // haplotype pairs per sample pass 2 evaluates again
@@ -239,7 +239,7 @@ struct hibag_hip_model {
 		if (side.fork) (void)hipEventDestroy(side.fork);
 		if (side.join) (void)hipEventDestroy(side.join);
 		if (side.stream) (void)hipStreamDestroy(side.stream);
-		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &d_pfac, &d_phdr, &ws_bt, &ws_bias, &ws_cells, &ws_sync, &ws_err, &ws_planes, &ws_cw, &ws_tot, &ws_inv,
+		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &d_pfac, &d_phdr, &d_parow, &ws_bt, &ws_bias, &ws_cells, &ws_sync, &ws_err, &ws_planes, &ws_cw, &ws_tot, &ws_inv, &ws_winv,
 		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_bed, &ws_bedidx})
 			b->release();
 	}
@@ -789,7 +789,7 @@ int finalize_model(hibag_hip_model *m)
 	// blocks of padding slots for the rest.
 	std::vector<uint32_t> ehdr, etile_cstart((size_t)n_tile * (C + 1), 0);
 	std::vector<uint64_t> etile_blk0(std::max(n_tile, 1), 0);
-	const uint32_t zero_entry_dword = (uint32_t)hap.size();          // an all-zero FP4 entry for padding blocks (factor +0.0: nothing is evaluated)
+	// (an all-zero FP4 entry behind the tables: reads of the haplotype table through a slot of a padding block land here)
 	hap.insert(hap.end(), HIBAG_ENGINE_HAP_DWORDS(HIBAG_ENGINE_FP4), 0u);
 	while (hap.size() % 4) hap.push_back(0u);
 	for (int t = 0; t < n_tile && store_mode != 1; t++) {
@@ -817,15 +817,14 @@ int finalize_model(hibag_hip_model *m)
 					for (int i = 0; i < HIBAG_PLIST_DWORDS; i++) closes += plist[first + (size_t)b * HIBAG_PLIST_DWORDS + i] >> 31;
 				const int nsb = std::max(0, std::min(HIBAG_STORED_PER_VISIT, ns - HIBAG_STORED_PER_VISIT * b));
 				if (c > 0xFFFF) return fail(HIBAG_HIP_EINVAL, "too many classifiers (%d) for the second pass's block headers", C);
-				const bool slots = b < nb;
+				// (pass 2 requests the operand rows of every block it passes, also of blocks that only carry stored sums: a
+				// classifier of the vector engine has no rows -- bt_row[c] is then the NEXT classifier's first row, or one past
+				// the last row of the batch's array for the model's last classifiers: rows 0 and 1 instead)
+				const uint32_t bt = (uint32_t)(HIBAG_ENGINE_ROWS(engine[c], n_snp_c[c]) > 0 ? bt_row[c] : 0);
+				if (bt > 0xFFFFu) return fail(HIBAG_HIP_EINVAL, "too many classifiers for the matrix engine's operand rows");
 				const uint32_t h[8] = {
-					(uint32_t)c | ((uint32_t)(slots ? n_snp_c[c] : 0) << 18) | ((uint32_t)nsb << 25),
-					slots ? hap_off[c] : zero_entry_dword,
-					// (pass 2 requests the operand rows of every block it passes, also of blocks that only carry stored sums: a
-					// classifier of the vector engine has no rows -- bt_row[c] is then the NEXT classifier's first row, or one past
-					// the last row of the batch's array for the model's last classifiers: rows 0 and 1 instead)
-					(uint32_t)(HIBAG_ENGINE_ROWS(engine[c], n_snp_c[c]) > 0 ? bt_row[c] : 0),
-					srow,
+					(uint32_t)c | (bt << 16), srow | ((uint32_t)nsb << 25),
+					0u, 0u,                                   // (the next block's first two words: filled in below)
 					(uint32_t)jp, (uint32_t)(jp >> 32),
 					(uint32_t)jps, 0u};
 				ehdr.insert(ehdr.end(), h, h + 8);
@@ -840,7 +839,7 @@ int finalize_model(hibag_hip_model *m)
 	const uint64_t estream_blocks = plist.size() / HIBAG_PLIST_DWORDS + 4;
 	plist.insert(plist.end(), 4 * HIBAG_PLIST_DWORDS, 0u);
 	ehdr.resize(estream_blocks * 8, 0u);
-	for (uint64_t b = estream_blocks - 4; b < estream_blocks; b++) ehdr[b * 8 + 1] = zero_entry_dword;
+	for (uint64_t b = 0; b + 1 < estream_blocks; b++) { ehdr[b * 8 + 2] = ehdr[(b + 1) * 8]; ehdr[b * 8 + 3] = ehdr[(b + 1) * 8 + 1]; }
 	const uint64_t p1_base = plist.size();
 	std::vector<uint32_t> blk_close;
 	// segments of the classifiers with several K steps (k_total_wide): {classifier, first stored row, blocks} + list offset
@@ -929,6 +928,31 @@ int finalize_model(hibag_hip_model *m)
 		while (n_valid < 32 && (live >> n_valid)) n_valid++;
 		phdr[4 * b] = ends; phdr[4 * b + 1] = stores; phdr[4 * b + 2] = (uint32_t)n_valid;
 	}
+	// Prebuilt A-operand rows (HibagModelView::parow): for every slot of a one-step FP4 classifier the element-wise sum of its
+	// two haplotypes' images -- the "sum" images for the lower K half (lanes 0..31), the "pair" images for the upper one
+	// (lanes 32..63); nibble sums never carry (codes 0..3 + 0..3).  Blocks outside a slot range (padding blocks) stay zero.
+	const size_t n_blocks_all = plist.size() / HIBAG_PLIST_DWORDS;
+	double pre_mb = 128;
+	if (const char *e = getenv("HIBAG_PREBUILT_MB")) pre_mb = atof(e);
+	bool p1_prebuilt = false;
+	{
+		size_t fp4_p1_blocks = 0;
+		for (int c = 0; c < C; c++) if (pass2_evaluates(c)) fp4_p1_blocks += (size_t)cls_nblk[c];
+		p1_prebuilt = fp4_p1_blocks > 0 && (double)(n_blocks_all) * 1024.0 <= pre_mb * 1e6;
+	}
+	const size_t parow_blocks = p1_prebuilt ? n_blocks_all : (size_t)estream_blocks;
+	std::vector<uint32_t> parow(parow_blocks * 256, 0u);
+	for (const SlotRange &r : slot_ranges) {
+		if (!pass2_evaluates(r.c)) continue;
+		const uint32_t *tab_c = hap.data() + hap_off[r.c];
+		for (size_t i = r.first; i < r.first + r.n; i++) {
+			const size_t b = i / HIBAG_PLIST_DWORDS, sl = i % HIBAG_PLIST_DWORDS;
+			if (b >= parow_blocks) break;
+			const uint32_t *e1 = tab_c + (size_t)(plist[i] & 0xFFFFu) * 12, *e2 = tab_c + (size_t)((plist[i] >> 16) & 0x3FFFu) * 12;
+			for (int h = 0; h < 2; h++)
+				for (int d = 0; d < 4; d++) parow[(b * 64 + (size_t)h * 32 + sl) * 4 + d] = e1[4 * h + d] + e2[4 * h + d];
+		}
+	}
 	// per (classifier, tile) record of pass 2 (one s_load_dwordx8)
 	std::vector<uint32_t> ctile((size_t)std::max(C, 1) * n_tile * 8 + 8, 0);
 	for (int c = 0; c < C; c++)
@@ -1004,6 +1028,8 @@ int finalize_model(hibag_hip_model *m)
 	HIP_TRY(hipMemcpy(m->d_pfac.p, pfac.data(), pfac.size() * sizeof(double), hipMemcpyHostToDevice));
 	if (int rc = m->d_phdr.reserve(phdr.size() * sizeof(uint32_t))) return rc;
 	HIP_TRY(hipMemcpy(m->d_phdr.p, phdr.data(), phdr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	if (int rc = m->d_parow.reserve(std::max<size_t>(parow.size(), 256) * sizeof(uint32_t))) return rc;
+	if (!parow.empty()) HIP_TRY(hipMemcpy(m->d_parow.p, parow.data(), parow.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(m->d_tab.p, m->tab, sizeof(m->tab), hipMemcpyHostToDevice));
 
 	HibagModelView &V = m->view;
@@ -1064,6 +1090,9 @@ int finalize_model(hibag_hip_model *m)
 	V.pfac = m->d_pfac.as<double>();
 	V.phdr = m->d_phdr.as<uint32_t>();
 	V.plist_dwords = plist.size();
+	V.parow = m->d_parow.as<uint4>();
+	V.parow_blocks = parow_blocks;
+	V.p1_prebuilt = p1_prebuilt ? 1 : 0;
 	m->bt_rows = bt_rows;
 	V.stream = m->d_stream.as<uint32_t>();
 	V.tab = m->d_tab.as<double>();
@@ -1081,11 +1110,11 @@ int finalize_model(hibag_hip_model *m)
 int batch_limit(const hibag_hip_model *m)
 {
 	const double per_sample = 8.0 * (m->view.n_cell + 3) + 24.0 * m->view.n_classifier +
-		4.0 * m->mask_rows + 4.0 * m->view.n_classifier + 16.0 * m->bt_rows + 8.0 * m->view.n_classifier + 8.0 * m->cell_rows;
+		4.0 * m->mask_rows + 4.0 * m->view.n_classifier + 16.0 * m->bt_rows + 24.0 * m->view.n_classifier + 8.0 * m->cell_rows;
 	double cap = 16e9 / std::max(per_sample, 1.0);
 	// k_accum addresses the operand, weight and 1/total arrays through raw buffers with 32-bit offsets: each stays below 4 GB
 	cap = std::min(cap, 3.5e9 / (16.0 * std::max(m->bt_rows, 1)));
-	cap = std::min(cap, 3.5e9 / (8.0 * std::max(m->view.n_classifier, 1)));
+	cap = std::min(cap, 3.5e9 / (16.0 * std::max(m->view.n_classifier, 1)));     // (winv: 16 bytes per classifier and sample)
 	int lim = (int)std::min(cap, 1e9);
 	lim = std::max(64, std::min(lim, 1 << 17));
 	return lim / 64 * 64;
@@ -1101,6 +1130,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	if (int rc = m->ws_cw.reserve(C * n_pad * sizeof(double))) return rc;
 	if (int rc = m->ws_tot.reserve(C * n_pad * sizeof(double))) return rc;
 	if (int rc = m->ws_inv.reserve(C * n_pad * sizeof(double))) return rc;
+	if (int rc = m->ws_winv.reserve(2 * C * n_pad * sizeof(double))) return rc;
 	if (int rc = m->ws_part.reserve((size_t)(m->view.n_cell + 3) * n_pad * sizeof(double))) return rc;
 	if (int rc = m->ws_codes.reserve((size_t)std::max(m->n_snp, 1) * n_pad)) return rc;
 	// (two rows more than the model has: k_accum reads rows bt and bt + 1 of every block header it passes, whatever the block holds)
@@ -1140,7 +1170,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	B.sync_total = B.sync + 8 * (((size_t)(n_pad / HIBAG_WAVE + 7) / 8 + 3) / 4) * (size_t)std::max(m->view.n_tile, 1);
 	B.n_samp = n_samp; B.n_pad = n_pad;
 	B.masks = m->ws_planes.as<uint32_t>();
-	B.cw = m->ws_cw.as<double>(); B.tot = m->ws_tot.as<double>(); B.inv = m->ws_inv.as<double>();
+	B.cw = m->ws_cw.as<double>(); B.tot = m->ws_tot.as<double>(); B.inv = m->ws_inv.as<double>(); B.winv = m->ws_winv.as<double>();
 	B.part = m->ws_part.as<double>();
 	B.bt = m->ws_bt.as<uint4>(); B.bias = m->ws_bias.as<int>();
 	B.bt_rows = std::max(m->bt_rows, 1) + 2;
@@ -2029,6 +2059,21 @@ int hibag_hip_test_inject_handover_fault(hibag_hip_model *m, int pass)
 	return 0;
 }
 
+// Diagnostic builds of the kernels (-DHIBAG_ACCUM_STAMPS) sum clock differences in the tail of the model's error buffer
+// (entries 2000 .. of the list behind byte 16): read `n` of them and zero them.  All zero with the shipped kernels.
+int hibag_hip_test_read_diag(hibag_hip_model *m, unsigned long long *out, int n)
+{
+	if (!m || !out || n < 0 || n > 40) return fail(HIBAG_HIP_EINVAL, "bad arguments");
+	if (!m->ws_err.p) { for (int i = 0; i < n; i++) out[i] = 0; return 0; }
+	std::lock_guard<std::mutex> g(m->lock);
+	HIP_TRY(hipSetDevice(m->device));
+	HIP_TRY(hipDeviceSynchronize());
+	char *at = m->ws_err.as<char>() + 16 + 8 * 2000;
+	HIP_TRY(hipMemcpy(out, at, (size_t)n * 8, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemset(at, 0, (size_t)n * 8));
+	return 0;
+}
+
 int hibag_hip_model_engine(const hibag_hip_model *m, int classifier, int *engine, int *k_steps)
 {
 	if (!m || !m->finalized) return fail(HIBAG_HIP_ESTATE, "model not finalized");
@@ -2071,6 +2116,10 @@ const PluginTable g_plugin_table = {
 } // namespace
 
 extern "C" const void *hibag_hip_gpu_ext_proc(void) { return &g_plugin_table; }
+
+// predict_avg_prob calls since the last predict_init whose full-width launch could not get all its workgroups resident (the
+// device is shared) and that were therefore repeated on a single workgroup; 0 on a device the process has to itself.
+extern "C" long long hibag_hip_plugin_degraded_calls(void) { return hibag_sample_degraded_calls(); }
 
 // The loop an unmodified HIBAG runs around predict_avg_prob (src/LibHLA.cpp:2362-2411 with :2433-2441), in C like the host's: for
 // every sample one call through the table with its packed genotypes and weights, then BestGuessEnsemble's scan of the posterior

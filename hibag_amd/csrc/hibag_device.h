@@ -193,6 +193,16 @@ struct HibagModelView {
 	// {end-of-cell mask, stored-cell mask, slots worth evaluating, 0}: both wave-uniform, read through the scalar cache
 	const double *pfac;          // [plist_dwords]
 	const uint32_t *phdr;        // [plist_dwords / 32][4]
+	// PREBUILT A-operand rows of the one-step FP4 engine: per block of plist 64 x 16 bytes in lane order -- what lane l would
+	// make of its slot's two haplotype images (their element-wise sum: lanes 0..31 the "sum" images, lanes 32..63 the "pair"
+	// images).  One coalesced 16-byte load per lane replaces the slot-word load, two 16-byte gathers from the haplotype table,
+	// four address instructions and four additions per block -- at 1 KB per block instead of 128 bytes.  Pass 2's E-stream
+	// always has them (its blocks come first in plist); the pass-1 lists of the one-step FP4 classifiers while all of it stays
+	// below HIBAG_PREBUILT_MB (default 128: the DRB1 shape would take 400 MB and every wavefront would stream its
+	// classifier's 4 MB from HBM; those models keep generating their rows from the O(H) table).
+	const uint4 *parow;          // [parow_blocks][64]
+	uint64_t parow_blocks;       // blocks of plist, from its first on, that have rows
+	int p1_prebuilt;             // 1: the pass-1 lists (k_total's FP4 walk) have rows too
 	const uint32_t *ctile;       // [C][n_tile][8]: everything pass 2 needs per (classifier, tile) in one s_load_dwordx8:
 	                             // {engine | k << 2 | #listed cells << 8 | (K steps - 1) << 13 | bt_row << 16    (k: SNPs of the LAST K step), dword offset of the first haplotype-table entry,
 	                             //  pair list dword offset lo/hi, #blocks, first stored row | #stored cells << 27, row list lo/hi}
@@ -212,9 +222,12 @@ struct HibagModelView {
 
 	// E-stream: what pass 2 (k_accum) reads when it evaluates pairs again (store_cells != 1).  Per tile the blocks of
 	// classifier 0, 1, 2 ... that have anything for the tile, back to back -- pair slots in `plist` (32 per block, as in the
-	// pass-1 lists), one 8-dword header per block in `ehdr`:
-	//   [0] classifier | SNPs << 18 | stored sums of this block (0..HIBAG_STORED_PER_VISIT) << 25     [1] dword offset of the classifier's haplotype table
-	//   [2] first B-operand row     [3] first stored-sum row (model-wide numbering, HibagBatchView::cells)
+	// pass-1 lists; the kernel reads their prebuilt rows, `parow`), one 8-dword header per block in `ehdr`:
+	//   [0] classifier | first B-operand row << 16
+	//   [1] first stored-sum row (model-wide numbering, HibagBatchView::cells) | stored sums of this block (0..HIBAG_STORED_PER_VISIT) << 25
+	//   [2], [3] the same two words of the NEXT block of the stream: what the kernel needs to REQUEST a block's per-lane data
+	//            (weight, 1/total, B operand, stored sums) it finds in the header of the block before, so that only two
+	//            headers are alive at a time -- the one in use and the one in flight -- and the loop, unrolled twice, rotates nothing
 	//   [4], [5] tile rows of the cells that CLOSE in this block, 4 bits each, in closing order
 	//   [6] tile rows of the stored sums, 4 bits each
 	// Only one-step FP4 classifiers have pair slots here; the others' blocks carry stored sums only (all slots padding).
@@ -236,6 +249,7 @@ struct HibagBatchView {
 	double *cw;         // [C][n_pad]
 	double *tot;        // [C][n_pad]
 	double *inv;        // [C][n_pad]
+	double *winv;       // [C][n_pad][2] {classifier weight (k_pack), 1/total (pass 1)}: what pass 2 reads per block, in ONE 16-byte load
 	double *cells;      // [n_pad / 64][cell_row[C]][64] the cell sums pass 1 stores
 	double *part;       // [P+3][n_pad]
 	// matrix-core engine: per classifier and sample group the B operand tiles

@@ -362,9 +362,15 @@ template <> struct FactorGroup<4> { typedef f64x4 type; };
 template <> struct FactorGroup<8> { typedef f64x8 type; };
 
 // G = records whose table look-ups are in flight together
+//
+// Where a cell closes the sum does not go back to zero and take the next product on top -- `cell = 0; cell += x` -- it simply
+// STARTS with the next product, `cell = x`: the same value bit for bit (0 + x = x for every x the path can produce: x is +0,
+// positive or NaN, never -0), one instruction instead of three (a move, a multiplication into a temporary, an addition).  Inside a
+// group the choice is part of the branch that closes the cell; across groups and blocks the wave-uniform `fresh` says that the
+// record before closed one (a scalar register; the walk that ends on it materialises the zero).
 template <int G, class Fin>
 __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename FactorGroup<G>::type F, uint32_t endmask, uint32_t storemask, int n_valid,
-	const v16i &D0, const v16i &D1, double &cell, const double *tab_s, Fin &&fin)
+	const v16i &D0, const v16i &D1, double &cell, bool &fresh, const double *tab_s, Fin &&fin)
 {
 	typedef typename FactorGroup<G>::type FG;
 #pragma unroll
@@ -381,58 +387,27 @@ __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename 
 			t[q] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab_s) + off);
 #endif
 		}
-		const double x0 = F[0] * t[0];
+		// the look-ups are waited for HERE (a use of the first one; LDS returns in order, and a scalar load in flight makes it a
+		// wait for everything), and only then are the next group's factors requested: they have this group's arithmetic to arrive
+		asm volatile("" : "+v"(t[0]));
 		__builtin_amdgcn_sched_barrier(0);
 		FG Fn = F;
 #ifndef HIBAG_ABL_NOFAC       // (timing ablation: every group multiplies by the block's first factors)
 		if (g + 1 < 32 / G) Fn = *(ConstPtr<FG>)(fac + G * (g + 1));
 #endif
 		__builtin_amdgcn_sched_barrier(0);
-		cell += x0;
+		if (fresh) { cell = F[0] * t[0]; asm volatile("" : "+v"(cell)); }     // (the asm keeps this a scalar branch, not a select)
+		else cell += F[0] * t[0];
+		fresh = false;
 #pragma unroll
-		for (int q = 1; q < G; q++) {
+		for (int q = 1; q < G; q += 2) {      // cells are padded to an even number of records: only odd positions close one
 			cell += F[q] * t[q];
-			if ((q & 1) && (endmask & (1u << (G * g + q)))) { fin(cell, (storemask & (1u << (G * g + q))) != 0); cell = 0; }
-		}
-		F = Fn;
-	}
-}
-
-// The same with the table look-ups of group g + 1 requested BEFORE group g is added up (pass 2: four wavefronts per SIMD,
-// each of which otherwise sits out an LDS round trip per group of four records).  Look-ups and scalar loads share
-// lgkmcnt, and a pending scalar load turns every wait into lgkmcnt(0): so per group ONE wait -- for this group's
-// look-ups and factors, both requested a group ago -- and behind it the next group's look-ups and factors.
-template <int G, class Fin>
-__device__ __forceinline__ void block_accumulate_ahead(ConstPtr<double> fac, typename FactorGroup<G>::type F, uint32_t endmask, int n_valid,
-	const v16i &D0, const v16i &D1, double &cell, const double *tab_s, Fin &&fin)
-{
-	typedef typename FactorGroup<G>::type FG;
-	auto look_up = [&](int g, double (&t)[G]) {
-#pragma unroll
-		for (int q = 0; q < G; q++) {
-			const int i = G * g + q;
-			const int off = (i & 7) < 4 ? D0[4 * (i >> 3) + (i & 3)] : D1[4 * (i >> 3) + (i & 3)];
-			t[q] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab_s) + off);
-		}
-	};
-	double t[32 / G + 1][G];
-	look_up(0, t[0]);
-#pragma unroll
-	for (int g = 0; g < 32 / G; g++) {
-		if (G * g >= n_valid) break;
-		const double x0 = F[0] * t[g][0];
-		__builtin_amdgcn_sched_barrier(0);
-		FG Fn = F;
-		if (g + 1 < 32 / G) {
-			Fn = *(ConstPtr<FG>)(fac + G * (g + 1));
-			if (G * (g + 1) < n_valid) look_up(g + 1, t[g + 1]);
-		}
-		__builtin_amdgcn_sched_barrier(0);
-		cell += x0;
-#pragma unroll
-		for (int q = 1; q < G; q++) {
-			cell += F[q] * t[g][q];
-			if ((q & 1) && (endmask & (1u << (G * g + q)))) { fin(cell, false); cell = 0; }
+			const bool end = (endmask & (1u << (G * g + q))) != 0;
+			const bool stored = (storemask & (1u << (G * g + q))) != 0;
+			if (q + 1 < G) {
+				if (end) { fin(cell, stored); cell = F[q + 1] * t[q + 1]; }
+				else cell += F[q + 1] * t[q + 1];
+			} else if (end) { fin(cell, stored); fresh = true; }
 		}
 		F = Fn;
 	}
@@ -474,12 +449,63 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // factors group by group inside block_accumulate (which explains how they avoid the table look-ups' waits).  The number
 // of slots worth evaluating follows from the last slot that closes a cell or has a non-zero factor (a zero factor adds
 // +0.0: skipping it is exact).  The lists are padded so that every look-ahead stays in bounds.
-template <int ENG, int G, class Fin>
+// PRE (one-step FP4 only): the A-operand rows are PREBUILT (HibagModelView::parow, 1 KB per block): one coalesced 16-byte load
+// per lane and block, requested a block ahead right behind the matrix instructions that consumed the current rows -- no
+// slot words, no gathers from the haplotype table, no address arithmetic, no additions.
+template <int ENG, int G, bool PRE, class Fin>
 __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at, int nblk, int lane, ListCursor &cur,
 	__amdgpu_buffer_rsrc_t hp, int k, const LaneOperand &T, const WideSrc &wide, const double *tab_s, double &cell, Fin &&fin)
 {
+	static_assert(!PRE || ENG == HIBAG_ENGINE_FP4, "prebuilt rows exist for one-step FP4 classifiers only");
 	if (nblk <= 0) return;
 	typedef typename FactorGroup<G>::type FG;
+	bool fresh = false;                              // block_accumulate: the record before closed a cell
+	ConstPtr<double> fac = as_const(M.pfac) + at;                            // this segment's factors and headers
+	ConstPtr<u32x4> hdr = (ConstPtr<u32x4>)(as_const(M.phdr) + at / HIBAG_PLIST_DWORDS * 4);
+	if (PRE) {
+		const uint64_t blk = at / HIBAG_PLIST_DWORDS;
+		const uint64_t left = (M.parow_blocks - blk) * 1024u;
+		const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void *)(M.parow + blk * 64), 0,
+			left > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left, 0x00020000);
+		const int vo = lane * 16;
+		v4i arow = load_hap_image(pr, (uint32_t)vo);
+		u32x4 H_n = hdr[0];
+		FG F_n = *(ConstPtr<FG>)fac;
+		uint32_t soff = 1024;
+		for (int b = 0; b < nblk; b++) {
+			const u32x4 H = H_n;
+			const FG F = F_n;
+#ifdef HIBAG_ABL_NOEND
+			const uint32_t endmask = 0, storemask = 0;
+#elif defined(HIBAG_ABL_NOSTORE)
+			const uint32_t endmask = H[0], storemask = 0;
+#else
+			const uint32_t endmask = H[0], storemask = H[1];
+#endif
+			const int n_valid = (int)H[2];
+			// (the header is waited for HERE, before the next scalar loads are issued: a wait behind them would be for them too)
+			asm volatile("" :: "s"(n_valid));
+			__builtin_amdgcn_sched_barrier(0);
+			H_n = hdr[b + 1];
+			F_n = *(ConstPtr<FG>)(fac + (size_t)(b + 1) * HIBAG_PLIST_DWORDS);
+			v4i a = arow;
+			asm volatile("" : "+v"(a));                   // (this block's rows have arrived: requested a block ago)
+			if (n_valid > 0) {
+				v16i D0, D1;
+				block_mfma<ENG>(a, v4i{0, 0, 0, 0}, lane, v4i{0, 0, 0, 0}, T, D0, D1);
+				__builtin_amdgcn_sched_barrier(0);
+				arow = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, vo, (int)soff, 0));    // the next block's, behind the instructions that read this one's
+				__builtin_amdgcn_sched_barrier(0);
+				block_own_sample(D0, D1, n_valid);
+				block_accumulate<G>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
+			} else {
+				arow = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, vo, (int)soff, 0));
+			}
+			soff += 1024;
+		}
+		if (fresh) cell = 0;
+		return;
+	}
 	// FP4W: an FP4 classifier of `wide.nstep` K steps; `k` = SNPs of its LAST step, the others have HIBAG_FP4_STEP_SNPS
 	constexpr bool FP4W = ENG == HIBAG_ENGINE_FP4W;
 	const uint32_t ES = FP4W ? 4u * (uint32_t)HIBAG_FP4_ENTRY_DWORDS(wide.nstep)
@@ -495,8 +521,6 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 	const uint64_t left = (M.plist_dwords - at) * 4;
 	const __amdgpu_buffer_rsrc_t pl = __builtin_amdgcn_make_buffer_rsrc((void *)(M.plist + at), 0,
 		left > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left, 0x00020000);
-	ConstPtr<double> fac = as_const(M.pfac) + at;                            // this segment's factors and headers
-	ConstPtr<u32x4> hdr = (ConstPtr<u32x4>)(as_const(M.phdr) + at / HIBAG_PLIST_DWORDS * 4);
 	uint32_t soff = 0;
 	if (cur.at != at) {                              // nothing usable fetched: slot words of blocks 0 and 1
 		cur.idx = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff, 0);
@@ -562,10 +586,11 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 				block_mfma<ENG>(a1, a2, lane, cterm, T, D0, D1);
 			}
 			block_own_sample(D0, D1, n_valid);
-			block_accumulate<G>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, tab_s, fin);
+			block_accumulate<G>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
 		}
 		soff += BB;
 	}
+	if (fresh) cell = 0;
 	cur.at = at + (uint64_t)nblk * HIBAG_PLIST_DWORDS;
 	cur.idx = idx_c; cur.idx_n = idx_n;
 }
@@ -850,7 +875,9 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 			B.masks[(size_t)(row0 + nwp + m) * B.n_pad + s] = mw;
 		}
 	}
-	B.cw[(size_t)c * B.n_pad + s] = (s < B.n_samp && den > 0) ? ((double)num / den) : 0.0;
+	const double cw = (s < B.n_samp && den > 0) ? ((double)num / den) : 0.0;
+	B.cw[(size_t)c * B.n_pad + s] = cw;
+	B.winv[2 * ((size_t)c * B.n_pad + s)] = cw;       // (and beside it, once pass 1 has it, 1/total: what pass 2 reads per block in one load)
 }
 
 // ---------------------------------------------------------------------------
@@ -1045,12 +1072,17 @@ __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, 
 				total += v;
 				asm("" : "+v"(total));                    // keeps the cell end a scalar branch
 			};
-#define CALL(E) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, lane, T);                                       \
+#define CALLX(E, PRE) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, lane, T);                                 \
 			ListCursor cur;                                                                                                \
-			walk_blocks<E, TOTAL_G>(M, M.blk_off[c] + (uint64_t)b0 * HIBAG_PLIST_DWORDS, b1 - b0, lane, cur,                 \
+			walk_blocks<E, TOTAL_G, PRE>(M, M.blk_off[c] + (uint64_t)b0 * HIBAG_PLIST_DWORDS, b1 - b0, lane, cur,            \
 				hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c], T, WideSrc(), tab_s, cell, fin); }
-			if (FP4ONLY) { CALL(HIBAG_ENGINE_FP4) } else { HIBAG_DISPATCH_ENGINE(nkb, CALL) }
+#define CALL(E) CALLX(E, false)
+			// one-step FP4 classifiers of a model small enough for prebuilt A-operand rows walk those (HibagModelView::parow)
+			if (FP4ONLY || nkb == HIBAG_ENGINE_FP4) { if (M.p1_prebuilt) CALLX(HIBAG_ENGINE_FP4, true) else CALLX(HIBAG_ENGINE_FP4, false) }
+			else if (nkb == HIBAG_ENGINE_I8) CALL(HIBAG_ENGINE_I8)
+			else CALL(HIBAG_ENGINE_I8S)
 #undef CALL
+#undef CALLX
 			if (!last) { B.tot[at] = total; B.inv[at] = cell; }
 		} else if (!FP4ONLY) {
 #define CALL(N) total = classifier_total<N>(M, B, c, s, item[1], item[2], item[3], rows, tab_s)
@@ -1062,6 +1094,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, 
 			const double inv = 1 / total;                 // src/LibHLA.cpp:1827 (inf when total == 0)
 			B.tot[at] = total;
 			B.inv[at] = inv;
+			B.winv[2 * at + 1] = inv;                     // (beside the weight k_pack left there: pass 2 reads both in one load)
 			note_infinite_reciprocal(B, c, s, B.cw[at], inv);
 		}
 	}
@@ -1099,13 +1132,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total_wide(HibagModelView 
 	LaneOperand T;
 	load_operand_row<HIBAG_ENGINE_FP4W>(B, M.bt_row[c], c, group, lane, T);
 	ListCursor cur;
-	walk_blocks<HIBAG_ENGINE_FP4W, TOTAL_G>(M, M.wide_seg_off[blockIdx.y], seg[2], lane, cur, hap_rsrc(M, M.hap_off[c]),
+	walk_blocks<HIBAG_ENGINE_FP4W, TOTAL_G, false>(M, M.wide_seg_off[blockIdx.y], seg[2], lane, cur, hap_rsrc(M, M.hap_off[c]),
 		M.n_snp_c[c] - HIBAG_FP4_STEP_SNPS * (wide.nstep - 1), T, wide, tab_s, cell, fin);
 	if (WHOLE) {
 		const size_t at = (size_t)c * B.n_pad + s;
 		const double inv = 1 / total;                 // src/LibHLA.cpp:1827 (inf when total == 0)
 		B.tot[at] = total;
 		B.inv[at] = inv;
+		B.winv[2 * at + 1] = inv;
 		note_infinite_reciprocal(B, c, s, B.cw[at], inv);
 	}
 }
@@ -1132,6 +1166,7 @@ __global__ void k_total_scan(HibagModelView M, HibagBatchView B)
 	for (; i < n; i++) total += rows[(size_t)i * HIBAG_WAVE];
 	B.tot[(size_t)c * B.n_pad + s] = total;
 	B.inv[(size_t)c * B.n_pad + s] = 1 / total;
+	B.winv[2 * ((size_t)c * B.n_pad + s) + 1] = 1 / total;
 	note_infinite_reciprocal(B, c, s, B.cw[(size_t)c * B.n_pad + s], 1 / total);
 }
 
@@ -1204,34 +1239,46 @@ __device__ __forceinline__ void poison_scalars_if_failed(const HibagModelView &M
 //
 // grid = 8 x (n_whole + K * (items per XCD - n_whole)): per XCD first the undivided items, then the others' first
 // chunks, second chunks, ... ("hand-overs" above).
-struct EHeader {
-	uint32_t h0;        // classifier | SNPs << 18 | stored sums << 25
-	uint32_t hap;       // dword offset of the classifier's haplotype table
-	uint32_t bt;        // its first B-operand row
-	uint32_t srow;      // first of the block's stored-sum rows (HibagBatchView::cells)
-	uint32_t jp_lo, jp_hi;   // tile rows of the cells that close in this block, 4 bits each, in closing order
-	uint32_t jps;       // tile rows of the stored sums
-};
-
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ EHeader read_header(u32x8 hv)         // the header's dwords, one scalar load
-{
-	EHeader H;
-	H.h0 = hv[0]; H.hap = hv[1]; H.bt = hv[2]; H.srow = hv[3]; H.jp_lo = hv[4]; H.jp_hi = hv[5]; H.jps = hv[6];
-	return H;
-}
 
+// Diagnostic build (-DHIBAG_ACCUM_STAMPS): where a wavefront's time goes inside pass 2's block loop -- the clock is read at the
+// phase boundaries of a block and the differences are summed per workgroup in LDS, then per launch in the tail of
+// HibagBatchView::err_dev (hibag_hip_test_read_diag).  Costs a drained lgkmcnt per stamp: the sums say where the time is, not
+// how much of it there would be without the stamps.
+#ifdef HIBAG_ACCUM_STAMPS
+#define ACCUM_STAMP_N 8
+#define ACCUM_STAMP(p) do { const unsigned long long now_ = __builtin_readcyclecounter();                                   \
+	if (lane == 0) atomicAdd(&stamp_s[p], now_ - stamp_t); stamp_t = now_; } while (0)
+#else
+#define ACCUM_STAMP(p) do { } while (0)
+#endif
 #ifndef ACCUM_OCC
 #define ACCUM_OCC 5                         // workgroups per CU pass 2 is compiled for (LDS: HIBAG_TILE in hibag_device.h; registers: HIBAG_STORED_PER_VISIT)
 #endif
+
+// What a block needs that is requested a block ahead and is still in use while the NEXT block's is in flight: its header,
+// the end-of-cell masks, its first factors (scalar registers) and the lane's weight and 1/total.  The loop body exists twice
+// (A -> B, B -> A): the two sets take turns, nothing is moved from a "next" register to a "current" one.
+struct AccumAhead {
+	u32x8 hv;           // the E-stream header (hibag_device.h)
+	u32x4 ph;           // {end-of-cell mask, -, slots worth evaluating, -}
+	FactorGroup<ACCUM_G>::type F;   // the first ACCUM_G factors
+	f64x2 winv;         // {weight, 1/total} of the block's classifier for this lane's sample
+};
+
 __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(HibagModelView M, HibagBatchView B, int n_whole, int K)
 {
 	// (pass 2 evaluates one-step FP4 classifiers only: distances up to 2 * 30, the first 64 table entries)
 	__shared__ double tab_s[ACCUM_TAB_N];
 	__shared__ double acc_s[ACCUM_WAVES][HIBAG_TILE][HIBAG_WAVE];
+#ifdef HIBAG_ACCUM_STAMPS
+	__shared__ unsigned long long stamp_s[ACCUM_STAMP_N];
+	if (threadIdx.x < ACCUM_STAMP_N) stamp_s[threadIdx.x] = 0;
+	unsigned long long stamp_t = 0;
+#endif
 
 	// Work item = (XCD, four sample groups, one tile); the four wavefronts of a workgroup take the four groups.
-	// They read the same blocks and the same haplotype-table entries at about the same time, so those
+	// They read the same blocks at about the same time, so those
 	// come from the CU's L1 for three of them.  Workgroups are dealt round-robin over the 8 XCDs, so sample
 	// group g goes to XCD g % 8 with all its tiles: its operands / weights / totals are fetched into one XCD's L2 only.
 	const int n_group = B.n_pad / HIBAG_WAVE;
@@ -1259,6 +1306,9 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 	const int group = (jq * ACCUM_WAVES + wave) * 8 + xcd;
 	unsigned long long *flag = B.sync + (size_t)xcd * n_item_x + item;
 	if (cb > 0) handover_wait(flag, B, (uint32_t)cb);
+#ifdef HIBAG_ACCUM_STAMPS
+	int bb_diag = 0, be_diag = 0;
+#endif
 	if (group < n_group) {
 	const int s = group * HIBAG_WAVE + lane;
 	const int ncell = M.tile_n[tile];
@@ -1277,77 +1327,63 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 
 	const ConstPtr<uint32_t> cst = as_const(M.etile_cstart) + (size_t)tile * (C + 1);
 	const int bb = __builtin_amdgcn_readfirstlane((int)cst[cb]), be = __builtin_amdgcn_readfirstlane((int)cst[ce]);
+#ifdef HIBAG_ACCUM_STAMPS
+	if (wave == 0) { bb_diag = bb; be_diag = be; }
+#endif
 #ifdef HIBAG_ABL2_NOLOOP
 	if (bb < be && B.n_pad < 0) {
 #else
 	if (bb < be) {
 #endif
-		// the tile's blocks [bb, be): the slot words as a raw buffer rebased at block bb (no 4 GB limit on the stream)
+		// the tile's blocks [bb, be): their prebuilt A-operand rows as a raw buffer rebased at block bb (no 4 GB limit on the stream)
 		const uint64_t blk0 = as_const(M.etile_blk0)[tile] + (uint64_t)bb;
-		const uint64_t left_s = (M.plist_dwords - blk0 * HIBAG_PLIST_DWORDS) * 4;
-		const __amdgpu_buffer_rsrc_t pl = __builtin_amdgcn_make_buffer_rsrc((void *)(M.plist + blk0 * HIBAG_PLIST_DWORDS), 0,
-			left_s > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left_s, 0x00020000);
-		const __amdgpu_buffer_rsrc_t hp = hap_rsrc(M, 0);      // the whole haplotype table; a block's classifier enters as the scalar offset
+		auto bytes32 = [](size_t n) { return n > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)(uint32_t)n; };
+		const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void *)(M.parow + blk0 * 64), 0,
+			bytes32((size_t)(M.parow_blocks - blk0) * 1024u), 0x00020000);
 		ConstPtr<double> fac = as_const(M.pfac) + blk0 * HIBAG_PLIST_DWORDS;                 // the slots' frequency factors
 		ConstPtr<u32x4> phdr = (ConstPtr<u32x4>)(as_const(M.phdr) + blk0 * 4);               // the blocks' {end mask, -, slots worth evaluating, -}
-		u32x4 PH_n = phdr[0];
+		ConstPtr<u32x8> eh = (ConstPtr<u32x8>)(as_const(M.ehdr) + blk0 * 8);                 // the blocks' 8-dword headers (scalar loads)
 		typedef FactorGroup<ACCUM_G>::type AFG;
-		AFG F_n = *(ConstPtr<AFG>)fac;
-		// the batch's operand / weight / 1/total rows and this group's stored sums as raw buffers too: a row is then a scalar
+		// the batch's operand / {weight, 1/total} rows and this group's stored sums as raw buffers too: a row is then a scalar
 		// offset (classifier or row number times the row size, SALU) added to one constant per-lane offset -- no 64-bit address
 		// arithmetic on the vector ALU.  (hibag_api.hip batch_limit keeps every one of these arrays below 4 GB.)
 		// (every descriptor ends where its array ends: a request past it -- a look-ahead through a header that names more than
 		// exists -- reads zeros instead of faulting)
-		auto bytes32 = [](size_t n) { return n > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)(uint32_t)n; };
-		const size_t row_bytes = (size_t)B.n_pad * 8u;
 		const __amdgpu_buffer_rsrc_t r_bt = __builtin_amdgcn_make_buffer_rsrc((void *)B.bt, 0, bytes32((size_t)B.bt_rows * B.n_pad * 16u), 0x00020000);
-		const __amdgpu_buffer_rsrc_t r_cw = __builtin_amdgcn_make_buffer_rsrc((void *)B.cw, 0, bytes32((size_t)C * row_bytes), 0x00020000);
-		const __amdgpu_buffer_rsrc_t r_inv = __builtin_amdgcn_make_buffer_rsrc((void *)B.inv, 0, bytes32((size_t)C * row_bytes), 0x00020000);
+		const __amdgpu_buffer_rsrc_t r_wi = __builtin_amdgcn_make_buffer_rsrc((void *)B.winv, 0, bytes32((size_t)C * B.n_pad * 16u), 0x00020000);
 		const __amdgpu_buffer_rsrc_t r_sv = __builtin_amdgcn_make_buffer_rsrc(
 			(void *)(B.cells + (size_t)group * (size_t)as_const(M.cell_row)[C] * HIBAG_WAVE), 0,
 			bytes32((size_t)as_const(M.cell_row)[C] * HIBAG_WAVE * 8u), 0x00020000);
-		const int vo_i = (lane & 31) * 4;
-		const int vo_bt = (group * HIBAG_WAVE + lane) * 16, vo_s = s * 8, vo_sv = lane * 8;
-		const uint32_t bt_stride = (uint32_t)B.n_pad * 16u, s_stride = (uint32_t)B.n_pad * 8u;      // bytes per operand row / per classifier's row
-		constexpr uint32_t ES = 4u * HIBAG_ENGINE_HAP_DWORDS(HIBAG_ENGINE_FP4);      // bytes per table entry: sum image, AND image, ff, f
-		const uint32_t img = (uint32_t)(lane >> 5) * 16u;     // lanes 0..31 fetch the "sum" image of their haplotypes, lanes 32..63 the "AND" image
+		const int vo_a = lane * 16, vo_row = (group * HIBAG_WAVE + lane) * 16, vo_sv = lane * 8;
+		const uint32_t row_stride = (uint32_t)B.n_pad * 16u;          // bytes per operand row and per classifier's {weight, 1/total} row
 		constexpr int NS = HIBAG_STORED_PER_VISIT;
 
-		uint32_t idx_c = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, 0, 0);
-		uint32_t idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, 4 * HIBAG_PLIST_DWORDS, 0);
-		ConstPtr<u32x8> eh = (ConstPtr<u32x8>)(as_const(M.ehdr) + blk0 * 8);                  // the blocks' 8-dword headers (scalar loads)
-		const u32x8 hv_0 = eh[0];
-		EHeader Hc = read_header(hv_0);
-		u32x8 hv_n = eh[1];
-
-		// everything block b needs, requested a block ahead
-		v4i e1, e2;                                   // the lane's images of its haplotype pair
-		v4i t0, t1;                                   // the B operand (two sample halves)
-		double w, inv, sv[NS];
-		auto request = [&](uint32_t idx, const EHeader &H) {
-			const uint32_t o1 = (idx & 0xFFFFu) * ES + img, o2 = ((idx >> 16) & 0x3FFFu) * ES + img;
-			const int so = (int)(H.hap * 4u);
-			const auto i1 = __builtin_amdgcn_raw_buffer_load_b128(hp, (int)o1, so, 0);
-			const auto i2 = __builtin_amdgcn_raw_buffer_load_b128(hp, (int)o2, so, 0);
-			e1 = v4i{(int)i1[0], (int)i1[1], (int)i1[2], (int)i1[3]};
-			e2 = v4i{(int)i2[0], (int)i2[1], (int)i2[2], (int)i2[3]};
-			const int sc = (int)((H.h0 & 0xFFFFu) * s_stride);
+		// per-lane data of the block in hand, requested a block ahead into the registers the block before has just finished with
+		v4i arow, t0, t1;                             // the A-operand row, the B operand (two sample halves)
+		double sv[NS];                                // the stored sums
+		double cell = 0;
+		bool fresh = false;                           // block_accumulate: the record before closed a cell
+		// words 0, 1 of a header (its own, or -- words 2, 3 -- the next block's): classifier | operand row << 16, stored row | stored sums << 25
+		auto request_lane = [&](uint32_t w0, uint32_t w1, int soff_a, f64x2 &winv) {
+			arow = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, vo_a, soff_a, 0));
+			const int sb = (int)((w0 >> 16) * row_stride);
+			t0 = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r_bt, vo_row, sb, 0));
+			t1 = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r_bt, vo_row, sb + (int)row_stride, 0));
 #ifdef HIBAG_ABL2_NOWINV
-			w = 1.0 + sc; inv = 2.0 + sc;
+			winv = f64x2{1.0 + (double)w0, 2.0};
 #else
-			w = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_cw, vo_s, sc, 0));
-			inv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_inv, vo_s, sc, 0));
+			winv = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r_wi, vo_row, (int)((w0 & 0xFFFFu) * row_stride), 0));
 #endif
 #ifdef HIBAG_ABL2_NOSV
 			const int ns = 0;
 #else
-			const int ns = (int)(H.h0 >> 25) & 15;
+			const int ns = (int)(w1 >> 25) & 15;
 #endif
 			if (ns > 0) {
 #ifdef HIBAG_ABL2_SVHOT       // (timing ablation: every stored sum read from the group's first rows -- cache hits instead of HBM)
-				const int sr = (int)((H.srow & 7u) * (uint32_t)(HIBAG_WAVE * 8));
+				const int sr = (int)((w1 & 7u) * (uint32_t)(HIBAG_WAVE * 8));
 #else
-				const int sr = (int)(H.srow * (uint32_t)(HIBAG_WAVE * 8));
+				const int sr = (int)((w1 & 0x1FFFFFFu) * (uint32_t)(HIBAG_WAVE * 8));
 #endif
 #pragma unroll
 				for (int i = 0; i < NS; i++) {
@@ -1356,61 +1392,47 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 				}
 			}
 		};
-		auto request_operand = [&](const EHeader &H) {
-			const int sb = (int)(H.bt * bt_stride);
-			const auto u0 = __builtin_amdgcn_raw_buffer_load_b128(r_bt, vo_bt, sb, 0);
-			const auto u1 = __builtin_amdgcn_raw_buffer_load_b128(r_bt, vo_bt, sb + (int)bt_stride, 0);
-			t0 = v4i{(int)u0[0], (int)u0[1], (int)u0[2], (int)u0[3]};
-			t1 = v4i{(int)u1[0], (int)u1[1], (int)u1[2], (int)u1[3]};
-		};
-		request(idx_c, Hc);
-		request_operand(Hc);
-		double cell = 0;
-		uint32_t soff = 0;                            // byte offset of block b's slot words
-		for (int b = bb; b < be; b++) {
-			// ---- block b: what was requested a block ago has arrived
-			const EHeader Hn = read_header(hv_n);
-			const double w_c = w, inv_c = inv;
+		// One block: `cur` = what it needs (arrived: requested a block ago), `nxt` = where the next block's goes.
+		// Order: the stored sums are added, the matrix instructions issued -- which frees this block's rows, operand and stored
+		// sums' registers -- then EVERYTHING of block b + 1 is requested, and only then the long part, the pairs' accumulation,
+		// runs: it covers every latency.  No load of the loop is waited for with a count: at the top of a block everything in
+		// flight is that block's.
+		auto one_block = [&](const int rel, AccumAhead &cur, AccumAhead &nxt) {
+			const double w_c = cur.winv[0];
 			const bool active = w_c > 0;
-			const bool any = __ballot(active) != 0;       // nobody in the group uses the classifier (src/LibHLA.cpp:2451): nothing to add
+			// (as integers in scalar registers: a bool that lives across the requests below ends up in a vector register and back)
+			const int any = __builtin_amdgcn_readfirstlane(__ballot(active) != 0 ? 1 : 0);   // 0: nobody in the group uses the classifier (src/LibHLA.cpp:2451): nothing to add
 			// inactive lanes (weight 0) must keep their sums: with 1/total replaced by 0 their term is
 			// (cell * 0) * 0 = +0 and a + 0 == a, which spares a select per closed cell
-			const double inv_e = active ? inv_c : 0.0;
-			// the block's header and its first factors through the scalar cache (walk_blocks; the header of block b + 1 is
-			// requested here too: it is first looked at a block later)
-			const u32x4 PH = PH_n;
-			asm volatile("" :: "s"(PH[2]));               // (waited for before the next scalar loads are issued)
+			const double inv_e = active ? cur.winv[1] : 0.0;
+			const uint32_t endmask = cur.ph[0];
+			const int n_valid = (int)cur.ph[2];
+			asm volatile("" :: "s"(n_valid));             // (this block's scalar data is waited for before the next block's is requested)
 			__builtin_amdgcn_sched_barrier(0);
-			PH_n = phdr[b - bb + 1];
-			const uint32_t endmask = PH[0];
-			const int n_valid = (int)PH[2];
-#ifdef HIBAG_ABL2_NOEVAL
-			const bool eval = false;
-#else
-			const bool eval = any && n_valid > 0;
-#endif
-			const AFG F = F_n;
-			F_n = *(ConstPtr<AFG>)(fac + (size_t)(b - bb + 1) * HIBAG_PLIST_DWORDS);
+			nxt.hv = eh[rel + 1];
+			nxt.ph = phdr[rel + 1];
+			nxt.F = *(ConstPtr<AFG>)(fac + (size_t)(rel + 1) * HIBAG_PLIST_DWORDS);
 			// The other three 64-byte lines of block b + 1's factors are touched a block ahead, so that the scalar loads of its
-			// later groups hit the scalar cache (-5 % on the kernel; pass 1, whose groups are twice as long, gains nothing):
-			// one dword each, volatile so that the loads stay HERE, "used" at the end of this block (the compiler waits for them
-			// there, where they are long done; and it knows about them, should it ever have to spill their registers).
+			// later groups hit the scalar cache (-5 % on the kernel): one dword each, volatile so that the loads stay HERE, "used"
+			// at the end of this block (the compiler waits for them there, where they are long done).
 			typedef const volatile __attribute__((address_space(4))) uint32_t *TouchPtr;
-			const TouchPtr touch = (TouchPtr)(uintptr_t)(fac + (size_t)(b - bb + 1) * HIBAG_PLIST_DWORDS);
+			const TouchPtr touch = (TouchPtr)(uintptr_t)(fac + (size_t)(rel + 1) * HIBAG_PLIST_DWORDS);
 			const uint32_t tch0 = touch[16], tch1 = touch[32], tch2 = touch[48];
-			// this block's A operand row: the two images' sum (lower K half) or AND (upper K half)
-			v4i arow;
-#pragma unroll
-			for (int d = 0; d < 4; d++) arow[d] = e1[d] + e2[d];      // sum image / pair image: one add either way
-			// the sums pass 1 stored for this block's classifier:   S[p] += (cell * (1/total)) * w
+			ACCUM_STAMP(0);
+#ifdef HIBAG_ABL2_NOEVAL
+			const int eval = 0;
+#else
+			const int eval = __builtin_amdgcn_readfirstlane(any & (n_valid > 0 ? 1 : 0));
+#endif
+			// ---- the sums pass 1 stored for this block's classifier:   S[p] += (cell * (1/total)) * w
 			{
 #ifdef HIBAG_ABL2_NOSV
 				const int ns = 0;
 #else
-				const int ns = (int)(Hc.h0 >> 25) & 15;
+				const int ns = (int)(cur.hv[1] >> 25) & 15;
 #endif
 				if (any && ns > 0) {
-					uint32_t jps = Hc.jps;
+					uint32_t jps = cur.hv[6];
 #pragma unroll
 					for (int i = 0; i < NS; i++) {
 						if (i >= ns) break;
@@ -1420,15 +1442,8 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 				}
 			}
 			__builtin_amdgcn_sched_barrier(0);
-			// ---- requests: block b + 1 (all but its B operand), slot words and header of block b + 2 -- before anything of
-			// block b is evaluated, so that the whole evaluation covers their latency
-			idx_c = idx_n;
-			request(idx_c, Hn);
-			idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + 2 * 4 * HIBAG_PLIST_DWORDS, 0);
-			hv_n = eh[b - bb + 2];
-			__builtin_amdgcn_sched_barrier(0);
-			// ---- block b: distances on the matrix pipe; behind the two instructions the next block's B operand is requested
-			// into the registers they have just read
+			ACCUM_STAMP(1);
+			// ---- distances on the matrix pipe (their operands have arrived with everything else of the block)
 			v16i D0, D1;
 			if (eval) {
 				v16f d0, d1;
@@ -1444,12 +1459,19 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 				D1 = __builtin_bit_cast(v16i, d1);
 			}
 			__builtin_amdgcn_sched_barrier(0);
-			request_operand(Hn);
+			ACCUM_STAMP(2);
+			// ---- everything of block b + 1, into the registers this block has finished with
+			request_lane(cur.hv[2], cur.hv[3], (rel + 1) * 1024, nxt.winv);
 			__builtin_amdgcn_sched_barrier(0);
+			ACCUM_STAMP(3);
 			// ---- every lane its own sample's distances, then cell += prod * TAB[d] in order
 			if (eval) {
 				block_own_sample(D0, D1, n_valid);
-				uint64_t jpack = ((uint64_t)Hc.jp_hi << 32) | Hc.jp_lo;
+#ifdef HIBAG_ACCUM_STAMPS
+				asm volatile("" :: "v"(D0[0]), "v"(D1[0]));
+				ACCUM_STAMP(4);
+#endif
+				uint64_t jpack = ((uint64_t)cur.hv[5] << 32) | cur.hv[4];
 				// S[p] += v as one LDS floating-point add (ds_add_f64: the same IEEE addition, no register for the old
 				// sum, nothing to wait for)
 				auto fin = [&](double c, bool) {
@@ -1457,16 +1479,28 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 					__hip_atomic_fetch_add(&acc[(int)(jpack & 15)][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					jpack >>= 4;
 				};
-#ifdef HIBAG_ACCUM_AHEAD
-				block_accumulate_ahead<ACCUM_G>(fac + (size_t)(b - bb) * HIBAG_PLIST_DWORDS, F, endmask, n_valid, D0, D1, cell, tab_s, fin);
-#else
-				block_accumulate<ACCUM_G>(fac + (size_t)(b - bb) * HIBAG_PLIST_DWORDS, F, endmask, 0u, n_valid, D0, D1, cell, tab_s, fin);
-#endif
+				block_accumulate<ACCUM_G>(fac + (size_t)rel * HIBAG_PLIST_DWORDS, cur.F, endmask, 0u, n_valid, D0, D1, cell, fresh, tab_s, fin);
 			}
 			asm volatile("" :: "s"(tch0), "s"(tch1), "s"(tch2));
-			Hc = Hn;
-			soff += 4 * HIBAG_PLIST_DWORDS;
+			ACCUM_STAMP(5);
+		};
+
+		AccumAhead A, Bn;
+		A.hv = eh[0];
+		A.ph = phdr[0];
+		A.F = *(ConstPtr<AFG>)fac;
+		request_lane(A.hv[0], A.hv[1], 0, A.winv);
+#ifdef HIBAG_ACCUM_STAMPS
+		stamp_t = __builtin_readcyclecounter();
+#endif
+		const int nb = be - bb;
+		for (int rel = 0;;) {
+			one_block(rel, A, Bn);
+			if (++rel >= nb) break;
+			one_block(rel, Bn, A);
+			if (++rel >= nb) break;
 		}
+		// (a walk that ends on a closed cell leaves `cell` unused: nothing to materialise -- every cell of a tile closes inside the tile's stream)
 	}
 
 	// the item's sums, or -- parked -- what the workgroup behind continues from
@@ -1475,6 +1509,12 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 	// order): one kernel and its launch gap less on the step.
 	if (tile == 0 && ce == C) ensemble_scalars(M, B, s, nullptr);
 	}
+#ifdef HIBAG_ACCUM_STAMPS
+	__syncthreads();
+	if (threadIdx.x < ACCUM_STAMP_N)
+		atomicAdd(reinterpret_cast<unsigned long long *>(B.err_dev + 4) + 2000 + threadIdx.x, stamp_s[threadIdx.x]);
+	if (threadIdx.x == ACCUM_STAMP_N) atomicAdd(reinterpret_cast<unsigned long long *>(B.err_dev + 4) + 2000 + ACCUM_STAMP_N, (unsigned long long)(be_diag - bb_diag) * ACCUM_WAVES);
+#endif
 	if (ce < C) handover_post(flag, B.epoch, (uint32_t)ce, B.drop_post == 2 && blockIdx.x == 8 * n_whole);
 }
 
@@ -1633,7 +1673,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WIDE ? 3 : VOTE_OCC) void k_vote_bes
 #define CALL(E) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, threadIdx.x & 63, T);                           \
 		ListCursor cur;                                                                                                \
 		double cell = 0;                                                                                               \
-		walk_blocks<E, TOTAL_G>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), k_last,         \
+		walk_blocks<E, TOTAL_G, false>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), k_last,  \
 			T, wide, tab_s, cell, fin); }
 		if (WIDE) { CALL(HIBAG_ENGINE_FP4W) } else { HIBAG_DISPATCH_ENGINE(nkb, CALL) }
 #undef CALL

@@ -35,6 +35,7 @@ struct PluginTable {                // TypeGPUExtProc, LibHLA_ext.h:358-388
 void hibag_sample_init(int n_hla, int n_classifier, const PluginHaplotype *const p_haplo[], const int n_haplo[], const int n_snp[]);
 void hibag_sample_avg_prob(const PluginGenotype geno[], const double weight[], double out_prob[], double out_match[]);
 void hibag_sample_done();
+long long hibag_sample_degraded_calls();   // calls of the current predict_init that had to be repeated on one workgroup (shared device)
 
 // training-side entries (hibag_build.hip); failures throw `const char *` like the
 // predict entries (the host's CORE_CATCH turns that into an R error, src/HIBAG.cpp:41-60)

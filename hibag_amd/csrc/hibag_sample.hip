@@ -55,6 +55,7 @@ struct OneView {
 	int n_hla, n_cell, n_classifier;
 	int stamps_on;                  // diagnostic (HIBAG_ONE_STAMPS): workgroup 0 stamps its phases
 	int n_group;                    // workgroups of a launch: min(classifiers, what the device holds at once) -- they meet at a barrier
+	unsigned spin_limit;            // polls at that barrier before a workgroup gives up and reports the call as not done
 	const OneCls *cls;              // [C]
 	const uint64_t *bits;           // [n_haplo_total][2] packed haplotypes, bits >= the classifier's SNP count cleared
 	const uint32_t *pair;           // per pair: first | second << 16 (classifier-local haplotype indices)
@@ -225,7 +226,8 @@ __global__ __launch_bounds__(ONE_THREADS) void k_one(OneView V, uint32_t seq, un
 		int ok = 1;
 		while (__hip_atomic_load(V.arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
 			__builtin_amdgcn_s_sleep(2);
-			if (++spins > (1u << 24)) { ok = 0; break; }                  // (seconds: something else holds the device's CUs)
+			if (++spins > V.spin_limit) { ok = 0; break; }                // (tenths of a second: something else holds the device's CUs --
+			                                                              //  the host then runs the call again on ONE workgroup, which needs nobody)
 		}
 		ok_s = ok;
 	}
@@ -303,13 +305,18 @@ __global__ __launch_bounds__(ONE_THREADS) void k_one(OneView V, uint32_t seq, un
 		pt += PT;
 	} while (pt < p_hi);
 	STAMP(7);
-	// ---- the last workgroup to have its outputs in host memory reports the call
+	// ---- the last workgroup to have its outputs in host memory reports the call.  The chain the host relies on is a formal one:
+	// every workgroup's output stores happen-before its release increment of `finished` (the workgroup barrier in between makes
+	// the other wavefronts' stores thread 0's to release), the last workgroup's increment acquires all of them (a release sequence
+	// on the counter), and its release store of the sequence number at system scope pairs with the host's acquire load of the flag.
+	// (The stores themselves already went past the caches -- system-scope write-through -- so the releases have next to nothing to
+	// write back.)
 	stores_done();
 	__syncthreads();
 	STAMP(10);
 	if (tid == 0) {
-		const unsigned long long n = __hip_atomic_fetch_add(V.finished, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (n + 1 == call * (unsigned long long)G) __hip_atomic_store((uint32_t *)V.flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		const unsigned long long n = __hip_atomic_fetch_add(V.finished, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		if (n + 1 == call * (unsigned long long)G) __hip_atomic_store((uint32_t *)V.flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
 
@@ -324,6 +331,9 @@ struct OneState {
 	hipStream_t st = nullptr;
 	uint32_t seq = 0;
 	unsigned long long calls = 0;                         // launches so far (the barrier counters count n_group arrivals per launch)
+	int n_group_full = 1;                                 // workgroups of a launch while the device is this process's alone
+	bool counters_stale = false;                          // a launch failed or timed out: the device counters are zeroed before the next one
+	long long degraded_calls = 0;                         // calls that had to be repeated on one workgroup (hibag_sample_degraded_calls)
 };
 OneState g1;
 thread_local char g1_msg[400];
@@ -475,12 +485,16 @@ void hibag_sample_init(int n_hla, int n_classifier, const PluginHaplotype *const
 	ONE_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hibag_selected_device()), "hipDeviceGetAttribute");
 	ONE_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_one, ONE_THREADS, 0), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
 	if (per_cu < 1 || cus < 1) one_throw("predict_init: the per-sample kernel does not fit the device");
-	V.n_group = std::max(1, std::min(C, per_cu * cus));
+	V.n_group = g1.n_group_full = std::max(1, std::min(C, per_cu * cus));
+	// ~2^21 polls of ~0.1 us: a fifth of a second.  (HIBAG_ONE_SPIN: tests shorten it to provoke the fall-back.)
+	V.spin_limit = getenv("HIBAG_ONE_SPIN") ? (unsigned)std::max(0, atoi(getenv("HIBAG_ONE_SPIN"))) : (1u << 21);
 	V.stamps_on = getenv("HIBAG_ONE_STAMPS") != nullptr;
 	g1.P = P; g1.C = C; g1.device = hibag_selected_device();
-	g1.seq = 0; g1.calls = 0;
+	g1.seq = 0; g1.calls = 0; g1.counters_stale = false; g1.degraded_calls = 0;
 	g1.active = true;
 }
+
+long long hibag_sample_degraded_calls() { return g1.degraded_calls; }
 
 // predict_avg_prob(geno[nClassifier], weight[nClassifier], out_prob[P], out_match[1]): src/LibHLA.cpp:2433-2441
 void hibag_sample_avg_prob(const PluginGenotype geno[], const double weight[], double out_prob[], double out_match[])
@@ -496,24 +510,55 @@ void hibag_sample_avg_prob(const PluginGenotype geno[], const double weight[], d
 	ONE_OK(hipSetDevice(g1.device), "hipSetDevice");
 	memcpy(h, geno, (size_t)C * sizeof(PluginGenotype));
 	memcpy(h + g1.o_w, weight, (size_t)C * 8);
-	const uint32_t seq = g1.seq = g1.seq % 0x7FFFFFFEu + 1;                // 1 .. 2^31 - 2: never the flag's initial value, top bit free
-	hipLaunchKernelGGL(k_one, dim3(g1.V.n_group), dim3(ONE_THREADS), 0, g1.st, g1.V, seq, ++g1.calls);
-	ONE_OK(hipGetLastError(), "launch");
-	// the last workgroup to finish stores the call's sequence number in host memory: poll it (sooner than the runtime's
-	// completion signal); after a second without it, ask the runtime what happened
 	volatile uint32_t *flag = (volatile uint32_t *)(h + g1.o_flag);
-	const auto t0 = std::chrono::steady_clock::now();
-	for (unsigned spins = 0; (*flag & 0x7FFFFFFFu) != seq; spins++) {
-		_mm_pause();
-		if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) {
-			ONE_OK(hipStreamSynchronize(g1.st), "predict_avg_prob");
-			if ((*flag & 0x7FFFFFFFu) != seq) { g1.active = false; one_throw("predict_avg_prob: the kernel finished without reporting the call"); }
+	// One launch of `groups` workgroups and the wait for its report.  Returns false when the launch's workgroups did not all
+	// become resident within the barrier's budget (the kernel's word, top bit of the flag); throws on anything the runtime
+	// reports.  Whatever goes wrong leaves `counters_stale` set, so that the next launch -- of this call or of a later one --
+	// starts from zeroed device counters: a failure never outlives the call it happened in.
+	auto run = [&](int groups) -> bool {
+		if (g1.counters_stale) {
+			ONE_OK(hipStreamSynchronize(g1.st), "predict_avg_prob (draining a failed launch)");     // its workgroups may still be giving up
+			ONE_OK(hipMemsetAsync(g1.V.arrived, 0, 16, g1.st), "hipMemsetAsync(counters)");
+			g1.calls = 0;
 		}
+		g1.counters_stale = true;                                          // until this launch has reported
+		const uint32_t seq = g1.seq = g1.seq % 0x7FFFFFFEu + 1;            // 1 .. 2^31 - 2: never the flag's initial value, top bit free
+		OneView V = g1.V;
+		V.n_group = groups;
+		hipLaunchKernelGGL(k_one, dim3(groups), dim3(ONE_THREADS), 0, g1.st, V, seq, g1.calls + 1);
+		ONE_OK(hipGetLastError(), "launch");
+		g1.calls++;                                                        // (only a launch that happened counts)
+		// the last workgroup to finish stores the call's sequence number in host memory: poll it (sooner than the runtime's
+		// completion signal) with acquire loads -- they pair with the kernel's release store, so the posterior read below is
+		// ordered behind it; after a second without it, ask the runtime what happened
+		const auto t0 = std::chrono::steady_clock::now();
+		uint32_t f;
+		for (unsigned spins = 0; ((f = __atomic_load_n((const uint32_t *)flag, __ATOMIC_ACQUIRE)) & 0x7FFFFFFFu) != seq; spins++) {
+			_mm_pause();
+			if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) {
+				ONE_OK(hipStreamSynchronize(g1.st), "predict_avg_prob");
+				if (((f = __atomic_load_n((const uint32_t *)flag, __ATOMIC_ACQUIRE)) & 0x7FFFFFFFu) != seq)
+					one_throw("predict_avg_prob: the kernel finished without reporting the call");
+				break;
+			}
+		}
+		if (f & 0x80000000u) return false;
+		g1.counters_stale = false;
+		return true;
+	};
+	// The full launch meets at a barrier over its workgroups, which therefore must all be resident at once.  The runtime
+	// cannot promise that on a shared device (another stream or process may hold compute units), so a launch whose
+	// workgroups gave up waiting is not an error: the call is run again on ONE workgroup -- slower (the classifiers one after
+	// the other), but it waits for nobody -- and so are the next calls, until one in `ONE_RETRY_FULL` tries the full width again.
+	constexpr long long ONE_RETRY_FULL = 64;
+	const bool try_full = g1.degraded_calls == 0 || g1.degraded_calls % ONE_RETRY_FULL == 0;
+	if (!(try_full && run(g1.n_group_full))) {
+		g1.degraded_calls++;
+		if (!run(1)) one_throw("predict_avg_prob: a single-workgroup launch reported a barrier time-out");      // (cannot happen: one arrival)
+	} else if (g1.degraded_calls > 0) {
+		g1.degraded_calls = 0;                                             // the device is ours again
 	}
-	if (*flag & 0x80000000u) {
-		g1.active = false;                                                 // (the barrier counters are out of step now: predict_init again)
-		one_throw("predict_avg_prob: the workgroups of the call did not all become resident (the device is shared with another long-running kernel)");
-	}
+	const uint32_t seq = g1.seq;
 	static const bool show = getenv("HIBAG_ONE_STAMPS") != nullptr;        // diagnostic: where a call's device time goes
 	if (show && seq >= 100 && seq < 104) {
 		const unsigned long long *t = (const unsigned long long *)(h + g1.o_stamps);

@@ -40,6 +40,7 @@ struct Rccl {
 	void *lib = nullptr;
 	decltype(&ncclCommInitAll) CommInitAll = nullptr;
 	decltype(&ncclCommDestroy) CommDestroy = nullptr;
+	decltype(&ncclCommAbort) CommAbort = nullptr;
 	decltype(&ncclAllReduce) AllReduce = nullptr;
 	decltype(&ncclGroupStart) GroupStart = nullptr;
 	decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -60,6 +61,7 @@ const Rccl *rccl()
 		if (!r.lib) return;
 		r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
 		r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+		r.CommAbort = (decltype(r.CommAbort))dlsym(r.lib, "ncclCommAbort");
 		r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
 		r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
 		r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
@@ -100,6 +102,7 @@ struct hibag_hip_shard_group {
 	int32_t *d_h1 = nullptr, *d_h2 = nullptr;
 	double *d_prob = nullptr, *d_match = nullptr, *d_dos = nullptr, *d_pp = nullptr;
 	int64_t allreduces = 0, retried = 0;
+	bool broken = false;            // a collective failed half-way: the communicators were aborted, the group serves no further call
 	std::mutex lock;
 
 	~hibag_hip_shard_group()
@@ -107,8 +110,8 @@ struct hibag_hip_shard_group {
 		const Rccl *R = rccl();
 		for (Rank &r : ranks) {
 			(void)hipSetDevice(r.device);
-			if (r.st) (void)hipStreamSynchronize(r.st);
-			if (r.comm && R) (void)R->CommDestroy(r.comm);
+			if (r.st && !broken) (void)hipStreamSynchronize(r.st);
+			if (r.comm && R) (void)R->CommDestroy(r.comm);          // (aborted communicators were set to null)
 			for (void *p : {(void *)r.d_geno, (void *)r.d_part, (void *)r.d_tmp}) if (p) (void)hipFree(p);
 			if (r.st) (void)hipStreamDestroy(r.st);
 		}
@@ -125,6 +128,8 @@ int run_batch(hibag_hip_shard_group *g, const int32_t *geno, int n, int32_t *H1,
 {
 	const Rccl *R = rccl();
 	const size_t P = (size_t)g->n_hla * (g->n_hla + 1) / 2, n_pad = ((size_t)n + 63) / 64 * 64, cnt = (P + 3) * n_pad;
+	// Every shard's partial pass is enqueued BEFORE any rank joins the collective: a pass that cannot be enqueued (an error
+	// code from the entry) ends the batch while no stream holds an all-reduce that its peers would never join.
 	for (Rank &r : g->ranks) {
 		HIP_OK(hipSetDevice(r.device));
 		HIP_OK(hipMemcpyAsync(r.d_geno, geno, (size_t)n * g->n_snp * sizeof(int32_t), hipMemcpyHostToDevice, r.st));
@@ -136,13 +141,25 @@ int run_batch(hibag_hip_shard_group *g, const int32_t *geno, int n, int32_t *H1,
 			first = false;
 		}
 	}
-	// the posterior merge: ONE all-reduce of [P + 3][n_pad] doubles over the devices (xGMI)
-	NCCL_OK(R->GroupStart());
+	// the posterior merge: ONE all-reduce of [P + 3][n_pad] doubles over the devices (xGMI).  A failure in here may leave
+	// some ranks' streams waiting in a collective the others never joined: the communicators are aborted (which releases
+	// those streams) and the group is marked unusable -- the caller must not synchronise on it and gets the error code.
+	auto collective_failed = [&](const char *what, ncclResult_t e) {
+		const int rc = hibag_fail(HIBAG_HIP_ENODEV, "RCCL: %s: %s (the shard group is unusable from here on)", what, R->GetErrorString(e));
+		g->broken = true;
+		for (Rank &r : g->ranks) {
+			if (r.comm && R->CommAbort) { (void)R->CommAbort(r.comm); r.comm = nullptr; }
+		}
+		return rc;
+	};
+	ncclResult_t e = R->GroupStart();
+	if (e != ncclSuccess) return collective_failed("ncclGroupStart", e);
 	for (Rank &r : g->ranks) {
-		ncclResult_t e = R->AllReduce(r.d_part, r.d_part, cnt, ncclDouble, ncclSum, r.comm, r.st);
-		if (e != ncclSuccess) { (void)R->GroupEnd(); return hibag_fail(HIBAG_HIP_ENODEV, "RCCL: ncclAllReduce: %s", R->GetErrorString(e)); }
+		e = R->AllReduce(r.d_part, r.d_part, cnt, ncclDouble, ncclSum, r.comm, r.st);
+		if (e != ncclSuccess) { (void)R->GroupEnd(); return collective_failed("ncclAllReduce", e); }
 	}
-	NCCL_OK(R->GroupEnd());
+	e = R->GroupEnd();
+	if (e != ncclSuccess) return collective_failed("ncclGroupEnd", e);
 	g->allreduces++;
 	Rank &r0 = g->ranks[0];
 	HIP_OK(hipSetDevice(r0.device));
@@ -259,6 +276,7 @@ int hibag_hip_shard_group_predict(hibag_hip_shard_group *g, const int32_t *geno,
 	if (n_samp > 0 && !geno) return hibag_fail(HIBAG_HIP_EINVAL, "geno is NULL");
 	if ((H1 == nullptr) != (H2 == nullptr)) return hibag_fail(HIBAG_HIP_EINVAL, "H1 and H2 must be given together");
 	std::lock_guard<std::mutex> lk(g->lock);
+	if (g->broken) return hibag_fail(HIBAG_HIP_ESTATE, "the shard group's communicators were aborted after a failed collective: create a new group");
 	int dev0 = 0;
 	(void)hipGetDevice(&dev0);
 	const size_t P = (size_t)g->n_hla * (g->n_hla + 1) / 2;
@@ -269,7 +287,8 @@ int hibag_hip_shard_group_predict(hibag_hip_shard_group *g, const int32_t *geno,
 			rc = run_batch(g, geno + (size_t)s0 * g->n_snp, n, H1 ? H1 + s0 : nullptr, H2 ? H2 + s0 : nullptr, max_prob ? max_prob + s0 : nullptr,
 				matching ? matching + s0 : nullptr, dosage ? dosage + (size_t)s0 * g->n_hla : nullptr, postprob ? postprob + (size_t)s0 * P : nullptr);
 			if (rc) {                                                  // nothing of a failed batch may still be running when the caller's buffers go away
-				for (Rank &r : g->ranks) { (void)hipSetDevice(r.device); (void)hipStreamSynchronize(r.st); }
+				// (not after an aborted collective: the abort released the streams, and what they held is void)
+				if (!g->broken) for (Rank &r : g->ranks) { (void)hipSetDevice(r.device); (void)hipStreamSynchronize(r.st); }
 				break;
 			}
 			// a failed hand-over on any shard poisoned the merged sums of every rank: the shard now launches without

@@ -184,6 +184,9 @@ int64_t hibag_hip_model_handover_faults(const hibag_hip_model *m);
 /* Fault injection for the tests of the above: the next batch on the model drops the first hand-over of pass `pass`
  * (1 or 2; 0 = disarm) and uses a short time-out.  Not for production use. */
 int hibag_hip_test_inject_handover_fault(hibag_hip_model *m, int pass);
+/* Diagnostic kernel builds only (-DHIBAG_ACCUM_STAMPS): the clock sums of pass 2's block phases since the last call
+ * (n <= 40 values; all zero with the shipped kernels). */
+int hibag_hip_test_read_diag(hibag_hip_model *m, unsigned long long *out, int n);
 
 /* How classifier `classifier` of a finalized model computes its distances: *engine = HIBAG_HIP_ENGINE_VALU (bit logic +
  * popcount on the vector ALU), _FP4 (v_mfma_scale_f32_32x32x64_f8f6f4, *k_steps instructions per sample half and
@@ -308,12 +311,16 @@ hibag_hip_trainer *hibag_hip_trainer_new(int n_snp, int n_samp, const int32_t *s
 	const int32_t *H1, const int32_t *H2);
 void hibag_hip_trainer_free(hibag_hip_trainer *t);
 
-/* Host threads the trainer fits the candidate SNPs of a growth step on (the EM of
- * CAlg_EM::ExpectationMaximization, src/LibHLA.cpp:1185-1255, runs on the host: its log() must be the
- * host libm's for bit equality with stored models).  Default: the CPUs the process may use (affinity
- * mask, cgroup quota) divided by LOCAL_WORLD_SIZE, so that the ranks of one node -- one process per GPU --
- * share the host instead of oversubscribing it; HIBAG_TRAIN_THREADS overrides the default, n_threads <= 0
- * restores it.  The counterpart of HIBAG_NewClassifiers' `nthread` (src/HIBAG.cpp:599-634). */
+/* Host threads of the trainer: they pack, reduce and -- in EM mode 1 -- fit the candidate SNPs of a growth step
+ * (CAlg_EM::ExpectationMaximization, src/LibHLA.cpp:1185-1255).  The count also SELECTS THE EM ROUTE while the mode is
+ * automatic (hibag_hip_trainer_set_em_mode 0, the default; HIBAG_TRAIN_EM=host|device overrides): a trainer with two
+ * threads or fewer -- what a torchrun rank on a small quota gets, or a caller passing 1 -- fits on the device, one
+ * with more on its threads.  Both routes give the same classifiers bit for bit (the device decides the stopping test
+ * with a margin for its own log() and hands the candidates it cannot decide back to a host thread).
+ * Default: the CPUs the process may use (affinity mask, cgroup quota) divided by LOCAL_WORLD_SIZE, so that the ranks of
+ * one node -- one process per GPU -- share the host instead of oversubscribing it; HIBAG_TRAIN_THREADS overrides the
+ * default, n_threads <= 0 restores it.  The counterpart of HIBAG_NewClassifiers' `nthread` (src/HIBAG.cpp:599-634),
+ * whose default in hlaAttrBagging is 1 (R/HIBAG.R:48-52): a deviation, see hibag_amd/train.py. */
 int hibag_hip_trainer_set_threads(hibag_hip_trainer *t, int n_threads);
 int hibag_hip_trainer_threads(const hibag_hip_trainer *t);
 /* Where the EM fits of a growth step's candidate SNPs run (CAlg_EM::ExpectationMaximization, src/LibHLA.cpp:1185-1255):
@@ -397,6 +404,13 @@ int hibag_hip_measure_issue_costs(double *fp64_op_ns, double *mfma_i8_ns, double
  * reference's single staging buffer (gpu_geno_buf, src/LibHLA.h:680), which is why the host must
  * call with nthread = 1. */
 const void *hibag_hip_gpu_ext_proc(void);
+
+/* predict_avg_prob is ONE kernel whose workgroups meet at a barrier, so they must all be resident at once.  On a device the
+ * process shares (another stream, another process, a profiler) that cannot be promised: a launch whose workgroups give up
+ * waiting (a fifth of a second) is repeated on a single workgroup, which waits for nobody -- same results, slower -- and so
+ * are the following calls, with the full width tried again every 64th.  Returns how many calls since the last predict_init
+ * took that route in a row (0: the device is the process's own). */
+long long hibag_hip_plugin_degraded_calls(void);
 
 /* The loop an unmodified HIBAG runs around predict_avg_prob (src/LibHLA.cpp:2362-2411, :2433-2441), compiled like the host's:
  * n_samp calls through the table -- geno: TGenotype [n_samp][n_classifier] (48 bytes each), weight [n_samp][n_classifier] --

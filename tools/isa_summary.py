@@ -18,7 +18,8 @@ for f in sorted(os.listdir(SRC)):
     if not f.endswith(".hip"):
         continue
     with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
-        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + sys.argv[1:] + [os.path.join(SRC, f), "-o", tmp.name], check=True, stderr=subprocess.DEVNULL)
+        extra = ["-mllvm", "-structurizecfg-skip-uniform-regions"] if f == "hibag_kernels.hip" else []      # (the Makefile's KFLAGS)
+        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + extra + sys.argv[1:] + [os.path.join(SRC, f), "-o", tmp.name], check=True, stderr=subprocess.DEVNULL)
         lines = open(tmp.name).read().split("\n")
     meta = {}
     blk = None                                   # one "- .agpr_count: ..." entry of amdhsa.kernels (keys in alphabetical order)
