@@ -12,8 +12,8 @@ from .hibag import (HlaAlleleClass, HlaAttrBagClass, hlaClose, hlaModelFromObj, 
                     hlaPredict, hlaSetKernelTarget)
 from .snpmatch import hlaGenoSwitchStrand, hlaSNPID  # noqa: F401
 from .bed import HlaBEDGeno, hlaBED2Geno, hlaLociInfo  # noqa: F401
-from .train import (RRandom, hlaAllele, hlaAttrBagging, hlaParallelAttrBagging, hlaUniqueAllele,  # noqa: F401
-                    set_seed)
+from .train import (RRandom, hlaAllele, hlaAttrBagging, hlaConcurrentAttrBagging, hlaParallelAttrBagging,  # noqa: F401
+                    hlaUniqueAllele, set_seed)
 from .merge import hlaAlleleDigit, hlaPredMerge  # noqa: F401
 from .evaluate import (hlaAlleleSubset, hlaCompareAllele, hlaFlankingSNP, hlaGenoSubset, hlaSplitAllele,  # noqa: F401
                        r_sample)
@@ -22,6 +22,6 @@ from ._lib import HibagHipError  # noqa: F401
 __all__ = ["engine_kind", "engine_nkb", "engine_steps", "NA_INTEGER", "Classifier", "HlaAttrBagObj", "HlaSNPGeno", "load_geno", "load_model", "model_to_robj", "save_model",
            "HlaAlleleClass", "HlaAttrBagClass", "hlaClose", "hlaModelFromObj", "hlaModelToObj",
            "hlaPredict", "hlaSetKernelTarget", "hlaGenoSwitchStrand", "hlaSNPID", "HibagHipError",
-           "HlaBEDGeno", "hlaBED2Geno", "hlaLociInfo", "RRandom", "hlaAllele", "hlaAttrBagging", "hlaParallelAttrBagging", "hlaUniqueAllele", "hlaAlleleDigit", "hlaPredMerge", "hlaAlleleSubset", "hlaCompareAllele", "hlaFlankingSNP", "hlaGenoSubset",
+           "HlaBEDGeno", "hlaBED2Geno", "hlaLociInfo", "RRandom", "hlaAllele", "hlaAttrBagging", "hlaConcurrentAttrBagging", "hlaParallelAttrBagging", "hlaUniqueAllele", "hlaAlleleDigit", "hlaPredMerge", "hlaAlleleSubset", "hlaCompareAllele", "hlaFlankingSNP", "hlaGenoSubset",
            "hlaSplitAllele", "r_sample",
            "set_seed"]

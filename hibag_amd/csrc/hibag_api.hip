@@ -198,7 +198,7 @@ struct hibag_hip_model {
 	size_t stream_bytes = 0;
 
 	// per-batch workspace (grow-only)
-	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_winv, ws_part, ws_best, ws_geno, ws_out, ws_codes, ws_bt, ws_bias, ws_cells, ws_sync;
+	DevBuf ws_planes, ws_cw, ws_tot, ws_inv, ws_winv, ws_part, ws_best, ws_vrec, ws_geno, ws_out, ws_codes, ws_bt, ws_bias, ws_cells, ws_sync;
 	std::vector<int> engine_of, steps_of;  // per classifier: HIBAG_HIP_ENGINE_* and K steps, as finalized
 	int store_mode = 0;                    // which cell sums pass 1 stores for pass 2 (HibagModelView::store_cells)
 	int64_t second_pass_pairs = 0;         // haplotype pairs per sample pass 2 evaluates again
@@ -240,7 +240,7 @@ struct hibag_hip_model {
 		if (side.join) (void)hipEventDestroy(side.join);
 		if (side.stream) (void)hipStreamDestroy(side.stream);
 		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &d_pfac, &d_phdr, &d_parow, &ws_bt, &ws_bias, &ws_cells, &ws_sync, &ws_err, &ws_planes, &ws_cw, &ws_tot, &ws_inv, &ws_winv,
-		                  &ws_part, &ws_best, &ws_geno, &ws_out, &ws_codes, &ws_bed, &ws_bedidx})
+		                  &ws_part, &ws_best, &ws_vrec, &ws_geno, &ws_out, &ws_codes, &ws_bed, &ws_bedidx})
 			b->release();
 	}
 };
@@ -1052,6 +1052,8 @@ int finalize_model(hibag_hip_model *m)
 	for (int c = 0; c < C; c++)
 		if (n_step[c] == 1 && !(engine[c] == HIBAG_ENGINE_FP4)) V.all_fp4 = 0;      // (classifiers of several K steps are not work items of k_total)
 	V.n_wide = (int)wide_cls.size(); V.wide_cls = base + o_wide;
+	V.n_valu = 0;
+	for (int c = 0; c < C; c++) V.n_valu += engine[c] == HIBAG_ENGINE_VALU;
 	V.n_wide_scan = (int)wide_scan.size(); V.wide_scan = base + o_wscan;
 	V.n_wide_seg = (int)wseg.size() / 4; V.wide_seg = base + o_wseg; V.wide_seg_off = (const uint64_t *)(tbase + tb_wsoff);
 	if (V.n_wide > 0 && !m->side.stream) {
@@ -1137,8 +1139,10 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	if (int rc = m->ws_bt.reserve((size_t)(std::max(m->bt_rows, 1) + 2) * n_pad * sizeof(uint4))) return rc;
 	if (int rc = m->ws_bias.reserve(2 * C * n_pad * sizeof(int))) return rc;
 	if (int rc = m->ws_cells.reserve((size_t)std::max(m->cell_rows, 1) * n_pad * sizeof(double))) return rc;
-	if (need_best)
+	if (need_best) {
 		if (int rc = m->ws_best.reserve(C * n_pad * sizeof(int))) return rc;
+		if (int rc = m->ws_vrec.reserve(C * 8 * n_pad * sizeof(uint4))) return rc;      // pass 1's record log (HibagBatchView::vrec)
+	}
 	{
 		// hand-over flags: one per pass-2 item (8 XCDs x group quads x tiles)
 		const size_t n_gq = ((size_t)(n_pad / HIBAG_WAVE + 7) / 8 + 3) / 4;
@@ -1175,6 +1179,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	B.bt = m->ws_bt.as<uint4>(); B.bias = m->ws_bias.as<int>();
 	B.bt_rows = std::max(m->bt_rows, 1) + 2;
 	B.cells = m->ws_cells.as<double>();
+	B.vrec = need_best ? m->ws_vrec.as<uint4>() : nullptr;
 	return 0;
 }
 
@@ -1196,7 +1201,7 @@ void run_core(hibag_hip_model *m, HibagBatchView &B, int vote_method, double *d_
 	B.part = d_part;
 	debug_stage("pack", st);
 	T.begin(HIBAG_HIP_K_TOTAL, st, true);      // (callers enqueue nothing between their pack and this)
-	hibag_launch_total(m->view, B, st, m->side);
+	hibag_launch_total(m->view, B, st, m->side, vote_method == 2);
 	T.end(st);
 	debug_stage("pass 1", st);
 	T.begin(HIBAG_HIP_K_ACCUM, st, true);

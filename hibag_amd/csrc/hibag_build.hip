@@ -64,7 +64,11 @@ struct BuildState {
 	void *h_up = nullptr; size_t cap_up = 0, up_at = 0;
 	void *d_pairs = nullptr; size_t cap_pairs = 0;
 };
-BuildState g;
+// One state per HOST THREAD (thread_local), and every copy / launch of this file on the calling thread's own default
+// stream (the file is compiled with -fgpu-default-stream=per-thread): several trainers of one process -- each driven by its
+// own host thread, hibag_amd.train.hlaConcurrentAttrBagging -- then share the device instead of queueing behind one another.
+// An unmodified HIBAG drives the build entries from one thread (nthread = 1 with a GPU plugin, src/LibHLA.h:680).
+thread_local BuildState g;
 thread_local char g_msg[400];
 
 [[noreturn]] void build_throw(const char *what, hipError_t e = hipSuccess)
@@ -690,7 +694,7 @@ uint32_t *hibag_build_haplomatch(const PluginHaplotype haplo[], const size_t n_h
 // build_acc_ib calls returns for n_cand candidate SNPs that extend the same genotype list
 // (src/LibHLA.cpp:2018-2038), evaluated together.  base_geno holds the committed SNPs
 // (position n_snp-1 missing); cand[i].column is the raw genotype of candidate i per sample.
-double g_batch_prof[6] = {0, 0, 0, 0, 0, 0};     // host packing, copies + kernels, read-back, host reductions; of the packing: staging copy, (re)allocation (s)
+thread_local double g_batch_prof[6] = {0, 0, 0, 0, 0, 0};     // host packing, copies + kernels, read-back, host reductions; of the packing: staging copy, (re)allocation (s)
 static double batch_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 void hibag_build_eval_batch(const PluginGenotype base_geno[], int n_snp, const HibagBuildCandidate cand[], int n_cand,

@@ -174,6 +174,7 @@ struct HibagModelView {
 	// matrix-core engine (classifiers with at most 112 SNPs; hibag_kernels.hip "MFMA engine")
 	const int *engine;           // [C] HIBAG_ENGINE_*
 	const int *n_step;           // [C] K steps of the FP4 engine (1 up to 28 SNPs; HIBAG_FP4_STEPS), 1 for the others
+	int n_valu;                  // classifiers on the VALU engine (more than 112 SNPs, or HIBAG_ENGINE=valu)
 	int n_wide;                  // classifiers with n_step > 1: pass 1 in k_total_wide, not among the work items; all their cells stored
 	const int *wide_cls;         // [n_wide]
 	int n_wide_scan;             // ... of them the ones whose in-order total k_total_scan forms from the stored sums (cut into several segments)
@@ -250,6 +251,15 @@ struct HibagBatchView {
 	double *tot;        // [C][n_pad]
 	double *inv;        // [C][n_pad]
 	double *winv;       // [C][n_pad][2] {classifier weight (k_pack), 1/total (pass 1)}: what pass 2 reads per block, in ONE 16-byte load
+	// Majority vote (vote_method = 2): the cell a classifier votes for is the FIRST strict maximum of cell * (1/total) in cell
+	// order (src/LibHLA.cpp:2465-2475 -> :1549-1566), and 1/total is only known when pass 1 ends.  Multiplying by a positive
+	// constant is monotone, so the winner is among the RECORDS of the raw cell sums -- the cells larger than every cell before
+	// them -- namely the earliest record whose product equals the last record's: only records within a few ulps of the
+	// maximum can tie with it (at most five doubles map to one product).  Pass 1 therefore logs its records per (classifier,
+	// sample) -- entry 0 {maximum, number of records}, entry 1 the first record (what wins where 1/total is infinite: the
+	// first positive cell), entries 2..7 a ring of the latest six {value, position in the classifier's cell list} -- and
+	// k_vote_pick settles the ties with the products themselves.  No second walk over the pairs.
+	uint4 *vrec;        // [C][8][n_pad] (16-byte entries; null unless the call votes)
 	double *cells;      // [n_pad / 64][cell_row[C]][64] the cell sums pass 1 stores
 	double *part;       // [P+3][n_pad]
 	// matrix-core engine: per classifier and sample group the B operand tiles

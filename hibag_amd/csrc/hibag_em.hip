@@ -283,7 +283,7 @@ struct EmState {
 	hipStream_t st = nullptr;
 	bool lds_set = false;                   // k_em_fit may use EM_LDS_BYTES of dynamic LDS on this device
 };
-EmState g_em;
+thread_local EmState g_em;          // (per host thread, like the build state: concurrent trainers each have their own arena and stream)
 thread_local char g_em_msg[300];
 
 [[noreturn]] void em_throw(const char *what, hipError_t e)
@@ -297,7 +297,7 @@ double em_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv
 
 } // namespace
 
-double g_em_prof[3] = {0, 0, 0};            // seconds in hibag_em_fit_batch: staging the upload, copy + kernel + copy back (waited for), total
+thread_local double g_em_prof[3] = {0, 0, 0};            // seconds in hibag_em_fit_batch: staging the upload, copy + kernel + copy back (waited for), total
 
 void hibag_em_release()
 {

@@ -18,7 +18,9 @@ void hibag_launch_bed_geno(const uint8_t *d_bed, int mode, size_t stride, int n_
 // `side`: a second stream and two events of the caller's, for the kernel that runs beside pass 1 where the model has
 // FP4 classifiers of several K steps (fork behind what is already on `st`, join before anything that follows)
 struct HibagSideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st, const HibagSideStream &side);
+// vote: the call is a majority vote (vote_method = 2) -- pass 1 logs the records of the cell sums (HibagBatchView::vrec) for
+// hibag_launch_vote, stores no cell sums for a second pass and cuts no work items
+void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st, const HibagSideStream &side, bool vote = false);
 // resident workgroups of k_total<STORE, occupancy> -- [0] <false, 5>, [1] <false, 6>, [2] <true, 5>, [3] <true, 6> -- and of
 // k_accum on the current device (0 = unknown)
 void hibag_query_slots(int total[4], int *accum);

@@ -73,6 +73,12 @@
 #ifndef ACCUM_G
 #define ACCUM_G 4                           // the same for pass 2
 #endif
+#ifndef TOTAL_AHEAD
+#define TOTAL_AHEAD false                   // pass 1: the next group's table look-ups requested before this group is added up (block_accumulate)
+#endif
+#ifndef ACCUM_AHEAD
+#define ACCUM_AHEAD false                   // the same for pass 2
+#endif
 #define ACCUM_TAB_N 64                      // table entries pass 2 stages: it evaluates one-step FP4 classifiers only
 static_assert(2 * HIBAG_FP4_MAX_SNPS + 1 <= ACCUM_TAB_N, "pass 2's table must cover every distance of a one-step FP4 classifier");
 #ifndef ACCUM_WAVES
@@ -368,15 +374,14 @@ template <> struct FactorGroup<8> { typedef f64x8 type; };
 // positive or NaN, never -0), one instruction instead of three (a move, a multiplication into a temporary, an addition).  Inside a
 // group the choice is part of the branch that closes the cell; across groups and blocks the wave-uniform `fresh` says that the
 // record before closed one (a scalar register; the walk that ends on it materialises the zero).
-template <int G, class Fin>
+// AHEAD: the table look-ups of group g + 1 are requested BEFORE group g is added up (one more group's worth of registers):
+// a wavefront then sits out an LDS round trip only for a block's first group.
+template <int G, bool AHEAD, class Fin>
 __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename FactorGroup<G>::type F, uint32_t endmask, uint32_t storemask, int n_valid,
 	const v16i &D0, const v16i &D1, double &cell, bool &fresh, const double *tab_s, Fin &&fin)
 {
 	typedef typename FactorGroup<G>::type FG;
-#pragma unroll
-	for (int g = 0; g < 32 / G; g++) {
-		if (G * g >= n_valid) break;
-		double t[G];
+	auto look_up = [&](int g, double (&t)[G]) {
 #pragma unroll
 		for (int q = 0; q < G; q++) {         // D = 8*d: already the byte offset into the table
 			const int i = G * g + q;          // record i = 8 m + r  ->  r < 4 ? D0[4 m + r] : D1[4 m + r - 4]
@@ -387,6 +392,14 @@ __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename 
 			t[q] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab_s) + off);
 #endif
 		}
+	};
+	double tt[AHEAD ? 2 : 1][G];
+	if (AHEAD) look_up(0, tt[0]);
+#pragma unroll
+	for (int g = 0; g < 32 / G; g++) {
+		if (G * g >= n_valid) break;
+		double (&t)[G] = tt[AHEAD ? (g & 1) : 0];
+		if (!AHEAD) look_up(g, t);
 		// the look-ups are waited for HERE (a use of the first one; LDS returns in order, and a scalar load in flight makes it a
 		// wait for everything), and only then are the next group's factors requested: they have this group's arithmetic to arrive
 		asm volatile("" : "+v"(t[0]));
@@ -395,6 +408,7 @@ __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename 
 #ifndef HIBAG_ABL_NOFAC       // (timing ablation: every group multiplies by the block's first factors)
 		if (g + 1 < 32 / G) Fn = *(ConstPtr<FG>)(fac + G * (g + 1));
 #endif
+		if (AHEAD && g + 1 < 32 / G && G * (g + 1) < n_valid) look_up(g + 1, tt[(g + 1) & 1]);
 		__builtin_amdgcn_sched_barrier(0);
 		if (fresh) { cell = F[0] * t[0]; asm volatile("" : "+v"(cell)); }     // (the asm keeps this a scalar branch, not a select)
 		else cell += F[0] * t[0];
@@ -497,7 +511,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 				arow = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, vo, (int)soff, 0));    // the next block's, behind the instructions that read this one's
 				__builtin_amdgcn_sched_barrier(0);
 				block_own_sample(D0, D1, n_valid);
-				block_accumulate<G>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
+				block_accumulate<G, TOTAL_AHEAD>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
 			} else {
 				arow = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, vo, (int)soff, 0));
 			}
@@ -586,7 +600,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 				block_mfma<ENG>(a1, a2, lane, cterm, T, D0, D1);
 			}
 			block_own_sample(D0, D1, n_valid);
-			block_accumulate<G>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
+			block_accumulate<G, TOTAL_AHEAD>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
 		}
 		soff += BB;
 	}
@@ -1011,9 +1025,12 @@ __device__ __forceinline__ int chunk_bound(const uint32_t *__restrict__ cum, int
 // k_accum_cells); otherwise only a split VALU-engine classifier stores its cells (for k_total_scan).
 // FP4ONLY: every work item is a one-step FP4 classifier (HibagModelView::all_fp4) -- the build for six workgroups per CU
 // carries that loop alone: at 80 registers the int8 and VALU-engine loops would spill, the FP4 loop does not.
-template <bool STORE, int OCC, bool FP4ONLY>
+// VOTE (majority vote; never together with STORE, whose sums only pass 2 reads, and never with chunked items): the walk
+// logs the records of its cell sums for k_vote_pick (HibagBatchView::vrec).
+template <bool STORE, int OCC, bool FP4ONLY, bool VOTE = false>
 __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, HibagBatchView B, int gx, int n_whole, int rest, int stride, int K)
 {
+	static_assert(!(STORE && VOTE), "the majority vote has no second pass to store cell sums for");
 	__shared__ double tab_s[HIBAG_TAB_N];
 	int li = blockIdx.x, k = 0;
 	if (li >= n_whole) {
@@ -1063,6 +1080,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, 
 			// (a store issued where the cell closes; parking the sums in LDS and sending them a block later, so that
 			// the vmcnt waits of the look-ahead gathers never include a young store, measured 10 % slower)
 			// (stores through a raw buffer with the row as a scalar offset -- no 64-bit address on the vector ALU -- measured 2 % slower)
+			// majority vote: the lane's records so far -- the largest cell sum, how many records, the log slot of the next one --
+			// and (wave-uniform) the position of the closing cell in the classifier's list of non-empty cells
+			double vmax = 0;
+			int vcnt = 0, vslot = 1, ci = 0;
+			uint4 *const vlog = VOTE ? B.vrec + (size_t)c * 8 * B.n_pad + s : nullptr;
 			auto fin = [&](double v, bool stored) {
 #ifdef HIBAG_STORE_PLAIN      // (variant: write-back stores instead of streaming ones)
 				if (STORE && stored) { rows[(size_t)row * HIBAG_WAVE + lane] = v; row++; }
@@ -1071,6 +1093,15 @@ __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, 
 #endif
 				total += v;
 				asm("" : "+v"(total));                    // keeps the cell end a scalar branch
+				if (VOTE) {
+					if (v > vmax) {                       // a record (NaN is none, like `best < prob` in the reference)
+						vmax = v;
+						vlog[(size_t)vslot * B.n_pad] = uint4{(uint32_t)__double2loint(v), (uint32_t)__double2hiint(v), (uint32_t)ci, 0u};
+						vslot = vslot == 1 || vslot == 7 ? 2 : vslot + 1;
+						vcnt++;
+					}
+					ci++;
+				}
 			};
 #define CALLX(E, PRE) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, lane, T);                                 \
 			ListCursor cur;                                                                                                \
@@ -1084,6 +1115,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, 
 #undef CALL
 #undef CALLX
 			if (!last) { B.tot[at] = total; B.inv[at] = cell; }
+			if (VOTE) vlog[0] = uint4{(uint32_t)__double2loint(vmax), (uint32_t)__double2hiint(vmax), (uint32_t)vcnt, 0u};
 		} else if (!FP4ONLY) {
 #define CALL(N) total = classifier_total<N>(M, B, c, s, item[1], item[2], item[3], rows, tab_s)
 			HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
@@ -1363,6 +1395,38 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		double sv[NS];                                // the stored sums
 		double cell = 0;
 		bool fresh = false;                           // block_accumulate: the record before closed a cell
+		// the stored sums of a block (word 1 of its header: first row | count << 25)
+		auto request_sv = [&](uint32_t w1) {
+#ifdef HIBAG_ABL2_NOSV
+			const int ns = 0;
+#else
+			const int ns = (int)(w1 >> 25) & 15;
+#endif
+#ifdef HIBAG_ABL2_SVHOT       // (timing ablation: every stored sum read from the group's first rows -- cache hits instead of HBM)
+			const int sr = (int)((w1 & 7u) * (uint32_t)(HIBAG_WAVE * 8));
+#else
+			const int sr = (int)((w1 & 0x1FFFFFFu) * (uint32_t)(HIBAG_WAVE * 8));
+#endif
+#ifdef HIBAG_SV_END
+			// ALWAYS NS loads: the ones a block does not have go out of the buffer's range (a vector offset past its end: no
+			// memory access, zeros back), so that the number of loads in flight is the same for every block and every wait of
+			// the loop is a counted one that the compiler gets exactly right -- the stored sums, the only loads that come from
+			// HBM, can then stay in flight while younger loads are waited for and used.
+#pragma unroll
+			for (int i = 0; i < NS; i++) {
+				const int vo = vo_sv + (i < ns ? 0 : (int)0xFFFFFE00u);
+				sv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_sv, vo, sr + i * HIBAG_WAVE * 8, 2));   // (read once: nt)
+			}
+#else
+			if (ns > 0) {
+#pragma unroll
+				for (int i = 0; i < NS; i++) {
+					if (i >= ns) break;
+					sv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_sv, vo_sv, sr + i * HIBAG_WAVE * 8, 2));   // (read once: nt)
+				}
+			}
+#endif
+		};
 		// words 0, 1 of a header (its own, or -- words 2, 3 -- the next block's): classifier | operand row << 16, stored row | stored sums << 25
 		auto request_lane = [&](uint32_t w0, uint32_t w1, int soff_a, f64x2 &winv) {
 			arow = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, vo_a, soff_a, 0));
@@ -1374,23 +1438,9 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 #else
 			winv = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r_wi, vo_row, (int)((w0 & 0xFFFFu) * row_stride), 0));
 #endif
-#ifdef HIBAG_ABL2_NOSV
-			const int ns = 0;
-#else
-			const int ns = (int)(w1 >> 25) & 15;
+#ifndef HIBAG_SV_END
+			request_sv(w1);
 #endif
-			if (ns > 0) {
-#ifdef HIBAG_ABL2_SVHOT       // (timing ablation: every stored sum read from the group's first rows -- cache hits instead of HBM)
-				const int sr = (int)((w1 & 7u) * (uint32_t)(HIBAG_WAVE * 8));
-#else
-				const int sr = (int)((w1 & 0x1FFFFFFu) * (uint32_t)(HIBAG_WAVE * 8));
-#endif
-#pragma unroll
-				for (int i = 0; i < NS; i++) {
-					if (i >= ns) break;
-					sv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_sv, vo_sv, sr + i * HIBAG_WAVE * 8, 2));   // (read once: nt)
-				}
-			}
 		};
 		// One block: `cur` = what it needs (arrived: requested a block ago), `nxt` = where the next block's goes.
 		// Order: the stored sums are added, the matrix instructions issued -- which frees this block's rows, operand and stored
@@ -1425,7 +1475,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			const int eval = __builtin_amdgcn_readfirstlane(any & (n_valid > 0 ? 1 : 0));
 #endif
 			// ---- the sums pass 1 stored for this block's classifier:   S[p] += (cell * (1/total)) * w
-			{
+			auto add_stored = [&]() {
 #ifdef HIBAG_ABL2_NOSV
 				const int ns = 0;
 #else
@@ -1440,7 +1490,10 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 						jps >>= 4;
 					}
 				}
-			}
+			};
+#ifndef HIBAG_SV_END
+			add_stored();
+#endif
 			__builtin_amdgcn_sched_barrier(0);
 			ACCUM_STAMP(1);
 			// ---- distances on the matrix pipe (their operands have arrived with everything else of the block)
@@ -1479,10 +1532,19 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 					__hip_atomic_fetch_add(&acc[(int)(jpack & 15)][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					jpack >>= 4;
 				};
-				block_accumulate<ACCUM_G>(fac + (size_t)rel * HIBAG_PLIST_DWORDS, cur.F, endmask, 0u, n_valid, D0, D1, cell, fresh, tab_s, fin);
+				block_accumulate<ACCUM_G, ACCUM_AHEAD>(fac + (size_t)rel * HIBAG_PLIST_DWORDS, cur.F, endmask, 0u, n_valid, D0, D1, cell, fresh, tab_s, fin);
 			}
 			asm volatile("" :: "s"(tch0), "s"(tch1), "s"(tch2));
 			ACCUM_STAMP(5);
+#ifdef HIBAG_SV_END
+			// (variant) the stored sums are added at the END of their block and the next block's requested right behind: they were
+			// requested a whole block ago, and nothing in between has waited for them (every wait of the loop is a counted one)
+			__builtin_amdgcn_sched_barrier(0);
+			add_stored();
+			__builtin_amdgcn_sched_barrier(0);
+			request_sv(cur.hv[3]);
+			ACCUM_STAMP(6);
+#endif
 		};
 
 		AccumAhead A, Bn;
@@ -1490,6 +1552,9 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		A.ph = phdr[0];
 		A.F = *(ConstPtr<AFG>)fac;
 		request_lane(A.hv[0], A.hv[1], 0, A.winv);
+#ifdef HIBAG_SV_END
+		request_sv(A.hv[1]);
+#endif
 #ifdef HIBAG_ACCUM_STAMPS
 		stamp_t = __builtin_readcyclecounter();
 #endif
@@ -1637,17 +1702,14 @@ __device__ __forceinline__ int classifier_best(const HibagModelView &M, const Hi
 	return best_p;
 }
 
-#ifndef VOTE_OCC
-#define VOTE_OCC 5                          // workgroups per CU the majority-vote walk is compiled for (4: 3.5 % slower, 6: 5 % slower)
-#endif
-// WIDE: the instance for FP4 classifiers of several K steps (their walk needs more registers than five workgroups per CU
-// leave: a kernel of their own, like k_total_wide); the other instance skips them, and vice versa.
-template <bool WIDE>
-__global__ __launch_bounds__(BLOCK_THREADS, WIDE ? 3 : VOTE_OCC) void k_vote_best(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
+// k_vote_best_valu: the majority vote's choice for the classifiers of the VALU engine (more than 112 SNPs) -- their pairs are
+// walked a second time, with 1/total in hand.  (Every other classifier: k_vote_pick / k_vote_scan below, no second walk.)
+// grid (group quads, classifiers); writes the winning cell index or -1.
+__global__ __launch_bounds__(BLOCK_THREADS) void k_vote_best_valu(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	const int c = M.c_order[blockIdx.y];
-	if ((M.n_step[c] > 1) != WIDE) return;
+	if (M.engine[c] != HIBAG_ENGINE_VALU) return;
 	stage_table(M, tab_s);
 	const int group = blockIdx.x * BLOCK_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (group * HIBAG_WAVE >= B.n_pad) return;
@@ -1657,33 +1719,68 @@ __global__ __launch_bounds__(BLOCK_THREADS, WIDE ? 3 : VOTE_OCC) void k_vote_bes
 	if (__ballot(active) == 0) { best_cell[at] = -1; return; }
 	const double inv = B.inv[at];
 	int bp;
-	const int nkb = M.engine[c];                      // matrix-engine variant, 0 = VALU engine
-	if (nkb > 0) {
-		// matrix-core engine: the cells close in the order of the classifier's non-empty cell list,
-		// so the winner is remembered by its position in that list
-		double best = 0;
-		int best_i = -1, i = 0;
-		auto fin = [&](double cell, bool) {
-			const double prob = cell * inv;
-			if (best < prob) { best = prob; best_i = i; }
-			i++;
-		};
-		const WideSrc wide = wide_src(B, M.bt_row[c], M.n_step[c], group);
-		const int k_last = M.n_snp_c[c] - HIBAG_FP4_STEP_SNPS * (wide.nstep - 1);
-#define CALL(E) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, threadIdx.x & 63, T);                           \
-		ListCursor cur;                                                                                                \
-		double cell = 0;                                                                                               \
-		walk_blocks<E, TOTAL_G, false>(M, M.blk_off[c], M.cls_nblk[c], threadIdx.x & 63, cur, hap_rsrc(M, M.hap_off[c]), k_last,  \
-			T, wide, tab_s, cell, fin); }
-		if (WIDE) { CALL(HIBAG_ENGINE_FP4W) } else { HIBAG_DISPATCH_ENGINE(nkb, CALL) }
-#undef CALL
-		bp = best_i < 0 ? -1 : (int)M.cls_cell[M.cls_off[c] + best_i];
-	} else if (!WIDE) {
 #define CALL(N) bp = classifier_best<N>(M, B, c, s, inv, tab_s)
-		HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
+	HIBAG_DISPATCH_NWP(M.nwp[c], CALL)
 #undef CALL
-	} else bp = -1;
 	best_cell[at] = active ? bp : -1;
+}
+
+// k_vote_pick: the cell a matrix-engine classifier of one K step votes for, from the records pass 1 logged
+// (HibagBatchView::vrec): the first strict maximum of cell * (1/total) in cell order (src/LibHLA.cpp:2468 -> :1549-1566) is
+// the EARLIEST record whose product equals the last record's.  Where 1/total is infinite every positive cell's product is
+// infinite and the first one wins; a NaN reciprocal wins nothing.  thread = (sample, classifier).
+__global__ __launch_bounds__(64) void k_vote_pick(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
+{
+	const int c = blockIdx.y, s = blockIdx.x * 64 + threadIdx.x;
+	if (M.engine[c] == HIBAG_ENGINE_VALU || M.n_step[c] > 1) return;      // k_vote_best_valu / k_vote_scan
+	const size_t at = (size_t)c * B.n_pad + s;
+	int pick = -1;
+	if (B.cw[at] > 0) {
+		const uint4 *__restrict__ rec = B.vrec + (size_t)c * 8 * B.n_pad + s;
+		const uint4 h = rec[0];
+		const double vmax = __hiloint2double((int)h.y, (int)h.x), inv = B.inv[at];
+		const int n = (int)h.z;
+		if (n > 0 && inv == inv) {
+			const uint4 f = rec[(size_t)B.n_pad];
+			if (!(fabs(inv) <= 1.79769313486231570815e+308)) pick = (int)f.z;
+			else {
+				const double pm = vmax * inv;
+				int best = 0x7FFFFFFF;
+				if (__hiloint2double((int)f.y, (int)f.x) * inv == pm) best = (int)f.z;
+				const int nr = min(n - 1, 6);             // ring entries that belong to this batch: slots 2 .. 1 + nr
+				for (int j = 0; j < nr; j++) {
+					const uint4 r = rec[(size_t)(2 + j) * B.n_pad];
+					if (__hiloint2double((int)r.y, (int)r.x) * inv == pm) best = min(best, (int)r.z);
+				}
+				pick = best;                              // (the last record itself always qualifies)
+			}
+		}
+	}
+	best_cell[at] = pick < 0 ? -1 : (int)M.cls_cell[M.cls_off[c] + pick];
+}
+
+// k_vote_scan: the same choice for the FP4 classifiers of several K steps, whose cell sums pass 1 stores one and all
+// (k_total_wide): the reference's scan itself over the stored sums, thread = sample, sixteen loads in flight.
+__global__ __launch_bounds__(64) void k_vote_scan(HibagModelView M, HibagBatchView B, int *__restrict__ best_cell)
+{
+	const int c = M.wide_cls[blockIdx.y], s = blockIdx.x * 64 + threadIdx.x;
+	const size_t at = (size_t)c * B.n_pad + s;
+	const bool active = B.cw[at] > 0;
+	if (__ballot(active) == 0) { best_cell[at] = -1; return; }            // (pass 1 skipped the classifier: its rows are stale)
+	const double *__restrict__ rows = cell_rows(M, B, c, s >> 6) + (s & 63);
+	const double inv = B.inv[at];
+	const int n = M.cls_n[c];
+	double best = 0;
+	int bi = -1, i = 0;
+	for (; i + 16 <= n; i += 16) {
+		double v[16];
+#pragma unroll
+		for (int j = 0; j < 16; j++) v[j] = rows[(size_t)(i + j) * HIBAG_WAVE];
+#pragma unroll
+		for (int j = 0; j < 16; j++) { const double prob = v[j] * inv; if (best < prob) { best = prob; bi = i + j; } }
+	}
+	for (; i < n; i++) { const double prob = rows[(size_t)i * HIBAG_WAVE] * inv; if (best < prob) { best = prob; bi = i; } }
+	best_cell[at] = active && bi >= 0 ? (int)M.cls_cell[M.cls_off[c] + bi] : -1;
 }
 
 // k_vote_tally: one-hot votes with weight 1.0 (src/LibHLA.cpp:2465-2475);
@@ -1969,7 +2066,7 @@ void hibag_query_slots(int total[4], int *accum)
 	*accum = resident_blocks(k_accum, ACCUM_WAVES * HIBAG_WAVE);
 }
 
-void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st, const HibagSideStream &side)
+void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st, const HibagSideStream &side, bool vote)
 {
 	if (M.n_classifier == 0) return;
 	const bool wide = M.n_wide > 0;
@@ -2008,21 +2105,27 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 	const unsigned n = gx * (unsigned)V.n_item;
 	// two rounds of the denser build's resident workgroups or more: six workgroups per CU, otherwise five (above)
 	static const int occ_env = getenv("HIBAG_TOT_OCC") ? atoi(getenv("HIBAG_TOT_OCC")) : 0;      // (diagnostic: 5 or 6)
-	const int slots_many = M.slots_total[(M.store_cells ? 2 : 0) + 1];
+	const int sbase = (M.store_cells && !vote) ? 2 : 0;       // (the vote's build stores no cell sums: the occupancy figures of the non-storing one)
+	const int slots_many = M.slots_total[sbase + 1];
 	// (the denser build holds the one-step FP4 loop only: models with other work items always take the general one)
 	const bool many = M.all_fp4 && !split && (occ_env ? occ_env == HIBAG_TOT_OCC_MANY : (slots_many > 0 && n >= 2u * (unsigned)slots_many));
-	const int slots = M.slots_total[(M.store_cells ? 2 : 0) + (many ? 1 : 0)];
+	const int slots = M.slots_total[sbase + (many ? 1 : 0)];
 	unsigned n_whole = n, rest = 0, stride = 8, K = 1;
 	static const int k1_env = getenv("HIBAG_TAIL_K1") ? std::max(1, std::min(64, atoi(getenv("HIBAG_TAIL_K1")))) : 0;     // (diagnostic: pass 1 only)
 	const int k_pass1 = (k1_env && B.tail_k == 0) ? k1_env : tail_chunks(B.tail_k, M.p1_blocks / std::max(M.n_classifier, 1));
-	if (k_pass1 > 1 && slots > 0 && n > (unsigned)slots) {
+	// (the majority vote's record log is not handed over between chunks: its items stay whole)
+	if (!vote && k_pass1 > 1 && slots > 0 && n > (unsigned)slots) {
 		K = (unsigned)k_pass1;
 		rest = n % (unsigned)slots + (unsigned)slots;
 		n_whole = n - rest;
 		stride = (rest + 7) / 8 * 8;
 	}
 	const dim3 grid(n_whole + (rest ? K * stride : 0));
-	if (M.store_cells) {
+	if (vote) {
+		// majority vote: no second pass, so no cell sums are stored for one; the walk logs its records instead
+		if (many) hipLaunchKernelGGL((k_total<false, HIBAG_TOT_OCC_MANY, true, true>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
+		else hipLaunchKernelGGL((k_total<false, HIBAG_TOT_OCC, false, true>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
+	} else if (M.store_cells) {
 		if (many) hipLaunchKernelGGL((k_total<true, HIBAG_TOT_OCC_MANY, true>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
 		else hipLaunchKernelGGL((k_total<true, HIBAG_TOT_OCC, false>), grid, dim3(BLOCK_THREADS), 0, st, V, B, (int)gx, (int)n_whole, (int)rest, (int)stride, (int)K);
 	} else {
@@ -2062,9 +2165,13 @@ void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStr
 void hibag_launch_vote(const HibagModelView &M, const HibagBatchView &B, int *d_best_cell, hipStream_t st)
 {
 	if (M.n_classifier > 0) {
-		const unsigned gx = (unsigned)((B.n_pad / HIBAG_WAVE + BLOCK_WAVES - 1) / BLOCK_WAVES);
-		hipLaunchKernelGGL(k_vote_best<false>, dim3(gx, M.n_classifier), dim3(BLOCK_THREADS), 0, st, M, B, d_best_cell);
-		if (M.n_wide > 0) hipLaunchKernelGGL(k_vote_best<true>, dim3(gx, M.n_classifier), dim3(BLOCK_THREADS), 0, st, M, B, d_best_cell);
+		// pass 1 (hibag_launch_total with vote = true) has logged the records of every one-step matrix-engine classifier
+		hipLaunchKernelGGL(k_vote_pick, dim3(B.n_pad / 64, M.n_classifier), dim3(64), 0, st, M, B, d_best_cell);
+		if (M.n_wide > 0) hipLaunchKernelGGL(k_vote_scan, dim3(B.n_pad / 64, M.n_wide), dim3(64), 0, st, M, B, d_best_cell);
+		if (M.n_valu > 0) {
+			const unsigned gx = (unsigned)((B.n_pad / HIBAG_WAVE + BLOCK_WAVES - 1) / BLOCK_WAVES);
+			hipLaunchKernelGGL(k_vote_best_valu, dim3(gx, M.n_classifier), dim3(BLOCK_THREADS), 0, st, M, B, d_best_cell);
+		}
 	}
 	hipLaunchKernelGGL(k_vote_tally, grid1(B.n_pad, 64), dim3(64), 0, st, M, B, (const int *)d_best_cell);
 }

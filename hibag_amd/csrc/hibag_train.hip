@@ -46,8 +46,8 @@
 
 int hibag_fail(int code, const char *fmt, ...);       // hibag_api.hip: sets the thread's last error
 int hibag_selected_device();                          // hibag_api.hip: the thread's hibag_hip_set_device() choice
-extern double g_batch_prof[6];                        // hibag_build.hip
-extern double g_em_prof[3];                           // hibag_em.hip
+extern thread_local double g_batch_prof[6];           // hibag_build.hip
+extern thread_local double g_em_prof[3];              // hibag_em.hip
 
 namespace {
 
@@ -201,8 +201,8 @@ struct Profile {
 	double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 };
-Profile g_prof;
-long long g_em_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // candidates fitted on the device, of them handed back to the host, device iterations; growth steps' pairs (sum, max), longest transposed list
+thread_local Profile g_prof;                          // (the calling thread's: trainers may run side by side)
+thread_local long long g_em_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // candidates fitted on the device, of them handed back to the host, device iterations; growth steps' pairs (sum, max), longest transposed list
 struct Tick {
 	int k; double t0;
 	explicit Tick(int k_) : k(k_), t0(Profile::now()) {}
@@ -673,7 +673,7 @@ void build_classifiers(T &t, int nclassifier, int mtry, bool prune, bool verbose
 {
 	struct Scope {                                                      // try_final_train_gpu, :2256-2266
 		Scope(int nh, int ns) { hibag_build_init(nh, ns); }
-		~Scope() { hibag_build_done(); }
+		~Scope() { hibag_build_done(); hibag_em_release(); }      // (both states are the calling thread's own: nothing of them outlives the call)
 	} scope(t.n_hla, t.n_samp);
 	Sampling vs;
 	const int n = t.n_samp;
@@ -783,8 +783,8 @@ int hibag_hip_trainer_new_classifiers(hibag_hip_trainer *t, int nclassifier, int
 	if (!t) return hibag_fail(HIBAG_HIP_EINVAL, "trainer is NULL");
 	if (nclassifier < 0 || mtry < 1) return hibag_fail(HIBAG_HIP_EINVAL, "invalid nclassifier / mtry");
 	std::lock_guard<std::mutex> g(t->lock);
-	static std::mutex device_state;                    // the build entries keep one device state per process
-	std::lock_guard<std::mutex> g2(device_state);
+	// (the build entries keep their device state per host thread, hibag_build.hip: trainers driven by different threads run
+	// side by side on the device -- hlaConcurrentAttrBagging)
 	const size_t before = t->out.size();
 	if (hibag_hip_set_device(t->device)) return HIBAG_HIP_ENODEV;     // the build entries allocate on the selected device
 	if (hipSetDevice(t->device) != hipSuccess) return hibag_fail(HIBAG_HIP_ENODEV, "hipSetDevice(%d) failed", t->device);

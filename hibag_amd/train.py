@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import sys
 import warnings
 from typing import List, Optional, Sequence, Union
@@ -356,6 +357,87 @@ def grow_classifier_sharded(grow_fn, nclassifier: int, group=None) -> List[Class
     parts: List = [None] * world
     dist.all_gather_object(parts, list(mine), group=group)
     return [c for part in parts for c in part]
+
+
+def _usable_cpus() -> int:
+    """CPUs the process may use: the affinity mask capped by the cgroup CPU quota (what the native trainer's default is made of)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def grow_concurrently(genomat, h1, h2, n_hla: int, nclassifier: int, mtry: int, prune: bool, n_trainers: int,
+                      threads_per_trainer: int, seed: int, device: Optional[int] = None, em: str = "auto") -> List[Classifier]:
+    """``n_trainers`` independent trainers of ONE process side by side on one device, each driven by its own host thread
+    (the native calls release the interpreter lock; the library keeps its training state and its default stream per host
+    thread) with ``threads_per_trainer`` host threads of its own for the EM fits: while one trainer's candidates are
+    fitted on the host, another's are scored on the device.  Trainer r grows ``shard_bounds(nclassifier, n_trainers, r)``
+    classifiers from R's Mersenne-Twister seeded with ``seed + r`` -- the streams of ``hlaParallelAttrBagging``'s workers
+    (``R/HIBAG.R:329-390``: ``clusterSetRNGStream``-like, one stream per worker) -- and the shares are concatenated in
+    trainer order.  Every classifier equals what a serial trainer grows from the same stream."""
+    import threading
+    from .dist import shard_bounds
+    k = max(1, min(int(n_trainers), max(int(nclassifier), 1)))
+    parts: List = [None] * k
+    errs: List = [None] * k
+
+    def work(r: int) -> None:
+        try:
+            if device is not None:
+                _lib.check(_lib.lib().hibag_hip_set_device(int(device)))      # (the selection is per host thread)
+            lo, hi = shard_bounds(int(nclassifier), k, r)
+            if hi <= lo:
+                parts[r] = []
+                return
+            tr = _Trainer(genomat, h1, h2, n_hla)
+            try:
+                tr.set_em_mode(em)
+                tr.set_threads(int(threads_per_trainer))
+                tr.set_seed(int(seed) + r)
+                tr.new_classifiers(hi - lo, mtry, prune, False, False)
+                parts[r] = tr.classifiers()
+            finally:
+                tr.close()
+        except BaseException as e:                                             # noqa: BLE001 -- re-raised by the caller's thread
+            errs[r] = e
+
+    ths = [threading.Thread(target=work, args=(r,), name=f"hibag-trainer-{r}") for r in range(k)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for e in errs:
+        if e is not None:
+            raise e
+    return [c for part in parts for c in part]
+
+
+def hlaConcurrentAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,
+                             mtry: Union[str, float, int] = "sqrt", prune: bool = True, na_rm: bool = True,
+                             mono_rm: bool = True, maf: float = float("nan"), n_trainers: int = 4,
+                             nthread: Optional[int] = None, seed: int = 0, verbose: bool = True,
+                             device: Optional[int] = None) -> HlaAttrBagClass:
+    """``hlaParallelAttrBagging``'s decomposition (``R/HIBAG.R:293-440``: independent workers, one random stream each, the
+    classifiers combined in worker order) inside ONE process on ONE device: ``n_trainers`` trainers side by side
+    (:func:`grow_concurrently`), ``nthread`` host threads in all (default: the usable CPUs) shared out evenly.  A single
+    trainer leaves the device idle about three quarters of a growth step -- the EM fits of its candidates run on the host --
+    which the others' scoring passes fill."""
+    total = int(nthread) if nthread else _usable_cpus()
+    per = max(1, total // max(int(n_trainers), 1))
+
+    def grow(genomat, h1, h2, n_hla, n, m, pr):
+        return grow_concurrently(genomat, h1, h2, n_hla, n, m, pr, n_trainers, per, seed, device)
+
+    return hlaAttrBagging(hla, snp, nclassifier=nclassifier, mtry=mtry, prune=prune, na_rm=na_rm, mono_rm=mono_rm,
+                          maf=maf, verbose=verbose, grow=grow, device=device)
 
 
 def hlaParallelAttrBagging(cl, hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,

@@ -158,11 +158,12 @@ def test_cfg5_training_1k_samples_300_snps(hib, oracle):
     mtry = int(np.ceil(np.sqrt(300)))
     tr = train._Trainer(G, truth[:, 0], truth[:, 1], model.n_hla)
     tr.set_seed(100)
-    tr.new_classifiers(3, mtry, True, False, False)
+    n_cls = 10                                            # (~4 s of oracle time each: ten classifiers at the named shape, field by field)
+    tr.new_classifiers(n_cls, mtry, True, False, False)
     got = tr.classifiers()
     tr.close()
-    want = oracle.train(G, truth[:, 0], truth[:, 1], model.n_hla, 3, mtry, True, 100)
-    assert len(got) == 3
+    want = oracle.train(G, truth[:, 0], truth[:, 1], model.n_hla, n_cls, mtry, True, 100)
+    assert len(got) == n_cls
     for i, (g, w) in enumerate(zip(got, want)):
         c = hib.Classifier(snpidx=w["snpidx"], freq=w["freq"], hla=w["hla"], haplo=w["haplo"], samp_num=w["samp_num"],
                            outofbag_acc=w["acc"])

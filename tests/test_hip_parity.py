@@ -508,6 +508,82 @@ def test_plugin_per_sample_route_beyond_one_round_of_workgroups_and_pairs(hib, o
         host.close()
 
 
+def test_tied_cells_of_mirrored_alleles_first_one_wins(hib, oracle):
+    """Two alleles with the SAME haplotypes and frequencies make bit-equal cell sums (both are summed in the same order), so
+    the call -- a first strict maximum, src/LibHLA.cpp:1549-1566 -- must go to the earlier cell, for the averaged posterior
+    and for the majority vote, whose choice per classifier comes from the records pass 1 logs (k_vote_pick) and is settled on
+    the products cell * (1/total) themselves.  Samples are built as sums of one haplotype of the mirrored pair and one of a
+    third allele, so that the tie is at the maximum: cells (0, 2) and (1, 2)."""
+    rng = np.random.default_rng(77)
+    n_snp, k = 40, 18
+    cls = []
+    pats_all = []
+    for j in range(6):
+        idx = np.sort(rng.choice(n_snp, k, replace=False))
+        a = ["".join(rng.choice(["0", "1"], k)) for _ in range(3)]
+        cpat = ["".join(rng.choice(["0", "1"], k)) for _ in range(2)]
+        fa = rng.uniform(0.05, 0.3, 3)
+        fc = rng.uniform(0.05, 0.3, 2)
+        haplo = a + a + cpat                                           # allele 0, its mirror allele 1, allele 2
+        freq = np.concatenate([fa, fa, fc])
+        hla = np.array([0] * 3 + [1] * 3 + [2] * 2, np.int32)
+        cls.append(hib.Classifier(snpidx=idx, freq=freq, hla=hla, haplo=haplo))
+        pats_all.append((idx, a, cpat))
+    model = hib.HlaAttrBagObj(n_samp=0, n_snp=n_snp, hla_allele=["a", "a'", "c"], classifiers=cls)
+    rows = []
+    for t in range(96):
+        idx, a, cpat = pats_all[t % 6]
+        g = rng.choice(np.array([0, 1, 2], np.int32), n_snp)
+        h1, h2 = a[t % 3], cpat[t % 2]
+        g[idx] = np.array([int(x) + int(y) for x, y in zip(h1, h2)], np.int32)
+        if t % 7 == 0:
+            g[rng.choice(n_snp, 3, replace=False)] = hib.NA_INTEGER
+        rows.append(g)
+    G = np.stack(rows).astype(np.int32)
+    m = hib.hlaModelFromObj(model)
+    for vote in (1, 2):
+        want = oracle.predict(oracle.flatten(model), G, vote_method=vote)
+        got = m.predict_raw(G, vote, want_dosage=True, want_prob=True)
+        assert_same(got, want)
+        called = want["h1"] != hib.NA_INTEGER
+        assert called.any() and not np.any((want["h1"][called] == 1) & (want["h2"][called] == 2))    # never the later twin
+    m.close()
+
+
+def test_plugin_falls_back_to_one_workgroup_when_the_barrier_times_out(hib, oracle, monkeypatch):
+    """predict_avg_prob is one kernel whose workgroups meet at a barrier, i.e. must all be resident at once -- which nobody can
+    promise on a shared device.  With the barrier's poll budget at zero (HIBAG_ONE_SPIN=0, read at predict_init) the first
+    workgroup to arrive gives up at once: the call must then be repeated on a single workgroup and still return the
+    oracle's numbers, and so must the calls after it (`hibag_hip_plugin_degraded_calls` counts them); a fresh predict_init
+    without the variable runs at full width again."""
+    from hibag_amd import synth, _lib
+    from hibag_amd.plugin import PluginHost
+    model, founders, af = synth.make_model("hla-a-small", seed=61, n_classifier=20, n_snp=80)
+    G, _ = synth.make_samples(founders, af, 10, seed=62, miss=0.05)
+    G[3, :] = hib.NA_INTEGER
+    want = oracle.predict(oracle.flatten(model), G, vote_method=1)
+    L = _lib.lib()
+
+    def run_all(host):
+        geno, wt = host.pack(G)
+        prob = np.zeros(model.n_cell); match = np.zeros(1)
+        for i in range(len(G)):
+            host.avg_prob(geno[i], wt[i], prob, match)
+            assert np.array_equal(prob, want["postprob"][i], equal_nan=True), i
+            assert match[0] == want["matching"][i] or (np.isnan(match[0]) and np.isnan(want["matching"][i])), i
+
+    monkeypatch.setenv("HIBAG_ONE_SPIN", "0")
+    host = PluginHost(model)
+    run_all(host)
+    assert L.hibag_hip_plugin_degraded_calls() == len(G)          # every call took the one-workgroup route
+    host.close()
+    monkeypatch.delenv("HIBAG_ONE_SPIN")
+    host = PluginHost(model)
+    run_all(host)
+    assert L.hibag_hip_plugin_degraded_calls() == 0
+    host.close()
+
+
 @pytest.mark.parametrize("k", [1, 2, 14, 15, 29, 30, 31, 32])
 def test_extreme_genotypes_and_zero_frequencies(hib, oracle, k):
     """The corners of the matrix engine's K layout (hibag_device.h): every SNP heterozygous with both haplotypes carrying

@@ -131,6 +131,42 @@ def test_parallel_entry_single_rank(hib, oracle):
     del remap
 
 
+@pytest.mark.parametrize("em", ["host", "device"])
+def test_concurrent_trainers_equal_a_serial_trainer_per_stream(hib, oracle, em):
+    """Several trainers of one process side by side on one device (train.grow_concurrently: one host thread, one default
+    stream and one training state each): trainer r draws from R's Mersenne-Twister seeded with seed + r, like the workers of
+    hlaParallelAttrBagging (R/HIBAG.R:329-390), so its classifiers must equal the oracle's serial run from that seed --
+    field by field, with the EM fits on the trainers' host threads and on the device."""
+    from hibag_amd import synth, train
+    from hibag_amd.dist import shard_bounds
+    model, founders, af = synth.make_model("hla-a-small", seed=15, n_snp=70)
+    G, truth = synth.make_samples(founders, af, 180, seed=16, miss=0.02)
+    n_hla, ncl, k, mtry = model.n_hla, 10, 4, 9
+    got = train.grow_concurrently(G, truth[:, 0], truth[:, 1], n_hla, ncl, mtry, True, n_trainers=k, threads_per_trainer=2,
+                                  seed=300, em=em)
+    assert len(got) == ncl
+    at = 0
+    for r in range(k):
+        lo, hi = shard_bounds(ncl, k, r)
+        want = oracle.train(G, truth[:, 0], truth[:, 1], n_hla, nclassifier=hi - lo, mtry=mtry, prune=True, seed=300 + r)
+        for w in want:
+            c = hib.Classifier(snpidx=w["snpidx"], freq=w["freq"], hla=w["hla"], haplo=w["haplo"], samp_num=w["samp_num"],
+                               outofbag_acc=w["acc"])
+            assert_same_classifier(_as_dict(got[at]), c, at)
+            at += 1
+    assert at == ncl
+    # the user-level entry: a model of the same classifiers, usable at once
+    ids = [f"s{i}" for i in range(len(G))]
+    hla = hib.hlaAllele(ids, [model.hla_allele[a] for a in truth[:, 0]], [model.hla_allele[a] for a in truth[:, 1]], locus="A",
+                        assembly="hg19")
+    snp = hib.HlaSNPGeno(genotype=np.ascontiguousarray(G.T), sample_id=ids, snp_id=list(model.snp_id),
+                         snp_position=model.snp_position, snp_allele=list(model.snp_allele), assembly="hg19")
+    m = hib.hlaConcurrentAttrBagging(hla, snp, nclassifier=6, mtry=mtry, n_trainers=3, nthread=6, seed=300, verbose=False,
+                                     mono_rm=False)
+    assert len(m.obj.classifiers) == 6 and m.obj.matching is not None
+    hib.hlaClose(m)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_random_training_problems(hib, oracle, seed):
     """Randomised cohorts (size, alleles, missingness, mtry, prune): the device-scored driver and the

@@ -178,6 +178,61 @@ def test_pred_merge_host_logic():
         hb.hlaPredMerge(a, fake(["01:01"], n=4), verbose=False)
 
 
+def test_pred_merge_known_answer():
+    """hlaPredMerge on two tiny posteriors, expected values worked out by hand from the reference's source
+    (R/HIBAG.R:825-1023: weights normalised to 3/4 and 1/4 (:897); merged alleles sorted (:946), pair rows
+    outer(x, x, paste)[lower.tri] = "x_i/x_j", i >= j, column by column (:953-954); HIBAG_SumList, HIBAG_UpdateAddProbW
+    (w2 = weight * matching[sample], out[row] += p * w2) and HIBAG_NormalizeProb (column sum in row order, then a
+    division) in src/HIBAG.cpp:1463-1547; H1 = second name of the winning row, H2 = the first (:997-998); dosage =
+    column sums over the rows naming the allele first plus those naming it second (:1012-1016)).
+    Every input is a dyadic fraction, so each product and sum below is exact and each quotient is ONE rounded division:
+    the comparison is `==`, not a tolerance.
+
+        set 1 (weight 3): alleles 01:01, 02:01       rows 01:01/01:01, 02:01/01:01, 02:01/02:01
+            sample 1   0.5    0.25   0.25     matching 0.5
+            sample 2   0.125  0.75   0.125    matching 1.0
+        set 2 (weight 1): alleles 02:01, 03:01       rows 02:01/02:01, 03:01/02:01, 03:01/03:01
+            sample 1   0.25   0.5    0.25     matching 1.0
+            sample 2   0.0    0.5    0.5      matching 0.25
+        w2: set 1 (0.375, 0.75), set 2 (0.25, 0.0625)
+        merged rows A/A, B/A, C/A, B/B, C/B, C/C  (A = 01:01, B = 02:01, C = 03:01), before the normalisation:
+            sample 1   0.1875   0.09375  0  0.09375 + 0.0625 = 0.15625   0.125    0.0625     sum 0.625
+            sample 2   0.09375  0.5625   0  0.09375 + 0      = 0.09375   0.03125  0.03125    sum 0.8125
+    """
+    import numpy as np
+    import hibag_amd as hb
+    from hibag_amd.hibag import HlaAlleleClass, _pair_names
+
+    def pred(alleles, post, matching):
+        p = np.array(post, np.float64).T                             # [rows][samples]
+        return HlaAlleleClass(locus="A", sample_id=["s1", "s2"], allele1=[None, None], allele2=[None, None],
+                              prob=p.max(axis=0), matching=np.array(matching), assembly="hg19", postprob=p,
+                              pair_names=_pair_names(alleles))
+
+    one = pred(["01:01", "02:01"], [[0.5, 0.25, 0.25], [0.125, 0.75, 0.125]], [0.5, 1.0])
+    two = pred(["02:01", "03:01"], [[0.25, 0.5, 0.25], [0.0, 0.5, 0.5]], [1.0, 0.25])
+    assert one.pair_names == ["01:01/01:01", "02:01/01:01", "02:01/02:01"]
+    m = hb.hlaPredMerge(one, two, weight=[3, 1], verbose=False, ret_postprob=True)
+    assert m.pair_names == ["01:01/01:01", "02:01/01:01", "03:01/01:01", "02:01/02:01", "03:01/02:01", "03:01/03:01"]
+    s1 = [0.1875 / 0.625, 0.09375 / 0.625, 0.0, 0.15625 / 0.625, 0.125 / 0.625, 0.0625 / 0.625]
+    s2 = [0.09375 / 0.8125, 0.5625 / 0.8125, 0.0, 0.09375 / 0.8125, 0.03125 / 0.8125, 0.03125 / 0.8125]
+    assert s1 == [0.3, 0.15, 0.0, 0.25, 0.2, 0.1]                     # (correctly rounded quotients of exact operands)
+    assert m.postprob[:, 0].tolist() == s1 and m.postprob[:, 1].tolist() == s2
+    assert m.matching.tolist() == [0.625, 0.8125]                     # 0.75 * 0.5 + 0.25 * 1.0,  0.75 * 1.0 + 0.25 * 0.25
+    assert m.prob.tolist() == [0.3, 0.5625 / 0.8125]
+    assert (m.allele1, m.allele2) == (["01:01", "01:01"], ["01:01", "02:01"])      # rows "01:01/01:01" and "02:01/01:01"
+    # dosage: rows naming the allele first + rows naming it second (the homozygous row counts twice)
+    want = np.array([[s1[0] + (s1[0] + s1[1] + s1[2]), s2[0] + (s2[0] + s2[1] + s2[2])],
+                     [(s1[1] + s1[3]) + (s1[3] + s1[4]), (s2[1] + s2[3]) + (s2[3] + s2[4])],
+                     [(s1[2] + s1[4] + s1[5]) + s1[5], (s2[2] + s2[4] + s2[5]) + s2[5]]])
+    assert np.allclose(m.dosage, want, rtol=4e-16, atol=0) and np.allclose(m.dosage.sum(axis=0), 2.0, rtol=1e-15)
+    assert np.allclose(m.dosage[:, 0], [0.75, 0.85, 0.4], rtol=1e-15)
+    # without the matching scale the weights alone count: sample 1's unnormalised sums are 0.375 0.1875 0 0.25 0.125 0.0625 = 1
+    u = hb.hlaPredMerge(one, two, weight=[3, 1], use_matching=False, verbose=False, ret_postprob=True)
+    assert u.postprob[:, 0].tolist() == [0.375, 0.1875, 0.0, 0.25, 0.125, 0.0625]
+    assert u.postprob[:, 1].tolist() == [0.09375, 0.5625, 0.0, 0.09375, 0.125, 0.125]
+
+
 def test_rdata_writer_round_trip(tmp_path, model_oob):
     """save_model writes the workspace hlaModelToObj() + save() would; the reader gets the same model back,
     and re-serialising the reference's own fixture reproduces its decoded structure."""
