@@ -45,6 +45,7 @@
 #include <algorithm>
 #include "hibag_device.h"
 #include "hibag_kernels.h"
+#include "hibag_ablation.h"
 
 #define NA_INTEGER (-2147483647 - 1)
 #define CH HIBAG_CHUNK
@@ -72,12 +73,6 @@
 #endif
 #ifndef ACCUM_G
 #define ACCUM_G 4                           // the same for pass 2
-#endif
-#ifndef TOTAL_AHEAD
-#define TOTAL_AHEAD false                   // pass 1: the next group's table look-ups requested before this group is added up (block_accumulate)
-#endif
-#ifndef ACCUM_AHEAD
-#define ACCUM_AHEAD false                   // the same for pass 2
 #endif
 #define ACCUM_TAB_N 64                      // table entries pass 2 stages: it evaluates one-step FP4 classifiers only
 static_assert(2 * HIBAG_FP4_MAX_SNPS + 1 <= ACCUM_TAB_N, "pass 2's table must cover every distance of a one-step FP4 classifier");
@@ -300,12 +295,11 @@ __device__ __forceinline__ void block_mfma(const v4i &e1, const v4i &e2, int lan
 		const v8i b0 = {T.b[0][0][0], T.b[0][0][1], T.b[0][0][2], T.b[0][0][3], 0, 0, 0, 0};
 		const v8i b1 = {T.b[1][0][0], T.b[1][0][1], T.b[1][0][2], T.b[1][0][3], 0, 0, 0, 0};
 		const int sb = upper ? HIBAG_FP4_SCALE_B_HI : HIBAG_FP4_SCALE_B_LO;
-#ifdef HIBAG_ABL_NOMFMA
-		d0[0] = __builtin_bit_cast(float, (a8[0] ^ b0[0]) & 0xF8); d1[0] = __builtin_bit_cast(float, (a8[1] ^ b1[1] ^ sb) & 0xF8);
-#else
-		d0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, d0, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sb);
-		d1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, d1, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sb);
-#endif
+		if (ABL_NOMFMA) { abl_fake_distances(a8, b0, b1, sb, d0, d1); }
+		else {
+			d0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, d0, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sb);
+			d1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, d1, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, sb);
+		}
 		acc0 = __builtin_bit_cast(v16i, d0);
 		acc1 = __builtin_bit_cast(v16i, d1);
 		return;
@@ -340,9 +334,7 @@ __device__ __forceinline__ void block_own_sample(v16i &D0, v16i &D1, int n_valid
 #pragma unroll
 	for (int g = 0; g < 4; g++) {
 		if (8 * g >= n_valid) break;
-#ifdef HIBAG_ABL_NOSWAP
-		continue;
-#endif
+		if (ABL_NOSWAP) continue;
 #pragma unroll
 		for (int r = 4 * g; r < 4 * g + 4; r++) {
 			const auto sw = __builtin_amdgcn_permlane32_swap(D0[r], D1[r], false, false);
@@ -374,41 +366,29 @@ template <> struct FactorGroup<8> { typedef f64x8 type; };
 // positive or NaN, never -0), one instruction instead of three (a move, a multiplication into a temporary, an addition).  Inside a
 // group the choice is part of the branch that closes the cell; across groups and blocks the wave-uniform `fresh` says that the
 // record before closed one (a scalar register; the walk that ends on it materialises the zero).
-// AHEAD: the table look-ups of group g + 1 are requested BEFORE group g is added up (one more group's worth of registers):
-// a wavefront then sits out an LDS round trip only for a block's first group.
-template <int G, bool AHEAD, class Fin>
+template <int G, class Fin>
 __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename FactorGroup<G>::type F, uint32_t endmask, uint32_t storemask, int n_valid,
 	const v16i &D0, const v16i &D1, double &cell, bool &fresh, const double *tab_s, Fin &&fin)
 {
 	typedef typename FactorGroup<G>::type FG;
-	auto look_up = [&](int g, double (&t)[G]) {
+#pragma unroll
+	for (int g = 0; g < 32 / G; g++) {
+		if (G * g >= n_valid) break;
+		double t[G];
 #pragma unroll
 		for (int q = 0; q < G; q++) {         // D = 8*d: already the byte offset into the table
 			const int i = G * g + q;          // record i = 8 m + r  ->  r < 4 ? D0[4 m + r] : D1[4 m + r - 4]
 			const int off = (i & 7) < 4 ? D0[4 * (i >> 3) + (i & 3)] : D1[4 * (i >> 3) + (i & 3)];
-#ifdef HIBAG_ABL_NOTAB
-			t[q] = __hiloint2double(0x3ff00000, off);
-#else
-			t[q] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab_s) + off);
-#endif
+			t[q] = table_value(tab_s, off);
 		}
-	};
-	double tt[AHEAD ? 2 : 1][G];
-	if (AHEAD) look_up(0, tt[0]);
-#pragma unroll
-	for (int g = 0; g < 32 / G; g++) {
-		if (G * g >= n_valid) break;
-		double (&t)[G] = tt[AHEAD ? (g & 1) : 0];
-		if (!AHEAD) look_up(g, t);
 		// the look-ups are waited for HERE (a use of the first one; LDS returns in order, and a scalar load in flight makes it a
-		// wait for everything), and only then are the next group's factors requested: they have this group's arithmetic to arrive
+		// wait for everything), and only then are the next group's factors requested: they have this group's arithmetic to arrive.
+		// (Requesting the NEXT group's look-ups here as well, before this group is added up, was measured twice -- round 4 and on
+		// this loop: +-1 %, eight registers.)
 		asm volatile("" : "+v"(t[0]));
 		__builtin_amdgcn_sched_barrier(0);
 		FG Fn = F;
-#ifndef HIBAG_ABL_NOFAC       // (timing ablation: every group multiplies by the block's first factors)
-		if (g + 1 < 32 / G) Fn = *(ConstPtr<FG>)(fac + G * (g + 1));
-#endif
-		if (AHEAD && g + 1 < 32 / G && G * (g + 1) < n_valid) look_up(g + 1, tt[(g + 1) & 1]);
+		if (!ABL_NOFAC && g + 1 < 32 / G) Fn = *(ConstPtr<FG>)(fac + G * (g + 1));
 		__builtin_amdgcn_sched_barrier(0);
 		if (fresh) { cell = F[0] * t[0]; asm volatile("" : "+v"(cell)); }     // (the asm keeps this a scalar branch, not a select)
 		else cell += F[0] * t[0];
@@ -458,7 +438,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // so that a whole block's evaluation covers their latency.  Lane l (and l+32: the other K half of
 // the same row) turns its pair (i1, i2) into the A-operand row (the sum of its two images).
 // What is the same for all lanes -- the block's header and the records' frequency factors ff[i1] * f[i2], both made by
-// the host (hibag_api.hip finalize_model) -- comes through the scalar cache into scalar registers: the header of block
+// the host (hibag_model.hip finalize_model) -- comes through the scalar cache into scalar registers: the header of block
 // b+1 and the first factors of block b are requested at the top of block b, before the matrix instructions; the other
 // factors group by group inside block_accumulate (which explains how they avoid the table look-ups' waits).  The number
 // of slots worth evaluating follows from the last slot that closes a cell or has a non-zero factor (a zero factor adds
@@ -489,13 +469,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 		for (int b = 0; b < nblk; b++) {
 			const u32x4 H = H_n;
 			const FG F = F_n;
-#ifdef HIBAG_ABL_NOEND
-			const uint32_t endmask = 0, storemask = 0;
-#elif defined(HIBAG_ABL_NOSTORE)
-			const uint32_t endmask = H[0], storemask = 0;
-#else
-			const uint32_t endmask = H[0], storemask = H[1];
-#endif
+			const uint32_t endmask = abl_endmask(H[0]), storemask = abl_storemask(H[1]);
 			const int n_valid = (int)H[2];
 			// (the header is waited for HERE, before the next scalar loads are issued: a wait behind them would be for them too)
 			asm volatile("" :: "s"(n_valid));
@@ -511,7 +485,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 				arow = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, vo, (int)soff, 0));    // the next block's, behind the instructions that read this one's
 				__builtin_amdgcn_sched_barrier(0);
 				block_own_sample(D0, D1, n_valid);
-				block_accumulate<G, TOTAL_AHEAD>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
+				block_accumulate<G>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
 			} else {
 				arow = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, vo, (int)soff, 0));
 			}
@@ -557,13 +531,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 			a1 = e1 + e2; a2 = v4i{0, 0, 0, 0};
 			asm volatile("" : "+v"(a1));
 		}
-#ifdef HIBAG_ABL_NOEND
-		const uint32_t endmask = 0, storemask = 0;
-#elif defined(HIBAG_ABL_NOSTORE)
-		const uint32_t endmask = H[0], storemask = 0;
-#else
-		const uint32_t endmask = H[0], storemask = H[1];
-#endif
+		const uint32_t endmask = abl_endmask(H[0]), storemask = abl_storemask(H[1]);
 		const int n_valid = (int)H[2];
 		const uint32_t ob1 = o1, ob2 = o2;           // (FP4W: where this block's entries are, for their further images)
 		// (the header is waited for HERE, before the next scalar loads are issued: a wait behind them would be for them too)
@@ -600,7 +568,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 				block_mfma<ENG>(a1, a2, lane, cterm, T, D0, D1);
 			}
 			block_own_sample(D0, D1, n_valid);
-			block_accumulate<G, TOTAL_AHEAD>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
+			block_accumulate<G>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
 		}
 		soff += BB;
 	}
@@ -961,7 +929,7 @@ __device__ __forceinline__ void handover_post(unsigned long long *flag, uint32_t
 }
 
 // Wait for the chunk before this one.  A flag that never comes (B.spin_limit polls: scaled with the model's longest
-// work item, hibag_api.hip make_batch) or that was written on another XCD is an error the caller must see: the host-mapped
+// work item, hibag_predict.hip make_batch) or that was written on another XCD is an error the caller must see: the host-mapped
 // word for the host (sticky model status), the device word for k_scalars, which poisons the batch's outputs.
 __device__ __forceinline__ void handover_wait(unsigned long long *flag, const HibagBatchView &B, uint32_t progress)
 {
@@ -1155,9 +1123,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total_wide(HibagModelView 
 	double *__restrict__ rows = cell_rows(M, B, c, group);
 	int row = seg[1];
 	auto fin = [&](double v, bool) {
-#ifndef HIBAG_ABL_WIDE_NOSTORE       // (timing ablation)
-		__builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++;
-#endif
+		if (!ABL_WIDE_NOSTORE) { __builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++; }
 		if (WHOLE) { total += v; asm("" : "+v"(total)); }   // (the asm keeps the cell end a scalar branch)
 	};
 	const WideSrc wide = wide_src(B, M.bt_row[c], M.n_step[c], group);
@@ -1273,17 +1239,6 @@ __device__ __forceinline__ void poison_scalars_if_failed(const HibagModelView &M
 // chunks, second chunks, ... ("hand-overs" above).
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
-// Diagnostic build (-DHIBAG_ACCUM_STAMPS): where a wavefront's time goes inside pass 2's block loop -- the clock is read at the
-// phase boundaries of a block and the differences are summed per workgroup in LDS, then per launch in the tail of
-// HibagBatchView::err_dev (hibag_hip_test_read_diag).  Costs a drained lgkmcnt per stamp: the sums say where the time is, not
-// how much of it there would be without the stamps.
-#ifdef HIBAG_ACCUM_STAMPS
-#define ACCUM_STAMP_N 8
-#define ACCUM_STAMP(p) do { const unsigned long long now_ = __builtin_readcyclecounter();                                   \
-	if (lane == 0) atomicAdd(&stamp_s[p], now_ - stamp_t); stamp_t = now_; } while (0)
-#else
-#define ACCUM_STAMP(p) do { } while (0)
-#endif
 #ifndef ACCUM_OCC
 #define ACCUM_OCC 5                         // workgroups per CU pass 2 is compiled for (LDS: HIBAG_TILE in hibag_device.h; registers: HIBAG_STORED_PER_VISIT)
 #endif
@@ -1362,11 +1317,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 #ifdef HIBAG_ACCUM_STAMPS
 	if (wave == 0) { bb_diag = bb; be_diag = be; }
 #endif
-#ifdef HIBAG_ABL2_NOLOOP
-	if (bb < be && B.n_pad < 0) {
-#else
-	if (bb < be) {
-#endif
+	if (bb < be && !(ABL2_NOLOOP && B.n_pad >= 0)) {
 		// the tile's blocks [bb, be): their prebuilt A-operand rows as a raw buffer rebased at block bb (no 4 GB limit on the stream)
 		const uint64_t blk0 = as_const(M.etile_blk0)[tile] + (uint64_t)bb;
 		auto bytes32 = [](size_t n) { return n > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)(uint32_t)n; };
@@ -1378,7 +1329,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		typedef FactorGroup<ACCUM_G>::type AFG;
 		// the batch's operand / {weight, 1/total} rows and this group's stored sums as raw buffers too: a row is then a scalar
 		// offset (classifier or row number times the row size, SALU) added to one constant per-lane offset -- no 64-bit address
-		// arithmetic on the vector ALU.  (hibag_api.hip batch_limit keeps every one of these arrays below 4 GB.)
+		// arithmetic on the vector ALU.  (hibag_predict.hip batch_limit keeps every one of these arrays below 4 GB.)
 		// (every descriptor ends where its array ends: a request past it -- a look-ahead through a header that names more than
 		// exists -- reads zeros instead of faulting)
 		const __amdgpu_buffer_rsrc_t r_bt = __builtin_amdgcn_make_buffer_rsrc((void *)B.bt, 0, bytes32((size_t)B.bt_rows * B.n_pad * 16u), 0x00020000);
@@ -1395,37 +1346,21 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		double sv[NS];                                // the stored sums
 		double cell = 0;
 		bool fresh = false;                           // block_accumulate: the record before closed a cell
-		// the stored sums of a block (word 1 of its header: first row | count << 25)
+		// the stored sums of a block (word 1 of its header: first row | count << 25).  Their number differs from block to block,
+		// so a wait that leaves them in flight would have to be a counted one the compiler cannot get right; ALWAYS requesting
+		// HIBAG_STORED_PER_VISIT of them (the ones a block lacks out of the buffer's range: no memory access) so that every wait
+		// is exact, and adding them at the end of the block, was measured: pass 2 +15 % -- the loads that fetch nothing still cost
+		// their issue (profiles/r05_pass2_notes.txt).
 		auto request_sv = [&](uint32_t w1) {
-#ifdef HIBAG_ABL2_NOSV
-			const int ns = 0;
-#else
-			const int ns = (int)(w1 >> 25) & 15;
-#endif
-#ifdef HIBAG_ABL2_SVHOT       // (timing ablation: every stored sum read from the group's first rows -- cache hits instead of HBM)
-			const int sr = (int)((w1 & 7u) * (uint32_t)(HIBAG_WAVE * 8));
-#else
-			const int sr = (int)((w1 & 0x1FFFFFFu) * (uint32_t)(HIBAG_WAVE * 8));
-#endif
-#ifdef HIBAG_SV_END
-			// ALWAYS NS loads: the ones a block does not have go out of the buffer's range (a vector offset past its end: no
-			// memory access, zeros back), so that the number of loads in flight is the same for every block and every wait of
-			// the loop is a counted one that the compiler gets exactly right -- the stored sums, the only loads that come from
-			// HBM, can then stay in flight while younger loads are waited for and used.
-#pragma unroll
-			for (int i = 0; i < NS; i++) {
-				const int vo = vo_sv + (i < ns ? 0 : (int)0xFFFFFE00u);
-				sv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_sv, vo, sr + i * HIBAG_WAVE * 8, 2));   // (read once: nt)
-			}
-#else
+			const int ns = abl2_stored(w1);
 			if (ns > 0) {
+				const int sr = (int)(abl2_stored_row(w1) * (uint32_t)(HIBAG_WAVE * 8));
 #pragma unroll
 				for (int i = 0; i < NS; i++) {
 					if (i >= ns) break;
 					sv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_sv, vo_sv, sr + i * HIBAG_WAVE * 8, 2));   // (read once: nt)
 				}
 			}
-#endif
 		};
 		// words 0, 1 of a header (its own, or -- words 2, 3 -- the next block's): classifier | operand row << 16, stored row | stored sums << 25
 		auto request_lane = [&](uint32_t w0, uint32_t w1, int soff_a, f64x2 &winv) {
@@ -1433,14 +1368,9 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			const int sb = (int)((w0 >> 16) * row_stride);
 			t0 = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r_bt, vo_row, sb, 0));
 			t1 = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r_bt, vo_row, sb + (int)row_stride, 0));
-#ifdef HIBAG_ABL2_NOWINV
-			winv = f64x2{1.0 + (double)w0, 2.0};
-#else
-			winv = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r_wi, vo_row, (int)((w0 & 0xFFFFu) * row_stride), 0));
-#endif
-#ifndef HIBAG_SV_END
+			if (ABL2_NOWINV) winv = f64x2{1.0 + (double)w0, 2.0};
+			else winv = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r_wi, vo_row, (int)((w0 & 0xFFFFu) * row_stride), 0));
 			request_sv(w1);
-#endif
 		};
 		// One block: `cur` = what it needs (arrived: requested a block ago), `nxt` = where the next block's goes.
 		// Order: the stored sums are added, the matrix instructions issued -- which frees this block's rows, operand and stored
@@ -1469,18 +1399,10 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			const TouchPtr touch = (TouchPtr)(uintptr_t)(fac + (size_t)(rel + 1) * HIBAG_PLIST_DWORDS);
 			const uint32_t tch0 = touch[16], tch1 = touch[32], tch2 = touch[48];
 			ACCUM_STAMP(0);
-#ifdef HIBAG_ABL2_NOEVAL
-			const int eval = 0;
-#else
-			const int eval = __builtin_amdgcn_readfirstlane(any & (n_valid > 0 ? 1 : 0));
-#endif
+			const int eval = ABL2_NOEVAL ? 0 : __builtin_amdgcn_readfirstlane(any & (n_valid > 0 ? 1 : 0));
 			// ---- the sums pass 1 stored for this block's classifier:   S[p] += (cell * (1/total)) * w
-			auto add_stored = [&]() {
-#ifdef HIBAG_ABL2_NOSV
-				const int ns = 0;
-#else
-				const int ns = (int)(cur.hv[1] >> 25) & 15;
-#endif
+			{
+				const int ns = abl2_stored(cur.hv[1]);
 				if (any && ns > 0) {
 					uint32_t jps = cur.hv[6];
 #pragma unroll
@@ -1490,10 +1412,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 						jps >>= 4;
 					}
 				}
-			};
-#ifndef HIBAG_SV_END
-			add_stored();
-#endif
+			}
 			__builtin_amdgcn_sched_barrier(0);
 			ACCUM_STAMP(1);
 			// ---- distances on the matrix pipe (their operands have arrived with everything else of the block)
@@ -1532,19 +1451,10 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 					__hip_atomic_fetch_add(&acc[(int)(jpack & 15)][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					jpack >>= 4;
 				};
-				block_accumulate<ACCUM_G, ACCUM_AHEAD>(fac + (size_t)rel * HIBAG_PLIST_DWORDS, cur.F, endmask, 0u, n_valid, D0, D1, cell, fresh, tab_s, fin);
+				block_accumulate<ACCUM_G>(fac + (size_t)rel * HIBAG_PLIST_DWORDS, cur.F, endmask, 0u, n_valid, D0, D1, cell, fresh, tab_s, fin);
 			}
 			asm volatile("" :: "s"(tch0), "s"(tch1), "s"(tch2));
 			ACCUM_STAMP(5);
-#ifdef HIBAG_SV_END
-			// (variant) the stored sums are added at the END of their block and the next block's requested right behind: they were
-			// requested a whole block ago, and nothing in between has waited for them (every wait of the loop is a counted one)
-			__builtin_amdgcn_sched_barrier(0);
-			add_stored();
-			__builtin_amdgcn_sched_barrier(0);
-			request_sv(cur.hv[3]);
-			ACCUM_STAMP(6);
-#endif
 		};
 
 		AccumAhead A, Bn;
@@ -1552,9 +1462,6 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		A.ph = phdr[0];
 		A.F = *(ConstPtr<AFG>)fac;
 		request_lane(A.hv[0], A.hv[1], 0, A.winv);
-#ifdef HIBAG_SV_END
-		request_sv(A.hv[1]);
-#endif
 #ifdef HIBAG_ACCUM_STAMPS
 		stamp_t = __builtin_readcyclecounter();
 #endif
@@ -2081,7 +1988,7 @@ void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStr
 			(void)hipStreamWaitEvent(side.stream, side.fork, 0);
 		}
 		// (a classifier of several K steps without haplotypes has no segment: its total still has to be written)
-		// (segments are either all whole classifiers or none: hibag_api.hip finalize_model)
+		// (segments are either all whole classifiers or none: hibag_model.hip finalize_model)
 		if (M.n_wide_seg > 0 && M.n_wide_scan < M.n_wide) hipLaunchKernelGGL(k_total_wide<true>, dim3(gq, M.n_wide_seg), dim3(BLOCK_THREADS), 0, ws, M, B);
 		else if (M.n_wide_seg > 0) hipLaunchKernelGGL(k_total_wide<false>, dim3(gq, M.n_wide_seg), dim3(BLOCK_THREADS), 0, ws, M, B);
 		if (M.n_wide_scan > 0) hipLaunchKernelGGL(k_total_scan, dim3(B.n_pad / 64, M.n_wide_scan), dim3(64), 0, ws, W, B);

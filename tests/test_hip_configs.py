@@ -290,7 +290,7 @@ def test_predict_multi_two_replicas_on_one_device_equal_the_single_call(hib, ora
 @pytest.mark.parametrize("n_haplo", [16383, 16384])
 def test_haplotype_count_at_the_matrix_engines_index_limit(hib, oracle, n_haplo):
     """A classifier of 16,383 haplotypes is the largest the matrix engines take (a block's slot word holds the second
-    haplotype's table index in 14 bits, the first's in 16: hibag_api.hip finalize_model); one of 16,384 goes to the vector
+    haplotype's table index in 14 bits, the first's in 16: hibag_model.hip finalize_model); one of 16,384 goes to the vector
     engine whatever its SNP count.  134 million haplotype pairs per sample either way; beside it an ordinary classifier."""
     rng = np.random.default_rng(n_haplo)
     n_hla, k = 40, 20
