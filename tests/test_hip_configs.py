@@ -210,6 +210,34 @@ def test_cfg4_at_the_benchmarks_size_chunked_items_against_oracle(hib, oracle):
         assert np.array_equal(got[k][sub], want[k], equal_nan=True), k
 
 
+@pytest.mark.parametrize("n", [700, 10_000])
+def test_generated_rows_and_prebuilt_rows_give_the_same_bits(hib, oracle, monkeypatch, n):
+    """The one-step FP4 walk of pass 1 has two sources for its A-operand rows: prebuilt (HibagModelView::parow: the model is
+    small enough, the default for every shape of the suite) and generated from the O(H) haplotype table (larger models,
+    HIBAG_PREBUILT_MB=0 here).  Both vote methods (the vote has builds of its own) at a batch of one round -- the general
+    build, five workgroups per CU -- and of several -- the FP4-only builds at six, with chunked items: bit-equal to each
+    other and, on a subset, to the oracle."""
+    from hibag_amd import synth
+    model, founders, af = synth.make_model("hla-b")
+    G, _ = synth.make_samples(founders, af, n, seed=77)
+    G[5, :] = hib.NA_INTEGER
+    pre = hib.hlaModelFromObj(model)
+    monkeypatch.setenv("HIBAG_PREBUILT_MB", "0")
+    gen = hib.hlaModelFromObj(model)
+    monkeypatch.delenv("HIBAG_PREBUILT_MB")
+    sub = np.arange(0, n, max(1, n // 30))[:30]
+    for vote in (1, 2):
+        a = pre.predict_raw(G, vote, want_dosage=True, want_prob=True)
+        b = gen.predict_raw(G, vote, want_dosage=True, want_prob=True)
+        for k in ("h1", "h2", "prob", "matching", "dosage", "postprob"):
+            assert np.array_equal(a[k], b[k], equal_nan=True), (vote, k)
+        want = oracle.predict(oracle.flatten(model), G[sub], vote_method=vote, avx2=True, n_threads=8)
+        for k in ("h1", "h2", "prob", "matching", "dosage", "postprob"):
+            assert np.array_equal(b[k][sub], want[k], equal_nan=True), (vote, k)
+    assert pre.handover_faults() == 0 and gen.handover_faults() == 0
+    pre.close(); gen.close()
+
+
 _TAIL_K_SCRIPT = r"""
 import os, sys, json
 import numpy as np
