@@ -1,0 +1,13 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05fuzz
+rm -f gpurun_out/r05fuzz/report.txt
+export HIBAG_FUZZ_REPORT=$PWD/gpurun_out/r05fuzz/report.txt
+{
+HIBAG_FUZZ_SECONDS=540 HIBAG_FUZZ_SEED=500000 timeout 1200 python -m pytest tests/test_hip_fuzz.py::test_wide_campaign -x -q -m gpu 2>&1 | tail -3
+HIBAG_FUZZ_SECONDS=240 HIBAG_FUZZ_SEED=520000 HIBAG_FUZZ_BIG_EVERY=2 timeout 900 python -m pytest tests/test_hip_fuzz.py::test_wide_campaign -x -q -m gpu 2>&1 | tail -3
+HIBAG_FUZZ_SECONDS=300 HIBAG_FUZZ_SEED=540000 timeout 900 python -m pytest tests/test_hip_fuzz.py::test_entry_points_campaign -x -q -m gpu 2>&1 | tail -3
+HIBAG_FUZZ_SECONDS=180 HIBAG_FUZZ_SEED=560000 timeout 900 python -m pytest tests/test_hip_fuzz.py::test_plugin_campaign -x -q -m gpu 2>&1 | tail -3
+HIBAG_FUZZ_SECONDS=300 HIBAG_FUZZ_SEED=580000 timeout 900 python -m pytest tests/test_hip_train_driver.py::test_training_campaign -x -q -m gpu 2>&1 | tail -3
+cat gpurun_out/r05fuzz/report.txt
+} > gpurun_out/r05fuzz/log.txt 2>&1
+cat gpurun_out/r05fuzz/log.txt
