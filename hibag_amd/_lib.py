@@ -20,7 +20,7 @@ K_PACK, K_TOTAL, K_ACCUM, K_FINISH, K_COUNT = 0, 1, 2, 3, 4
 KERNEL_NAMES = {K_PACK: "pack", K_TOTAL: "total", K_ACCUM: "accum", K_FINISH: "finish"}
 
 EXPORTS = [
-    "hibag_hip_abi_version", "hibag_hip_last_error", "hibag_hip_device_count", "hibag_hip_set_device",
+    "hibag_hip_abi_version", "hibag_hip_last_error", "hibag_hip_device_count", "hibag_hip_set_device", "hibag_hip_get_device",
     "hibag_hip_set_kernel_target", "hibag_hip_model_new", "hibag_hip_model_add_classifier",
     "hibag_hip_model_add_classifier_packed", "hibag_hip_model_finalize", "hibag_hip_model_free",
     "hibag_hip_model_n_hla", "hibag_hip_model_n_snp", "hibag_hip_model_n_classifier",

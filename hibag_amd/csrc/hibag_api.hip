@@ -52,6 +52,8 @@ int hibag_hip_set_device(int device)
 	return 0;
 }
 
+int hibag_hip_get_device(void) { return g_device; }
+
 int hibag_hip_set_kernel_target(const char *target, char *info, size_t info_len)
 {
 	if (!target || strcmp(target, "hip") != 0)

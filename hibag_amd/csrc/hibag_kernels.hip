@@ -281,6 +281,9 @@ void hibag_launch_finish(const HibagModelView &M, const HibagBatchView &B, doubl
 	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching,
 	double *d_dosage, double *d_postprob, hipStream_t st)
 {
+	// (One read of the ensemble sums instead of three -- call and dosage from LDS chunks of 128 cells, 32 samples x 32 threads per
+	// workgroup -- was built and measured in round 5: 76 us against 47.  The three-read kernel has 785 workgroups of independent
+	// loads and runs at 6.5 TB/s; the one-read one has 314 workgroups with a barrier per chunk.  profiles/r05_pass2_notes.txt item 9.)
 	if (d_dosage) {
 		const unsigned n_group = (unsigned)(B.n_pad / 64);
 		hipLaunchKernelGGL(k_finish, dim3(n_group * (1u + (unsigned)((M.n_hla + FIN_SEG - 1) / FIN_SEG))), dim3(64 * FIN_SEG), 0, st,

@@ -326,6 +326,9 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 		HIP_TRY(hipEventRecord(ss->up[i & 1], ss->in));
 		return 0;
 	};
+	bool small_staged = false;
+	if (!piped)
+		if (int rc = m->pin_out.reserve(o_ds)) return rc;
 	// device -> host of slice i's outputs: straight into the caller's arrays (one slice), or into the pinned staging buffer
 	auto download = [&](int i) -> int {
 		int s0, n; slice_of(i, s0, n);
@@ -338,12 +341,14 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 			return 0;
 		}
 		hipStream_t st = ss->run;
-		if (H1) {
-			HIP_TRY(hipMemcpyAsync(H1 + s0, o + o_h1, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-			HIP_TRY(hipMemcpyAsync(H2 + s0, o + o_h2, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+		// One slice: the four per-sample vectors (calls, probability, matching: 24 bytes per sample, contiguous on the device)
+		// come down in ONE copy into pinned staging and are handed out behind the final synchronisation -- a copy into the
+		// caller's pageable memory holds the calling thread for ~12 us whatever its size, and there were four of them; the
+		// large ones (dosage, posterior) go straight to the caller's arrays.
+		if (H1 || max_prob || matching) {
+			HIP_TRY(hipMemcpyAsync(m->pin_out.p, o, o_ds, hipMemcpyDeviceToHost, st));
+			small_staged = true;
 		}
-		if (max_prob) HIP_TRY(hipMemcpyAsync(max_prob + s0, o + o_mp, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-		if (matching) HIP_TRY(hipMemcpyAsync(matching + s0, o + o_mt, (size_t)n * 8, hipMemcpyDeviceToHost, st));
 		if (dosage) HIP_TRY(hipMemcpyAsync(dosage + (size_t)s0 * nh, o + o_ds, (size_t)n * nh * 8, hipMemcpyDeviceToHost, st));
 		if (postprob) HIP_TRY(hipMemcpyAsync(postprob + (size_t)s0 * P, o + o_pp, (size_t)n * P * 8, hipMemcpyDeviceToHost, st));
 		return 0;
@@ -400,6 +405,12 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 	}
 	if (trace) tr[4] = now();
 	HIP_TRY(hipStreamSynchronize(ss->run));
+	if (small_staged) {                                  // (one slice: s0 = 0, n = n_samp)
+		const char *o = (const char *)m->pin_out.p;
+		if (H1) { memcpy(H1, o + o_h1, (size_t)n_samp * 4); memcpy(H2, o + o_h2, (size_t)n_samp * 4); }
+		if (max_prob) memcpy(max_prob, o + o_mp, (size_t)n_samp * 8);
+		if (matching) memcpy(matching, o + o_mt, (size_t)n_samp * 8);
+	}
 	if (trace) {
 		tr[5] = now();
 		if (!piped) fprintf(stderr, "[hibag staged] n=%d upload %.3f  enqueue %.3f  kernels %.3f  download calls %.3f  final sync %.3f ms\n", n_samp,

@@ -333,6 +333,7 @@ struct OneState {
 	unsigned long long calls = 0;                         // launches so far (the barrier counters count n_group arrivals per launch)
 	int n_group_full = 1;                                 // workgroups of a launch while the device is this process's alone
 	bool counters_stale = false;                          // a launch failed or timed out: the device counters are zeroed before the next one
+	int last_groups = 0;                                  // workgroups of the last launch (the counters count per launch of THAT width)
 	long long degraded_calls = 0;                         // calls that had to be repeated on one workgroup (hibag_sample_degraded_calls)
 };
 OneState g1;
@@ -490,7 +491,7 @@ void hibag_sample_init(int n_hla, int n_classifier, const PluginHaplotype *const
 	V.spin_limit = getenv("HIBAG_ONE_SPIN") ? (unsigned)std::max(0, atoi(getenv("HIBAG_ONE_SPIN"))) : (1u << 21);
 	V.stamps_on = getenv("HIBAG_ONE_STAMPS") != nullptr;
 	g1.P = P; g1.C = C; g1.device = hibag_selected_device();
-	g1.seq = 0; g1.calls = 0; g1.counters_stale = false; g1.degraded_calls = 0;
+	g1.seq = 0; g1.calls = 0; g1.counters_stale = false; g1.degraded_calls = 0; g1.last_groups = 0;
 	g1.active = true;
 }
 
@@ -516,12 +517,15 @@ void hibag_sample_avg_prob(const PluginGenotype geno[], const double weight[], d
 	// reports.  Whatever goes wrong leaves `counters_stale` set, so that the next launch -- of this call or of a later one --
 	// starts from zeroed device counters: a failure never outlives the call it happened in.
 	auto run = [&](int groups) -> bool {
-		if (g1.counters_stale) {
+		// (the barrier counters only ever grow, `calls * groups` arrivals ending call number `calls`: a launch of another width
+		// than the last one starts them over, like a failed one)
+		if (g1.counters_stale || (g1.last_groups != 0 && g1.last_groups != groups)) {
 			ONE_OK(hipStreamSynchronize(g1.st), "predict_avg_prob (draining a failed launch)");     // its workgroups may still be giving up
 			ONE_OK(hipMemsetAsync(g1.V.arrived, 0, 16, g1.st), "hipMemsetAsync(counters)");
 			g1.calls = 0;
 		}
 		g1.counters_stale = true;                                          // until this launch has reported
+		g1.last_groups = groups;
 		const uint32_t seq = g1.seq = g1.seq % 0x7FFFFFFEu + 1;            // 1 .. 2^31 - 2: never the flag's initial value, top bit free
 		OneView V = g1.V;
 		V.n_group = groups;

@@ -386,13 +386,14 @@ def grow_concurrently(genomat, h1, h2, n_hla: int, nclassifier: int, mtry: int, 
     import threading
     from .dist import shard_bounds
     k = max(1, min(int(n_trainers), max(int(nclassifier), 1)))
+    if device is None:
+        device = int(_lib.lib().hibag_hip_get_device())      # the caller's selection: the workers' threads start from the default
     parts: List = [None] * k
     errs: List = [None] * k
 
     def work(r: int) -> None:
         try:
-            if device is not None:
-                _lib.check(_lib.lib().hibag_hip_set_device(int(device)))      # (the selection is per host thread)
+            _lib.check(_lib.lib().hibag_hip_set_device(int(device)))          # (the selection is per host thread)
             lo, hi = shard_bounds(int(nclassifier), k, r)
             if hi <= lo:
                 parts[r] = []

@@ -53,6 +53,8 @@ int hibag_hip_device_count(void);
 
 /* Device used by models created afterwards on this thread (default 0). */
 int hibag_hip_set_device(int device);
+/* The calling thread's selection (what a host passes on to the worker threads it starts: the selection is per thread). */
+int hibag_hip_get_device(void);
 
 /* Kernel-target selection -- the extension of hlaSetKernelTarget()
  * (R/HIBAG.R:1668-1674 -> HIBAG_Kernel_SetTarget, src/HIBAG.cpp:1430-1435 ->
