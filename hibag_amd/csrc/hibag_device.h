@@ -67,6 +67,14 @@
 #ifndef HIBAG_CHUNK
 #define HIBAG_CHUNK 4            // pair records per chunk
 #endif
+// wavefronts per workgroup of pass 1 (each on its own work item: four sample groups on one classifier) and of pass 2 (the
+// sample groups that share a tile's blocks in L1); the host sizes the hand-over flags by them
+#ifndef HIBAG_BLOCK_WAVES
+#define HIBAG_BLOCK_WAVES 4
+#endif
+#ifndef HIBAG_ACCUM_WAVES
+#define HIBAG_ACCUM_WAVES 4
+#endif
 #define HIBAG_TILE_META (4 + HIBAG_TILE)   // dwords of one tile_meta entry
 static_assert(HIBAG_TILE <= 16, "cell rows are packed 4 bits each");
 #define HIBAG_MAX_NWP 12         // ceil(3*128/32) words of the packed pair string
@@ -224,13 +232,16 @@ struct HibagModelView {
 	// E-stream: what pass 2 (k_accum) reads when it evaluates pairs again (store_cells != 1).  Per tile the blocks of
 	// classifier 0, 1, 2 ... that have anything for the tile, back to back -- pair slots in `plist` (32 per block, as in the
 	// pass-1 lists; the kernel reads their prebuilt rows, `parow`), one 8-dword header per block in `ehdr`:
-	//   [0] classifier | first B-operand row << 16
+	//   [0] the block's end-of-cell mask (bit i: slot i closes a cell)
 	//   [1] first stored-sum row (model-wide numbering, HibagBatchView::cells) | stored sums of this block (0..HIBAG_STORED_PER_VISIT) << 25
-	//   [2], [3] the same two words of the NEXT block of the stream: what the kernel needs to REQUEST a block's per-lane data
-	//            (weight, 1/total, B operand, stored sums) it finds in the header of the block before, so that only two
-	//            headers are alive at a time -- the one in use and the one in flight -- and the loop, unrolled twice, rotates nothing
+	//   [2], [3] the request words of the NEXT block of the stream -- its classifier | first B-operand row << 16, and its word 1:
+	//            what the kernel needs to REQUEST a block's per-lane data (weight, 1/total, B operand, stored sums) it finds in
+	//            the header of the block before, so that only two headers are alive at a time -- the one in use and the one in
+	//            flight -- and the loop, unrolled twice, rotates nothing
 	//   [4], [5] tile rows of the cells that CLOSE in this block, 4 bits each, in closing order
-	//   [6] tile rows of the stored sums, 4 bits each
+	//   [6] tile rows of the stored sums, 4 bits each (28 bits) | groups of four slots worth evaluating (0..8) << 28
+	//   [7] this block's own classifier | first B-operand row << 16 (a walk requests its FIRST block from words 7 and 1)
+	// The header is all the scalar data of a block besides its slots' factors (`pfac`): one s_load_dwordx8.
 	// Only one-step FP4 classifiers have pair slots here; the others' blocks carry stored sums only (all slots padding).
 	const uint32_t *ehdr;        // [estream_blocks][8]
 	uint64_t estream_blocks;     // blocks of all tiles together, incl. the look-ahead slack behind the last

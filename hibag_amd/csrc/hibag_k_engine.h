@@ -291,9 +291,13 @@ template <> struct FactorGroup<8> { typedef f64x8 type; };
 // record before closed one (a scalar register; the walk that ends on it materialises the zero).
 template <int G, class Fin>
 __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename FactorGroup<G>::type F, uint32_t endmask, uint32_t storemask, int n_valid,
-	const v16i &D0, const v16i &D1, double &cell, bool &fresh, const double *tab_s, Fin &&fin)
+	const v16i &D0, const v16i &D1, double &cell, uint32_t &fresh, const double *tab_s, Fin &&fin)
 {
 	typedef typename FactorGroup<G>::type FG;
+	// (a copy of the end mask for the "starts" tests below: tested on the same register as the "end" test of the group before,
+	// the two become ONE test kept as a 64-bit mask -- a select and two mask operations where two bit tests do)
+	uint32_t startmask = endmask;
+	asm volatile("" : "+s"(startmask));
 #pragma unroll
 	for (int g = 0; g < 32 / G; g++) {
 		if (G * g >= n_valid) break;
@@ -313,9 +317,11 @@ __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename 
 		FG Fn = F;
 		if (!ABL_NOFAC && g + 1 < 32 / G) Fn = *(ConstPtr<FG>)(fac + G * (g + 1));
 		__builtin_amdgcn_sched_barrier(0);
-		if (fresh) { cell = F[0] * t[0]; asm volatile("" : "+v"(cell)); }     // (the asm keeps this a scalar branch, not a select)
+		// the record before this group closed a cell: the caller's word for the block's first group, the end mask's own bit for
+		// the others (a bit test and a branch where a carried flag cost a select and a compare per group)
+		const bool starts = g == 0 ? fresh != 0 : (startmask & (1u << (G * g - 1))) != 0;
+		if (starts) { cell = F[0] * t[0]; asm volatile("" : "+v"(cell)); }     // (the asm keeps this a scalar branch, not a select)
 		else cell += F[0] * t[0];
-		fresh = false;
 #pragma unroll
 		for (int q = 1; q < G; q += 2) {      // cells are padded to an even number of records: only odd positions close one
 			cell += F[q] * t[q];
@@ -324,10 +330,13 @@ __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename 
 			if (q + 1 < G) {
 				if (end) { fin(cell, stored); cell = F[q + 1] * t[q + 1]; }
 				else cell += F[q + 1] * t[q + 1];
-			} else if (end) { fin(cell, stored); fresh = true; }
+			} else if (end) fin(cell, stored);
 		}
 		F = Fn;
 	}
+	// what the next block's first group starts from: the end bit of the last record gone through (once per block)
+	const int groups = n_valid >= 32 ? 32 / G : (n_valid + G - 1) / G;
+	if (groups > 0) fresh = (endmask >> (G * groups - 1)) & 1u;
 }
 
 // (the LDS staging area of round 2 -- the factors parked by lanes 0..31 and read back as broadcasts -- is gone)
@@ -376,7 +385,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 	static_assert(!PRE || ENG == HIBAG_ENGINE_FP4, "prebuilt rows exist for one-step FP4 classifiers only");
 	if (nblk <= 0) return;
 	typedef typename FactorGroup<G>::type FG;
-	bool fresh = false;                              // block_accumulate: the record before closed a cell
+	uint32_t fresh = 0;                              // block_accumulate: the record before closed a cell
 	ConstPtr<double> fac = as_const(M.pfac) + at;                            // this segment's factors and headers
 	ConstPtr<u32x4> hdr = (ConstPtr<u32x4>)(as_const(M.phdr) + at / HIBAG_PLIST_DWORDS * 4);
 	if (PRE) {

@@ -35,8 +35,7 @@ typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 // the end-of-cell masks, its first factors (scalar registers) and the lane's weight and 1/total.  The loop body exists twice
 // (A -> B, B -> A): the two sets take turns, nothing is moved from a "next" register to a "current" one.
 struct AccumAhead {
-	u32x8 hv;           // the E-stream header (hibag_device.h)
-	u32x4 ph;           // {end-of-cell mask, -, slots worth evaluating, -}
+	u32x8 hv;           // the E-stream header (hibag_device.h): end-of-cell mask, stored sums, the next block's request words, tile rows, groups worth evaluating
 	FactorGroup<ACCUM_G>::type F;   // the first ACCUM_G factors
 	f64x2 winv;         // {weight, 1/total} of the block's classifier for this lane's sample
 };
@@ -109,10 +108,12 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		// the tile's blocks [bb, be): their prebuilt A-operand rows as a raw buffer rebased at block bb (no 4 GB limit on the stream)
 		const uint64_t blk0 = as_const(M.etile_blk0)[tile] + (uint64_t)bb;
 		auto bytes32 = [](size_t n) { return n > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)(uint32_t)n; };
+		// (every descriptor gets a flags word of its own: sharing one constant register between the four made the compiler keep
+		// two copies of three of them -- twelve scalar registers, and three moves per block)
+		auto rsrc_flags = [] { int f = 0x00020000; asm volatile("" : "+s"(f)); return f; };
 		const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void *)(M.parow + blk0 * 64), 0,
-			bytes32((size_t)(M.parow_blocks - blk0) * 1024u), 0x00020000);
+			bytes32((size_t)(M.parow_blocks - blk0) * 1024u), rsrc_flags());
 		ConstPtr<double> fac = as_const(M.pfac) + blk0 * HIBAG_PLIST_DWORDS;                 // the slots' frequency factors
-		ConstPtr<u32x4> phdr = (ConstPtr<u32x4>)(as_const(M.phdr) + blk0 * 4);               // the blocks' {end mask, -, slots worth evaluating, -}
 		ConstPtr<u32x8> eh = (ConstPtr<u32x8>)(as_const(M.ehdr) + blk0 * 8);                 // the blocks' 8-dword headers (scalar loads)
 		typedef FactorGroup<ACCUM_G>::type AFG;
 		// the batch's operand / {weight, 1/total} rows and this group's stored sums as raw buffers too: a row is then a scalar
@@ -123,12 +124,12 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		// (both rebased at this wavefront's 64 samples: the lane's offset into a row is then the same 16 * lane as into a block's rows)
 		const size_t g_bytes = (size_t)group * HIBAG_WAVE * 16u;
 		const __amdgpu_buffer_rsrc_t r_bt = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)B.bt + g_bytes), 0,
-			bytes32((size_t)B.bt_rows * B.n_pad * 16u - g_bytes), 0x00020000);
+			bytes32((size_t)B.bt_rows * B.n_pad * 16u - g_bytes), rsrc_flags());
 		const __amdgpu_buffer_rsrc_t r_wi = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)B.winv + g_bytes), 0,
-			bytes32((size_t)C * B.n_pad * 16u - g_bytes), 0x00020000);
+			bytes32((size_t)C * B.n_pad * 16u - g_bytes), rsrc_flags());
 		const __amdgpu_buffer_rsrc_t r_sv = __builtin_amdgcn_make_buffer_rsrc(
 			(void *)(B.cells + (size_t)group * (size_t)as_const(M.cell_row)[C] * HIBAG_WAVE), 0,
-			bytes32((size_t)as_const(M.cell_row)[C] * HIBAG_WAVE * 8u), 0x00020000);
+			bytes32((size_t)as_const(M.cell_row)[C] * HIBAG_WAVE * 8u), rsrc_flags());
 		const int vo_a = lane * 16, vo_row = vo_a, vo_sv = lane * 8;
 		const uint32_t row_stride = (uint32_t)B.n_pad * 16u;          // bytes per operand row and per classifier's {weight, 1/total} row
 		constexpr int NS = HIBAG_STORED_PER_VISIT;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		v4i arow, t0, t1;                             // the A-operand row, the B operand (two sample halves)
 		double sv[NS];                                // the stored sums
 		double cell = 0;
-		bool fresh = false;                           // block_accumulate: the record before closed a cell
+		uint32_t fresh = 0;                           // block_accumulate: the record before closed a cell
 		// the stored sums of a block (word 1 of its header: first row | count << 25).  Their number differs from block to block,
 		// so a wait that leaves them in flight would have to be a counted one the compiler cannot get right; ALWAYS requesting
 		// HIBAG_STORED_PER_VISIT of them (the ones a block lacks out of the buffer's range: no memory access) so that every wait
@@ -147,14 +148,16 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			const int ns = abl2_stored(w1);
 			if (ns > 0) {
 				const int sr = (int)(abl2_stored_row(w1) * (uint32_t)(HIBAG_WAVE * 8));
+				int vo = vo_sv;
+				asm volatile("" : "+v"(vo));                  // (kept out of the loop-invariant code: vo + 512 i in six registers instead of the instructions' offset fields)
 #pragma unroll
 				for (int i = 0; i < NS; i++) {
 					if (i >= ns) break;
-					sv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_sv, vo_sv, sr + i * HIBAG_WAVE * 8, 2));   // (read once: nt)
+					sv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_sv, vo + i * HIBAG_WAVE * 8, sr, 2));   // (read once: nt; the row's distance as the instruction's immediate offset)
 				}
 			}
 		};
-		// words 0, 1 of a header (its own, or -- words 2, 3 -- the next block's): classifier | operand row << 16, stored row | stored sums << 25
+		// the request words of a header (its own -- words 7, 1 -- or the next block's, words 2, 3): classifier | operand row << 16, stored row | stored sums << 25
 		auto request_lane = [&](uint32_t w0, uint32_t w1, int soff_a, f64x2 &winv) {
 			arow = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, vo_a, soff_a, 0));
 			const int sb = (int)((w0 >> 16) * row_stride);
@@ -172,17 +175,17 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		auto one_block = [&](const int rel, AccumAhead &cur, AccumAhead &nxt) {
 			const double w_c = cur.winv[0];
 			const bool active = w_c > 0;
-			// (as integers in scalar registers: a bool that lives across the requests below ends up in a vector register and back)
-			const int any = __builtin_amdgcn_readfirstlane(__ballot(active) != 0 ? 1 : 0);   // 0: nobody in the group uses the classifier (src/LibHLA.cpp:2451): nothing to add
+			// (as integers in scalar registers -- a count of lanes is one scalar instruction; a bool that lives across the requests
+			// below ends up in a vector register and back)
+			const int any = __builtin_popcountll(__ballot(active));   // 0: nobody in the group uses the classifier (src/LibHLA.cpp:2451): nothing to add
 			// inactive lanes (weight 0) must keep their sums: with 1/total replaced by 0 their term is
 			// (cell * 0) * 0 = +0 and a + 0 == a, which spares a select per closed cell
 			const double inv_e = active ? cur.winv[1] : 0.0;
-			const uint32_t endmask = cur.ph[0];
-			const int n_valid = (int)cur.ph[2];
+			const uint32_t endmask = cur.hv[0];
+			const int n_valid = (int)(cur.hv[6] >> 28) * 4;           // (the header counts the groups of four records worth evaluating)
 			asm volatile("" :: "s"(n_valid));             // (this block's scalar data is waited for before the next block's is requested)
 			__builtin_amdgcn_sched_barrier(0);
 			nxt.hv = eh[rel + 1];
-			nxt.ph = phdr[rel + 1];
 			nxt.F = *(ConstPtr<AFG>)(fac + (size_t)(rel + 1) * HIBAG_PLIST_DWORDS);
 			// The other three 64-byte lines of block b + 1's factors are touched a block ahead, so that the scalar loads of its
 			// later groups hit the scalar cache (-5 % on the kernel): one dword each, volatile so that the loads stay HERE, "used"
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			const TouchPtr touch = (TouchPtr)(uintptr_t)(fac + (size_t)(rel + 1) * HIBAG_PLIST_DWORDS);
 			const uint32_t tch0 = touch[16], tch1 = touch[32], tch2 = touch[48];
 			ACCUM_STAMP(0);
-			const int eval = ABL2_NOEVAL ? 0 : __builtin_amdgcn_readfirstlane(any & (n_valid > 0 ? 1 : 0));
+			const int eval = ABL2_NOEVAL ? 0 : (any != 0 ? n_valid : 0);
 			// ---- the sums pass 1 stored for this block's classifier:   S[p] += (cell * (1/total)) * w
 			{
 				const int ns = abl2_stored(cur.hv[1]);
@@ -245,15 +248,16 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 				};
 				block_accumulate<ACCUM_G>(fac + (size_t)rel * HIBAG_PLIST_DWORDS, cur.F, endmask, 0u, n_valid, D0, D1, cell, fresh, tab_s, fin);
 			}
-			asm volatile("" :: "s"(tch0), "s"(tch1), "s"(tch2));
+			// (the header's word 7 counts as in use to the end of the block: otherwise its register -- free as far as the compiler
+			// can see, but still to be written by the header load in flight -- is handed to one of the loads above, which then has to wait for that load)
+			asm volatile("" :: "s"(tch0), "s"(tch1), "s"(tch2), "s"(nxt.hv[7]));
 			ACCUM_STAMP(5);
 		};
 
 		AccumAhead A, Bn;
 		A.hv = eh[0];
-		A.ph = phdr[0];
 		A.F = *(ConstPtr<AFG>)fac;
-		request_lane(A.hv[0], A.hv[1], 0, A.winv);
+		request_lane(A.hv[7], A.hv[1], 0, A.winv);
 #ifdef HIBAG_ACCUM_STAMPS
 		stamp_t = __builtin_readcyclecounter();
 #endif

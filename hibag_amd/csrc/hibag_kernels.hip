@@ -52,9 +52,7 @@
 #ifndef HIBAG_GATHER_DEPTH
 #define HIBAG_GATHER_DEPTH 1                // blocks of look-ahead of the haplotype-entry gathers
 #endif
-#ifndef BLOCK_WAVES
-#define BLOCK_WAVES 4                       // wavefronts per workgroup (each on its own work item)
-#endif
+#define BLOCK_WAVES HIBAG_BLOCK_WAVES         // wavefronts per workgroup (each on its own work item; hibag_device.h)
 #define BLOCK_THREADS (BLOCK_WAVES * HIBAG_WAVE)
 #ifndef TOTAL_G
 #define TOTAL_G 8                           // records of pass 1 whose look-ups are in flight together (and whose factors arrive in one scalar load)
@@ -76,9 +74,7 @@
 #endif
 #define ACCUM_TAB_N 64                      // table entries pass 2 stages: it evaluates one-step FP4 classifiers only
 static_assert(2 * HIBAG_FP4_MAX_SNPS + 1 <= ACCUM_TAB_N, "pass 2's table must cover every distance of a one-step FP4 classifier");
-#ifndef ACCUM_WAVES
-#define ACCUM_WAVES 4                       // wavefronts per workgroup of pass 2 (sample groups that share a tile's lists in L1)
-#endif
+#define ACCUM_WAVES HIBAG_ACCUM_WAVES         // wavefronts per workgroup of pass 2 (sample groups that share a tile's blocks in L1)
 
 // The device code, in the order of a step (each file says what it holds):
 #include "hibag_k_engine.h"
@@ -123,14 +119,20 @@ void hibag_launch_bed_geno(const uint8_t *d_bed, int mode, size_t stride, int n_
 
 // resident workgroups of a kernel on the current device (0 = unknown)
 template <class F>
-static int resident_blocks(F kernel, int threads)
+static int resident_blocks(F kernel, int threads, size_t dyn_lds = 0)
 {
 	int per_cu = 0, cus = 0, dev = 0;
 	(void)hipGetDevice(&dev);
 	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess) return 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, dyn_lds) != hipSuccess) return 0;
 	return per_cu > 0 && cus > 0 ? per_cu * cus : 0;
 }
+
+#ifdef HIBAG_ABL2_LDSPAD                      // (timing ablation, hibag_ablation.h: pass 2 at fewer resident workgroups, same code)
+#define ACCUM_DYN_LDS HIBAG_ABL2_LDSPAD
+#else
+#define ACCUM_DYN_LDS 0
+#endif
 
 // chunks per item of the last rounds of passes 1 and 2 ("hand-overs"; HIBAG_TAIL_K=1: undivided items only).
 // A hand-over costs about as much as a tenth of a block list of the benchmark model, so 4 chunks there (2 and 8 measure 1-3 %
@@ -154,7 +156,7 @@ void hibag_query_slots(int total[4], int *accum)
 	total[1] = resident_blocks(k_total<false, HIBAG_TOT_OCC_MANY, 2>, BLOCK_THREADS);
 	total[2] = resident_blocks(k_total<true, HIBAG_TOT_OCC, 0>, BLOCK_THREADS);
 	total[3] = resident_blocks(k_total<true, HIBAG_TOT_OCC_MANY, 2>, BLOCK_THREADS);
-	*accum = resident_blocks(k_accum, ACCUM_WAVES * HIBAG_WAVE);
+	*accum = resident_blocks(k_accum, ACCUM_WAVES * HIBAG_WAVE, ACCUM_DYN_LDS);
 }
 
 void hibag_launch_total(const HibagModelView &M, const HibagBatchView &B, hipStream_t st, const HibagSideStream &side, bool vote)
@@ -249,7 +251,7 @@ void hibag_launch_accum(const HibagModelView &M, const HibagBatchView &B, hipStr
 		K = (unsigned)tail_chunks(B.tail_k, 0, 2);
 		n_whole = nx - (nx % sx + sx);
 	}
-	hipLaunchKernelGGL(k_accum, dim3(8 * (n_whole + K * (nx - n_whole))), dim3(ACCUM_WAVES * HIBAG_WAVE), 0, st, M, B, (int)n_whole, (int)K);
+	hipLaunchKernelGGL(k_accum, dim3(8 * (n_whole + K * (nx - n_whole))), dim3(ACCUM_WAVES * HIBAG_WAVE), ACCUM_DYN_LDS, st, M, B, (int)n_whole, (int)K);
 }
 
 void hibag_launch_vote(const HibagModelView &M, const HibagBatchView &B, int *d_best_cell, hipStream_t st)

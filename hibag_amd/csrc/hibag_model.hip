@@ -698,6 +698,14 @@ int finalize_model(hibag_hip_model *m)
 		while (n_valid < 32 && (live >> n_valid)) n_valid++;
 		phdr[4 * b] = ends; phdr[4 * b + 1] = stores; phdr[4 * b + 2] = (uint32_t)n_valid;
 	}
+	// Pass 2 takes everything of a block from its E-stream header alone (hibag_device.h): the end mask goes where the block's
+	// own request words were (word 0; they move to word 7 -- a walk needs them for its first block only, every other block
+	// is requested through the words 2, 3 of the header before it), the groups of four records worth evaluating above the stored cells' rows.
+	for (uint64_t b = 0; b < estream_blocks; b++) {
+		ehdr[b * 8 + 7] = ehdr[b * 8];
+		ehdr[b * 8] = phdr[4 * b];
+		ehdr[b * 8 + 6] = (ehdr[b * 8 + 6] & 0x0FFFFFFFu) | (((phdr[4 * b + 2] + 3) / 4) << 28);
+	}
 	// Prebuilt A-operand rows (HibagModelView::parow): for every slot of a one-step FP4 classifier the element-wise sum of its
 	// two haplotypes' images -- the "sum" images for the lower K half (lanes 0..31), the "pair" images for the upper one
 	// (lanes 32..63); nibble sums never carry (codes 0..3 + 0..3).  Blocks outside a slot range (padding blocks) stay zero.

@@ -48,9 +48,9 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	}
 	{
 		// hand-over flags: one per pass-2 item (8 XCDs x group quads x tiles)
-		const size_t n_gq = ((size_t)(n_pad / HIBAG_WAVE + 7) / 8 + 3) / 4;
+		const size_t n_gq = ((size_t)(n_pad / HIBAG_WAVE + 7) / 8 + HIBAG_ACCUM_WAVES - 1) / HIBAG_ACCUM_WAVES;
 		const size_t n_flag2 = 8 * n_gq * (size_t)std::max(m->view.n_tile, 1);
-		const size_t n_flag1 = (size_t)((n_pad / HIBAG_WAVE + 3) / 4) * (size_t)std::max(std::max(m->view.n_item_whole, m->view.n_item_split), 1);
+		const size_t n_flag1 = (size_t)((n_pad / HIBAG_WAVE + HIBAG_BLOCK_WAVES - 1) / HIBAG_BLOCK_WAVES) * (size_t)std::max(std::max(m->view.n_item_whole, m->view.n_item_split), 1);
 		const size_t n_flag = n_flag2 + n_flag1;
 		const size_t had = m->ws_sync.cap;
 		if (int rc = m->ws_sync.reserve(n_flag * sizeof(unsigned long long))) return rc;
@@ -74,7 +74,7 @@ int make_batch(hibag_hip_model *m, int n_samp, bool need_best, HibagBatchView &B
 	B.tail_k = m->no_chunks ? 1 : 0;
 	B.drop_post = m->drop_next;
 	if (m->drop_next) { B.spin_limit = 4096; m->drop_next = 0; }     // (the injected fault should not take the full time-out)
-	B.sync_total = B.sync + 8 * (((size_t)(n_pad / HIBAG_WAVE + 7) / 8 + 3) / 4) * (size_t)std::max(m->view.n_tile, 1);
+	B.sync_total = B.sync + 8 * (((size_t)(n_pad / HIBAG_WAVE + 7) / 8 + HIBAG_ACCUM_WAVES - 1) / HIBAG_ACCUM_WAVES) * (size_t)std::max(m->view.n_tile, 1);
 	B.n_samp = n_samp; B.n_pad = n_pad;
 	B.masks = m->ws_planes.as<uint32_t>();
 	B.cw = m->ws_cw.as<double>(); B.tot = m->ws_tot.as<double>(); B.inv = m->ws_inv.as<double>(); B.winv = m->ws_winv.as<double>();
