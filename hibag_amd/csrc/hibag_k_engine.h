@@ -289,7 +289,7 @@ template <> struct FactorGroup<8> { typedef f64x8 type; };
 // positive or NaN, never -0), one instruction instead of three (a move, a multiplication into a temporary, an addition).  Inside a
 // group the choice is part of the branch that closes the cell; across groups and blocks the wave-uniform `fresh` says that the
 // record before closed one (a scalar register; the walk that ends on it materialises the zero).
-template <int G, class Fin>
+template <int G, bool BITS = true, class Fin>
 __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename FactorGroup<G>::type F, uint32_t endmask, uint32_t storemask, int n_valid,
 	const v16i &D0, const v16i &D1, double &cell, uint32_t &fresh, const double *tab_s, Fin &&fin)
 {
@@ -319,7 +319,7 @@ __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename 
 		__builtin_amdgcn_sched_barrier(0);
 		// the record before this group closed a cell: the caller's word for the block's first group, the end mask's own bit for
 		// the others (a bit test and a branch where a carried flag cost a select and a compare per group)
-		const bool starts = g == 0 ? fresh != 0 : (startmask & (1u << (G * g - 1))) != 0;
+		const bool starts = g == 0 || !BITS ? fresh != 0 : (startmask & (1u << (G * g - 1))) != 0;
 		if (starts) { cell = F[0] * t[0]; asm volatile("" : "+v"(cell)); }     // (the asm keeps this a scalar branch, not a select)
 		else cell += F[0] * t[0];
 #pragma unroll
@@ -330,13 +330,16 @@ __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename 
 			if (q + 1 < G) {
 				if (end) { fin(cell, stored); cell = F[q + 1] * t[q + 1]; }
 				else cell += F[q + 1] * t[q + 1];
-			} else if (end) fin(cell, stored);
+			} else if (end) { fin(cell, stored); if (!BITS) fresh = 1; }
+			else if (!BITS) fresh = 0;
 		}
 		F = Fn;
 	}
 	// what the next block's first group starts from: the end bit of the last record gone through (once per block)
-	const int groups = n_valid >= 32 ? 32 / G : (n_valid + G - 1) / G;
-	if (groups > 0) fresh = (endmask >> (G * groups - 1)) & 1u;
+	if (BITS) {
+		const int groups = n_valid >= 32 ? 32 / G : (n_valid + G - 1) / G;
+		if (groups > 0) fresh = (endmask >> (G * groups - 1)) & 1u;
+	}
 }
 
 // (the LDS staging area of round 2 -- the factors parked by lanes 0..31 and read back as broadcasts -- is gone)
@@ -417,7 +420,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 				arow = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, vo, (int)soff, 0));    // the next block's, behind the instructions that read this one's
 				__builtin_amdgcn_sched_barrier(0);
 				block_own_sample(D0, D1, n_valid);
-				block_accumulate<G>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
+				block_accumulate<G, TOTAL_BITS>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
 			} else {
 				arow = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, vo, (int)soff, 0));
 			}
@@ -500,7 +503,7 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 				block_mfma<ENG>(a1, a2, lane, cterm, T, D0, D1);
 			}
 			block_own_sample(D0, D1, n_valid);
-			block_accumulate<G>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
+			block_accumulate<G, TOTAL_BITS>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
 		}
 		soff += BB;
 	}

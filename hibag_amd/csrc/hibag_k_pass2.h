@@ -194,17 +194,23 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			const TouchPtr touch = (TouchPtr)(uintptr_t)(fac + (size_t)(rel + 1) * HIBAG_PLIST_DWORDS);
 			const uint32_t tch0 = touch[16], tch1 = touch[32], tch2 = touch[48];
 			ACCUM_STAMP(0);
-			const int eval = ABL2_NOEVAL ? 0 : (any != 0 ? n_valid : 0);
+			// (`eval` and `eval_b`: the same number in two scalar registers the compiler cannot tell are equal -- one condition used in
+			// two places became a lane mask parked in a vector register between them)
+			int eval = ABL2_NOEVAL ? 0 : (any != 0 ? n_valid : 0), eval_b = eval;
+			asm volatile("" : "+s"(eval), "+s"(eval_b));
 			// ---- the sums pass 1 stored for this block's classifier:   S[p] += (cell * (1/total)) * w
 			{
 				const int ns = abl2_stored(cur.hv[1]);
-				if (any && ns > 0) {
-					uint32_t jps = cur.hv[6];
+				if (any) {
+					asm volatile("");                         // (two scalar branches, not one over a combined lane mask)
+					if (ns > 0) {
+						uint32_t jps = cur.hv[6];
 #pragma unroll
-					for (int i = 0; i < NS; i++) {
-						if (i >= ns) break;
-						__hip_atomic_fetch_add(&acc[(int)(jps & 15)][lane], (sv[i] * inv_e) * w_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						jps >>= 4;
+						for (int i = 0; i < NS; i++) {
+							if (i >= ns) break;
+							__hip_atomic_fetch_add(&acc[(int)(jps & 15)][lane], (sv[i] * inv_e) * w_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							jps >>= 4;
+						}
 					}
 				}
 			}
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			__builtin_amdgcn_sched_barrier(0);
 			ACCUM_STAMP(3);
 			// ---- every lane its own sample's distances, then cell += prod * TAB[d] in order
-			if (eval) {
+			if (eval_b) {
 				block_own_sample(D0, D1, n_valid);
 #ifdef HIBAG_ACCUM_STAMPS
 				asm volatile("" :: "v"(D0[0]), "v"(D1[0]));

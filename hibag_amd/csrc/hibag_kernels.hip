@@ -69,6 +69,9 @@
 #ifndef HIBAG_TOT_OCC_MANY
 #define HIBAG_TOT_OCC_MANY 6
 #endif
+#ifndef TOTAL_BITS
+#define TOTAL_BITS true                     // pass 1: block_accumulate tests the end mask's bits for a group's start (false: a carried flag)
+#endif
 #ifndef ACCUM_G
 #define ACCUM_G 4                           // the same for pass 2
 #endif
