@@ -13,6 +13,8 @@
 //   HIBAG_ABL_WIDE_NOSTORE  k_total_wide stores no cell sums
 //   HIBAG_ABL2_NOLOOP       pass 2 without its block loop; _NOEVAL: without the pairs' evaluation; _NOSV: without stored sums;
 //   HIBAG_ABL2_SVHOT        stored sums read from eight cache-hot rows instead of HBM; _NOWINV: weight and 1/total constants
+//   HIBAG_ABL2_SVNOLOAD / _SVNOADD   pass 2's stored sums added but never loaded / loaded but never added
+//   HIBAG_ABL2_NOADD        pass 2's closing cells make their product but do not add it to the LDS sums
 //   HIBAG_ABL2_LDSPAD=bytes pass 2 with that much more LDS per workgroup: fewer resident wavefronts, same code
 //   HIBAG_ACCUM_STAMPS      (diagnostic, right results) pass 2 reads the clock at the phase boundaries of every block and sums
 //                           the differences per launch (hibag_hip_test_read_diag, tools/accum_stamps.py)

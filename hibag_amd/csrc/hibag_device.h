@@ -234,11 +234,13 @@ struct HibagModelView {
 	// pass-1 lists; the kernel reads their prebuilt rows, `parow`), one 8-dword header per block in `ehdr`:
 	//   [0] the block's end-of-cell mask (bit i: slot i closes a cell)
 	//   [1] first stored-sum row (model-wide numbering, HibagBatchView::cells) | stored sums of this block (0..HIBAG_STORED_PER_VISIT) << 25
+	//       | (the record before the block's first one closed a cell: the first product starts a sum) << 29
 	//   [2], [3] the request words of the NEXT block of the stream -- its classifier | first B-operand row << 16, and its word 1:
 	//            what the kernel needs to REQUEST a block's per-lane data (weight, 1/total, B operand, stored sums) it finds in
 	//            the header of the block before, so that only two headers are alive at a time -- the one in use and the one in
 	//            flight -- and the loop, unrolled twice, rotates nothing
-	//   [4], [5] tile rows of the cells that CLOSE in this block, 4 bits each, in closing order
+	//   [4], [5] tile rows of the cells that CLOSE in this block, 4 bits each: field i / 2 for the cell that closes at slot i
+	//            (cells are padded to an even number of slots: only odd slots close one)
 	//   [6] tile rows of the stored sums, 4 bits each (28 bits) | groups of four slots worth evaluating (0..8) << 28
 	//   [7] this block's own classifier | first B-operand row << 16 (a walk requests its FIRST block from words 7 and 1)
 	// The header is all the scalar data of a block besides its slots' factors (`pfac`): one s_load_dwordx8.

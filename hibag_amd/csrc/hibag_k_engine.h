@@ -252,11 +252,12 @@ __device__ __forceinline__ void block_mfma(const v4i &e1, const v4i &e2, int lan
 // Swap the upper lanes of half 0 with the lower lanes of half 1: afterwards every
 // lane holds its OWN sample: record i = 8g + q  ->  q < 4 ? D0[4g + q] : D1[4g + q - 4].
 // Only the register groups that hold valid records are moved (a partly filled last block).
-__device__ __forceinline__ void block_own_sample(v16i &D0, v16i &D1, int n_valid)    // in place: (acc0, acc1) -> (D0, D1)
+template <class Live8>
+__device__ __forceinline__ void block_own_sample(v16i &D0, v16i &D1, Live8 &&live8)    // in place: (acc0, acc1) -> (D0, D1); live8(g): records 8 g .. 8 g + 7 have valid ones
 {
 #pragma unroll
 	for (int g = 0; g < 4; g++) {
-		if (8 * g >= n_valid) break;
+		if (!live8(g)) break;
 		if (ABL_NOSWAP) continue;
 #pragma unroll
 		for (int r = 4 * g; r < 4 * g + 4; r++) {
@@ -265,9 +266,13 @@ __device__ __forceinline__ void block_own_sample(v16i &D0, v16i &D1, int n_valid
 		}
 	}
 }
+__device__ __forceinline__ void block_own_sample(v16i &D0, v16i &D1, int n_valid)
+{
+	block_own_sample(D0, D1, [&](int g) { return 8 * g < n_valid; });
+}
 
 // cell += prod_i * TAB[d_i] for the first n_valid records of a block, in order;
-// `fin(cell, stored)` at every record that closes a cell (end mask, store mask; cells are padded to
+// `fin(cell, stored, slot)` at every record that closes a cell (end mask, store mask; cells are padded to
 // an even number of records, so only odd positions can close one).
 // The factors prod_i are wave-uniform: they come from HibagModelView::pfac through the SCALAR cache, G at a time
 // (one s_load), and multiply as scalar-register operands -- no LDS traffic, no vector register, no instruction to
@@ -289,37 +294,44 @@ template <> struct FactorGroup<8> { typedef f64x8 type; };
 // positive or NaN, never -0), one instruction instead of three (a move, a multiplication into a temporary, an addition).  Inside a
 // group the choice is part of the branch that closes the cell; across groups and blocks the wave-uniform `fresh` says that the
 // record before closed one (a scalar register; the walk that ends on it materialises the zero).
-template <int G, bool BITS = true, class Fin>
-__device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename FactorGroup<G>::type F, uint32_t endmask, uint32_t storemask, int n_valid,
-	const v16i &D0, const v16i &D1, double &cell, uint32_t &fresh, const double *tab_s, Fin &&fin)
+// `live(g)`: group g of the block has records worth evaluating (the groups before it then have too).
+template <int G, bool AHEAD = false, class Live, class Fin>
+__device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename FactorGroup<G>::type F, uint32_t endmask, uint32_t storemask, Live &&live,
+	const v16i &D0, const v16i &D1, double &cell, uint32_t fresh, const double *tab_s, Fin &&fin)
 {
 	typedef typename FactorGroup<G>::type FG;
 	// (a copy of the end mask for the "starts" tests below: tested on the same register as the "end" test of the group before,
 	// the two become ONE test kept as a 64-bit mask -- a select and two mask operations where two bit tests do)
 	uint32_t startmask = endmask;
 	asm volatile("" : "+s"(startmask));
-#pragma unroll
-	for (int g = 0; g < 32 / G; g++) {
-		if (G * g >= n_valid) break;
-		double t[G];
+	auto look_up = [&](int g, double (&t)[G]) {
 #pragma unroll
 		for (int q = 0; q < G; q++) {         // D = 8*d: already the byte offset into the table
 			const int i = G * g + q;          // record i = 8 m + r  ->  r < 4 ? D0[4 m + r] : D1[4 m + r - 4]
 			const int off = (i & 7) < 4 ? D0[4 * (i >> 3) + (i & 3)] : D1[4 * (i >> 3) + (i & 3)];
 			t[q] = table_value(tab_s, off);
 		}
+	};
+	double tt[AHEAD ? 2 : 1][G];
+	if (AHEAD) look_up(0, tt[0]);
+#pragma unroll
+	for (int g = 0; g < 32 / G; g++) {
+		if (!live(g)) break;
+		double (&t)[G] = tt[AHEAD ? (g & 1) : 0];
+		if (!AHEAD) look_up(g, t);
 		// the look-ups are waited for HERE (a use of the first one; LDS returns in order, and a scalar load in flight makes it a
 		// wait for everything), and only then are the next group's factors requested: they have this group's arithmetic to arrive.
-		// (Requesting the NEXT group's look-ups here as well, before this group is added up, was measured twice -- round 4 and on
-		// this loop: +-1 %, eight registers.)
+		// (AHEAD, a measured variant: the NEXT group's look-ups requested here as well, before this group is added up -- round 4
+		// and twice in round 5: between +1 % and -0.6 % on pass 2 for six registers, slower on pass 1, which has none to spare.)
 		asm volatile("" : "+v"(t[0]));
 		__builtin_amdgcn_sched_barrier(0);
 		FG Fn = F;
 		if (!ABL_NOFAC && g + 1 < 32 / G) Fn = *(ConstPtr<FG>)(fac + G * (g + 1));
+		if (AHEAD && g + 1 < 32 / G && live(g + 1)) look_up(g + 1, tt[(g + 1) & 1]);
 		__builtin_amdgcn_sched_barrier(0);
 		// the record before this group closed a cell: the caller's word for the block's first group, the end mask's own bit for
 		// the others (a bit test and a branch where a carried flag cost a select and a compare per group)
-		const bool starts = g == 0 || !BITS ? fresh != 0 : (startmask & (1u << (G * g - 1))) != 0;
+		const bool starts = g == 0 ? fresh != 0 : (startmask & (1u << (G * g - 1))) != 0;
 		if (starts) { cell = F[0] * t[0]; asm volatile("" : "+v"(cell)); }     // (the asm keeps this a scalar branch, not a select)
 		else cell += F[0] * t[0];
 #pragma unroll
@@ -328,18 +340,21 @@ __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename 
 			const bool end = (endmask & (1u << (G * g + q))) != 0;
 			const bool stored = (storemask & (1u << (G * g + q))) != 0;
 			if (q + 1 < G) {
-				if (end) { fin(cell, stored); cell = F[q + 1] * t[q + 1]; }
+				if (end) { fin(cell, stored, G * g + q); cell = F[q + 1] * t[q + 1]; }
 				else cell += F[q + 1] * t[q + 1];
-			} else if (end) { fin(cell, stored); if (!BITS) fresh = 1; }
-			else if (!BITS) fresh = 0;
+			} else if (end) fin(cell, stored, G * g + q);
 		}
 		F = Fn;
 	}
-	// what the next block's first group starts from: the end bit of the last record gone through (once per block)
-	if (BITS) {
-		const int groups = n_valid >= 32 ? 32 / G : (n_valid + G - 1) / G;
-		if (groups > 0) fresh = (endmask >> (G * groups - 1)) & 1u;
-	}
+}
+
+// `fresh` for the block behind one whose first n_valid records were gone through in groups of G: the end bit of the last of
+// them (nothing gone through: unchanged)
+template <int G>
+__device__ __forceinline__ uint32_t fresh_behind(uint32_t fresh, uint32_t endmask, int n_valid)
+{
+	const int groups = n_valid >= 32 ? 32 / G : (n_valid + G - 1) / G;
+	return groups > 0 ? (endmask >> (G * groups - 1)) & 1u : fresh;
 }
 
 // (the LDS staging area of round 2 -- the factors parked by lanes 0..31 and read back as broadcasts -- is gone)
@@ -420,7 +435,8 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 				arow = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, vo, (int)soff, 0));    // the next block's, behind the instructions that read this one's
 				__builtin_amdgcn_sched_barrier(0);
 				block_own_sample(D0, D1, n_valid);
-				block_accumulate<G, TOTAL_BITS>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
+				block_accumulate<G>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, [&](int g) { return G * g < n_valid; }, D0, D1, cell, fresh, tab_s, fin);
+				fresh = fresh_behind<G>(fresh, endmask, n_valid);
 			} else {
 				arow = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, vo, (int)soff, 0));
 			}
@@ -503,7 +519,8 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 				block_mfma<ENG>(a1, a2, lane, cterm, T, D0, D1);
 			}
 			block_own_sample(D0, D1, n_valid);
-			block_accumulate<G, TOTAL_BITS>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, n_valid, D0, D1, cell, fresh, tab_s, fin);
+			block_accumulate<G>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, [&](int g) { return G * g < n_valid; }, D0, D1, cell, fresh, tab_s, fin);
+			fresh = fresh_behind<G>(fresh, endmask, n_valid);
 		}
 		soff += BB;
 	}

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, 
 			double vmax = 0;
 			int vcnt = 0, vslot = 1, ci = 0;
 			uint4 *const vlog = VOTE ? B.vrec + (size_t)c * 8 * B.n_pad + s : nullptr;
-			auto fin = [&](double v, bool stored) {
+			auto fin = [&](double v, bool stored, int) {
 #ifdef HIBAG_STORE_PLAIN      // (variant: write-back stores instead of streaming ones)
 				if (STORE && stored) { rows[(size_t)row * HIBAG_WAVE + lane] = v; row++; }
 #else
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total_wide(HibagModelView 
 	double cell = 0, total = 0;
 	double *__restrict__ rows = cell_rows(M, B, c, group);
 	int row = seg[1];
-	auto fin = [&](double v, bool) {
+	auto fin = [&](double v, bool, int) {
 		if (!ABL_WIDE_NOSTORE) { __builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++; }
 		if (WHOLE) { total += v; asm("" : "+v"(total)); }   // (the asm keeps the cell end a scalar branch)
 	};

@@ -138,7 +138,6 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		v4i arow, t0, t1;                             // the A-operand row, the B operand (two sample halves)
 		double sv[NS];                                // the stored sums
 		double cell = 0;
-		uint32_t fresh = 0;                           // block_accumulate: the record before closed a cell
 		// the stored sums of a block (word 1 of its header: first row | count << 25).  Their number differs from block to block,
 		// so a wait that leaves them in flight would have to be a counted one the compiler cannot get right; ALWAYS requesting
 		// HIBAG_STORED_PER_VISIT of them (the ones a block lacks out of the buffer's range: no memory access) so that every wait
@@ -153,7 +152,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 #pragma unroll
 				for (int i = 0; i < NS; i++) {
 					if (i >= ns) break;
+#ifdef HIBAG_ABL2_SVNOLOAD                    // (timing ablation: the stored sums are added, never loaded)
+					asm volatile("" : "=v"(sv[i]));
+#else
 					sv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_sv, vo + i * HIBAG_WAVE * 8, sr, 2));   // (read once: nt; the row's distance as the instruction's immediate offset)
+#endif
 				}
 			}
 		};
@@ -182,8 +185,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			// (cell * 0) * 0 = +0 and a + 0 == a, which spares a select per closed cell
 			const double inv_e = active ? cur.winv[1] : 0.0;
 			const uint32_t endmask = cur.hv[0];
-			const int n_valid = (int)(cur.hv[6] >> 28) * 4;           // (the header counts the groups of four records worth evaluating)
-			asm volatile("" :: "s"(n_valid));             // (this block's scalar data is waited for before the next block's is requested)
+			// the groups of four records worth evaluating, 0..8, are the top bits of word 6: "group g has any" is one compare of the
+			// word with a constant
+			const uint32_t gword = cur.hv[6];
+			auto live4 = [&](int g) { return g == 0 || gword >= ((uint32_t)(g + 1) << 28); };      // (asked only where the block has any: `eval`)
+			// (this block's scalar data has arrived: the block before waited for it at its end, see the last statement below)
 			__builtin_amdgcn_sched_barrier(0);
 			nxt.hv = eh[rel + 1];
 			nxt.F = *(ConstPtr<AFG>)(fac + (size_t)(rel + 1) * HIBAG_PLIST_DWORDS);
@@ -196,19 +202,26 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			ACCUM_STAMP(0);
 			// (`eval` and `eval_b`: the same number in two scalar registers the compiler cannot tell are equal -- one condition used in
 			// two places became a lane mask parked in a vector register between them)
-			int eval = ABL2_NOEVAL ? 0 : (any != 0 ? n_valid : 0), eval_b = eval;
+			int eval = ABL2_NOEVAL ? 0 : (any != 0 ? (int)(gword >> 28) : 0), eval_b = eval;
 			asm volatile("" : "+s"(eval), "+s"(eval_b));
 			// ---- the sums pass 1 stored for this block's classifier:   S[p] += (cell * (1/total)) * w
 			{
 				const int ns = abl2_stored(cur.hv[1]);
-				if (any) {
+				// (a classifier nobody in the group uses is passed over: its blocks leave `cell` as it was, and the next block's
+				// header bit describes a stream in which they were evaluated -- so the sum goes back to zero here)
+				if (!any) asm volatile("v_mov_b64 %0, 0" : "+v"(cell));    // (cell = 0, in its own register: as an assignment it cost the common path two moves)
+				else {
 					asm volatile("");                         // (two scalar branches, not one over a combined lane mask)
 					if (ns > 0) {
 						uint32_t jps = cur.hv[6];
 #pragma unroll
 						for (int i = 0; i < NS; i++) {
 							if (i >= ns) break;
+#ifdef HIBAG_ABL2_SVNOADD                     // (timing ablation: the stored sums are loaded and waited for, never added)
+							asm volatile("" :: "v"(sv[i]));
+#else
 							__hip_atomic_fetch_add(&acc[(int)(jps & 15)][lane], (sv[i] * inv_e) * w_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 							jps >>= 4;
 						}
 					}
@@ -239,20 +252,28 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			ACCUM_STAMP(3);
 			// ---- every lane its own sample's distances, then cell += prod * TAB[d] in order
 			if (eval_b) {
-				block_own_sample(D0, D1, n_valid);
+				block_own_sample(D0, D1, [&](int g) { return live4(2 * g); });
 #ifdef HIBAG_ACCUM_STAMPS
 				asm volatile("" :: "v"(D0[0]), "v"(D1[0]));
 				ACCUM_STAMP(4);
 #endif
-				uint64_t jpack = ((uint64_t)cur.hv[5] << 32) | cur.hv[4];
 				// S[p] += v as one LDS floating-point add (ds_add_f64: the same IEEE addition, no register for the old
-				// sum, nothing to wait for)
-				auto fin = [&](double c, bool) {
+				// sum, nothing to wait for).  The tile row of the cell that closes at slot i (odd) is field i / 2 of the header's
+				// words 4, 5: a fixed place per slot, so one bit-field extract, no shifting along of a packed list.
+				const uint32_t jp_lo = cur.hv[4], jp_hi = cur.hv[5];
+				auto fin = [&](double c, bool, int slot) {
+					uint32_t row;                             // (s_bfe_u32 by hand: the compiler's shift-and-mask form takes two instructions)
+					asm volatile("s_bfe_u32 %0, %1, %2" : "=s"(row) : "s"(slot < 16 ? jp_lo : jp_hi), "n"(4 * ((slot >> 1) & 7) | (4 << 16)) : "scc");
 					const double v = (c * inv_e) * w_c;
-					__hip_atomic_fetch_add(&acc[(int)(jpack & 15)][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					jpack >>= 4;
+#ifdef HIBAG_ABL2_NOADD                       // (timing ablation: the product is made, the LDS addition is not)
+					asm volatile("" :: "v"(v), "s"(row));
+#else
+					__hip_atomic_fetch_add(&acc[(int)row][lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 				};
-				block_accumulate<ACCUM_G>(fac + (size_t)rel * HIBAG_PLIST_DWORDS, cur.F, endmask, 0u, n_valid, D0, D1, cell, fresh, tab_s, fin);
+				// what the block's first record starts from is a bit of its header (the record before it in the stream closed a cell)
+				uint32_t fresh = (cur.hv[1] >> 29) & 1u;
+				block_accumulate<ACCUM_G, ACCUM_AHEAD>(fac + (size_t)rel * HIBAG_PLIST_DWORDS, cur.F, endmask, 0u, live4, D0, D1, cell, fresh, tab_s, fin);
 			}
 			// (the header's word 7 counts as in use to the end of the block: otherwise its register -- free as far as the compiler
 			// can see, but still to be written by the header load in flight -- is handed to one of the loads above, which then has to wait for that load)

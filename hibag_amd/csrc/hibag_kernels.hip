@@ -69,8 +69,8 @@
 #ifndef HIBAG_TOT_OCC_MANY
 #define HIBAG_TOT_OCC_MANY 6
 #endif
-#ifndef TOTAL_BITS
-#define TOTAL_BITS true                     // pass 1: block_accumulate tests the end mask's bits for a group's start (false: a carried flag)
+#ifndef ACCUM_AHEAD
+#define ACCUM_AHEAD false                   // pass 2: the next group's table look-ups requested before this group is added up (measured: no gain)
 #endif
 #ifndef ACCUM_G
 #define ACCUM_G 4                           // the same for pass 2

@@ -582,9 +582,16 @@ int finalize_model(hibag_hip_model *m)
 			uint64_t jps = jp >> (4 * tile_nlist[ct]);
 			uint32_t srow = (uint32_t)cell_row[c] + tile_k0[ct];
 			for (int b = 0; b < nvb; b++) {
-				uint32_t closes = 0;
+				// the tile rows of the cells that close in this block, each at the place of its closing slot: slot i (odd: cells
+				// are padded to an even number of slots) -> field i / 2
+				uint64_t jq = 0;
 				if (b < nb)
-					for (int i = 0; i < HIBAG_PLIST_DWORDS; i++) closes += plist[first + (size_t)b * HIBAG_PLIST_DWORDS + i] >> 31;
+					for (int i = 0; i < HIBAG_PLIST_DWORDS; i++)
+						if (plist[first + (size_t)b * HIBAG_PLIST_DWORDS + i] >> 31) {
+							if (!(i & 1)) return hibag_fail(HIBAG_HIP_ESTATE, "internal: a cell of classifier %d closes at an even slot", c);
+							jq |= (jp & 15u) << (4 * (i >> 1));
+							jp >>= 4;
+						}
 				const int nsb = std::max(0, std::min(HIBAG_STORED_PER_VISIT, ns - HIBAG_STORED_PER_VISIT * b));
 				if (c > 0xFFFF) return hibag_fail(HIBAG_HIP_EINVAL, "too many classifiers (%d) for the second pass's block headers", C);
 				// (pass 2 requests the operand rows of every block it passes, also of blocks that only carry stored sums: a
@@ -595,10 +602,9 @@ int finalize_model(hibag_hip_model *m)
 				const uint32_t h[8] = {
 					(uint32_t)c | (bt << 16), srow | ((uint32_t)nsb << 25),
 					0u, 0u,                                   // (the next block's first two words: filled in below)
-					(uint32_t)jp, (uint32_t)(jp >> 32),
+					(uint32_t)jq, (uint32_t)(jq >> 32),
 					(uint32_t)jps, 0u};
 				ehdr.insert(ehdr.end(), h, h + 8);
-				jp = closes >= 16 ? 0 : jp >> (4 * closes);
 				jps >>= 4 * nsb;
 				srow += (uint32_t)nsb;
 			}
@@ -701,11 +707,20 @@ int finalize_model(hibag_hip_model *m)
 	// Pass 2 takes everything of a block from its E-stream header alone (hibag_device.h): the end mask goes where the block's
 	// own request words were (word 0; they move to word 7 -- a walk needs them for its first block only, every other block
 	// is requested through the words 2, 3 of the header before it), the groups of four records worth evaluating above the stored cells' rows.
+	// Bit 29 of word 1: the record before the block's first one -- the last record gone through of the nearest block before it
+	// that has any -- closed a cell, so the block's first product STARTS a sum (block_accumulate); a block that is passed over
+	// (nobody uses its classifier) resets the sum instead, and a walk that begins at the block begins at zero: the bit is
+	// right whichever blocks came before.
+	uint32_t closed_before = 0;
 	for (uint64_t b = 0; b < estream_blocks; b++) {
+		const uint32_t groups = (phdr[4 * b + 2] + 3) / 4;
 		ehdr[b * 8 + 7] = ehdr[b * 8];
 		ehdr[b * 8] = phdr[4 * b];
-		ehdr[b * 8 + 6] = (ehdr[b * 8 + 6] & 0x0FFFFFFFu) | (((phdr[4 * b + 2] + 3) / 4) << 28);
+		ehdr[b * 8 + 1] |= closed_before << 29;
+		ehdr[b * 8 + 6] = (ehdr[b * 8 + 6] & 0x0FFFFFFFu) | (groups << 28);
+		if (groups > 0) closed_before = (phdr[4 * b] >> (4 * groups - 1)) & 1u;
 	}
+	for (uint64_t b = 0; b + 1 < estream_blocks; b++) ehdr[b * 8 + 3] = ehdr[(b + 1) * 8 + 1];
 	// Prebuilt A-operand rows (HibagModelView::parow): for every slot of a one-step FP4 classifier the element-wise sum of its
 	// two haplotypes' images -- the "sum" images for the lower K half (lanes 0..31), the "pair" images for the upper one
 	// (lanes 32..63); nibble sums never carry (codes 0..3 + 0..3).  Blocks outside a slot range (padding blocks) stay zero.

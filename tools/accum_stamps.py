@@ -16,8 +16,8 @@ import torch
 import hibag_amd
 from hibag_amd import synth, _lib
 
-PHASES = ["top wait (weight, 1/total, headers of this block)", "stored sums added", "next block requested",
-          "matrix instructions issued (+ B operand wait)", "lane swaps (matrix results waited for)", "pairs added up", "-", "-"]
+PHASES = ["top of the block (this block's loads waited for, the next headers requested)", "stored sums added",
+          "matrix instructions issued", "next block requested", "lane swaps (matrix results waited for)", "pairs added up", "-", "-"]
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000
 hibag_amd.hlaSetKernelTarget("hip")
