@@ -98,6 +98,8 @@ __device__ __forceinline__ uint32_t abl2_stored_row(uint32_t w1)
 {
 #ifdef HIBAG_ABL2_SVHOT
 	return w1 & 7u;
+#elif defined(HIBAG_ABL2_SVL2)                // (64 rows per sample group: 5 MB in all -- L2 hits, not L1 hits)
+	return w1 & 63u;
 #else
 	return w1 & 0x1FFFFFFu;
 #endif
