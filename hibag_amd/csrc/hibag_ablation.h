@@ -10,10 +10,12 @@
 //   HIBAG_ABL_NOTAB         no table look-up in LDS: the value is made from the distance's bits
 //   HIBAG_ABL_NOFAC         every group of records multiplies by the block's first factors (no further scalar loads)
 //   HIBAG_ABL_NOEND         no cell ever closes; HIBAG_ABL_NOSTORE: cells close, none is stored
+//   HIBAG_ABL_STX4 / _STHALF   pass 1's stores 16 bytes per lane instead of 8 (overlapping: the same lines) / only every second stored cell written
 //   HIBAG_ABL_WIDE_NOSTORE  k_total_wide stores no cell sums
 //   HIBAG_ABL2_NOLOOP       pass 2 without its block loop; _NOEVAL: without the pairs' evaluation; _NOSV: without stored sums;
 //   HIBAG_ABL2_SVHOT        stored sums read from eight cache-hot rows instead of HBM; _NOWINV: weight and 1/total constants
 //   HIBAG_ABL2_SVNOLOAD / _SVNOADD   pass 2's stored sums added but never loaded / loaded but never added
+//   HIBAG_ABL2_SVX4 / _SVHALF   the stored sums' loads 16 bytes per lane instead of 8 (overlapping: the same lines) / only every second one issued
 //   HIBAG_ABL2_NOADD        pass 2's closing cells make their product but do not add it to the LDS sums
 //   HIBAG_ABL2_LDSPAD=bytes pass 2 with that much more LDS per workgroup: fewer resident wavefronts, same code
 //   HIBAG_ACCUM_STAMPS      (diagnostic, right results) pass 2 reads the clock at the phase boundaries of every block and sums

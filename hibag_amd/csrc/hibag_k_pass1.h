@@ -202,6 +202,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, 
 			auto fin = [&](double v, bool stored, int) {
 #ifdef HIBAG_STORE_PLAIN      // (variant: write-back stores instead of streaming ones)
 				if (STORE && stored) { rows[(size_t)row * HIBAG_WAVE + lane] = v; row++; }
+#elif defined(HIBAG_ABL_STX4)      // (timing ablation: as many stores, 16 bytes per lane each -- overlapping: the same memory lines)
+				if (STORE && stored) { __builtin_nontemporal_store(f64x2{v, v}, (f64x2 *)&rows[(size_t)row * HIBAG_WAVE + lane]); row++; }
+#elif defined(HIBAG_ABL_STHALF)    // (timing ablation: every second stored cell is written)
+				if (STORE && stored) { if (!(row & 1)) __builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++; }
 #else
 				if (STORE && stored) { __builtin_nontemporal_store(v, &rows[(size_t)row * HIBAG_WAVE + lane]); row++; }
 #endif

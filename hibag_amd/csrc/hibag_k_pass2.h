@@ -154,6 +154,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 					if (i >= ns) break;
 #ifdef HIBAG_ABL2_SVNOLOAD                    // (timing ablation: the stored sums are added, never loaded)
 					asm volatile("" : "=v"(sv[i]));
+#elif defined(HIBAG_ABL2_SVX4)                // (timing ablation: as many loads, 16 bytes per lane each -- overlapping: the same memory lines)
+					sv[i] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r_sv, vo + i * HIBAG_WAVE * 8, sr, 2))[0];
+#elif defined(HIBAG_ABL2_SVHALF)              // (timing ablation: every second stored sum is loaded)
+					if (i & 1) asm volatile("" : "=v"(sv[i]));
+					else sv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_sv, vo + i * HIBAG_WAVE * 8, sr, 2));
 #else
 					sv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_sv, vo + i * HIBAG_WAVE * 8, sr, 2));   // (read once: nt; the row's distance as the instruction's immediate offset)
 #endif

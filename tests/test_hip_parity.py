@@ -147,6 +147,30 @@ def test_ragged_batch_sizes(hib, oracle, n):
     assert_same(got, want)
 
 
+@pytest.mark.parametrize("vote", [1, 2])
+def test_classifiers_unused_by_whole_sample_groups(hib, oracle, vote):
+    """Classifiers whose SNPs are all missing for every sample of one 64-sample group (weight 0: src/LibHLA.cpp:2451
+    passes them over) while other groups use them: pass 2 skips their blocks for that group only -- the running cell sum must
+    come out of the skipped blocks as if they had been walked (the E-stream's 'starts a sum' header bit describes the walked
+    stream) -- including first and last classifiers, runs of consecutive ones, and a group that uses none at all."""
+    from hibag_amd import synth
+    model, founders, af = synth.make_model("hla-b", n_classifier=24, n_samp=400)
+    G, _ = synth.make_samples(founders, af, 64 * 5 + 17, seed=synth.DEFAULT_SEED + 11)
+    G = G.copy()
+    snps = [np.asarray(c.snpidx) for c in model.classifiers]
+    def knock(rows, classifiers):
+        for k in classifiers:
+            G[np.ix_(rows, snps[k])] = hib.NA_INTEGER
+    knock(range(0, 64), [0, 1, 2, 9, 23])                   # group 0: the first ones, one in the middle, the last
+    knock(range(64, 128), range(5, 15))                     # group 1: a run
+    knock(range(128, 192), range(24))                       # group 2: uses nothing
+    knock(range(192, 250), [3])                             # group 3: most of the group only -- the classifier stays in use
+    knock(range(320, 337), [7, 8])                          # the ragged last group: all its real samples
+    got = hib.hlaModelFromObj(model).predict_raw(G, vote, want_dosage=True, want_prob=True)
+    want = oracle.predict(oracle.flatten(model), G, vote_method=vote)
+    assert_same(got, want)
+
+
 def test_underflow_gives_nan_like_the_reference(hib, oracle):
     """A classifier whose every pair is >= 65 mismatches away has total 0, so
     1/total = inf and 0*inf = NaN poisons the whole sample (src/LibHLA.cpp:1826-1828)."""
