@@ -426,6 +426,9 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 			__builtin_amdgcn_sched_barrier(0);
 			H_n = hdr[b + 1];
 			F_n = *(ConstPtr<FG>)(fac + (size_t)(b + 1) * HIBAG_PLIST_DWORDS);
+#ifdef HIBAG_TOTAL_PRIO            // (measured variant: the head of a block at raised priority)
+			__builtin_amdgcn_s_setprio(1);
+#endif
 			v4i a = arow;
 			asm volatile("" : "+v"(a));                   // (this block's rows have arrived: requested a block ago)
 			if (n_valid > 0) {
@@ -434,6 +437,9 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 				__builtin_amdgcn_sched_barrier(0);
 				arow = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, vo, (int)soff, 0));    // the next block's, behind the instructions that read this one's
 				__builtin_amdgcn_sched_barrier(0);
+#ifdef HIBAG_TOTAL_PRIO
+				__builtin_amdgcn_s_setprio(0);
+#endif
 				block_own_sample(D0, D1, n_valid);
 				block_accumulate<G>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, [&](int g) { return G * g < n_valid; }, D0, D1, cell, fresh, tab_s, fin);
 				fresh = fresh_behind<G>(fresh, endmask, n_valid);

@@ -181,6 +181,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 		// runs: it covers every latency.  No load of the loop is waited for with a count: at the top of a block everything in
 		// flight is that block's.
 		auto one_block = [&](const int rel, AccumAhead &cur, AccumAhead &nxt) {
+#if defined(HIBAG_ACCUM_PRIO) && HIBAG_ACCUM_PRIO == 1      // (measured variant: the head of a block -- waits, stored sums, matrix instructions, requests -- at raised priority)
+			__builtin_amdgcn_s_setprio(1);
+#elif defined(HIBAG_ACCUM_PRIO) && HIBAG_ACCUM_PRIO == 2    // (measured variant: the pairs' accumulation at raised priority)
+			__builtin_amdgcn_s_setprio(0);
+#endif
 			const double w_c = cur.winv[0];
 			const bool active = w_c > 0;
 			// (as integers in scalar registers -- a count of lanes is one scalar instruction; a bool that lives across the requests
@@ -255,6 +260,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			request_lane(cur.hv[2], cur.hv[3], (rel + 1) * 1024, nxt.winv);
 			__builtin_amdgcn_sched_barrier(0);
 			ACCUM_STAMP(3);
+#if defined(HIBAG_ACCUM_PRIO) && HIBAG_ACCUM_PRIO == 1
+			__builtin_amdgcn_s_setprio(0);
+#elif defined(HIBAG_ACCUM_PRIO) && HIBAG_ACCUM_PRIO == 2
+			__builtin_amdgcn_s_setprio(1);
+#endif
 			// ---- every lane its own sample's distances, then cell += prod * TAB[d] in order
 			if (eval_b) {
 				block_own_sample(D0, D1, [&](int g) { return live4(2 * g); });
