@@ -263,7 +263,7 @@ struct HibagBatchView {
 	double *cw;         // [C][n_pad]
 	double *tot;        // [C][n_pad]
 	double *inv;        // [C][n_pad]
-	double *winv;       // [C][n_pad][2] {classifier weight (k_pack), 1/total (pass 1)}: what pass 2 reads per block, in ONE 16-byte load
+	double *winv;       // [C][n_pad][2] {classifier weight (k_pack), 1/total -- 0 where the weight is not positive -- (pass 1)}: what pass 2 reads per block, in ONE 16-byte load
 	// Majority vote (vote_method = 2): the cell a classifier votes for is the FIRST strict maximum of cell * (1/total) in cell
 	// order (src/LibHLA.cpp:2465-2475 -> :1549-1566), and 1/total is only known when pass 1 ends.  Multiplying by a positive
 	// constant is monotone, so the winner is among the RECORDS of the raw cell sums -- the cells larger than every cell before

@@ -246,7 +246,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, 
 			const double inv = 1 / total;                 // src/LibHLA.cpp:1827 (inf when total == 0)
 			B.tot[at] = total;
 			B.inv[at] = inv;
-			B.winv[2 * at + 1] = inv;                     // (beside the weight k_pack left there: pass 2 reads both in one load)
+			// (beside the weight k_pack left there: pass 2 reads both in one load -- and reads 0 instead of 1/total where the sample
+			// does not use the classifier: its term there is (cell * 0) * 0 = +0, which pass 2 would otherwise select per block)
+			B.winv[2 * at + 1] = B.cw[at] > 0 ? inv : 0.0;
 			note_infinite_reciprocal(B, c, s, B.cw[at], inv);
 		}
 	}
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total_wide(HibagModelView 
 		const double inv = 1 / total;                 // src/LibHLA.cpp:1827 (inf when total == 0)
 		B.tot[at] = total;
 		B.inv[at] = inv;
-		B.winv[2 * at + 1] = inv;
+		B.winv[2 * at + 1] = B.cw[at] > 0 ? inv : 0.0;
 		note_infinite_reciprocal(B, c, s, B.cw[at], inv);
 	}
 }
@@ -316,7 +318,7 @@ __global__ void k_total_scan(HibagModelView M, HibagBatchView B)
 	for (; i < n; i++) total += rows[(size_t)i * HIBAG_WAVE];
 	B.tot[(size_t)c * B.n_pad + s] = total;
 	B.inv[(size_t)c * B.n_pad + s] = 1 / total;
-	B.winv[2 * ((size_t)c * B.n_pad + s) + 1] = 1 / total;
+	B.winv[2 * ((size_t)c * B.n_pad + s) + 1] = B.cw[(size_t)c * B.n_pad + s] > 0 ? 1 / total : 0.0;
 	note_infinite_reciprocal(B, c, s, B.cw[(size_t)c * B.n_pad + s], 1 / total);
 }
 

@@ -192,8 +192,8 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 			// below ends up in a vector register and back)
 			const int any = __builtin_popcountll(__ballot(active));   // 0: nobody in the group uses the classifier (src/LibHLA.cpp:2451): nothing to add
 			// inactive lanes (weight 0) must keep their sums: with 1/total replaced by 0 their term is
-			// (cell * 0) * 0 = +0 and a + 0 == a, which spares a select per closed cell
-			const double inv_e = active ? cur.winv[1] : 0.0;
+			// (cell * 0) * 0 = +0 and a + 0 == a, which spares a select per closed cell -- and pass 1 has written that 0 (winv)
+			const double inv_e = cur.winv[1];
 			const uint32_t endmask = cur.hv[0];
 			// the groups of four records worth evaluating, 0..8, are the top bits of word 6: "group g has any" is one compare of the
 			// word with a constant
