@@ -125,16 +125,20 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 	if (c >= M.n_classifier) return;
 	const int lane = threadIdx.x & 63;
 	const int s = blockIdx.x * HIBAG_WAVE + lane;
-	const int k = M.n_snp_c[c];
-	const int nwp = M.nwp[c];
-	const int *__restrict__ idx = M.snp_index + M.snp_off[c];
-	const int row0 = M.mask_row[c];
-	const int nkb = M.engine[c];                      // matrix-engine variant, 0 = VALU engine
+	// (the model's tables through the constant address space: the kernel stores, so a plain wave-uniform load would be a VECTOR
+	// load plus a readfirstlane -- three dependent memory round trips per SNP instead of scalar-cache hits)
+	const int k = as_const(M.n_snp_c)[c];
+	const int nwp = as_const(M.nwp)[c];
+	const ConstPtr<int> idx = as_const(M.snp_index) + as_const(M.snp_off)[c];
+	const ConstPtr<int> snp_weight = as_const(M.snp_weight);
+	const int row0 = as_const(M.mask_row)[c];
+	const int nkb = as_const(M.engine)[c];            // matrix-engine variant, 0 = VALU engine
+	const int bt_row_c = as_const(M.bt_row)[c];
 	int num = 0, den = 0;
 	if (nkb > 0) {
 	// one pass over the SNPs of each K step (independent byte loads, several in flight): all k <= 32 of them, or 28 per
 	// step of a multi-step FP4 classifier
-	const int steps = M.n_step[c];
+	const int steps = as_const(M.n_step)[c];
 	for (int st = 0; st < steps; st++) {
 		const int j0 = steps > 1 ? HIBAG_FP4_STEP_SNPS * st : 0, kj = steps > 1 ? min(HIBAG_FP4_STEP_SNPS, k - j0) : k;
 		uint32_t X = 0, Z = 0, E = 0;          // bit j: g == 2, g == 0, g == 1 at SNP j0 + j
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 		for (int j = 0; j < kj; j++) {
 			const int snp = idx[j0 + j];
 			const uint32_t g = codes[(size_t)snp * B.n_pad + s];
-			const int wt = M.snp_weight[snp];
+			const int wt = snp_weight[snp];
 			den += wt;
 			if (g != 3) num += wt;
 			X |= (uint32_t)(g == 2) << j;
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 				const unsigned __int128 d128 = (unsigned __int128)digits << (4 * kj);
 #pragma unroll
 				for (int q = 0; q < 4; q++) a[q] |= (uint32_t)(d128 >> (32 * q));
-				B.bt[((size_t)(M.bt_row[c] + 2 * st + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (lane & 31)] =
+				B.bt[((size_t)(bt_row_c + 2 * st + n) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (lane & 31)] =
 					uint4{a[0], a[1], a[2], a[3]};
 			}
 		} else {
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 #pragma unroll
 					for (int q = 0; q < 4; q++) a[q] = (uint32_t)pos[q] * 0x08u | (uint32_t)neg[q] * 0xF8u | (uint32_t)one[q] * 0x10u;
 					if (m == 0 && h == 1 && k < 32) a[3] |= offset << 24;       // K position 31 meets the A operand's 8
-					B.bt[((size_t)(M.bt_row[c] + n * 2 + m) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (lane & 31)] =
+					B.bt[((size_t)(bt_row_c + n * 2 + m) * gridDim.x + blockIdx.x) * HIBAG_WAVE + h * 32 + (lane & 31)] =
 						uint4{a[0], a[1], a[2], a[3]};
 				}
 			}
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 			for (int j = j0; j < j1; j++) {
 				const int snp = idx[j];
 				const uint32_t g = codes[(size_t)snp * B.n_pad + s];
-				const int wt = M.snp_weight[snp];
+				const int wt = snp_weight[snp];
 				den += wt;
 				if (g != 3) num += wt;
 				X |= (uint32_t)(g == 2) << (j - j0);
