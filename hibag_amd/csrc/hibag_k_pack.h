@@ -141,18 +141,41 @@ __global__ __launch_bounds__(PACK_WAVES * HIBAG_WAVE) void k_pack(HibagModelView
 	const int steps = as_const(M.n_step)[c];
 	for (int st = 0; st < steps; st++) {
 		const int j0 = steps > 1 ? HIBAG_FP4_STEP_SNPS * st : 0, kj = steps > 1 ? min(HIBAG_FP4_STEP_SNPS, k - j0) : k;
-		uint32_t X = 0, Z = 0, E = 0;          // bit j: g == 2, g == 0, g == 1 at SNP j0 + j
+		// The codes (0, 1, 2, 3 = missing) are gathered two bits per SNP -- one shift-or each -- and the three bit fields the
+		// operands are made of (bit j: g == 2, g == 0, g == 1 at SNP j0 + j; a missing SNP is in none) come out of the two packed
+		// words at the end: 70 vector instructions for a K step instead of nine per SNP.
+		uint32_t packed[2] = {0u, 0u};         // SNPs 0..15, 16..31 of the step
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			const int jb = 16 * h, je = min(kj, jb + 16);
+			uint32_t w = 0;
 #pragma unroll 8
-		for (int j = 0; j < kj; j++) {
-			const int snp = idx[j0 + j];
-			const uint32_t g = codes[(size_t)snp * B.n_pad + s];
-			const int wt = snp_weight[snp];
-			den += wt;
-			if (g != 3) num += wt;
-			X |= (uint32_t)(g == 2) << j;
-			Z |= (uint32_t)(g == 0) << j;
-			E |= (uint32_t)(g == 1) << j;
+			for (int j = jb; j < je; j++) {
+				const int snp = idx[j0 + j];
+				const uint32_t g = codes[(size_t)snp * B.n_pad + s];
+				const int wt = snp_weight[snp];
+				den += wt;
+				if (g != 3) num += wt;
+				w |= g << (2 * (j - jb));
+			}
+			packed[h] = w;
 		}
+		auto even_bits = [](uint32_t x) {      // bits 0, 2, 4 ... 30 -> bits 0 ... 15
+			x &= 0x55555555u;
+			x = (x | (x >> 1)) & 0x33333333u;
+			x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+			x = (x | (x >> 4)) & 0x00FF00FFu;
+			return (x | (x >> 8)) & 0xFFFFu;
+		};
+		uint32_t X = 0, Z = 0, E = 0;
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			const uint32_t lo = packed[h], hi = packed[h] >> 1;
+			X |= even_bits(hi & ~lo) << (16 * h);
+			E |= even_bits(lo & ~hi) << (16 * h);
+			Z |= even_bits(~(hi | lo)) << (16 * h);
+		}
+		Z &= kj >= 32 ? ~0u : (1u << kj) - 1u;     // (positions behind the step's last SNP hold code 0)
 		const uint32_t offset = 2u * (uint32_t)__popc(X) + (uint32_t)__popc(E);     // <= 64
 		const int n = lane >> 5;
 		if (nkb == HIBAG_ENGINE_FP4) {
