@@ -9,13 +9,14 @@
 // with the tile's S in LDS (one row of 64 doubles per cell, conflict-free).  What a classifier contributes to a tile is
 // either evaluated again from its haplotype pairs (the cells with few pairs) or read back from the sums pass 1 stored
 // (HibagModelView::store_cells); both arrive here as ONE STREAM OF BLOCKS per tile (hibag_device.h, "E-stream"): the
-// blocks of classifier 0, 1, 2 ... that have anything for the tile, each block 32 pair slots plus a 32-byte header that
-// names the block's classifier (-> weight and 1/total rows), its operand row and haplotype table, the tile rows its
-// cells close into and up to eight stored sums to add.  Round 2 walked (classifier, tile) "visits" -- mostly one short
+// blocks of classifier 0, 1, 2 ... that have anything for the tile, each block 32 pair slots -- their prebuilt A-operand rows --
+// plus a 32-byte header that holds everything scalar about it besides the slots' factors: its end-of-cell mask, the tile rows
+// its cells close into, up to seven stored sums to add, how many of its slots are worth evaluating, and what names the NEXT
+// block's classifier (-> weight and 1/total rows), operand row and stored sums (hibag_device.h).  Round 2 walked (classifier, tile) "visits" -- mostly one short
 // block each -- with a scalar prologue per visit (record, descriptors, engine dispatch) and nothing of the next visit in
 // flight while the current one ran: 0.73 us of SIMD time per visit against 0.35 us of instructions.  As a stream the loop
-// body is one block, and at its top EVERYTHING of block b + 1 is requested -- haplotype entries, B operand, weight,
-// 1/total, stored sums -- plus the slot words and header of block b + 2, so a whole block's evaluation covers each
+// body is one block, and behind its matrix instructions EVERYTHING of block b + 1 is requested -- A rows, B operand, weight,
+// 1/total, stored sums (its header and first factors at the top already) -- so a whole block's evaluation covers each
 // latency, across classifier boundaries too.  Only one-step FP4 classifiers are evaluated here; every other engine has all
 // its cells stored by pass 1 (their blocks carry stored sums only).
 //
@@ -31,8 +32,8 @@ typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 #define ACCUM_OCC 5                         // workgroups per CU pass 2 is compiled for (LDS: HIBAG_TILE in hibag_device.h; registers: HIBAG_STORED_PER_VISIT)
 #endif
 
-// What a block needs that is requested a block ahead and is still in use while the NEXT block's is in flight: its header,
-// the end-of-cell masks, its first factors (scalar registers) and the lane's weight and 1/total.  The loop body exists twice
+// What a block needs that is requested a block ahead and is still in use while the NEXT block's is in flight: its header
+// and its first factors (scalar registers) and the lane's weight and 1/total.  The loop body exists twice
 // (A -> B, B -> A): the two sets take turns, nothing is moved from a "next" register to a "current" one.
 struct AccumAhead {
 	u32x8 hv;           // the E-stream header (hibag_device.h): end-of-cell mask, stored sums, the next block's request words, tile rows, groups worth evaluating
