@@ -161,7 +161,11 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 					if (i & 1) asm volatile("" : "=v"(sv[i]));
 					else sv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_sv, vo + i * HIBAG_WAVE * 8, sr, 2));
 #else
+#ifdef HIBAG_SV_PLAIN                         // (correct variant: default cache policy instead of nt)
+					sv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_sv, vo + i * HIBAG_WAVE * 8, sr, 0));
+#else
 					sv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_sv, vo + i * HIBAG_WAVE * 8, sr, 2));   // (read once: nt; the row's distance as the instruction's immediate offset)
+#endif
 #endif
 				}
 			}
