@@ -60,6 +60,8 @@ __global__ __launch_bounds__(64) void k_nan_cells(HibagModelView M, HibagBatchVi
 // NormalizeSumPostProb (src/LibHLA.cpp:1509-1518: S *= 1/sum_w when sum_w > 0)
 // on the fly, which rounds exactly like scaling in place first.
 __device__ __forceinline__ double normalised(double v, bool scale, double ff) { return scale ? v * ff : v; }
+// (The call and the dosage read the ensemble sums with the default cache policy: the second and third read come out of the
+// caches.  Streamed (nt) they were measured 17 % slower for no gain elsewhere; k_finish_prob, the last reader, streams.)
 
 // k_finish_call: BestGuessEnsemble (src/LibHLA.cpp:1549-1566: first strict
 // maximum in cell order, NA when nothing is positive), the called pair's
@@ -195,12 +197,14 @@ __global__ __launch_bounds__(256) void k_finish_prob(HibagModelView M, HibagBatc
 	const double ff = 1.0 / sum_w;
 	for (int r = ty; r < 64; r += 4) {
 		const int p = p0 + r;
-		tile[r][tx] = (p < P) ? (sum_w != sum_w ? sum_w : normalised(part[(size_t)p * B.n_pad + s0 + tx], scale, ff)) : 0.0;   // (NaN weight sum: poisoned batch)
+		// (the last read of the sums, and a matrix as large as they are going out: both streamed -- with the default policy
+		// the 100 MB written here pushed pass 1's rows and operands out of the caches, and pass 1 of the NEXT batch took 14 % longer)
+		tile[r][tx] = (p < P) ? (sum_w != sum_w ? sum_w : normalised(__builtin_nontemporal_load(&part[(size_t)p * B.n_pad + s0 + tx]), scale, ff)) : 0.0;   // (NaN weight sum: poisoned batch)
 	}
 	__syncthreads();
 	for (int r = ty; r < 64; r += 4) {
 		const int s = s0 + r, p = p0 + tx;
-		if (s < B.n_samp && p < P) postprob[(size_t)s * P + p] = tile[tx][r];
+		if (s < B.n_samp && p < P) __builtin_nontemporal_store(tile[tx][r], &postprob[(size_t)s * P + p]);
 	}
 }
 
