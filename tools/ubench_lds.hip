@@ -52,6 +52,18 @@ __global__ __launch_bounds__(256) void k(int iters, const double *gtab, unsigned
 				"s_nop 0\n v_add_u32 %0, s4, %0\n v_add_u32 %0, s9, %0"
 				: "+v"(u) : "v"(v), "v"(lane) : "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11");
 		}
+		if (KIND == 12) {    // 8 x v_permlane32_swap (what gives a lane its own sample's column of a 32x32 matrix result)
+			asm volatile(
+				"v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %0, %1\n"
+				"v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %0, %1"
+				: "+v"(u), "+v"(v));
+		}
+		if (KIND == 13) {    // 8 x v_mul_f64 / v_add_f64 on independent registers
+			asm volatile(
+				"v_mul_f64 %0, %0, %2\n v_add_f64 %1, %1, %2\n v_mul_f64 %0, %0, %2\n v_add_f64 %1, %1, %2\n"
+				"v_mul_f64 %0, %0, %2\n v_add_f64 %1, %1, %2\n v_mul_f64 %0, %0, %2\n v_add_f64 %1, %1, %2"
+				: "+v"(acc), "+v"(t0) : "v"(1.0000001));
+		}
 		if (KIND == 6 || KIND == 7) {
 			const char *p = gp + (KIND == 6 ? a_bcast : a_gather);
 			asm volatile("global_load_dwordx2 %0, %8, off\n global_load_dwordx2 %1, %8, off offset:8\n global_load_dwordx2 %2, %8, off offset:16\n global_load_dwordx2 %3, %8, off offset:24\n"
@@ -123,6 +135,8 @@ int main()
 	run<10>("ds_add_f64 lane*8 (accumulator rows)", gtab, d_out, 8);
 	run<11>("ds_write_b64 lane*8", gtab, d_out, 8);
 	run<5>("v_readlane_b32 (x2 = one factor)", gtab, d_out, 16);
+	run<12>("v_permlane32_swap_b32", gtab, d_out, 8);
+	run<13>("v_mul_f64 / v_add_f64", gtab, d_out, 8);
 	run<6>("global_load_dwordx2 broadcast (L1 hit)", gtab, d_out, 8);
 	run<7>("global_load_dwordx2 gather 61 doubles (L1)", gtab, d_out, 8);
 	return 0;
