@@ -321,8 +321,9 @@ __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename 
 		if (!AHEAD) look_up(g, t);
 		// the look-ups are waited for HERE (a use of the first one; LDS returns in order, and a scalar load in flight makes it a
 		// wait for everything), and only then are the next group's factors requested: they have this group's arithmetic to arrive.
-		// (AHEAD, a measured variant: the NEXT group's look-ups requested here as well, before this group is added up -- round 4
-		// and twice in round 5: between +1 % and -0.6 % on pass 2 for six registers, slower on pass 1, which has none to spare.)
+		// (AHEAD: the NEXT group's look-ups are requested here as well, before this group is added up.  Pass 2 ships with it
+		// -- measured three times on round 5's loops: between +1 % and -0.6 %, the last two runs -0.5 % each, for six registers it
+		// has to spare; pass 1 has none to spare: +7 %.)
 		asm volatile("" : "+v"(t[0]));
 		__builtin_amdgcn_sched_barrier(0);
 		FG Fn = F;

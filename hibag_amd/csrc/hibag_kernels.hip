@@ -70,7 +70,7 @@
 #define HIBAG_TOT_OCC_MANY 6
 #endif
 #ifndef ACCUM_AHEAD
-#define ACCUM_AHEAD false                   // pass 2: the next group's table look-ups requested before this group is added up (measured: no gain)
+#define ACCUM_AHEAD true                    // pass 2: the next group's table look-ups requested before this group is added up (-0.6 %, six registers; false: the wait right behind the look-ups)
 #endif
 #ifndef ACCUM_G
 #define ACCUM_G 4                           // the same for pass 2
