@@ -137,6 +137,20 @@ __device__ __forceinline__ void load_operand_row(const HibagBatchView &B, int bt
 	}
 }
 
+// One-step FP4, the walk without lane swaps (walk_blocks, OWN): b[0][0] = the "sum" side (K half 0 of the packed operand) and
+// b[1][0] = the "pair" side (K half 1) of the LANE'S OWN sample -- lanes 0..31 take theirs from the operand row of samples
+// 0..31, lanes 32..63 from the row of samples 32..63 (k_pack's layout: row = sample half, position = K half * 32 + sample).
+__device__ __forceinline__ void load_operand_own_sample(const HibagBatchView &B, int bt_row, int group, int lane, LaneOperand &T)
+{
+	const size_t n_group = (size_t)(B.n_pad / HIBAG_WAVE);
+	const uint4 *row = B.bt + ((size_t)(bt_row + (lane >> 5)) * n_group + group) * HIBAG_WAVE + (lane & 31);
+	const uint4 va = row[0], vb = row[32];
+	T.b[0][0] = v4i{(int)va.x, (int)va.y, (int)va.z, (int)va.w};
+	T.b[1][0] = v4i{(int)vb.x, (int)vb.y, (int)vb.z, (int)vb.w};
+	T.b[0][1] = T.b[1][1] = v4i{0, 0, 0, 0};
+	T.bias[0] = T.bias[1] = 0;
+}
+
 __device__ __forceinline__ WideSrc wide_src(const HibagBatchView &B, int bt_row, int nstep, int group)
 {
 	WideSrc w;
@@ -295,7 +309,8 @@ template <> struct FactorGroup<8> { typedef f64x8 type; };
 // group the choice is part of the branch that closes the cell; across groups and blocks the wave-uniform `fresh` says that the
 // record before closed one (a scalar register; the walk that ends on it materialises the zero).
 // `live(g)`: group g of the block has records worth evaluating (the groups before it then have too).
-template <int G, bool AHEAD = false, class Live, class Fin>
+// LINEAR: record i's distance is D0[i] (i < 16) / D1[i - 16] -- the layout of the walk without lane swaps (walk_blocks, OWN).
+template <int G, bool AHEAD = false, bool LINEAR = false, class Live, class Fin>
 __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename FactorGroup<G>::type F, uint32_t endmask, uint32_t storemask, Live &&live,
 	const v16i &D0, const v16i &D1, double &cell, uint32_t fresh, const double *tab_s, Fin &&fin)
 {
@@ -308,7 +323,7 @@ __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename 
 #pragma unroll
 		for (int q = 0; q < G; q++) {         // D = 8*d: already the byte offset into the table
 			const int i = G * g + q;          // record i = 8 m + r  ->  r < 4 ? D0[4 m + r] : D1[4 m + r - 4]
-			const int off = (i & 7) < 4 ? D0[4 * (i >> 3) + (i & 3)] : D1[4 * (i >> 3) + (i & 3)];
+			const int off = LINEAR ? (i < 16 ? D0[i] : D1[i - 16]) : (i & 7) < 4 ? D0[4 * (i >> 3) + (i & 3)] : D1[4 * (i >> 3) + (i & 3)];
 			t[q] = table_value(tab_s, off);
 		}
 	};
@@ -397,7 +412,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // PRE (one-step FP4 only): the A-operand rows are PREBUILT (HibagModelView::parow, 1 KB per block): one coalesced 16-byte load
 // per lane and block, requested a block ahead right behind the matrix instructions that consumed the current rows -- no
 // slot words, no gathers from the haplotype table, no address arithmetic, no additions.
-template <int ENG, int G, bool PRE, class Fin>
+// OWN (with PRE): NO LANE SWAPS.  A 32 x 32 matrix result leaves rows 8m .. 8m+3 of sample column j in lane j and rows
+// 8m+4 .. 8m+7 in lane j + 32, and sixteen v_permlane32_swap per block (1.7 FP64 operations each) gave every lane its own
+// sample's 32 rows.  Instead the A operand holds each of SIXTEEN slots in two rows -- row 8m+q with the slot's image in K half 0
+// and zeros in K half 1, row 8m+4+q the other way round -- and the B operand's column j has sample j in K half 0 and sample
+// j + 32 in K half 1 (load_operand_own_sample): lane j then receives slot . sample j, lane j + 32 slot . sample (j + 32), both
+// in register r = 4m + q.  The two images of a slot (the "sum" side and the "pair" side of the dot product) take two matrix
+// instructions that accumulate, the block's 32 slots two such chains: four matrix instructions instead of two, no swap, and
+// record i simply sits in register i.  The four A operands are the block's prebuilt row itself, read with one per-lane offset
+// (a lane whose row-half is zeros does not load and keeps its zeros).
+// MEASURED (round 5, profiles/r05_pass2_notes.txt item 20): every output bit-identical, pass 1 0.760-0.786 ms against 0.743-0.747
+// with the swaps -- two more matrix instructions (which FP64 work does not overlap with) and three more loads per block cost
+// more than sixteen swaps, whose removal alone is worth 8 %.  Kept as a variant (-DTOTAL_OWN=true), not shipped.
+template <int ENG, int G, bool PRE, bool OWN = false, class Fin>
 __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at, int nblk, int lane, ListCursor &cur,
 	__amdgpu_buffer_rsrc_t hp, int k, const LaneOperand &T, const WideSrc &wide, const double *tab_s, double &cell, Fin &&fin)
 {
@@ -407,6 +434,76 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 	uint32_t fresh = 0;                              // block_accumulate: the record before closed a cell
 	ConstPtr<double> fac = as_const(M.pfac) + at;                            // this segment's factors and headers
 	ConstPtr<u32x4> hdr = (ConstPtr<u32x4>)(as_const(M.phdr) + at / HIBAG_PLIST_DWORDS * 4);
+	if (PRE && OWN) {
+		const uint64_t blk = at / HIBAG_PLIST_DWORDS;
+		const uint64_t left = (M.parow_blocks - blk) * 1024u;
+		const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void *)(M.parow + blk * 64), 0,
+			left > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left, 0x00020000);
+		const int row = lane & 31;
+		const bool supplies = ((row >> 2) & 1) == (lane >> 5);        // this lane's (row, K half) of the A operand is not zeros
+		const int vo = (4 * (row >> 3) + (row & 3)) * 16;              // its slot among the chain's sixteen (an entry is 16 bytes)
+		// A[2 c + image]: chain c = slots 16 c .. 16 c + 15; the prebuilt row has the "sum" images of the 32 slots, then the "pair" images
+		v4i A[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) A[k] = v4i{0, 0, 0, 0};
+		auto request_rows = [&](uint32_t soff) {
+			if (supplies) {
+				int v = vo;
+				asm volatile("" : "+v"(v));                   // (kept out of the loop-invariant code: the four offsets as the instructions' immediates, not as registers)
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					A[k] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(pr, v + (k & 1) * 512 + (k >> 1) * 256, (int)soff, 0));
+			}
+		};
+		request_rows(0);
+		u32x4 H_n = hdr[0];
+		FG F_n = *(ConstPtr<FG>)fac;
+		uint32_t soff = 1024;
+		const v8i b_sum = {T.b[0][0][0], T.b[0][0][1], T.b[0][0][2], T.b[0][0][3], 0, 0, 0, 0};
+		const v8i b_pair = {T.b[1][0][0], T.b[1][0][1], T.b[1][0][2], T.b[1][0][3], 0, 0, 0, 0};
+		for (int b = 0; b < nblk; b++) {
+			const u32x4 H = H_n;
+			const FG F = F_n;
+			const uint32_t endmask = abl_endmask(H[0]), storemask = abl_storemask(H[1]);
+			const int n_valid = (int)H[2];
+			// (the header is waited for HERE, before the next scalar loads are issued: a wait behind them would be for them too)
+			asm volatile("" :: "s"(n_valid));
+			__builtin_amdgcn_sched_barrier(0);
+			H_n = hdr[b + 1];
+			F_n = *(ConstPtr<FG>)(fac + (size_t)(b + 1) * HIBAG_PLIST_DWORDS);
+			if (n_valid > 0) {
+				v16f x0, x1;
+#pragma unroll
+				for (int r = 0; r < 16; r++) { x0[r] = 0.0f; x1[r] = 0.0f; }
+				{
+					// (the two chains interleaved: a matrix instruction that accumulates onto the one before it waits for its result)
+					const v8i a0 = {A[0][0], A[0][1], A[0][2], A[0][3], 0, 0, 0, 0}, a1 = {A[1][0], A[1][1], A[1][2], A[1][3], 0, 0, 0, 0};
+					const v8i a2 = {A[2][0], A[2][1], A[2][2], A[2][3], 0, 0, 0, 0}, a3 = {A[3][0], A[3][1], A[3][2], A[3][3], 0, 0, 0, 0};
+					// (always all four: pass 1's blocks are 96 % full, and a branch here lets the compiler put the next block's loads in
+					// front of the second chain -- whose operands' wait then becomes a wait for those loads)
+					x0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b_sum, x0, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, HIBAG_FP4_SCALE_B_LO);
+					x1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a2, b_sum, x1, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, HIBAG_FP4_SCALE_B_LO);
+					__builtin_amdgcn_sched_barrier(0);
+					x0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b_pair, x0, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, HIBAG_FP4_SCALE_B_HI);
+					x1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a3, b_pair, x1, 4, 4, 0, HIBAG_FP4_SCALE_A, 0, HIBAG_FP4_SCALE_B_HI);
+					// (both results count as used HERE: the second chain is only read by the block's later groups, and the compiler
+					// would sink its matrix instructions down to them -- behind the next block's loads, in the middle of the additions)
+					asm volatile("" : "+v"(x0), "+v"(x1));
+				}
+				__builtin_amdgcn_sched_barrier(0);
+				request_rows(soff);                           // the next block's, behind the instructions that read this one's
+				__builtin_amdgcn_sched_barrier(0);
+				const v16i D0 = __builtin_bit_cast(v16i, x0), D1 = __builtin_bit_cast(v16i, x1);
+				block_accumulate<G, false, true>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, [&](int g) { return G * g < n_valid; }, D0, D1, cell, fresh, tab_s, fin);
+				fresh = fresh_behind<G>(fresh, endmask, n_valid);
+			} else {
+				request_rows(soff);
+			}
+			soff += 1024;
+		}
+		if (fresh) cell = 0;
+		return;
+	}
 	if (PRE) {
 		const uint64_t blk = at / HIBAG_PLIST_DWORDS;
 		const uint64_t left = (M.parow_blocks - blk) * 1024u;

@@ -221,9 +221,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, 
 					ci++;
 				}
 			};
-#define CALLX(E, PRE) { LaneOperand T; load_operand_row<E>(B, M.bt_row[c], c, group, lane, T);                                 \
+#define CALLX(E, PRE) { LaneOperand T;                                                                                         \
+			constexpr bool OWN = PRE && E == HIBAG_ENGINE_FP4 && TOTAL_OWN && !VOTE;   /* the walk without lane swaps (walk_blocks); the vote build has no registers for it */ \
+			if (OWN) load_operand_own_sample(B, M.bt_row[c], group, lane, T); else load_operand_row<E>(B, M.bt_row[c], c, group, lane, T); \
 			ListCursor cur;                                                                                                \
-			walk_blocks<E, TOTAL_G, PRE>(M, M.blk_off[c] + (uint64_t)b0 * HIBAG_PLIST_DWORDS, b1 - b0, lane, cur,            \
+			walk_blocks<E, TOTAL_G, PRE, OWN>(M, M.blk_off[c] + (uint64_t)b0 * HIBAG_PLIST_DWORDS, b1 - b0, lane, cur,       \
 				hap_rsrc(M, M.hap_off[c]), M.n_snp_c[c], T, WideSrc(), tab_s, cell, fin); }
 #define CALL(E) CALLX(E, false)
 			// one-step FP4 classifiers of a model small enough for prebuilt A-operand rows walk those (HibagModelView::parow)

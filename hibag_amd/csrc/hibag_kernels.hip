@@ -69,6 +69,9 @@
 #ifndef HIBAG_TOT_OCC_MANY
 #define HIBAG_TOT_OCC_MANY 6
 #endif
+#ifndef TOTAL_OWN
+#define TOTAL_OWN false                     // true: pass 1 over prebuilt rows with four matrix instructions per block and NO lane swaps (walk_blocks, OWN) -- bit-identical, measured 2-5 % slower than two and sixteen swaps
+#endif
 #ifndef ACCUM_AHEAD
 #define ACCUM_AHEAD true                    // pass 2: the next group's table look-ups requested before this group is added up (-0.6 %, six registers; false: the wait right behind the look-ups)
 #endif
