@@ -28,6 +28,7 @@ EXPORTS = [
     "hibag_hip_predict_device", "hibag_hip_model_set_snp_weights", "hibag_hip_predict_partial_device",
     "hibag_hip_finish_device", "hibag_hip_set_timing", "hibag_hip_get_timing", "hibag_hip_reset_timing",
     "hibag_hip_gpu_ext_proc", "hibag_hip_bed_flag", "hibag_hip_conv_bed", "hibag_hip_predict_bed", "hibag_hip_predict_mapped", "hibag_hip_predict_mapped_device",
+    "hibag_hip_predict_snp_major", "hibag_hip_predict_snp_major_device",
     "hibag_hip_trainer_new", "hibag_hip_trainer_free", "hibag_hip_trainer_set_rng", "hibag_hip_trainer_set_seed",
     "hibag_hip_trainer_new_classifiers", "hibag_hip_trainer_n_classifier", "hibag_hip_trainer_classifier_dims",
     "hibag_hip_trainer_classifier_get", "hibag_hip_trainer_set_threads", "hibag_hip_trainer_threads", "hibag_hip_trainer_set_em_mode",
@@ -117,6 +118,8 @@ def lib() -> C.CDLL:
     L.hibag_hip_predict_bed.argtypes = [vp, C.c_char_p, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.hibag_hip_predict_mapped.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.hibag_hip_predict_mapped_device.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.hibag_hip_predict_snp_major.argtypes = [vp, vp, C.c_size_t, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.hibag_hip_predict_snp_major_device.argtypes = [vp, vp, C.c_size_t, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.hibag_hip_model_status.argtypes = [vp]
     L.hibag_hip_model_clear_status.argtypes = [vp]
     L.hibag_hip_model_handover_faults.argtypes = [vp]

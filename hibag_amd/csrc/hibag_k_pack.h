@@ -42,6 +42,26 @@ __global__ __launch_bounds__(256) void k_codes(HibagModelView M, HibagBatchView 
 	}
 }
 
+// k_codes_rows: the same for a SNP-MAJOR matrix, int32 [rows][ld] with one row of genotypes per SNP (a C / numpy
+// [snp][sample] array, the transpose of R's memory; `ld` >= n_samp elements between rows): no transpose to make -- block =
+// 256 samples of one model SNP, the read of the row and the write of the codes both contiguous.  col[k] = the row that
+// holds model SNP k (-1 = absent -> missing; nullptr = row k), flip[k] != 0 reverses its allele count.
+__global__ __launch_bounds__(256) void k_codes_rows(HibagModelView M, HibagBatchView B,
+	const int32_t *__restrict__ geno, size_t ld, const int32_t *__restrict__ col, const int32_t *__restrict__ flip,
+	uint8_t *__restrict__ codes)
+{
+	const int k = blockIdx.y;
+	const int s = blockIdx.x * 256 + threadIdx.x;
+	if (s >= B.n_pad) return;
+	const int c = col ? col[k] : k;
+	uint8_t v = 3;
+	if (s < B.n_samp && c >= 0) {
+		const int g = geno[(size_t)c * ld + s];
+		if (g >= 0 && g <= 2) v = (flip && flip[k]) ? (uint8_t)(2 - g) : (uint8_t)g;
+	}
+	codes[(size_t)k * B.n_pad + s] = v;
+}
+
 // ---------------------------------------------------------------------------
 // PLINK BED sources (HIBAG_ConvBED, src/HIBAG.cpp:1094-1191).  `bed` is the
 // payload after the 3-byte prefix: rows of `stride` bytes, 4 two-bit codes per

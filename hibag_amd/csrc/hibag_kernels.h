@@ -10,6 +10,9 @@
 // d_col / d_flip (optional): the cohort's own matrix with `row_len` SNPs per sample, gathered and flipped on the device
 void hibag_launch_pack(const HibagModelView &M, const HibagBatchView &B, const int32_t *d_geno, int row_len,
 	const int32_t *d_col, const int32_t *d_flip, uint8_t *d_codes, hipStream_t st);
+// the same for a SNP-major matrix: int32 [rows][ld], row d_col[k] (nullptr: k) holds model SNP k
+void hibag_launch_pack_rows(const HibagModelView &M, const HibagBatchView &B, const int32_t *d_geno, size_t ld,
+	const int32_t *d_col, const int32_t *d_flip, uint8_t *d_codes, hipStream_t st);
 // PLINK BED sources: `d_bed` is the payload after the 3-byte prefix, rows of `stride` bytes
 void hibag_launch_pack_bed(const HibagModelView &M, const HibagBatchView &B, const uint8_t *d_bed, int mode,
 	size_t stride, int samp0, const int32_t *d_snp_row, const int32_t *d_flip, uint8_t *d_codes, hipStream_t st);

@@ -105,6 +105,16 @@ void hibag_launch_pack(const HibagModelView &M, const HibagBatchView &B, const i
 		(const uint8_t *)d_codes);
 }
 
+// the genotypes as a SNP-major matrix int32 [rows][ld] (k_codes_rows)
+void hibag_launch_pack_rows(const HibagModelView &M, const HibagBatchView &B, const int32_t *d_geno, size_t ld,
+	const int32_t *d_col, const int32_t *d_flip, uint8_t *d_codes, hipStream_t st)
+{
+	if (M.n_classifier == 0 || M.n_snp == 0) return;
+	hipLaunchKernelGGL(k_codes_rows, dim3((B.n_pad + 255) / 256, M.n_snp), dim3(256), 0, st, M, B, d_geno, ld, d_col, d_flip, d_codes);
+	hipLaunchKernelGGL(k_pack, dim3(B.n_pad / HIBAG_WAVE, (M.n_classifier + PACK_WAVES - 1) / PACK_WAVES), dim3(PACK_WAVES * HIBAG_WAVE), 0, st, M, B,
+		(const uint8_t *)d_codes);
+}
+
 void hibag_launch_pack_bed(const HibagModelView &M, const HibagBatchView &B, const uint8_t *d_bed, int mode,
 	size_t stride, int samp0, const int32_t *d_snp_row, const int32_t *d_flip, uint8_t *d_codes, hipStream_t st)
 {

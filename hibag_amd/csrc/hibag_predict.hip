@@ -187,6 +187,7 @@ struct WorkspaceGuard {
 struct PackSource {
 	const int32_t *d_geno = nullptr;       // [n_samp][row_len]
 	int row_len = 0;                       // SNPs per sample in d_geno (0: the model's n_snp, model order)
+	size_t ld = 0;                         // != 0: d_geno is SNP-MAJOR, [rows][ld] with one row of genotypes per SNP (k_codes_rows); d_col = row of each model SNP
 	const int32_t *d_col = nullptr;        // [n_snp] column of each model SNP in d_geno (-1 = absent), nullptr = identity
 	const uint8_t *d_bed = nullptr;        // payload rows (see k_bed_codes)
 	int mode = 0;
@@ -215,6 +216,8 @@ int predict_device_locked(hibag_hip_model *m, const PackSource &src, int n_samp,
 		if (src.d_bed)
 			hibag_launch_pack_bed(m->view, B, src.d_bed, src.mode, src.stride, src.samp0 + s0, src.d_row, src.d_flip,
 				m->ws_codes.as<uint8_t>(), st);
+		else if (src.ld)
+			hibag_launch_pack_rows(m->view, B, src.d_geno + s0, src.ld, src.d_col, src.d_flip, m->ws_codes.as<uint8_t>(), st);
 		else
 			hibag_launch_pack(m->view, B, src.d_geno + (size_t)s0 * (src.d_col ? src.row_len : m->n_snp), src.row_len,
 				src.d_col, src.d_flip, m->ws_codes.as<uint8_t>(), st);
@@ -271,16 +274,26 @@ int staged_slice(const hibag_hip_model *m, int n_samp, size_t row_len)
 	return (int)std::max<long long>(64, (slice + 63) / 64 * 64);
 }
 
+// A SNP-major host matrix (hibag_hip_predict_snp_major): geno[rows[r] * ld + s] is staged as row r of a slice's
+// [rows.size()][n] device matrix -- only the rows the model uses travel.
+struct HostRows {
+	size_t ld = 0;
+	std::vector<size_t> rows;
+	bool consecutive = false;              // rows[r] = rows[0] + r: a slice is one strided block of the caller's matrix
+};
+
 int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSource *bed, int n_samp, int vote_method,
 	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob,
-	const PackSource *map = nullptr, bool is_retry = false)
+	const PackSource *map = nullptr, bool is_retry = false, const HostRows *hr = nullptr)
 {
 	// `map`: geno is the cohort's own matrix (map->row_len SNPs per sample); map->d_col / d_flip sit on the device
+	// `hr` (with `map` for d_col / d_flip): the cohort's matrix is SNP-major, see HostRows
 	// A device-pointer launch still running on another stream may yet fail a hand-over: wait for it, so that its fault
 	// becomes the model's sticky status (its caller's to see) instead of being taken for this call's own and repaired away.
 	if (m->ws_pending && m->ws_done && !is_retry) HIP_TRY(hipEventSynchronize(m->ws_done));
 	if (int rc = sticky_fault(m)) return rc;
-	const size_t P = (size_t)m->view.n_cell, nh = (size_t)m->n_hla, S = map ? (size_t)map->row_len : (size_t)m->n_snp;
+	const size_t P = (size_t)m->view.n_cell, nh = (size_t)m->n_hla,
+		S = hr ? std::max<size_t>(hr->rows.size(), 1) : map ? (size_t)map->row_len : (size_t)m->n_snp;
 	const int slice = staged_slice(m, n_samp, bed ? 1 : S);
 	const size_t geno_bytes = ((size_t)slice * std::max<size_t>(S, 1) * sizeof(int32_t) + 255) / 256 * 256;
 	const size_t o_h1 = 0, o_h2 = o_h1 + (size_t)slice * 4, o_mp = (o_h2 + (size_t)slice * 4 + 7) / 8 * 8,
@@ -304,6 +317,8 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 		// memory are as fast on this platform, but the calls block: tools/copy_probe, profiles/r03_copy_probe.txt)
 		if (!bed) if (int rc = m->pin_geno.reserve(geno_bytes * 2)) return rc;
 		if (int rc = m->pin_out.reserve(out_bytes * 2)) return rc;
+	} else if (hr && !hr->consecutive) {
+		if (int rc = m->pin_geno.reserve(geno_bytes)) return rc;          // (scattered rows are gathered on the host side)
 	}
 	auto slice_of = [&](int i, int &s0, int &n) {
 		if (i == 0) { s0 = 0; n = std::min(first, n_samp); }
@@ -314,6 +329,25 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 		int s0, n; slice_of(i, s0, n);
 		const size_t bytes = (size_t)n * S * sizeof(int32_t);
 		char *dst = m->ws_geno.as<char>() + (size_t)(i % nbuf) * geno_bytes;
+		if (hr) {
+			// SNP-major source: row r of the slice's device matrix [rows][n] = n genotypes of the caller's row rows[r] from sample s0
+			const size_t nr = hr->rows.size(), w = (size_t)n * sizeof(int32_t);
+			if (nr == 0) return 0;
+			const int32_t *first = geno + hr->rows[0] * hr->ld + (size_t)s0;
+			if (!piped && hr->consecutive) {
+				// one block of the caller's matrix (the whole of it when the cohort's SNPs are the model's): no host copy
+				if (hr->ld == (size_t)n) HIP_TRY(hipMemcpyAsync(dst, first, nr * w, hipMemcpyHostToDevice, ss->run));
+				else HIP_TRY(hipMemcpy2DAsync(dst, w, first, hr->ld * sizeof(int32_t), w, nr, hipMemcpyHostToDevice, ss->run));
+				return 0;
+			}
+			char *pin = (char *)m->pin_geno.p + (piped ? (size_t)(i & 1) * geno_bytes : 0);
+			if (piped && i >= 2) HIP_TRY(hipEventSynchronize(ss->up[i & 1]));
+			for (size_t r = 0; r < nr; r++) memcpy(pin + r * w, geno + hr->rows[r] * hr->ld + (size_t)s0, w);
+			if (piped && i >= 2) HIP_TRY(hipStreamWaitEvent(ss->in, ss->ran[i & 1], 0));
+			HIP_TRY(hipMemcpyAsync(dst, pin, nr * w, hipMemcpyHostToDevice, piped ? ss->in : ss->run));
+			if (piped) HIP_TRY(hipEventRecord(ss->up[i & 1], ss->in));
+			return 0;
+		}
 		if (!piped) {
 			HIP_TRY(hipMemcpyAsync(dst, geno + (size_t)s0 * S, bytes, hipMemcpyHostToDevice, ss->run));
 			return 0;
@@ -380,6 +414,7 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 		} else {
 			if (map) src = *map;
 			src.d_geno = (const int32_t *)(m->ws_geno.as<char>() + (size_t)(i % nbuf) * geno_bytes);
+			if (hr) src.ld = (size_t)n;
 			if (piped) HIP_TRY(hipStreamWaitEvent(ss->run, ss->up[i & 1], 0));
 		}
 		if (piped && i >= 2) HIP_TRY(hipStreamWaitEvent(ss->run, ss->down[i & 1], 0));    // slice i - 2 has left the device output buffer
@@ -420,7 +455,7 @@ int predict_staged_locked(hibag_hip_model *m, const int32_t *geno, const PackSou
 	if (take_fault(m)) {
 		// poisoned outputs: once more, now without hand-overs (take_fault switched them off) -- never returned to the caller
 		if (is_retry) return hibag_fail(HIBAG_HIP_EHANDOVER, "a hand-over between workgroups failed in a launch without hand-overs");
-		return predict_staged_locked(m, geno, bed, n_samp, vote_method, H1, H2, max_prob, matching, dosage, postprob, map, true);
+		return predict_staged_locked(m, geno, bed, n_samp, vote_method, H1, H2, max_prob, matching, dosage, postprob, map, true, hr);
 	}
 	return 0;
 }
@@ -616,6 +651,62 @@ int hibag_hip_predict_mapped_device(hibag_hip_model *m, const int32_t *d_geno, i
 	if (int rc = sticky_fault(m)) return rc;
 	PackSource src;
 	src.d_geno = d_geno; src.row_len = n_geno_snp; src.d_col = d_snp_col; src.d_flip = d_flip;
+	return predict_device_locked(m, src, n_samp, vote_method, d_H1, d_H2, d_max_prob, d_matching,
+		d_dosage, d_postprob, (hipStream_t)stream);
+}
+
+// The cohort's matrix SNP-major: geno[row][sample] with `ld` elements between rows.  Only the model's rows are uploaded.
+int hibag_hip_predict_snp_major(hibag_hip_model *m, const int32_t *geno, size_t ld, int n_samp, int n_geno_snp,
+	const int32_t *snp_col, const int32_t *flip, int vote_method,
+	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob)
+{
+	if (int rc = check_predict_args(m, geno, n_samp, vote_method, H1, H2)) return rc;
+	if (n_geno_snp <= 0) return hibag_fail(HIBAG_HIP_EINVAL, "n_geno_snp must be positive");
+	if (ld < (size_t)n_samp) return hibag_fail(HIBAG_HIP_EINVAL, "ld = %zu is smaller than n_samp = %d", ld, n_samp);
+	if (!snp_col && m->n_snp > n_geno_snp)
+		return hibag_fail(HIBAG_HIP_EINVAL, "snp_col is NULL (rows in model order) but the matrix has %d rows for the model's %d SNPs", n_geno_snp, m->n_snp);
+	for (int k = 0; snp_col && k < m->n_snp; k++)
+		if (snp_col[k] >= n_geno_snp) return hibag_fail(HIBAG_HIP_EINVAL, "snp_col[%d] = %d outside the %d SNPs of the genotype matrix", k, snp_col[k], n_geno_snp);
+	if (n_samp == 0) return 0;
+	std::lock_guard<std::mutex> g(m->lock);
+	HIP_TRY(hipSetDevice(m->device));
+	const size_t S = (size_t)std::max(m->n_snp, 1);
+	HostRows hr;
+	std::vector<int32_t> idx;
+	try {
+		idx.assign(2 * S, 0);
+		hr.ld = ld;
+		hr.rows.reserve(S);
+		for (int k = 0; k < m->n_snp; k++) {
+			const int c = snp_col ? snp_col[k] : k;
+			idx[k] = c < 0 ? -1 : (int32_t)hr.rows.size();           // (the staged matrix holds the model's rows only, in model order)
+			if (c >= 0) hr.rows.push_back((size_t)c);
+			idx[S + k] = flip ? (flip[k] != 0) : 0;
+		}
+	} catch (...) { return hibag_fail(HIBAG_HIP_ENOMEM, "out of host memory"); }
+	hr.consecutive = true;
+	for (size_t r = 1; r < hr.rows.size(); r++) if (hr.rows[r] != hr.rows[0] + r) { hr.consecutive = false; break; }
+	if (int rc = m->ws_bedidx.reserve(idx.size() * sizeof(int32_t))) return rc;
+	HIP_TRY(hipMemcpyAsync(m->ws_bedidx.p, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, 0));
+	HIP_TRY(hipStreamSynchronize(0));            // `idx` is pageable host memory about to go out of scope
+	PackSource map;
+	map.d_col = m->ws_bedidx.as<int32_t>();
+	map.d_flip = flip ? m->ws_bedidx.as<int32_t>() + S : nullptr;
+	return predict_staged_locked(m, geno, nullptr, n_samp, vote_method, H1, H2, max_prob, matching, dosage, postprob, &map, false, &hr);
+}
+
+int hibag_hip_predict_snp_major_device(hibag_hip_model *m, const int32_t *d_geno, size_t ld, int n_samp, int n_geno_snp,
+	const int32_t *d_snp_col, const int32_t *d_flip, int vote_method,
+	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching, double *d_dosage,
+	double *d_postprob, void *stream)
+{
+	if (int rc = check_predict_args(m, d_geno, n_samp, vote_method, d_H1, d_H2)) return rc;
+	if (n_geno_snp <= 0 || ld < (size_t)std::max(n_samp, 0)) return hibag_fail(HIBAG_HIP_EINVAL, "n_geno_snp must be positive and ld >= n_samp");
+	if (!d_snp_col && m->n_snp > n_geno_snp) return hibag_fail(HIBAG_HIP_EINVAL, "d_snp_col is NULL but the matrix has fewer rows than the model SNPs");
+	std::lock_guard<std::mutex> g(m->lock);
+	if (int rc = sticky_fault(m)) return rc;
+	PackSource src;
+	src.d_geno = d_geno; src.ld = std::max<size_t>(ld, 1); src.d_col = d_snp_col; src.d_flip = d_flip;
 	return predict_device_locked(m, src, n_samp, vote_method, d_H1, d_H2, d_max_prob, d_matching,
 		d_dosage, d_postprob, (hipStream_t)stream);
 }

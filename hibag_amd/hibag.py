@@ -16,7 +16,6 @@ from __future__ import annotations
 import ctypes as C
 import os
 import sys
-from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Union
 
 import numpy as np
@@ -261,6 +260,42 @@ class HlaAttrBagClass:
             _as_ptr(out.get("dosage")), _as_ptr(out.get("postprob"))))
         return out
 
+    def predict_snp_major(self, genomat: np.ndarray, snp_col: Optional[np.ndarray] = None, flip: Optional[np.ndarray] = None,
+                          vote_method: int = 1, want_dosage: bool = True, want_prob: bool = False) -> dict:
+        """``PredictHLA`` on a SNP-MAJOR matrix ``genomat`` [n_geno_snp, n_samp] in C order -- numpy's own layout for the
+        [SNP, sample] matrix of an ``hlaSNPGenoClass`` (``hibag_hip_predict_snp_major``): row ``snp_col[k]`` holds model SNP k
+        (-1 = absent; ``None`` = row k), ``flip[k]`` reverses its allele count.  Nothing is transposed on the host."""
+        g = np.asarray(genomat)
+        if g.ndim != 2 or g.dtype != np.int32 or g.strides[1] != 4 or g.strides[0] % 4 or (g.shape[0] > 1 and g.strides[0] < 4 * g.shape[1]):
+            g = np.ascontiguousarray(g, np.int32)
+            if g.ndim != 2:
+                raise ValueError("genomat must be [n_geno_snp, n_samp]")
+        col = None
+        if snp_col is not None:
+            col = np.ascontiguousarray(snp_col, np.int32)
+            if col.shape != (self.obj.n_snp,):
+                raise ValueError("snp_col must have one entry per model SNP")
+        elif g.shape[0] < self.obj.n_snp:
+            raise ValueError("nrow(snp) == object$n.snp is not TRUE")
+        fl = None if flip is None else np.ascontiguousarray(np.asarray(flip) != 0, np.int32)
+        n = g.shape[1]
+        out = self._outputs(n, want_dosage, want_prob)
+        ld = g.strides[0] // 4 if g.shape[0] > 1 else max(n, 1)
+        _lib.check(_lib.lib().hibag_hip_predict_snp_major(
+            self.handle, _as_ptr(g), ld, n, max(g.shape[0], 1), _as_ptr(col), _as_ptr(fl), int(vote_method),
+            _as_ptr(out["h1"]), _as_ptr(out["h2"]), _as_ptr(out["prob"]), _as_ptr(out["matching"]),
+            _as_ptr(out.get("dosage")), _as_ptr(out.get("postprob"))))
+        return out
+
+    def _outputs(self, n: int, want_dosage: bool, want_prob: bool) -> dict:
+        """The output arrays of ``PredictHLA`` for n samples (every element is written by the library)."""
+        out = dict(h1=np.empty(n, np.int32), h2=np.empty(n, np.int32), prob=np.empty(n, np.float64), matching=np.empty(n, np.float64))
+        if want_dosage:
+            out["dosage"] = np.empty((n, self.obj.n_hla), np.float64)
+        if want_prob:
+            out["postprob"] = np.empty((n, self.obj.n_cell), np.float64)
+        return out
+
     def predict_device(self, d_geno, n_samp: int, vote_method: int = 1, d_h1=None, d_h2=None, d_prob=None,
                        d_matching=None, d_dosage=None, d_postprob=None, stream=None):
         """Device-pointer form; arguments are ints (``tensor.data_ptr()``) or None."""
@@ -393,21 +428,60 @@ def hlaClose(model: HlaAttrBagClass) -> None:
     model.close()
 
 
-@dataclass
 class HlaAlleleClass:
-    """``hlaAlleleClass`` as returned by ``hlaPredict`` (``R/HIBAG.R:729-748``)."""
-    locus: str
-    sample_id: List
-    allele1: List[Optional[str]]
-    allele2: List[Optional[str]]
-    prob: Optional[np.ndarray] = None
-    matching: Optional[np.ndarray] = None
-    assembly: str = "unknown"
-    dosage: Optional[np.ndarray] = None        # [n_hla, n_samp], rows = hla.allele
-    postprob: Optional[np.ndarray] = None      # [n_cell, n_samp], rows = pair_names
-    pair_names: List[str] = field(default_factory=list)
-    h1: Optional[np.ndarray] = None            # 0-based allele indices (NA = INT_MIN)
-    h2: Optional[np.ndarray] = None
+    """``hlaAlleleClass`` as returned by ``hlaPredict`` (``R/HIBAG.R:729-748``): ``locus``, ``sample_id``, ``allele1`` /
+    ``allele2`` (lists of allele names, ``None`` = NA), ``prob``, ``matching``, ``assembly``, ``dosage`` [n_hla, n_samp] (rows =
+    ``hla.allele``), ``postprob`` [n_cell, n_samp] (rows = ``pair_names``), and the calls as 0-based allele indices ``h1`` /
+    ``h2`` (NA = INT_MIN).
+
+    R builds the two name columns with one vectorised gather, ``object$hla.allele[H1 + 1L]`` -- pointers into its string
+    cache.  The counterpart here is a categorical: a result of ``hlaPredict`` keeps the indices and the model's allele
+    names (``levels``) and makes the lists the first time ``allele1`` / ``allele2`` is read, so that a caller who wants the
+    indices, the probabilities or the dosages does not pay 2 x n_samp Python objects per call."""
+
+    def __init__(self, locus: str, sample_id: List, allele1: Optional[List[Optional[str]]] = None,
+                 allele2: Optional[List[Optional[str]]] = None, prob: Optional[np.ndarray] = None,
+                 matching: Optional[np.ndarray] = None, assembly: str = "unknown", dosage: Optional[np.ndarray] = None,
+                 postprob: Optional[np.ndarray] = None, pair_names: Optional[List[str]] = None,
+                 h1: Optional[np.ndarray] = None, h2: Optional[np.ndarray] = None, levels: Optional[Sequence[str]] = None):
+        if (allele1 is None or allele2 is None) and (h1 is None or h2 is None or levels is None):
+            raise TypeError("HlaAlleleClass needs allele1 and allele2, or h1, h2 and levels")
+        self.locus, self.sample_id = locus, sample_id
+        self._allele1, self._allele2, self._levels = allele1, allele2, levels
+        self.prob, self.matching, self.assembly = prob, matching, assembly
+        self.dosage, self.postprob = dosage, postprob
+        self.pair_names = [] if pair_names is None else pair_names
+        self.h1, self.h2 = h1, h2
+
+    def _names_of(self, h: np.ndarray) -> List[Optional[str]]:
+        n = len(self._levels)
+        lv = np.empty(n + 1, dtype=np.object_)
+        lv[:n] = list(self._levels)
+        lv[n] = None
+        return lv.take(np.where(np.asarray(h) == NA_INTEGER, n, h)).tolist()
+
+    @property
+    def allele1(self) -> List[Optional[str]]:
+        if self._allele1 is None:
+            self._allele1 = self._names_of(self.h1)
+        return self._allele1
+
+    @allele1.setter
+    def allele1(self, v):
+        self._allele1 = v
+
+    @property
+    def allele2(self) -> List[Optional[str]]:
+        if self._allele2 is None:
+            self._allele2 = self._names_of(self.h2)
+        return self._allele2
+
+    @allele2.setter
+    def allele2(self, v):
+        self._allele2 = v
+
+    def __repr__(self):
+        return f"HlaAlleleClass(locus={self.locus!r}, {len(self.sample_id)} samples, assembly={self.assembly!r})"
 
 
 def _pair_names(alleles: Sequence[str]) -> List[str]:
@@ -430,8 +504,62 @@ def _snp_ids(obj, match_type: str) -> List:
     raise ValueError("'arg' should be one of \"Position\", \"Pos+Allele\", \"RefSNP+Position\", \"RefSNP\"")
 
 
+def _model_pair_names(model: "HlaAttrBagClass") -> List[str]:
+    """:func:`_pair_names` of the model's alleles, made once per model (P = nHLA(nHLA+1)/2 strings)."""
+    names = model.__dict__.get("_pair_names")
+    if names is None:
+        names = model.__dict__["_pair_names"] = _pair_names(model.obj.hla_allele)
+    return list(names)
+
+
 _TYPES = ("response+dosage", "response", "prob", "response+prob")
 _VOTES = ("prob", "majority")
+
+
+def _as_integer(g: np.ndarray) -> np.ndarray:
+    """``as.integer(snp)`` for a numeric matrix (``R/HIBAG.R:715``): int32 in the array's OWN memory order, NA / NaN /
+    anything an int cannot hold -> ``NA_integer_``.  An int32 array is returned as it is -- no copy."""
+    g = np.asarray(g)
+    if g.dtype == np.int32:
+        return g
+    if g.dtype.kind == "f":
+        with np.errstate(invalid="ignore"):
+            gi = g.astype(np.int32, order="K")
+        bad = ~((g > -2147483648.0) & (g < 2147483648.0))         # NaN, +-inf, out of range: whatever the cast made of them
+        if bad.any():
+            gi[bad] = NA_INTEGER
+        return gi
+    if g.dtype.kind in "iub":
+        if g.dtype.itemsize < 4 or g.dtype.kind == "b":
+            return g.astype(np.int32, order="K")
+        big = (g > 2147483647) | (g < -2147483647)
+        gi = g.astype(np.int32, order="K")
+        if big.any():
+            gi[big] = NA_INTEGER
+        return gi
+    raise TypeError("is.numeric(snp) is not TRUE")
+
+
+def _predict_matrix(model: "HlaAttrBagClass", g: np.ndarray, sel: Optional[np.ndarray], flip: Optional[np.ndarray],
+                    vote_method: int, want_dosage: bool, want_prob: bool) -> dict:
+    """``PredictHLA`` on the matrix ``g`` [SNP, sample] of an ``hlaSNPGenoClass`` (or the numeric matrix handed to
+    ``hlaPredict``) WITHOUT building a second matrix on the host: row ``sel[k]`` holds model SNP k (-1 = absent, ``None`` =
+    row k), ``flip[k]`` reverses its allele count -- both applied on the device while the genotypes are packed.  The entry
+    follows the array's memory: column-major (R's own order: the transpose view is the C side's sample-major matrix) ->
+    ``hibag_hip_predict`` / ``_mapped``; row-major (numpy's default) -> ``hibag_hip_predict_snp_major``.  Bit-identical."""
+    g = _as_integer(g)
+    if flip is not None and not np.any(flip):
+        flip = None
+    if g.flags.f_contiguous:
+        cohort = g.T                          # a view: [n_samp, cohort SNPs], C-contiguous
+        if sel is None and flip is None:
+            return model.predict_raw(cohort, vote_method, want_dosage=want_dosage, want_prob=want_prob)
+        if sel is None:
+            sel = np.arange(model.obj.n_snp, dtype=np.int32)
+        return model.predict_mapped(cohort, sel, flip, vote_method, want_dosage=want_dosage, want_prob=want_prob)
+    if not g.flags.c_contiguous:
+        g = np.ascontiguousarray(g)
+    return model.predict_snp_major(g, sel, flip, vote_method, want_dosage=want_dosage, want_prob=want_prob)
 
 
 def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, HlaBEDGeno, np.ndarray], cl=False,
@@ -449,6 +577,12 @@ def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, HlaBEDGeno, np.nd
     the model's own device processes the whole cohort.
     Returns :class:`HlaAlleleClass`, or for ``type="prob"`` the posterior matrix
     [n_cell, n_samp] like the reference.
+
+    Cost: like the reference (``R/HIBAG.R:715-748``: one ``.Call`` and O(1) R-level work per cohort besides the result's
+    data frame) the host side does nothing per sample in the interpreter and copies no matrix: the genotypes go to the
+    device from the caller's own memory in either memory order, SNP selection and allele flips happen on the device, and
+    ``dosage`` / ``postprob`` are returned as [row, sample] VIEWS of the C side's sample-major output -- R's own memory
+    order for those matrices.  What `bench.py` reports as ``api_inclusive``.
     """
     if not isinstance(object, HlaAttrBagClass):
         raise TypeError("inherits(object, \"hlaAttrBagClass\") is not TRUE")
@@ -482,28 +616,31 @@ def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, HlaBEDGeno, np.nd
         mat = None
     elif not isinstance(snp, HlaSNPGeno):
         g = np.asarray(snp)
+        if g.dtype.kind not in "iufb":
+            raise TypeError("is.numeric(snp) is not TRUE")
         if g.ndim == 1:
             if g.shape[0] != obj.n_snp:
                 raise ValueError("length(snp) == object$n.snp is not TRUE")
             g = g.reshape(-1, 1)
         elif g.ndim != 2 or g.shape[0] != obj.n_snp:
             raise ValueError("nrow(snp) == object$n.snp is not TRUE")
-        geno_sampid: List = list(range(1, g.shape[1] + 1))
+        geno_sampid = range(1, g.shape[1] + 1)
         assembly = "auto-silent"
         mat = g
     else:
         # the SNP matching / strand check (R/HIBAG.R:550-686) decides on the annotation; the rows are
-        # picked and flipped on the device while the genotypes are packed (hibag_hip_predict_mapped)
+        # picked and flipped on the device while the genotypes are packed (hibag_hip_predict_mapped / _snp_major)
         from .snpmatch import _row_afreq, plan_snps_for_predict
-        map_plan = plan_snps_for_predict(obj, snp, lambda rows: _row_afreq(snp.genotype[rows]), match_type,
+        mat = np.asarray(snp.genotype)
+        if mat.ndim != 2:
+            raise ValueError("'snp$genotype' must be a matrix [n.snp, n.samp]")
+        map_plan = plan_snps_for_predict(obj, snp, lambda rows: _row_afreq(_as_integer(mat[rows])), match_type,
                                          allele_check, same_strand, verbose, verbose_match)
         assembly = map_plan.assembly
-        geno_sampid = list(snp.sample_id)
-        mat = None
+        geno_sampid = snp.sample_id
+        if len(geno_sampid) != mat.shape[1]:
+            raise ValueError("length(snp$sample.id) == ncol(snp$genotype) is not TRUE")
 
-    if mat is not None and mat.shape[0] != obj.n_snp:
-        raise ValueError("The number of SNPs is not valid, and it maybe due to duplicated 'snp.id' "
-                         "or incorrect dimension of genotype matrix.")
     n_samp = len(geno_sampid) if mat is None else mat.shape[1]
     if verbose:
         print(f"# of samples: {n_samp}", file=out)
@@ -511,6 +648,10 @@ def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, HlaBEDGeno, np.nd
 
     want_prob = type in ("prob", "response+prob")
     want_dosage = type != "response"
+    sel = flip = None
+    if map_plan is not None:
+        sel = None if map_plan.identity else map_plan.sel
+        flip = map_plan.flip if (map_plan.flip is not None and np.any(map_plan.flip)) else None
     devices = list(cl) if isinstance(cl, (list, tuple)) else None
     if devices is not None:
         # a device list: validated up front (an index out of range used to surface as ENODEV from deep inside replicate())
@@ -523,24 +664,21 @@ def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, HlaBEDGeno, np.nd
             # the caller asked for
             raise ValueError("hlaPredict(cl = [devices]) takes a genotype matrix or an hlaSNPGenoClass; for a lazily opened BED "
                              "file (hlaBED2Geno(lazy=True)) predict on one device, or load the genotypes first (hlaBED2Geno())")
-    if devices is not None and bed_plan is None:
-        # several devices: the model-order matrix is built on the host (the model's few hundred columns of the
-        # cohort), then sliced over the replicas
-        if map_plan is not None:
-            g = np.asarray(snp.genotype)
-            sel = np.asarray(map_plan.sel)
-            rows = g[np.maximum(sel, 0)]
-            if rows.dtype.kind == "f":
-                rows = np.where(np.isfinite(rows), rows, NA_INTEGER)
-            rows = rows.astype(np.int32)
-            ok = (rows >= 0) & (rows <= 2)
-            fl = np.asarray(map_plan.flip) != 0 if map_plan.flip is not None else np.zeros(len(sel), bool)
-            rows = np.where(ok & fl[:, None], 2 - rows, rows)
-            rows[sel < 0] = NA_INTEGER
-            genomat = np.ascontiguousarray(rows.T, np.int32)
+    if devices is not None:
+        # several devices: hibag_hip_predict_multi slices ONE sample-major matrix in model order over the replicas.  R's memory
+        # order with the model's own SNPs is that matrix already; anything else is put in that form on the host (the model's
+        # few hundred rows of the cohort)
+        g = _as_integer(mat)
+        if sel is None and flip is None and g.flags.f_contiguous:
+            genomat = g.T
         else:
-            gi = np.where(np.isfinite(mat), mat, NA_INTEGER) if mat.dtype.kind == "f" else mat
-            genomat = np.ascontiguousarray(np.asarray(gi).T, np.int32)
+            idx = np.arange(obj.n_snp) if sel is None else np.asarray(sel)
+            rows = g[np.maximum(idx, 0)]
+            if flip is not None:
+                fl = np.asarray(flip, bool)[:, None]
+                rows = np.where(fl & (rows >= 0) & (rows <= 2), 2 - rows, rows)
+            rows[idx < 0] = NA_INTEGER
+            genomat = np.ascontiguousarray(rows.T, np.int32)
         cache = object.__dict__.setdefault("_replicas", {})
         reps = []
         for d in devices:
@@ -553,32 +691,22 @@ def hlaPredict(object: HlaAttrBagClass, snp: Union[HlaSNPGeno, HlaBEDGeno, np.nd
         col = np.where(bed_plan.sel >= 0, snp.bed_index[np.maximum(bed_plan.sel, 0)], -1)
         rv = object.predict_bed(snp.bed_fn, snp.n_bed_samp, snp.n_bed_snp, col, bed_plan.flip, vote_method,
                                 want_dosage=want_dosage, want_prob=want_prob)
-    elif map_plan is not None:
-        g = np.asarray(snp.genotype)
-        if g.dtype.kind == "f":
-            g = np.where(np.isfinite(g), g, NA_INTEGER)
-        cohort = np.ascontiguousarray(g.T, np.int32)      # [n_samp, cohort SNPs]: R's memory order
-        rv = object.predict_mapped(cohort, map_plan.sel, map_plan.flip, vote_method,
-                                   want_dosage=want_dosage, want_prob=want_prob)
     else:
-        # as.integer(snp): R's NA -> NA_integer_ ; the C side treats anything outside 0..2 as missing
-        gi = np.where(np.isfinite(mat), mat, NA_INTEGER) if mat.dtype.kind == "f" else mat
-        genomat = np.ascontiguousarray(np.asarray(gi).T, np.int32)     # [n_samp, n_snp]
-        rv = object.predict_raw(genomat, vote_method, want_dosage=want_dosage, want_prob=want_prob)
+        rv = _predict_matrix(object, mat, sel, flip, vote_method, want_dosage, want_prob)
 
-    names = _pair_names(obj.hla_allele)
     if type == "prob":
-        res = np.ascontiguousarray(rv["postprob"].T)
-        na_cnt = int(np.nansum(res.sum(axis=0) <= 0))
+        res = rv["postprob"].T                # [n_cell, n_samp]: a view of the sample-major output = R's memory order
+        with np.errstate(invalid="ignore"):
+            na_cnt = int(np.count_nonzero(rv["postprob"].sum(axis=1) <= 0))
     else:
-        def nm(ix):
-            return [None if int(k) == NA_INTEGER else obj.hla_allele[int(k)] for k in ix]
-        res = HlaAlleleClass(locus=obj.hla_locus, sample_id=geno_sampid, allele1=nm(rv["h1"]), allele2=nm(rv["h2"]),
+        h1, h2 = rv["h1"], rv["h2"]
+        na_cnt = int(np.count_nonzero((h1 == NA_INTEGER) | (h2 == NA_INTEGER)))
+        # (allele1 / allele2: object$hla.allele[H1 + 1L] (R/HIBAG.R:729-736), made from h1 / h2 and the levels when first read)
+        res = HlaAlleleClass(locus=obj.hla_locus, sample_id=list(geno_sampid), h1=h1, h2=h2, levels=obj.hla_allele,
                              prob=rv["prob"], matching=rv["matching"], assembly=assembly,
-                             dosage=(np.ascontiguousarray(rv["dosage"].T) if type != "response" else None),
-                             postprob=(np.ascontiguousarray(rv["postprob"].T) if want_prob else None),
-                             pair_names=names if want_prob else [], h1=rv["h1"], h2=rv["h2"])
-        na_cnt = sum(1 for a, b in zip(res.allele1, res.allele2) if a is None or b is None)
+                             dosage=(rv["dosage"].T if type != "response" else None),
+                             postprob=(rv["postprob"].T if want_prob else None),
+                             pair_names=_model_pair_names(object) if want_prob else [])
 
     if na_cnt > 0:   # R/HIBAG.R:811-815
         import warnings

@@ -110,7 +110,9 @@ def engine_nkb(n_snp_c: int) -> int:
 @dataclass
 class HlaSNPGeno:
     """``hlaSNPGenoClass``: ``genotype`` is [n_snp, n_samp] like the R matrix
-    (values 0/1/2 = number of A alleles, NA = INT_MIN)."""
+    (values 0/1/2 = number of A alleles, NA = INT_MIN).  Either memory order is first class: column-major is R's own
+    (objects read from ``.RData`` keep it: no copy) and reaches the device through ``hibag_hip_predict[_mapped]``,
+    row-major is numpy's default and goes through ``hibag_hip_predict_snp_major``; ``hlaPredict`` copies neither."""
     genotype: np.ndarray
     sample_id: List[str]
     snp_id: List[str]
@@ -179,9 +181,10 @@ def geno_from_robj(obj) -> HlaSNPGeno:
         raise TypeError("inherits(obj, \"hlaSNPGenoClass\") is not TRUE")
     g = obj["genotype"]
     dim = [int(v) for v in np.asarray(g.attrs["dim"])]
-    mat = np.asarray(g, np.int32).reshape(dim[1], dim[0]).T  # R is column-major: [n_snp, n_samp]
+    # R is column-major: [n_snp, n_samp] as a VIEW of R's own memory (Fortran order) -- what hlaPredict hands the C side as it is
+    mat = np.asarray(g, np.int32).reshape(dim[1], dim[0]).T
     asm = _strs(obj.get("assembly"))
-    return HlaSNPGeno(genotype=np.ascontiguousarray(mat), sample_id=_strs(obj["sample.id"]),
+    return HlaSNPGeno(genotype=mat, sample_id=_strs(obj["sample.id"]),
                       snp_id=_strs(obj["snp.id"]),
                       snp_position=np.asarray(obj["snp.position"], np.float64),
                       snp_allele=_strs(obj["snp.allele"]),

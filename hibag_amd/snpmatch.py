@@ -12,6 +12,8 @@ from __future__ import annotations
 import sys
 import warnings
 from dataclasses import dataclass
+from functools import lru_cache
+from itertools import repeat
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -41,6 +43,13 @@ def hlaSNPID(obj, type: str = "Position") -> List:
     return list(obj.snp_id)
 
 
+def _ids(obj, type: str):
+    """:func:`hlaSNPID` for comparisons: positions stay one float64 array (no per-SNP Python objects)."""
+    if type == "Position" and obj.snp_position is not None:
+        return np.asarray(obj.snp_position, np.float64)
+    return hlaSNPID(obj, type)
+
+
 def _split_allele(txt: Optional[str]) -> Tuple[str, str]:
     txt = "" if txt is None else txt
     a, sep, b = txt.partition("/")
@@ -51,76 +60,94 @@ def _is_base(s: str) -> bool:
     return s in _COMPLEMENT
 
 
-def allele_strand_flags(template_allele: Sequence[str], template_afreq: Sequence[float],
-                        target_allele: Sequence[str], target_afreq: Sequence[float],
+@lru_cache(maxsize=65536)
+def _strand_rule(template: Optional[str], target: Optional[str], check_strand: bool) -> int:
+    """The decision of ``HIBAG_AlleleStrand`` (``src/HIBAG.cpp:221-342``) for ONE SNP, which depends on the two allele strings
+    only: bit 0 = swap A/B, bits 1-2 = 0 decided / 1 strand ambiguity / 2 allele mismatch (both: compare which allele is the
+    minor one instead), bit 3 = counted as a swapped strand.  Cached: a cohort has a handful of distinct allele pairs."""
+    s1, s2 = _split_allele(template)
+    p1, p2 = _split_allele(target)
+    by_freq = 0      # 1: strand ambiguity, 2: allele mismatch
+    sw = swapped = False
+    if all(_is_base(x) for x in (s1, s2, p1, p2)):
+        if s1 == p1 and s2 == p2:
+            if check_strand and s1 == _COMPLEMENT[p2]:
+                by_freq = 1
+        elif s1 == p2 and s2 == p1:
+            if check_strand and s1 == _COMPLEMENT[p1]:
+                by_freq = 1
+            else:
+                sw = True
+        elif check_strand:
+            if s1 == _COMPLEMENT[p1] and s2 == _COMPLEMENT[p2]:
+                if s1 == p2:
+                    by_freq = 1
+                else:
+                    swapped = True
+            elif s1 == _COMPLEMENT[p2] and s2 == _COMPLEMENT[p1]:
+                sw = True
+                swapped = True
+            else:
+                by_freq = 2
+        else:
+            by_freq = 2
+    else:
+        if s1 == p1 and s2 == p2:
+            if s1 == s2:
+                by_freq = 1
+        elif s1 == p2 and s2 == p1:
+            if s1 == s2:
+                by_freq = 1
+            else:
+                sw = True
+        else:
+            by_freq = 2
+    return int(sw) | (by_freq << 1) | (int(swapped) << 3)
+
+
+def allele_strand_flags(template_allele: Sequence[str], template_afreq, target_allele: Sequence[str], target_afreq,
                         same_strand: bool):
     """Decide per SNP whether the target's A/B alleles must be swapped to agree
     with the template (``HIBAG_AlleleStrand``, ``src/HIBAG.cpp:221-342``).
 
     Returns ``(flip[bool n], n_ambiguous, n_mismatch, n_swapped_strand)``.
     Ambiguous (e.g. C/G) and mismatching SNPs fall back to comparing which
-    allele is the minor one."""
+    allele is the minor one.  ``template_afreq`` / ``target_afreq``: a sequence of A-allele frequencies, or a callable
+    ``f(indices) -> frequencies`` that is asked for those SNPs only (the reference computes every row mean up front,
+    ``R/DataUtilities.R:455-460``; the decision reads them for the undecided SNPs alone, so the result is the same)."""
     n = len(template_allele)
-    flip = np.zeros(n, bool)
-    n_amb = n_mis = n_swap = 0
     check_strand = not same_strand
-    for i in range(n):
-        s1, s2 = _split_allele(template_allele[i])
-        p1, p2 = _split_allele(target_allele[i])
-        by_freq = 0      # 1: strand ambiguity, 2: allele mismatch
-        sw = False
-        if all(_is_base(x) for x in (s1, s2, p1, p2)):
-            if s1 == p1 and s2 == p2:
-                if check_strand and s1 == _COMPLEMENT[p2]:
-                    by_freq = 1
-            elif s1 == p2 and s2 == p1:
-                if check_strand and s1 == _COMPLEMENT[p1]:
-                    by_freq = 1
-                else:
-                    sw = True
-            elif check_strand:
-                if s1 == _COMPLEMENT[p1] and s2 == _COMPLEMENT[p2]:
-                    if s1 == p2:
-                        by_freq = 1
-                    else:
-                        n_swap += 1
-                elif s1 == _COMPLEMENT[p2] and s2 == _COMPLEMENT[p1]:
-                    sw = True
-                    n_swap += 1
-                else:
-                    by_freq = 2
-            else:
-                by_freq = 2
-        else:
-            if s1 == p1 and s2 == p2:
-                if s1 == s2:
-                    by_freq = 1
-            elif s1 == p2 and s2 == p1:
-                if s1 == s2:
-                    by_freq = 1
-                else:
-                    sw = True
-            else:
-                by_freq = 2
-        if by_freq:
-            f1, f2 = template_afreq[i], target_afreq[i]
-            # ALLELE_MINOR(f) = (f <= 0.5) ? 0 : 1 ; NaN compares false -> 1
-            sw = (0 if f1 <= 0.5 else 1) != (0 if f2 <= 0.5 else 1)
-            if by_freq == 1:
-                n_amb += 1
-            else:
-                n_mis += 1
-        flip[i] = sw
-    return flip, n_amb, n_mis, n_swap
+    code = np.fromiter(map(_strand_rule, template_allele, target_allele, repeat(check_strand)), np.uint8, n)
+    flip = (code & 1).astype(bool)
+    by_freq = (code >> 1) & 3
+    und = np.flatnonzero(by_freq)
+    if len(und):
+        def freq_of(src):
+            v = src(und) if callable(src) else np.asarray(src, np.float64)[und]
+            return np.asarray(v, np.float64)
+        # ALLELE_MINOR(f) = (f <= 0.5) ? 0 : 1 ; NaN compares false -> 1
+        with np.errstate(invalid="ignore"):
+            flip[und] = (freq_of(template_afreq) <= 0.5) != (freq_of(target_afreq) <= 0.5)
+    return flip, int(np.count_nonzero(by_freq == 1)), int(np.count_nonzero(by_freq == 2)), int(np.count_nonzero(code & 8))
 
 
 def _row_afreq(geno: np.ndarray) -> np.ndarray:
     """``rowMeans(genotype, na.rm=TRUE) * 0.5`` with NA = anything outside 0..2 stored as INT_MIN."""
-    g = geno.astype(np.float64)
+    geno = np.asarray(geno)
     ok = geno != NA_INTEGER
     cnt = ok.sum(axis=1)
+    tot = np.where(ok, geno, 0).sum(axis=1, dtype=np.float64)
     with np.errstate(invalid="ignore", divide="ignore"):
-        return np.where(cnt > 0, (g * ok).sum(axis=1) / cnt, np.nan) * 0.5
+        return np.where(cnt > 0, tot / cnt, np.nan) * 0.5
+
+
+def _same_ids(a, b) -> bool:
+    """``length(a) == length(b) && all(a == b)`` (``R/HIBAG.R:627-632``)."""
+    if len(a) != len(b):
+        return False
+    if isinstance(a, np.ndarray) and isinstance(b, np.ndarray):
+        return bool(np.array_equal(a, b))
+    return list(a) == list(b)
 
 
 def hlaGenoSwitchStrand(target: HlaSNPGeno, template, match_type: str = "Position",
@@ -130,7 +157,7 @@ def hlaGenoSwitchStrand(target: HlaSNPGeno, template, match_type: str = "Positio
     genotypes to the template's allele orientation."""
     s1 = hlaSNPID(template, match_type)
     s2 = hlaSNPID(target, match_type)
-    if len(s1) == len(s2) and all(a == b for a, b in zip(s1, s2)):
+    if _same_ids(s1, s2):
         I1 = I2 = list(range(len(s1)))
     else:
         first2 = {}
@@ -144,13 +171,14 @@ def hlaGenoSwitchStrand(target: HlaSNPGeno, template, match_type: str = "Positio
             raise ValueError("There is no common SNP.")
     out = sys.stdout
     if match_type != "Pos+Allele":
-        t_af = _row_afreq(target.genotype)
-        m_af = getattr(template, "snp_allele_freq", None)
-        if m_af is None:
-            m_af = _row_afreq(template.genotype)
+        a1, a2 = np.asarray(I1, np.int64), np.asarray(I2, np.int64)
+
+        def m_af(idx):                     # (row means only of the SNPs the allele strings leave undecided)
+            af = getattr(template, "snp_allele_freq", None)
+            return _row_afreq(np.asarray(template.genotype)[a1[idx]]) if af is None else np.asarray(af, np.float64)[a1[idx]]
         flip, n_amb, n_mis, n_swap = allele_strand_flags(
-            [template.snp_allele[i] for i in I1], [m_af[i] for i in I1],
-            [target.snp_allele[i] for i in I2], [t_af[i] for i in I2], same_strand)
+            [template.snp_allele[i] for i in I1], m_af,
+            [target.snp_allele[i] for i in I2], lambda idx: _row_afreq(np.asarray(target.genotype)[a2[idx]]), same_strand)
         if verbose:
             x = int(flip.sum())
             print(f"# of SNP loci with flipped alleles: {x}" if x > 0
@@ -184,6 +212,7 @@ class SNPPlan:
     sel: np.ndarray          # int64 [n.snp]
     flip: np.ndarray         # bool  [n.snp]
     assembly: str
+    identity: bool = False   # the cohort's SNPs ARE the model's, in the model's order (sel = 0 .. n.snp - 1)
 
 
 def plan_snps_for_predict(obj: HlaAttrBagObj, snp, afreq_of_rows: Callable[[np.ndarray], np.ndarray],
@@ -224,12 +253,15 @@ def plan_snps_for_predict(obj: HlaAttrBagObj, snp, afreq_of_rows: Callable[[np.n
     elif verbose:
         print(f"Using match.type='{match_type}' for SNP matching", file=out)
 
-    obj_id = hlaSNPID(obj, match_type)
-    geno_id = hlaSNPID(snp, match_type)
-    if len(obj_id) == len(geno_id) and all(a == b for a, b in zip(obj_id, geno_id)):
+    obj_id = _ids(obj, match_type)
+    geno_id = _ids(snp, match_type)
+    identity = _same_ids(obj_id, geno_id)
+    if identity:
         sel = np.arange(len(obj_id), dtype=np.int64)
-        alleles = list(snp.snp_allele)
+        alleles = snp.snp_allele
     else:
+        if isinstance(obj_id, np.ndarray):
+            obj_id, geno_id = obj_id.tolist(), geno_id.tolist()
         first = {}
         for j, v in enumerate(geno_id):
             first.setdefault(v, j)
@@ -258,11 +290,14 @@ def plan_snps_for_predict(obj: HlaAttrBagObj, snp, afreq_of_rows: Callable[[np.n
     flip = np.zeros(len(obj_id), bool)
     if allele_check:
         if match_type != "Pos+Allele":
-            af = np.full(len(obj_id), np.nan)
-            have = sel >= 0
-            if have.any():
-                af[have] = afreq_of_rows(sel[have])
-            flip, n_amb, n_mis, n_swap = allele_strand_flags(obj.snp_allele, _model_afreq(obj), alleles, af, same_strand)
+            def cohort_afreq(idx):             # asked for the SNPs the allele strings leave undecided only
+                af = np.full(len(idx), np.nan)
+                have = sel[idx] >= 0
+                if have.any():
+                    af[have] = afreq_of_rows(sel[idx][have])
+                return af
+            flip, n_amb, n_mis, n_swap = allele_strand_flags(obj.snp_allele, lambda idx: np.asarray(_model_afreq(obj), np.float64)[idx],
+                                                             alleles, cohort_afreq, same_strand)
             if verbose:
                 x = int(flip.sum())
                 print(f"# of SNP loci with flipped alleles: {x}" if x > 0
@@ -275,7 +310,7 @@ def plan_snps_for_predict(obj: HlaAttrBagObj, snp, afreq_of_rows: Callable[[np.n
                     print(f"# of SNP loci with mismatched alleles: {n_mis} (comparing allele frequencies)", file=out)
         elif verbose:
             print("No allele is flipped since match.type='Pos+Allele'.", file=out)
-    return SNPPlan(sel=sel, flip=np.asarray(flip, bool), assembly=assembly)
+    return SNPPlan(sel=sel, flip=np.asarray(flip, bool), assembly=assembly, identity=identity)
 
 
 def _model_afreq(obj):

@@ -100,9 +100,10 @@ def make_samples(founders: np.ndarray, allele_freq: np.ndarray, n_samp: int, see
     return np.ascontiguousarray(g), np.sort(a, axis=1).astype(np.int32)
 
 
-def as_snp_geno(model: HlaAttrBagObj, genomat: np.ndarray) -> HlaSNPGeno:
-    """Wrap a sample-major matrix as an ``hlaSNPGenoClass`` over the model's SNPs."""
+def as_snp_geno(model: HlaAttrBagObj, genomat: np.ndarray, order: str = "C") -> HlaSNPGeno:
+    """Wrap a sample-major matrix as an ``hlaSNPGenoClass`` over the model's SNPs: ``genotype`` [n_snp, n_samp] in
+    numpy's row-major order (``"C"``, a transposed copy) or in R's column-major order (``"F"``: a view of ``genomat``)."""
     n = genomat.shape[0]
-    return HlaSNPGeno(genotype=np.ascontiguousarray(genomat.T), sample_id=[f"S{i + 1}" for i in range(n)],
+    return HlaSNPGeno(genotype=(np.ascontiguousarray(genomat.T) if order == "C" else np.ascontiguousarray(genomat).T), sample_id=[f"S{i + 1}" for i in range(n)],
                       snp_id=list(model.snp_id), snp_position=model.snp_position,
                       snp_allele=list(model.snp_allele), assembly=model.assembly)

@@ -21,8 +21,9 @@
 extern "C" {
 #endif
 
-#define HIBAG_HIP_ABI_VERSION 6   /* 2: + PLINK BED entries, training driver; 3: + hibag_hip_predict_mapped[_device]; 4: + hibag_hip_model_stored_cells;
-                                     5: + hibag_hip_model_status / _clear_status, hibag_hip_predict_multi, hibag_hip_model_replicate, hibag_hip_model_engine */
+#define HIBAG_HIP_ABI_VERSION 7   /* 2: + PLINK BED entries, training driver; 3: + hibag_hip_predict_mapped[_device]; 4: + hibag_hip_model_stored_cells;
+                                     5: + hibag_hip_model_status / _clear_status, hibag_hip_predict_multi, hibag_hip_model_replicate, hibag_hip_model_engine;
+                                     7: + hibag_hip_predict_snp_major[_device] */
 
 /* error codes */
 #define HIBAG_HIP_OK          0
@@ -152,6 +153,22 @@ int hibag_hip_predict_mapped(hibag_hip_model *m, const int32_t *geno, int n_samp
 	const int32_t *snp_col, const int32_t *flip, int vote_method,
 	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob);
 int hibag_hip_predict_mapped_device(hibag_hip_model *m, const int32_t *d_geno, int n_samp, int n_geno_snp,
+	const int32_t *d_snp_col, const int32_t *d_flip, int vote_method,
+	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching, double *d_dosage,
+	double *d_postprob, void *stream);
+
+/* The same for a cohort matrix stored SNP-MAJOR -- geno[row * ld + sample], one row of n_samp genotypes per SNP, `ld` >= n_samp
+ * elements from one row to the next: a C / numpy [snp][sample] array, i.e. the TRANSPOSE of the memory R hands
+ * HIBAG_Predict_* (R/HIBAG.R:715-725), which a host that is not R would otherwise have to transpose first.
+ *   snp_col[model n_snp]  row of each model SNP in geno, -1 = the cohort lacks it; NULL = row k holds model SNP k
+ *   flip[model n_snp]     NULL, or != 0 where the allele count must be reversed
+ * The host-pointer form uploads only the rows the model uses (one block of the caller's matrix when they are consecutive,
+ * otherwise gathered through pinned staging); no transpose happens anywhere -- the kernels' packed form is SNP-major itself.
+ * Results are bit-identical to hibag_hip_predict_mapped on the transposed matrix. */
+int hibag_hip_predict_snp_major(hibag_hip_model *m, const int32_t *geno, size_t ld, int n_samp, int n_geno_snp,
+	const int32_t *snp_col, const int32_t *flip, int vote_method,
+	int32_t *H1, int32_t *H2, double *max_prob, double *matching, double *dosage, double *postprob);
+int hibag_hip_predict_snp_major_device(hibag_hip_model *m, const int32_t *d_geno, size_t ld, int n_samp, int n_geno_snp,
 	const int32_t *d_snp_col, const int32_t *d_flip, int vote_method,
 	int32_t *d_H1, int32_t *d_H2, double *d_max_prob, double *d_matching, double *d_dosage,
 	double *d_postprob, void *stream);

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.hibag_hip_abi_version() == 6
+    assert L.hibag_hip_abi_version() == 7
 
 
 def test_no_cpu_fallback_in_product():
