@@ -251,6 +251,7 @@ def main():
             fn()
         fence()
         dt_ = time.perf_counter() - t0
+        timed.local_dt = dt_                   # (this rank's own clock; the line's figure is the max over ranks)
         tm = mdl.get_timing()
         mdl.set_timing(False)
         if world > 1:
@@ -260,6 +261,7 @@ def main():
         return dt_, tm
 
     dt, timing = timed(step, args.warmup, args.steps, model)
+    dt_local = timed.local_dt
     faults = {"timed_model": int(model.handover_faults())}
 
     # sanity on the timed outputs: calls of samples drawn from the model
@@ -299,11 +301,25 @@ def main():
     floor_ns, ns1 = issue_floor(obj_rank, ms1, n, K, model)
     ns2 = N_SIMD * ms2 * 1e6 / (max(pairs2, 1) * n / 64.0)
     ns_both = N_SIMD * (ms1 + ms2) * 1e6 / ((pe_rank + pairs2) * n / 64.0)
+    # The dominant kernel against the ceiling that BINDS it -- SIMD issue: per evaluated haplotype pair and wavefront one FP64
+    # multiply + one FP64 add in the reference's order plus the pair's share of the matrix instructions, priced with the costs
+    # measured in this process -- in pair evaluations per second; the HBM figure the metric names stays beside it (hbm_*).
+    dom_ns, dom_pairs = (ns1, pe_rank) if dom == "total" else (ns2, pairs2)
+    dom_rate = dom_pairs * n / (avg_ms * 1e-3) / 1e9                      # G pair evaluations / s of the dominant kernel
+    dom_peak = dom_rate * dom_ns / floor_ns                               # ... at the issue floor
     roofline = {
-        "kernel": f"k_{dom}", "bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-        "avg_launch_ms": round(avg_ms, 4), "launches": int(dom_launches),
+        "kernel": f"k_{dom}", "bound": "simd-issue", "achieved": round(dom_rate, 2), "peak": round(dom_peak, 2),
+        "unit": "G pair-evals/s", "frac": round(floor_ns / dom_ns, 4),
+        "issue_frac_both_passes": round(floor_ns / ns_both, 4),
+        "k_total_issue_frac": round(floor_ns / ns1, 4), "k_accum_issue_frac": round(floor_ns / ns2, 4),
+        "k_total_ms": round(ms1, 4), "k_accum_ms": round(ms2, 4),
+        "floor_ns_per_wave_pair": round(floor_ns, 2), "fp64_op_ns": K["fp64_op_ns"], "mfma_fp4_ns": K["mfma_fp4_32x32x64_ns"],
+        "hbm_achieved_gbs": round(achieved_gbs, 3), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": achieved_gbs / HBM_PEAK_GBS,
         "algorithmic_bytes_per_launch": int(alg_bytes),
+        "traffic": traffic, "traffic_source": traffic_source,
+        "avg_launch_ms": round(avg_ms, 4), "launches": int(dom_launches),
+        "bound_note": "not HBM: ~1e3 pair evaluations per algorithmic byte (SURVEY 8d 'Which roofline binds'); `frac` = issue floor / "
+                      "measured SIMD time per wavefront-pair of the dominant kernel, hbm_frac = algorithmic bytes / launch time / 8 TB/s",
         "issue": {"pair_evals_per_s": (pe_rank + pairs2) * n / ((ms1 + ms2) * 1e-3),
                   "pairs_evaluated_per_sample": {"pass1": pe_rank, "pass2": pairs2},
                   "cell_sums_stored_per_sample": stored,
@@ -356,9 +372,14 @@ def main():
     # 100,000 samples, the partial posterior sums merged by one RCCL all-reduce per 25,000 samples
     sharded_line = None
     if strong and not args.no_extras and vote_method == 1:
-        # Fail-soft: this leg must never cost the main line.  Everything that can fail without a collective (the shard's
-        # model, its buffers) is done first and the ranks agree -- one all-reduce of a flag -- on whether to run it at all; an
-        # exception later on one rank is reported in the line ("error") instead of ending the run.
+        # Fail-soft as far as SET-UP goes: everything that can fail without a collective (the shard's model, its buffers) is
+        # done first and the ranks agree -- one all-reduce of a flag -- on whether to run the leg at all.  A failure INSIDE the
+        # timed section (it contains the all-reduce) cannot be made soft: the peers are inside the collective, so the failing
+        # rank exits non-zero and the launcher ends the group.  The main line is therefore written to stderr first: a run that
+        # dies in this leg still leaves its measurement in the log.
+        if rank == 0:
+            print("[bench] main line before the classifier-sharded leg: " + json.dumps(
+                {"value": value, "ms_per_step": dt / args.steps * 1e3, "n_gpus": world, "samples": n_total}), file=sys.stderr, flush=True)
         err, m2 = None, None
         try:
             sub2, sw2 = hdist.classifier_shard(model_obj, world, rank)
@@ -391,14 +412,24 @@ def main():
                 except Exception as e:                  # noqa: BLE001
                     sharded_line["check"] = {"error": repr(e)}
                 faults["classifier_sharded_model"] = int(m2.handover_faults())
-            except Exception as e:                      # noqa: BLE001
-                sharded_line = {"error": repr(e)}
+            except Exception as e:                      # noqa: BLE001 -- see above: not soft
+                print(f"[bench] rank {rank}: the classifier-sharded leg failed inside its timed section: {e!r}", file=sys.stderr, flush=True)
+                os._exit(3)
         try:
             if m2 is not None:
                 m2.close()
         except Exception:                               # noqa: BLE001
             pass
         g2 = o2 = None
+
+    # what every rank saw: the first real multi-GPU run has to diagnose itself from its one line
+    mine = {"rank": rank, "local_rank": local_rank, "device": int(model.device()), "devices_visible": int(hibag_amd._lib.lib().hibag_hip_device_count()),
+            "samples": int(n), "ms_per_step": round(dt_local / args.steps * 1e3, 4),
+            "k_total_ms": round(ms1, 4), "k_accum_ms": round(ms2, 4), "handover_faults": int(model.handover_faults())}
+    ranks_seen = [mine]
+    if world > 1:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, mine)
 
     out = {
         "metric": "hlaPredict() samples/sec, 10k samples x 100-classifier HLA-B",
@@ -415,6 +446,7 @@ def main():
         "pair_evals_per_s": value * pair_evals,
         "call_accuracy_vs_truth": call_acc,
         "rccl_ranks": rccl_ranks,
+        "ranks": ranks_seen,
         "roofline": roofline,
     }
     if dry:
@@ -435,6 +467,15 @@ def main():
         out["protocol"]["device_resident_median_samples_per_s"] = n / out["protocol"]["device_resident_median_ms"] * 1e3
         out["host_inclusive"] = host_inclusive(model, geno, n)
         out["host_inclusive"]["frac_of_device_resident"] = out["host_inclusive"]["value"] / out["protocol"]["device_resident_median_samples_per_s"]
+        # ... and the API the metric is named after: hibag_amd.hlaPredict() itself (the mirror of R/HIBAG.R:481-818) on the same cohort
+        out["api_inclusive"] = api_inclusive(model, model_obj, geno, n, (h1, h2))
+        out["api_inclusive"]["frac_of_host_inclusive"] = out["api_inclusive"]["value"] / out["host_inclusive"]["value"]
+        # (scalars the driver's parsed record keeps: SURVEY 8(d)'s protocol number and the API's, beside the device-resident `value`)
+        out["config"].update({
+            "host_inclusive_samples_per_s": round(out["host_inclusive"]["value"], 1), "host_inclusive_ms_per_step": round(out["host_inclusive"]["ms_per_step"], 4),
+            "api_inclusive_samples_per_s": round(out["api_inclusive"]["value"], 1), "api_inclusive_ms_per_step": round(out["api_inclusive"]["ms_per_step"], 4),
+            "api_inclusive_frac_of_host_inclusive": round(out["api_inclusive"]["frac_of_host_inclusive"], 4),
+            "api_inclusive_numpy_order_samples_per_s": round(out["api_inclusive"]["numpy_order"]["value"], 1)})
         faults["host_inclusive"] = int(model.handover_faults()) - faults["timed_model"]
         if args.shape == SHAPE and n == SAMPLES_PER_GPU:
             out["host_inclusive_100k"] = host_inclusive_cohort(model, model_obj, founders, afreq, dev, 100_000)
@@ -515,6 +556,36 @@ def host_inclusive(model, geno, n, reps=12):
     return {"value": n / ms * 1e3, "unit": "samples/s", "ms_per_step": ms, "repetitions": reps,
             "what": "hibag_hip_predict: H2D of the int32 genotype matrix + kernels + D2H of H1, H2, prob, matching, dosage "
                     "(pageable host memory), median; never `value`"}
+
+
+def api_inclusive(model, model_obj, geno, n, calls, reps=12):
+    """hibag_amd.hlaPredict(model, hlaSNPGenoClass, type="response+dosage", verbose=FALSE) -- the function the metric is
+    named after -- on the timed cohort: SNP matching and strand check on the annotation, the int32 genotypes from the
+    caller's memory to the device (no host copy), kernels, calls / prob / matching / dosage back, the result object.
+    Median of `reps` calls for the genotype matrix in R's memory order (column-major [SNP, sample]: what an R host holds,
+    hibag_hip_predict) and in numpy's (row-major: hibag_hip_predict_snp_major)."""
+    import numpy as np
+    import hibag_amd
+    from hibag_amd import synth
+    res = {}
+    for key, order in (("r_order", "F"), ("numpy_order", "C")):
+        snp = synth.as_snp_geno(model_obj, geno, order=order)
+        last = [None]
+
+        def call():
+            last[0] = hibag_amd.hlaPredict(model, snp, type="response+dosage", verbose=False)
+        ms = median_ms(call, reps)
+        r = last[0]
+        res[key] = {"value": n / ms * 1e3, "ms_per_step": ms,
+                    "calls_identical_to_timed_step": bool(np.array_equal(r.h1, calls[0]) and np.array_equal(r.h2, calls[1])),
+                    "result": f"hlaAlleleClass: {len(r.sample_id)} samples, dosage {tuple(r.dosage.shape)}"}
+    out = dict(res["r_order"])
+    out.update({"unit": "samples/s", "repetitions": reps, "numpy_order": res["numpy_order"],
+                "what": "hibag_amd.hlaPredict(model, hlaSNPGenoClass, type='response+dosage', verbose=False): annotation matching + "
+                        "H2D of the int32 genotypes (pageable, the caller's own array) + kernels + D2H + the result object, median; "
+                        "`value`: genotype matrix in R's memory order, `numpy_order`: row-major [SNP, sample] through "
+                        "hibag_hip_predict_snp_major; never the line's `value`"})
+    return out
 
 
 def host_inclusive_cohort(model, model_obj, founders, afreq, dev, n_big):
@@ -795,9 +866,24 @@ def other_configs(K, faults=None):
         res["cfg5_training"]["cpu_baseline"] = {
             "value": 1.0 / dto, "unit": "classifiers/s", "s_per_classifier": dto, "cores": 1, "kind": "port",
             "sample": f"the first 2 classifiers of the same training run (seed 100, {dto * 2:.1f} s): oracle/hibag_oracle_train.c, the "
-                      "reference's driver restated for one core (its CPU kernels' nthread applies to prediction only)",
+                      "reference's driver restated for ONE core",
             "classifiers_identical_to_gpu": bool(same)}
-        res["cfg5_training"]["speedup_vs_cpu_baseline"] = dto * res["cfg5_training"]["classifiers_per_s"]
+        # The reference threads training too (HIBAG_NewClassifiers runs BuildClassifiers inside tbb::task_arena(nthread),
+        # src/HIBAG.cpp:599-634; PARALLEL_FOR in the EM, src/LibHLA.cpp:1104/:1159/:1204, and in _OutOfBagAccuracy / _InBagLogLik,
+        # :1944/:1966), so the GPU line's host-thread budget is matched on the CPU side: `cores` independent oracle streams side
+        # by side, one classifier each (classifiers are independent: the best the host can do with those cores).
+        import threading
+        tcpu = time.perf_counter()
+        th = [threading.Thread(target=lambda r=r: O.train(G, truth[:, 0], truth[:, 1], mdl.n_hla, 1, mtry, True, 200 + r)) for r in range(cores)]
+        [x.start() for x in th]; [x.join() for x in th]
+        dtc = time.perf_counter() - tcpu
+        res["cfg5_training"]["cpu_baseline_all_cores"] = {
+            "value": cores / dtc, "unit": "classifiers/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} oracle trainers side by side, one classifier each, seeds 200.. ({dtc:.1f} s)"}
+        res["cfg5_training"]["speedup_vs_one_cpu_thread"] = dto * res["cfg5_training"]["classifiers_per_s"]
+        res["cfg5_training"]["speedup_vs_cpu_baseline"] = res["cfg5_training"]["classifiers_per_s"] / (cores / dtc)
+        res["cfg5_training"]["speedup_note"] = ("speedup_vs_cpu_baseline: the GPU line (device + `threads` host threads) against the same "
+                                                "number of host threads running the CPU port; speedup_vs_one_cpu_thread: against one core")
     except Exception as e:
         res["cfg5_training"] = dict(res.get("cfg5_training", {}), error=repr(e))
     # A REAL model: the reference's bundled HLA-A model (inst/extdata/ModelList.RData: 100 classifiers, 14 alleles, 18-87

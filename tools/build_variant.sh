@@ -6,7 +6,9 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 src=hibag_amd/csrc
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -Wall -Wno-unused-result"
-/opt/rocm/bin/hipcc $FLAGS -mllvm -structurizecfg-skip-uniform-regions "$@" -c $src/hibag_kernels.hip -o /tmp/var_$name.o
+# (the kernels' extra LLVM option comes from the Makefile's probe; NO_KFLAGS=1 leaves it out: the other half of the parity check)
+KFLAGS=$([ -n "${NO_KFLAGS:-}" ] || make -s -C $src print-kflags)
+/opt/rocm/bin/hipcc $FLAGS $KFLAGS "$@" -c $src/hibag_kernels.hip -o /tmp/var_$name.o
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $src/hibag_model.hip -o /tmp/var_${name}_model.o
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $src/hibag_predict.hip -o /tmp/var_${name}_predict.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_var_$name.so /tmp/var_$name.o /tmp/var_${name}_model.o /tmp/var_${name}_predict.o $src/hibag_api.o $src/hibag_build.o $src/hibag_train.o $src/hibag_sample.o $src/hibag_shard.o $src/hibag_ubench.o $src/hibag_em.o -ldl

@@ -9,6 +9,8 @@ import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "hibag_amd", "csrc")
 FLAGS = "-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 --cuda-device-only -S".split()
+# the kernels' extra LLVM option: from the Makefile's probe, the one place that names it
+KFLAGS = subprocess.run(["make", "-s", "-C", SRC, "print-kflags"], capture_output=True, text=True).stdout.split()
 def demangle(n):
     try:
         return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", n], capture_output=True, text=True).stdout.strip().split("(")[0]
@@ -18,7 +20,7 @@ for f in sorted(os.listdir(SRC)):
     if not f.endswith(".hip"):
         continue
     with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
-        extra = ["-mllvm", "-structurizecfg-skip-uniform-regions"] if f == "hibag_kernels.hip" else []      # (the Makefile's KFLAGS)
+        extra = KFLAGS if f == "hibag_kernels.hip" else []
         subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + extra + sys.argv[1:] + [os.path.join(SRC, f), "-o", tmp.name], check=True, stderr=subprocess.DEVNULL)
         lines = open(tmp.name).read().split("\n")
     meta = {}

@@ -1,6 +1,7 @@
 #!/bin/bash
 # pass 2: stored cells against evaluating the pairs again -- the model's own choice, each form forced
 # (HIBAG_PASS2=stream / hybrid / recompute), and the pairs-per-cell threshold of the hybrid (HIBAG_STORE_PAIRS)
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 cd $GRAFT_REPO_ROOT
 timeout 600 python tools/parity_quick.py 2>&1 | tail -1
 for mode in stream hybrid recompute; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # SQ / LDS / TCP counters of both passes for the current build (GPU box, via gpurun): outputs gpurun_out/$1/pmc_summary.txt
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/${1:-r02pmc}; rm -rf $out; mkdir -p $out
 ARGS="${BENCH_ARGS:---steps 2 --warmup 1 --no-cpu-baseline --no-extras}"
 PROG="${PMC_PROG:-$R/bench.py $ARGS}"      # PMC_PROG="$GRAFT_REPO_ROOT/tools/wide_bench.py": the counters of another workload

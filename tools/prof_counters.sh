@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): bash tools/prof_counters.sh <outdir> "<counter list 1>" "<counter list 2>" ...
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$1; shift; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 i=0

@@ -1,5 +1,7 @@
+#!/bin/bash
 # times every gpurun_var_*.so on the benchmark step, twice (variants of one call on one box are comparable); PARITY=1 first
 # checks each against the oracle (ablation builds fail that on purpose)
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/var
 if [ -n "$PARITY" ]; then

@@ -1,4 +1,5 @@
 #!/bin/bash
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/staged_trace; rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $out -- python3 $R/tools/staged_trace.py > $out/log.txt 2>&1

@@ -1,6 +1,7 @@
 #!/bin/bash
 # step time of the benchmark configuration over the store threshold of pass 1 (HIBAG_STORE_PAIRS: cells with more pairs are stored
 # for pass 2, the others evaluated again) and the fit rule (HIBAG_STORE_FIT); one box, so the lines are comparable
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 cd $GRAFT_REPO_ROOT
 for fit in ${FITS:-5 0}; do
 for sp in ${PAIRS:-4 6 8 10 12 14 16 20 28 40}; do

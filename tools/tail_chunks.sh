@@ -1,6 +1,7 @@
 #!/bin/bash
 # Chunked tail items (HIBAG_TAIL_K, hibag_kernels.hip "hand-overs"): parity at sizes that use them, then the bench
 # with undivided items (K = 1) and with 2 .. 8 chunks, on the HLA-B and the DRB1 shape.
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 cd $GRAFT_REPO_ROOT
 timeout 600 python tools/parity_balanced.py 2200 3400 10000 2>&1 | tail -4
 for k in 1 2 4 8; do

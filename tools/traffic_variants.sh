@@ -1,5 +1,6 @@
 #!/bin/bash
 # FETCH_SIZE of k_accum for every gpurun_var_*.so (XCD-mapping experiments); one counter pass each
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/tv; rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for so in $R/gpurun_var_*.so; do
