@@ -32,6 +32,7 @@ EXPORTS = [
     "hibag_hip_trainer_new", "hibag_hip_trainer_free", "hibag_hip_trainer_set_rng", "hibag_hip_trainer_set_seed",
     "hibag_hip_trainer_new_classifiers", "hibag_hip_trainer_n_classifier", "hibag_hip_trainer_classifier_dims",
     "hibag_hip_trainer_classifier_get", "hibag_hip_trainer_set_threads", "hibag_hip_trainer_threads", "hibag_hip_trainer_set_em_mode",
+    "hibag_hip_trainer_set_shared", "hibag_hip_train_set_thread_budget", "hibag_hip_train_combine_stats", "hibag_hip_train_combine_times",
     "hibag_hip_model_status", "hibag_hip_model_clear_status", "hibag_hip_model_handover_faults",
     "hibag_hip_test_inject_handover_fault", "hibag_hip_model_engine", "hibag_hip_model_replicate",
     "hibag_hip_multi_slice", "hibag_hip_predict_multi", "hibag_hip_model_device",
@@ -111,6 +112,10 @@ def lib() -> C.CDLL:
     L.hibag_hip_trainer_set_threads.argtypes = [vp, i32]
     L.hibag_hip_trainer_threads.argtypes = [vp]
     L.hibag_hip_trainer_set_em_mode.argtypes = [vp, i32]
+    L.hibag_hip_trainer_set_shared.argtypes = [vp, i32]
+    L.hibag_hip_train_set_thread_budget.argtypes = [i32]
+    L.hibag_hip_train_combine_stats.argtypes = [C.POINTER(i64), C.POINTER(i64), i32]
+    L.hibag_hip_train_combine_times.argtypes = [C.POINTER(dbl), i32]
     L.hibag_hip_trainer_classifier_dims.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.hibag_hip_trainer_classifier_get.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.POINTER(dbl)]
     L.hibag_hip_bed_flag.argtypes = [C.c_char_p]

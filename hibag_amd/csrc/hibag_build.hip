@@ -30,6 +30,7 @@
 
 int hibag_selected_device();      // hibag_api.hip
 #include "hibag_plugin.h"
+#include "hibag_combine.h"
 
 namespace {
 
@@ -57,11 +58,12 @@ struct BuildState {
 	// one half of a growth step's candidates the host threads still fit the other half
 	struct Slot {
 		void *d = nullptr, *h = nullptr; size_t cap_d = 0, cap_h = 0;
-		hipEvent_t done = nullptr;
 		int n_cand = 0, np = 0; size_t o_best = 0, o_post = 0;
 		double t_launch = 0;
 	} slot[2];
 	void *h_up = nullptr; size_t cap_up = 0, up_at = 0;
+	std::vector<void *> h_retired;          // staging areas outgrown while an operation was being put together (freed at the next rewind)
+	void *h_dn = nullptr; size_t cap_dn = 0; // pinned landing area of the pair-list step's read-backs
 	void *d_pairs = nullptr; size_t cap_pairs = 0;
 };
 // One state per HOST THREAD (thread_local), and every copy / launch of this file on the calling thread's own default
@@ -70,6 +72,10 @@ struct BuildState {
 // An unmodified HIBAG drives the build entries from one thread (nthread = 1 with a GPU plugin, src/LibHLA.h:680).
 thread_local BuildState g;
 thread_local char g_msg[400];
+// The operation the calling thread is putting together (hibag_combine.h): upload() then RECORDS its copies instead of
+// issuing them -- the driver's entries (pair lists, batched scoring) run as operations, alone or fused with other trainers';
+// the plugin-table entries an unmodified HIBAG drives (set_haplo_geno + acc_oob / acc_ib) copy and launch directly.
+thread_local HibagOp *g_op = nullptr;
 
 [[noreturn]] void build_throw(const char *what, hipError_t e = hipSuccess)
 {
@@ -83,14 +89,20 @@ void dev_free(void *&p) { if (p) (void)hipFree(p); p = nullptr; }
 
 // Host -> device through the pinned staging area, asynchronously on the null stream (in order with the kernels that
 // follow).  The area is rewound by upload_rewind() at a point where everything sent before has been consumed.
-void upload_rewind() { g.up_at = 0; }
+void upload_rewind()
+{
+	g.up_at = 0;
+	for (void *p : g.h_retired) (void)hipHostFree(p);
+	g.h_retired.clear();
+}
 void upload(void *dst, const void *src, size_t bytes, const char *what)
 {
 	if (bytes == 0) return;
 	if (g.up_at + bytes > g.cap_up) {
-		// (rare: grow; what is in flight from the old area must land first)
-		HIP_OK(hipStreamSynchronize(0), what);
-		if (g.h_up) (void)hipHostFree(g.h_up);
+		// (rare: grow; what is in flight from the old area must land first -- or, while an operation is being put together,
+		// the old area stays alive until that operation has run: its recorded copies point into it)
+		if (!g_op) HIP_OK(hipStreamSynchronize(0), what);
+		if (g.h_up) { if (g_op) g.h_retired.push_back(g.h_up); else (void)hipHostFree(g.h_up); }
 		g.h_up = nullptr;
 		g.cap_up = std::max<size_t>((g.up_at + bytes) * 2, 1 << 20);
 		HIP_OK(hipHostMalloc(&g.h_up, g.cap_up, hipHostMallocDefault), "hipHostMalloc(upload staging)");
@@ -99,7 +111,19 @@ void upload(void *dst, const void *src, size_t bytes, const char *what)
 	char *at = (char *)g.h_up + g.up_at;
 	memcpy(at, src, bytes);
 	g.up_at += (bytes + 63) & ~(size_t)63;
-	HIP_OK(hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, 0), what);
+	if (g_op) g_op->up.push_back(HibagCopy{dst, at, bytes});
+	else HIP_OK(hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, 0), what);
+}
+
+void *landing(size_t bytes)
+{
+	if (bytes > g.cap_dn) {
+		if (g.h_dn) (void)hipHostFree(g.h_dn);
+		g.h_dn = nullptr; g.cap_dn = 0;
+		HIP_OK(hipHostMalloc(&g.h_dn, bytes * 2 + 4096, hipHostMallocDefault), "hipHostMalloc(read-back staging)");
+		g.cap_dn = bytes * 2 + 4096;
+	}
+	return g.h_dn;
 }
 
 void reserve(void *&p, size_t &cap, size_t bytes, const char *what)
@@ -324,12 +348,18 @@ __device__ __forceinline__ void batch_cells(const BatchView &B, int c, int sg, i
 		for (int i = i1; i < (i1 + SCAN_NB - 1) / SCAN_NB * SCAN_NB; i++) out[(size_t)i * HIBAG_WAVE] = 0.0;
 }
 
-__global__ __launch_bounds__(BATCH_WAVES * HIBAG_WAVE) void k_batch_cells(BatchView B)
+// (a launch scores the growth steps of several trainers at once, hibag_combine.h: workgroup -> its step's view and its place in
+// that step's own grid (sample group quads, cell segments, candidates))
+__global__ __launch_bounds__(BATCH_WAVES * HIBAG_WAVE) void k_batch_cells(HibagMulti<BatchView> M)
 {
 	__shared__ double tab_s[HIBAG_TAB_N];
 	__shared__ double hf_s[BATCH_LDS_HAPLO];
 	__shared__ uint32_t hb_s[NW * BATCH_LDS_HAPLO];
-	const int c = blockIdx.z;
+	const int owner = hibag_multi_owner(M, (int)blockIdx.x);
+	const BatchView B = M.v[owner];
+	const int local = (int)blockIdx.x - M.first[owner];
+	const int gx = (B.n_pad / HIBAG_WAVE + BATCH_WAVES - 1) / BATCH_WAVES;
+	const int bx = local % gx, by = (local / gx) % B.n_seg, c = local / (gx * B.n_seg);
 	const int *st = B.start + (size_t)c * (B.n_hla + 1);
 	const int h_lo = st[0], n_h = st[B.n_hla] - st[0];
 	const bool staged = n_h <= BATCH_LDS_HAPLO;
@@ -340,21 +370,25 @@ __global__ __launch_bounds__(BATCH_WAVES * HIBAG_WAVE) void k_batch_cells(BatchV
 			for (int i = threadIdx.x; i < n_h; i += blockDim.x) hb_s[w * n_h + i] = B.hb[(size_t)w * B.n_haplo_total + h_lo + i];
 	}
 	__syncthreads();
-	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	const int s = bx * (int)blockDim.x + (int)threadIdx.x;
 	if (s >= B.n_pad) return;
 	const uint32_t *hbp = staged ? hb_s : nullptr;
 	switch (B.nw) {
-	case 1:  batch_cells<1>(B, c, blockIdx.y, s, tab_s, hbp, hf_s, h_lo, n_h); break;
-	case 2:  batch_cells<2>(B, c, blockIdx.y, s, tab_s, hbp, hf_s, h_lo, n_h); break;
-	case 3:  batch_cells<3>(B, c, blockIdx.y, s, tab_s, hbp, hf_s, h_lo, n_h); break;
-	default: batch_cells<4>(B, c, blockIdx.y, s, tab_s, hbp, hf_s, h_lo, n_h); break;
+	case 1:  batch_cells<1>(B, c, by, s, tab_s, hbp, hf_s, h_lo, n_h); break;
+	case 2:  batch_cells<2>(B, c, by, s, tab_s, hbp, hf_s, h_lo, n_h); break;
+	case 3:  batch_cells<3>(B, c, by, s, tab_s, hbp, hf_s, h_lo, n_h); break;
+	default: batch_cells<4>(B, c, by, s, tab_s, hbp, hf_s, h_lo, n_h); break;
 	}
 }
 
-__global__ __launch_bounds__(HIBAG_WAVE) void k_batch_scan(BatchView B)
+__global__ __launch_bounds__(HIBAG_WAVE) void k_batch_scan(HibagMulti<BatchView> M)
 {
-	const int c = blockIdx.y;
-	const int s = blockIdx.x * HIBAG_WAVE + threadIdx.x;
+	const int owner = hibag_multi_owner(M, (int)blockIdx.x);
+	const BatchView B = M.v[owner];
+	const int local = (int)blockIdx.x - M.first[owner];
+	const int ng = B.n_pad / HIBAG_WAVE;
+	const int c = local / ng;
+	const int s = (local % ng) * HIBAG_WAVE + (int)threadIdx.x;
 	const int *cl = B.cells + (size_t)c * B.max_cells;
 	const int n = B.seg[c * (B.n_seg + 1) + B.n_seg];
 	const int wpos = B.wpos[(size_t)c * B.n_pad + s];
@@ -396,8 +430,9 @@ struct MatchView {
 	const int *a1, *a2;      // [n_inbag] true alleles, a1 <= a2
 	int *min_d;              // [n_inbag]
 	int *count;              // [n_inbag]
-	const int *offset;       // [n_inbag] (pass 1)
+	const int *offset;       // [n_inbag] (pass 1); nullptr: pass 1 sums the counts of the samples before its own
 	uint32_t *out;           // pairs: {k, (i2<<16)|i1}
+	int n_inbag;             // = the step's workgroups in a fused launch
 };
 
 __device__ __forceinline__ int match_dist(const MatchView &V, int s, int i, int j)
@@ -412,9 +447,11 @@ __device__ __forceinline__ int match_dist(const MatchView &V, int s, int i, int 
 }
 
 template <int PASS>
-__global__ __launch_bounds__(HIBAG_WAVE) void k_build_match(MatchView V)
+__global__ __launch_bounds__(HIBAG_WAVE) void k_build_match(HibagMulti<MatchView> M)
 {
-	const int k = blockIdx.x, lane = threadIdx.x;
+	const int owner = hibag_multi_owner(M, (int)blockIdx.x);
+	const MatchView V = M.v[owner];
+	const int k = (int)blockIdx.x - M.first[owner], lane = threadIdx.x;
 	const int s = V.samp[k];
 	const int a1 = V.a1[k], a2 = V.a2[k];
 	const int st1 = V.start[a1], n1 = V.start[a1 + 1] - st1;
@@ -423,7 +460,17 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_build_match(MatchView V)
 	const long long npair = (long long)n1 * n2;
 	int best = 0x7FFFFFFF, cnt = 0;
 	const int target = PASS ? V.min_d[k] : 0;
-	int written = PASS ? V.offset[k] : 0;
+	int written = 0;
+	if (PASS) {
+		if (V.offset) written = V.offset[k];
+		else {
+			// both passes in one operation: the pairs of the samples before this one, from the first pass's counts
+			int acc = 0;
+			for (int i = lane; i < k; i += HIBAG_WAVE) acc += V.count[i];
+			for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+			written = acc;
+		}
+	}
 	for (long long q0 = 0; q0 < npair; q0 += HIBAG_WAVE) {
 		const long long q = q0 + lane;
 		bool valid = q < npair;
@@ -542,6 +589,60 @@ int compare_hla(int p1, int p2, int t1, int t2)
 	return cnt;
 }
 
+// ---- fused launches (hibag_combine.h): the operations' views as kernel arguments, their workgroups back to back ----
+template <class V, class Blocks>
+HibagMulti<V> multi_of(const HibagOp *const ops[], int n, Blocks &&blocks, int &total)
+{
+	HibagMulti<V> M;
+	M.n = n;
+	int at = 0;
+	for (int j = 0; j < n; j++) {
+		M.v[j] = *(const V *)ops[j]->view;
+		M.first[j] = at;
+		at += blocks(M.v[j]);
+	}
+	for (int j = n; j <= HIBAG_COMBINE_MAX; j++) M.first[j] = at;
+	total = at;
+	return M;
+}
+
+void match0_launch(const HibagOp *const ops[], int n, hipStream_t st)
+{
+	int total = 0;
+	const HibagMulti<MatchView> M = multi_of<MatchView>(ops, n, [](const MatchView &v) { return v.n_inbag; }, total);
+	if (total > 0) hipLaunchKernelGGL(k_build_match<0>, dim3(total), dim3(HIBAG_WAVE), 0, st, M);
+}
+
+void match1_launch(const HibagOp *const ops[], int n, hipStream_t st)
+{
+	int total = 0;
+	const HibagMulti<MatchView> M = multi_of<MatchView>(ops, n, [](const MatchView &v) { return v.n_inbag; }, total);
+	if (total > 0) hipLaunchKernelGGL(k_build_match<1>, dim3(total), dim3(HIBAG_WAVE), 0, st, M);
+}
+
+void match_launch(const HibagOp *const ops[], int n, hipStream_t st)
+{
+	int total = 0;
+	const HibagMulti<MatchView> M = multi_of<MatchView>(ops, n, [](const MatchView &v) { return v.n_inbag; }, total);
+	if (total > 0) {
+		hipLaunchKernelGGL(k_build_match<0>, dim3(total), dim3(HIBAG_WAVE), 0, st, M);
+		hipLaunchKernelGGL(k_build_match<1>, dim3(total), dim3(HIBAG_WAVE), 0, st, M);
+	}
+}
+
+void eval_launch(const HibagOp *const ops[], int n, hipStream_t st)
+{
+	int total = 0;
+	const HibagMulti<BatchView> Mc = multi_of<BatchView>(ops, n, [](const BatchView &b) {
+		return ((b.n_pad / HIBAG_WAVE + BATCH_WAVES - 1) / BATCH_WAVES) * b.n_seg * b.n_cand; }, total);
+	if (total > 0) hipLaunchKernelGGL(k_batch_cells, dim3(total), dim3(BATCH_WAVES * HIBAG_WAVE), 0, st, Mc);
+	const HibagMulti<BatchView> Ms = multi_of<BatchView>(ops, n, [](const BatchView &b) { return (b.n_pad / HIBAG_WAVE) * b.n_cand; }, total);
+	if (total > 0) hipLaunchKernelGGL(k_batch_scan, dim3(total), dim3(HIBAG_WAVE), 0, st, Ms);
+}
+
+const bool g_build_registered = (hibag_combine_register(HIBAG_OP_MATCH0, match0_launch), hibag_combine_register(HIBAG_OP_MATCH1, match1_launch),
+	hibag_combine_register(HIBAG_OP_EVAL, eval_launch), hibag_combine_register(HIBAG_OP_MATCH, match_launch), true);
+
 } // namespace
 
 // build_init(nHLA, nSample): src/LibHLA.cpp:2256-2260
@@ -578,7 +679,6 @@ void hibag_build_done()
 	for (BuildState::Slot &sl : g.slot) {
 		dev_free(sl.d);
 		if (sl.h) (void)hipHostFree(sl.h);
-		if (sl.done) (void)hipEventDestroy(sl.done);
 		sl = BuildState::Slot();
 	}
 	g.d_hf = nullptr;
@@ -586,6 +686,10 @@ void hibag_build_done()
 	g.h_stage = nullptr;
 	if (g.h_up) (void)hipHostFree(g.h_up);
 	g.h_up = nullptr;
+	for (void *p : g.h_retired) (void)hipHostFree(p);
+	g.h_retired.clear();
+	if (g.h_dn) (void)hipHostFree(g.h_dn);
+	g.h_dn = nullptr; g.cap_dn = 0;
 	dev_free(g.d_pairs);
 	g.cap_h = g.cap_s = g.cap_match = g.cap_batch = g.cap_stage = g.cap_up = g.up_at = g.cap_pairs = 0;
 	g.active = false; g.evaluated = false;
@@ -646,31 +750,117 @@ uint32_t *hibag_build_haplomatch(const PluginHaplotype haplo[], const size_t n_h
 		if (n_haplo[h] > 65535) build_throw("There are too many HLA allele-specific haplotypes (# > 65535).");
 		H += n_haplo[h];
 	}
-	upload_rewind();                               // (every earlier upload was consumed: the entries end with a blocking read)
-	upload_haplo(haplo, (int)H, n_snp, false, n_haplo);
-	upload_geno(geno);
-	g.evaluated = false;
-	const int nib = (int)g.inbag.size();
-	if (nib == 0) {
-		uint32_t *buf = (uint32_t *)malloc(sizeof(uint32_t));
-		if (!buf) build_throw("out of memory");
-		buf[0] = 0; out_n = 1;
-		return buf;
+	upload_rewind();                               // (every earlier upload was consumed: an operation returns when its results are back)
+	{
+		// ONE operation where an upper bound on the number of pairs is small (it always is for the driver's growth steps: the
+		// bound is the number of candidate pairs, a few per in-bag sample): the step's inputs in one copy into one arena, both
+		// passes back to back -- the second finds its offsets from the first's counts on the device --, counts and pairs back in
+		// one copy sized by the bound.  Two device round trips and a dozen copies less per growth step.
+		const int nib1 = (int)g.inbag.size(), nh = g.n_hla, np = g.n_pad, n = g.n_sample;
+		const int nw = std::max(1, (n_snp + 31) / 32);
+		std::vector<int> start(nh + 1, 0);
+		for (int h = 0; h < nh; h++) start[h + 1] = start[h] + (int)n_haplo[h];
+		g.n_haplo = (int)H; g.n_snp = n_snp;
+		g.true1.assign(n, 0); g.true2.assign(n, 0);
+		for (int s = 0; s < n; s++) {
+			int a1 = geno[s].hla1, a2 = geno[s].hla2;
+			if (a1 > a2) std::swap(a1, a2);
+			if (a1 < 0 || a2 >= nh) build_throw("genotype with an invalid true HLA pair");
+			g.true1[s] = a1; g.true2[s] = a2;
+		}
+		size_t bound = 0;
+		for (int k = 0; k < nib1; k++) {
+			const size_t n1 = n_haplo[g.true1[g.inbag[k]]], n2 = n_haplo[g.true2[g.inbag[k]]];
+			bound += g.true1[g.inbag[k]] == g.true2[g.inbag[k]] ? n1 * (n1 + 1) / 2 : n1 * n2;
+		}
+		if (nib1 > 0 && bound > 0 && bound <= ((size_t)1 << 20)) {
+			g.evaluated = false;
+			const size_t Hs = std::max<size_t>(H, 1);
+			// the arena, in 4-byte units: inputs [hb | start | planes | samp | a1 | a2], scratch [min_d], results [count | pairs]
+			const size_t o_hb = 0, o_start = o_hb + (size_t)nw * Hs, o_planes = o_start + (nh + 1), o_samp = o_planes + (size_t)2 * NW * np,
+				o_a1 = o_samp + nib1, o_a2 = o_a1 + nib1, in_end = o_a2 + nib1, o_min = in_end, o_cnt = o_min + nib1, o_pairs = o_cnt + nib1,
+				end = o_pairs + 2 * bound;
+			std::vector<uint32_t> blob(in_end, 0);
+			for (size_t i = 0; i < H; i++)
+				for (int w = 0; w < nw; w++) {
+					uint32_t v = (uint32_t)((uint64_t)haplo[i].packed[w >> 1] >> (32 * (w & 1)));
+					const int lo = 32 * w;                   // clear bits >= n_snp (uninitialised in the reference, src/LibHLA.cpp:287-292)
+					if (n_snp < lo + 32) v &= (n_snp <= lo) ? 0u : ((1u << (n_snp - lo)) - 1);
+					blob[o_hb + (size_t)w * Hs + i] = v;
+				}
+			for (int h = 0; h <= nh; h++) blob[o_start + h] = (uint32_t)start[h];
+			for (int w = 0; w < NW; w++)
+				for (int s = 0; s < np; s++) {               // padding lanes: all missing
+					blob[o_planes + (size_t)w * np + s] = s < n ? (uint32_t)((uint64_t)geno[s].snp1[w >> 1] >> (32 * (w & 1))) : 0u;
+					blob[o_planes + (size_t)(NW + w) * np + s] = s < n ? (uint32_t)((uint64_t)geno[s].snp2[w >> 1] >> (32 * (w & 1))) : 0xFFFFFFFFu;
+				}
+			for (int k = 0; k < nib1; k++) {
+				blob[o_samp + k] = (uint32_t)g.inbag[k];
+				blob[o_a1 + k] = (uint32_t)g.true1[g.inbag[k]];
+				blob[o_a2 + k] = (uint32_t)g.true2[g.inbag[k]];
+			}
+			reserve(g.d_match, g.cap_match, end * 4 + 64, "hipMalloc(match)");
+			uint32_t *const d = (uint32_t *)g.d_match;
+			HibagOp op;
+			op.kind = HIBAG_OP_MATCH;
+			{
+				struct Collect { Collect(HibagOp *o) { g_op = o; } ~Collect() { g_op = nullptr; } } collecting(&op);
+				upload(d, blob.data(), in_end * 4, "copy match inputs");
+			}
+			const MatchView V{(int)Hs, nw, np, d + o_hb, (const int *)(d + o_start), d + o_planes, (const int *)(d + o_samp),
+				(const int *)(d + o_a1), (const int *)(d + o_a2), (int *)(d + o_min), (int *)(d + o_cnt), nullptr, d + o_pairs, nib1};
+			op.view = &V;
+			uint32_t *const land = (uint32_t *)landing((end - o_cnt) * 4);
+			op.down.push_back(HibagCopy{land, d + o_cnt, (end - o_cnt) * 4});
+			hibag_combine_run(op);
+			size_t total = 0;
+			for (int k = 0; k < nib1; k++) total += (size_t)(int)land[k];
+			if (total > bound) build_throw("build_haplomatch: the device returned more pairs than the candidates allow");
+			uint32_t *buf = (uint32_t *)malloc((1 + 2 * total) * sizeof(uint32_t));
+			if (!buf) build_throw("out of memory");
+			buf[0] = (uint32_t)(2 * total);
+			memcpy(buf + 1, land + nib1, 2 * total * sizeof(uint32_t));
+			out_n = 1 + 2 * total;
+			return buf;
+		}
 	}
-	std::vector<int> samp(g.inbag), a1(nib), a2(nib);
-	for (int k = 0; k < nib; k++) { a1[k] = g.true1[samp[k]]; a2[k] = g.true2[samp[k]]; }
-	// layout of the scratch buffer: samp, a1, a2, min_d, count, offset (ints), then the pairs
-	const size_t ints = (size_t)6 * nib;
-	reserve(g.d_match, g.cap_match, ints * sizeof(int) + 64, "hipMalloc(match)");
-	int *d_i = (int *)g.d_match;
-	upload(d_i, samp.data(), nib * sizeof(int), "copy match args");
-	upload(d_i + nib, a1.data(), nib * sizeof(int), "copy match args");
-	upload(d_i + 2 * nib, a2.data(), nib * sizeof(int), "copy match args");
-	MatchView V{(int)H, std::max(1, (n_snp + 31) / 32), g.n_pad, (const uint32_t *)g.d_hb, (const int *)g.d_start,
-		(const uint32_t *)g.d_planes, d_i, d_i + nib, d_i + 2 * nib, d_i + 3 * nib, d_i + 4 * nib, d_i + 5 * nib, nullptr};
-	hipLaunchKernelGGL(k_build_match<0>, dim3(nib), dim3(HIBAG_WAVE), 0, 0, V);
-	std::vector<int> count(nib), offset(nib);
-	HIP_OK(hipMemcpy(count.data(), d_i + 4 * nib, nib * sizeof(int), hipMemcpyDeviceToHost), "read match counts");
+	// Otherwise two operations (hibag_combine.h): pass 0 -- the step's uploads, per in-bag sample the minimum distance and the
+	// number of pairs at it --, then, once the host has turned the counts into offsets, pass 1, which writes the pairs.
+	HibagOp op0;
+	op0.kind = HIBAG_OP_MATCH0;
+	struct Collect { Collect(HibagOp *o) { g_op = o; } ~Collect() { g_op = nullptr; } };
+	const int nib = (int)g.inbag.size();
+	MatchView V{};                                 // (no in-bag sample: no workgroup)
+	op0.view = &V;
+	{
+		Collect collecting(&op0);
+		upload_haplo(haplo, (int)H, n_snp, false, n_haplo);
+		upload_geno(geno);
+		g.evaluated = false;
+		if (nib == 0) {
+			hibag_combine_run(op0);                        // (the uploads alone: a later build_set_haplo_geno-free evaluation may rely on them)
+			uint32_t *buf = (uint32_t *)malloc(sizeof(uint32_t));
+			if (!buf) build_throw("out of memory");
+			buf[0] = 0; out_n = 1;
+			return buf;
+		}
+		std::vector<int> samp(g.inbag), a1(nib), a2(nib);
+		for (int k = 0; k < nib; k++) { a1[k] = g.true1[samp[k]]; a2[k] = g.true2[samp[k]]; }
+		// layout of the scratch buffer: samp, a1, a2, min_d, count, offset (ints), then the pairs
+		const size_t ints = (size_t)6 * nib;
+		reserve(g.d_match, g.cap_match, ints * sizeof(int) + 64, "hipMalloc(match)");
+		int *d_i = (int *)g.d_match;
+		upload(d_i, samp.data(), nib * sizeof(int), "copy match args");
+		upload(d_i + nib, a1.data(), nib * sizeof(int), "copy match args");
+		upload(d_i + 2 * nib, a2.data(), nib * sizeof(int), "copy match args");
+		V = MatchView{(int)H, std::max(1, (n_snp + 31) / 32), g.n_pad, (const uint32_t *)g.d_hb, (const int *)g.d_start,
+			(const uint32_t *)g.d_planes, d_i, d_i + nib, d_i + 2 * nib, d_i + 3 * nib, d_i + 4 * nib, d_i + 5 * nib, nullptr, nib};
+	}
+	int *const d_i = (int *)g.d_match;
+	int *const count = (int *)landing((size_t)nib * sizeof(int));
+	op0.down.push_back(HibagCopy{count, d_i + 4 * nib, (size_t)nib * sizeof(int)});
+	hibag_combine_run(op0);
+	std::vector<int> offset(nib);
 	size_t total = 0;
 	for (int k = 0; k < nib; k++) { offset[k] = (int)total; total += (size_t)count[k]; }
 	uint32_t *buf = (uint32_t *)malloc((1 + 2 * total) * sizeof(uint32_t));
@@ -680,9 +870,17 @@ uint32_t *hibag_build_haplomatch(const PluginHaplotype haplo[], const size_t n_h
 		struct Guard { uint32_t *b; ~Guard() { free(b); } } guard{buf};       // (the calls below throw on failure)
 		reserve(g.d_pairs, g.cap_pairs, 2 * total * sizeof(uint32_t), "hipMalloc(pairs)");
 		V.out = (uint32_t *)g.d_pairs;
-		upload(d_i + 5 * nib, offset.data(), nib * sizeof(int), "copy match offsets");
-		hipLaunchKernelGGL(k_build_match<1>, dim3(nib), dim3(HIBAG_WAVE), 0, 0, V);
-		HIP_OK(hipMemcpy(buf + 1, g.d_pairs, 2 * total * sizeof(uint32_t), hipMemcpyDeviceToHost), "read haplotype pairs");
+		HibagOp op1;
+		op1.kind = HIBAG_OP_MATCH1;
+		op1.view = &V;
+		{
+			Collect collecting(&op1);
+			upload(d_i + 5 * nib, offset.data(), nib * sizeof(int), "copy match offsets");
+		}
+		uint32_t *const pairs = (uint32_t *)landing(2 * total * sizeof(uint32_t));
+		op1.down.push_back(HibagCopy{pairs, g.d_pairs, 2 * total * sizeof(uint32_t)});
+		hibag_combine_run(op1);
+		memcpy(buf + 1, pairs, 2 * total * sizeof(uint32_t));
 		guard.b = nullptr;
 	}
 	out_n = 1 + 2 * total;
@@ -854,7 +1052,6 @@ void hibag_build_eval_launch(int slot, const PluginGenotype base_geno[], int n_s
 		HIP_OK(hipHostMalloc(&SL.h, out_end * 2, hipHostMallocDefault), "hipHostMalloc(staging)");
 		SL.cap_h = out_end * 2;
 	}
-	if (!SL.done) HIP_OK(hipEventCreateWithFlags(&SL.done, hipEventDisableTiming), "hipEventCreate");
 	const double t_res1 = batch_now();
 	char *d = (char *)SL.d, *h = (char *)SL.h;
 	memcpy(h + o_hb, hb.data(), hb.size() * 4);
@@ -869,16 +1066,18 @@ void hibag_build_eval_launch(int slot, const PluginGenotype base_geno[], int n_s
 	memcpy(h + o_hf, hf.data(), hf.size() * 8);
 	const double t1 = batch_now();
 	g_batch_prof[4] += t1 - t_res1; g_batch_prof[5] += t_res1 - t_res0;
-	HIP_OK(hipMemcpyAsync(d, h, in_end, hipMemcpyHostToDevice, 0), "copy batch");
 	BatchView B{nh, np, nw, n_cand, n_seg, word, (const uint32_t *)(d + o_hb), (const double *)(d + o_hf), (int)Hs,
 		(const int *)(d + o_start), (const uint32_t *)(d + o_planes), (const uint32_t *)(d + o_cw), (const int *)(d + o_cells),
 		(const int4 *)(d + o_cellb), (const int *)(d + o_seg), max_cells, (const int *)(d + o_true), (const int *)(d + o_wpos), (const double *)g.d_tab, (double *)(d + o_cellv),
 		(int *)(d + o_best), (double *)(d + o_post)};
-	hipLaunchKernelGGL(k_batch_cells, dim3((np / HIBAG_WAVE + BATCH_WAVES - 1) / BATCH_WAVES, n_seg, n_cand), dim3(BATCH_WAVES * HIBAG_WAVE), 0, 0, B);
-	hipLaunchKernelGGL(k_batch_scan, dim3(np / HIBAG_WAVE, n_cand), dim3(HIBAG_WAVE), 0, 0, B);
-	HIP_OK(hipGetLastError(), "k_batch");
-	HIP_OK(hipMemcpyAsync(h + o_best, d + o_best, out_end - o_best, hipMemcpyDeviceToHost, 0), "read batch");
-	HIP_OK(hipEventRecord(SL.done, 0), "hipEventRecord");
+	// one operation (hibag_combine.h): the step's inputs in one copy, the two kernels -- alone, or fused with the scoring of
+	// the other trainers' steps of the moment --, the results back in one; returns when they are in the staging area
+	HibagOp op;
+	op.kind = HIBAG_OP_EVAL;
+	op.view = &B;
+	op.up.push_back(HibagCopy{d, h, in_end});
+	op.down.push_back(HibagCopy{h + o_best, d + o_best, out_end - o_best});
+	hibag_combine_run(op);
 	const double t2 = batch_now();
 	SL.np = np; SL.o_best = o_best; SL.o_post = o_post; SL.t_launch = t2;
 	g_batch_prof[0] += t1 - t0; g_batch_prof[1] += t2 - t1;
@@ -890,8 +1089,7 @@ void hibag_build_eval_collect(int slot, int *acc_floor, int acc_oob[], double lo
 	BuildState::Slot &SL = g.slot[slot];
 	const int n_cand = SL.n_cand, np = SL.np;
 	if (n_cand == 0) return;
-	const double t2 = batch_now();
-	HIP_OK(hipEventSynchronize(SL.done), "batch");
+	const double t2 = batch_now();                 // (the slot's operation was waited for by hibag_build_eval_launch)
 	const char *h = (const char *)SL.h;
 	const int *best = (const int *)(h + SL.o_best);
 	const double *post = (const double *)(h + SL.o_post);

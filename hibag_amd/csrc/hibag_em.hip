@@ -41,8 +41,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <ctime>
+#include <mutex>
 #include <vector>
 #include "hibag_em.h"
+#include "hibag_combine.h"
 
 namespace {
 
@@ -54,6 +56,7 @@ namespace {
 struct EmView {
 	int n_ib, n_pair, n_hap, n_samp_total;  // in-bag samples, their pairs, doubled haplotypes, all samples (the M step's 0.5 / total)
 	int n_ent;                              // entries of hent (padding included)
+	int n_cand;                             // candidates of this growth step (= its workgroups in a fused launch)
 	const uint32_t *pw;                     // [n_pair] h1 | h2 << 14
 	const int *off;                         // [n_ib + 1]
 	const int *boot;                        // [n_ib]
@@ -89,8 +92,12 @@ struct EmLayout {
 // microseconds), runs BESIDE them on a thread that does nothing else: a third of the chain in each phase of the NEXT
 // iteration (the terms are double-buffered).  So the stopping test of iteration k is known at the end of iteration k + 1; a
 // fit that stops at k returns the frequencies it had then -- oldf, which iteration k + 1 only read.
-__global__ __launch_bounds__(EM_THREADS) void k_em_fit(EmView V)
+// A launch fits the candidates of SEVERAL growth steps -- one per trainer that runs beside others (hibag_combine.h) --: the
+// workgroups of step j are M.first[j] .. M.first[j + 1] - 1, each with its own pair set, sizes and LDS layout.
+__global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 {
+	const int owner = hibag_multi_owner(M, (int)blockIdx.x);
+	const EmView V = M.v[owner];
 	extern __shared__ __attribute__((aligned(16))) char lds[];
 	__shared__ int verdict_s;                                         // of the iteration before: 0 = go on, 1 = converged, 2 = cannot tell (host)
 	__shared__ unsigned long long tmax_s[2];                          // largest |term| of an iteration (bits of a non-negative double), by parity
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(EmView V)
 	uint32_t *hent = (uint32_t *)((((uintptr_t)(lds + L.hent)) + 15) & ~(uintptr_t)15);
 	uint16_t *ps = (uint16_t *)(lds + L.ps);                          // the sample of each pair
 	double *rs = (double *)(lds + L.rs);                              // boot_i / psum_i
-	const int tid = threadIdx.x, c = blockIdx.x, n_ib = V.n_ib, n_pair = V.n_pair, n_hap = V.n_hap;
+	const int tid = threadIdx.x, c = (int)blockIdx.x - M.first[owner], n_ib = V.n_ib, n_pair = V.n_pair, n_hap = V.n_hap;
 	const bool summer = tid == EM_THREADS - 1;                        // the thread of the loglik chain (no other work)
 	const int nw = EM_THREADS - 1;                                    // worker threads
 	// the growth step's pair set (the same for every candidate) and this candidate's genotypes: once into LDS
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(EmView V)
 	for (int h = tid; h < n_hap; h += EM_THREADS) V.out_freq[(size_t)c * n_hap + h] = res[h];
 	if (tid == 0) {
 		V.status[c] = verdict_s == 2 ? 2 : 1;                         // (500 iterations without convergence end the host's loop too)
-		V.status[gridDim.x + c] = stopped ? iter - 1 : iter;
+		V.status[V.n_cand + c] = stopped ? iter - 1 : iter;
 	}
 }
 
@@ -280,8 +287,6 @@ struct EmState {
 	int device = -1;
 	void *d = nullptr, *h = nullptr;        // one device arena, one pinned staging area (upload, then download behind it)
 	size_t cap_d = 0, cap_h = 0;
-	hipStream_t st = nullptr;
-	bool lds_set = false;                   // k_em_fit may use EM_LDS_BYTES of dynamic LDS on this device
 };
 thread_local EmState g_em;          // (per host thread, like the build state: concurrent trainers each have their own arena and stream)
 thread_local char g_em_msg[300];
@@ -295,13 +300,43 @@ thread_local char g_em_msg[300];
 
 double em_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
+// The fused launch of the EM fits of n growth steps (hibag_combine.h): grid = their candidates back to back, dynamic LDS = the
+// largest step's layout.
+void em_launch(const HibagOp *const ops[], int n, hipStream_t st)
+{
+	static std::mutex lds_m;
+	static bool lds_set[64] = {};
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	{
+		std::lock_guard<std::mutex> lk(lds_m);                        // k_em_fit may use EM_LDS_BYTES of dynamic LDS: once per device
+		if (dev >= 0 && dev < 64 && !lds_set[dev]) {
+			(void)hipFuncSetAttribute((const void *)k_em_fit, hipFuncAttributeMaxDynamicSharedMemorySize, EM_LDS_BYTES);
+			lds_set[dev] = true;
+		}
+	}
+	HibagMulti<EmView> M;
+	M.n = n;
+	size_t lds = 0;
+	int at = 0;
+	for (int j = 0; j < n; j++) {
+		const EmView &V = *(const EmView *)ops[j]->view;
+		M.v[j] = V;
+		M.first[j] = at;
+		at += V.n_cand;
+		lds = std::max(lds, EmLayout(V.n_ib, V.n_pair, V.n_hap).total);
+	}
+	for (int j = n; j <= HIBAG_COMBINE_MAX; j++) M.first[j] = at;
+	hipLaunchKernelGGL(k_em_fit, dim3(at), dim3(EM_THREADS), lds, st, M);
+}
+const bool g_em_registered = (hibag_combine_register(HIBAG_OP_EM, em_launch), true);
+
 } // namespace
 
 thread_local double g_em_prof[3] = {0, 0, 0};            // seconds in hibag_em_fit_batch: staging the upload, copy + kernel + copy back (waited for), total
 
 void hibag_em_release()
 {
-	if (g_em.st) { (void)hipStreamSynchronize(g_em.st); (void)hipStreamDestroy(g_em.st); }
 	if (g_em.d) (void)hipFree(g_em.d);
 	if (g_em.h) (void)hipHostFree(g_em.h);
 	g_em = EmState();
@@ -315,13 +350,8 @@ void hibag_em_fit_batch(const HibagEmPairs &P, const int8_t *const geno[], const
 	int dev = 0;
 	EM_OK(hipGetDevice(&dev), "hipGetDevice");
 	if (g_em.device != dev) { hibag_em_release(); g_em.device = dev; }
-	if (!g_em.st) EM_OK(hipStreamCreateWithFlags(&g_em.st, hipStreamNonBlocking), "hipStreamCreate");
 	const size_t np = (size_t)P.n_pair, nib = (size_t)P.n_ib, nh = (size_t)P.n_hap, nc = (size_t)n_cand;
 	const EmLayout L(P.n_ib, P.n_pair, P.n_hap);
-	if (!g_em.lds_set) {                                              // (per device: the state is reset when the device changes)
-		EM_OK(hipFuncSetAttribute((const void *)k_em_fit, hipFuncAttributeMaxDynamicSharedMemorySize, EM_LDS_BYTES), "hipFuncSetAttribute");
-		g_em.lds_set = true;
-	}
 	// upload area (one copy), then the results (one copy back)
 	size_t o = 0;
 	auto take = [&](size_t bytes) { const size_t at = o; o = (o + std::max<size_t>(bytes, 8) + 63) & ~(size_t)63; return at; };
@@ -331,8 +361,7 @@ void hibag_em_fit_batch(const HibagEmPairs &P, const int8_t *const geno[], const
 	const size_t o_out = take(nc * nh * 8), o_stat = take(2 * nc * 4);
 	const size_t down_bytes = o - o_out;
 	if (o > g_em.cap_d) {
-		EM_OK(hipStreamSynchronize(g_em.st), "hipStreamSynchronize");
-		if (g_em.d) (void)hipFree(g_em.d);
+		if (g_em.d) (void)hipFree(g_em.d);            // (nothing of this thread's is in flight: every operation is waited for)
 		g_em.d = nullptr; g_em.cap_d = 0;
 		EM_OK(hipMalloc(&g_em.d, o + o / 2), "hipMalloc(EM arena)");
 		g_em.cap_d = o + o / 2;
@@ -365,17 +394,21 @@ void hibag_em_fit_batch(const HibagEmPairs &P, const int8_t *const geno[], const
 	for (size_t c = 0; c < nc; c++) memcpy(h + o_geno + c * nib, geno[c], nib);
 	memcpy(h + o_af, afreq, nc * 8);
 	const double t_up = em_now();
-	EM_OK(hipMemcpyAsync(d, h, up_bytes, hipMemcpyHostToDevice, g_em.st), "copy pairs");
 	EmView V;
+	V.n_cand = n_cand;
 	V.n_ib = P.n_ib; V.n_pair = P.n_pair; V.n_hap = P.n_hap; V.n_samp_total = P.n_samp_total;
 	V.pw = (const uint32_t *)(d + o_pw); V.off = (const int *)(d + o_off); V.boot = (const int *)(d + o_boot);
 	V.hoff = (const int *)(d + o_hoff); V.hent = (const uint32_t *)(d + o_hent); V.n_ent = (int)n_ent; V.cur_freq = (const double *)(d + o_cur);
 	V.geno = (const int8_t *)(d + o_geno); V.afreq = (const double *)(d + o_af);
 	V.out_freq = (double *)(d + o_out); V.status = (int *)(d + o_stat);
-	hipLaunchKernelGGL(k_em_fit, dim3(n_cand), dim3(EM_THREADS), L.total, g_em.st, V);
-	EM_OK(hipGetLastError(), "launch");
-	EM_OK(hipMemcpyAsync(h + o_out, d + o_out, down_bytes, hipMemcpyDeviceToHost, g_em.st), "read frequencies");
-	EM_OK(hipStreamSynchronize(g_em.st), "EM fit");
+	// one operation: the step's upload, its candidates' workgroups (alone, or fused with the other trainers' of the moment:
+	// hibag_combine.h), the results back -- returns when they are in the staging area
+	HibagOp op;
+	op.kind = HIBAG_OP_EM;
+	op.view = &V;
+	op.up.push_back(HibagCopy{d, h, up_bytes});
+	op.down.push_back(HibagCopy{h + o_out, d + o_out, down_bytes});
+	hibag_combine_run(op);
 	const double t_done = em_now();
 	memcpy(out_freq, h + o_out, nc * nh * 8);
 	const int *st = (const int *)(h + o_stat);

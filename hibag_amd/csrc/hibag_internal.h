@@ -205,6 +205,7 @@ struct hibag_hip_model {
 	bool staged_ready = false;
 	// PLINK BED payload + SNP map of hibag_hip_predict_bed
 	DevBuf ws_bed, ws_bedidx;
+	DevBuf ws_thrash;                      // HIBAG_DEBUG_THRASH_MB (hibag_predict.hip run_core): scratch a measurement overwrites between the passes
 
 	KernelTimer timer;
 	std::mutex lock;
@@ -223,7 +224,7 @@ struct hibag_hip_model {
 		if (side.join) (void)hipEventDestroy(side.join);
 		if (side.stream) (void)hipStreamDestroy(side.stream);
 		for (DevBuf *b : {&d_int, &d_stream, &d_tile, &d_tab, &d_blk, &d_pfac, &d_phdr, &d_parow, &ws_bt, &ws_bias, &ws_cells, &ws_sync, &ws_err, &ws_planes, &ws_cw, &ws_tot, &ws_inv, &ws_winv,
-		                  &ws_part, &ws_best, &ws_vrec, &ws_geno, &ws_out, &ws_codes, &ws_bed, &ws_bedidx})
+		                  &ws_part, &ws_best, &ws_vrec, &ws_geno, &ws_out, &ws_codes, &ws_bed, &ws_bedidx, &ws_thrash})
 			b->release();
 	}
 };

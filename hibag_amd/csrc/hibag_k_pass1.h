@@ -48,9 +48,9 @@ __device__ __forceinline__ double classifier_total(const HibagModelView &M, cons
 // workgroup only ever waits for one that was dispatched (a whole round of chunks) earlier, and no cycle can form.
 //
 // Visibility.  Chunks of one item run on one XCD (workgroups b and b + 8 share an XCD, and an item's chunks sit a
-// multiple of 8 apart), so the hand-over goes through that XCD's L2: the parked sums are plain stores, complete in L2
-// once the storing wavefront's vmcnt is 0 (the vector L1 writes through); the flag follows behind a workgroup barrier
-// as an L1-bypassing (sc1) store; the reader polls it with sc1 loads and fetches the sums with sc1 loads, which
+// multiple of 8 apart), so the hand-over goes through that XCD's L2: the parked sums are sc1 stores (store_parked), complete
+// once the storing wavefront's vmcnt is 0; the flag follows behind a workgroup barrier
+// as an sc1 store too; the reader polls it with sc1 loads and fetches the sums with sc1 loads, which
 // bypass its CU's L1.  No cache is flushed or invalidated (agent-scope fences cost 2-7 us each here and
 // evict everybody's L1).  The dispatch order is observed behaviour, not a contract: every flag carries the XCD
 // number of its writer, and a reader on another XCD reports the launch as failed instead of using the sums.
@@ -108,10 +108,16 @@ __device__ __forceinline__ void note_infinite_reciprocal(const HibagBatchView &B
 	}
 }
 
-// a parked sum: read past the CU's L1
+// a parked sum: read past the CU's L1 (global_load_dwordx2 ... sc1), and WRITTEN sc1 too -- producer and consumer then match
+// the first row of MI355X_MICROARCH.md's hand-off table ("stores, all sc1 / loads, all sc1", one lane's sc1 flag store behind
+// every storing wave's vmcnt(0) and the workgroup barrier, an sc1 poll).  A handful of 8-byte stores per chunk: no measurable cost.
 __device__ __forceinline__ double load_parked(const double *p)
 {
 	return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void store_parked(double *p, double v)
+{
+	__hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // first classifier of a tile whose cost prefix reaches `target` (acc_cum row of the tile: C + 1 entries)
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, 
 			else CALL(HIBAG_ENGINE_I8S)
 #undef CALL
 #undef CALLX
-			if (!last) { B.tot[at] = total; B.inv[at] = cell; }
+			if (!last) { store_parked(&B.tot[at], total); store_parked(&B.inv[at], cell); }
 			if (VOTE) vlog[0] = uint4{(uint32_t)__double2loint(vmax), (uint32_t)__double2hiint(vmax), (uint32_t)vcnt, 0u};
 		} else if (!FP4ONLY) {
 #define CALL(N) total = classifier_total<N>(M, B, c, s, item[1], item[2], item[3], rows, tab_s)

@@ -319,7 +319,9 @@ __global__ __launch_bounds__(ACCUM_WAVES * HIBAG_WAVE, ACCUM_OCC) void k_accum(H
 	}
 
 	// the item's sums, or -- parked -- what the workgroup behind continues from
-	for (int j = 0; j < ncell; j++) B.part[(size_t)(p0 + j) * B.n_pad + s] = acc[j][lane];
+	// (parked sums leave as sc1 stores, like the loads that pick them up: load_parked / store_parked)
+	if (ce < C) for (int j = 0; j < ncell; j++) store_parked(&B.part[(size_t)(p0 + j) * B.n_pad + s], acc[j][lane]);
+	else for (int j = 0; j < ncell; j++) B.part[(size_t)(p0 + j) * B.n_pad + s] = acc[j][lane];
 	// The workgroup that ends tile 0 of its sample groups also forms their ensemble scalars (k_scalars' loop, classifiers in
 	// order): one kernel and its launch gap less on the step.
 	if (tile == 0 && ce == C) ensemble_scalars<8>(M, B, s, nullptr);      // (eight loads in flight: sixteen would set the kernel's register count)

@@ -107,7 +107,13 @@ void run_core(hibag_hip_model *m, HibagBatchView &B, int vote_method, double *d_
 	hibag_launch_total(m->view, B, st, m->side, vote_method == 2);
 	T.end(st);
 	debug_stage("pass 1", st);
-	T.begin(HIBAG_HIP_K_ACCUM, st, true);
+	// HIBAG_DEBUG_THRASH_MB=<mb> (measurement only, profiles/r06_notes.txt): overwrite that much scratch memory between the
+	// passes, so that pass 2 finds nothing of pass 1's stored sums in the L2s or the Infinity Cache -- what a schedule that keeps
+	// them cache-resident could gain at most is the difference to the run without.
+	static const long thrash_mb = getenv("HIBAG_DEBUG_THRASH_MB") ? atol(getenv("HIBAG_DEBUG_THRASH_MB")) : 0;
+	if (thrash_mb > 0 && m->ws_thrash.reserve((size_t)thrash_mb << 20) == 0)
+		(void)hipMemsetAsync(m->ws_thrash.p, 0x5a, (size_t)thrash_mb << 20, st);
+	T.begin(HIBAG_HIP_K_ACCUM, st, thrash_mb <= 0);
 	if (vote_method == 1) {
 		hibag_launch_accum(m->view, B, st);
 		debug_stage("pass 2 (accumulate)", st);

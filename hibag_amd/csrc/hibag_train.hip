@@ -43,6 +43,7 @@
 #include "hibag_plugin.h"
 #include "hibag_pool.h"
 #include "hibag_em.h"
+#include "hibag_combine.h"
 
 int hibag_fail(int code, const char *fmt, ...);       // hibag_api.hip: sets the thread's last error
 int hibag_selected_device();                          // hibag_api.hip: the thread's hibag_hip_set_device() choice
@@ -181,6 +182,7 @@ struct hibag_hip_trainer {
 	PairSet pl;
 	int n_threads = 1;                          // host threads that fit candidate SNPs concurrently
 	int em_mode = 0;                            // where the EM fits run: 0 = by the thread count, 1 = host threads, 2 = device (hibag_em.hip)
+	bool shared = false;                        // runs beside other trainers of the process: its device work goes through the combiners (hibag_combine.h)
 	std::unique_ptr<Pool> pool;                 // n_threads - 1 helpers, created by the first training call
 
 	double unif() { return unif_fn ? unif_fn(unif_ctx) : rng.unif(); }
@@ -199,14 +201,16 @@ typedef hibag_hip_trainer T;
 // wall-clock split of a training call, printed when HIBAG_TRAIN_PROFILE is set
 struct Profile {
 	double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};           // the calling thread's CPU time in the same phases (what the phase costs the host, waits excluded)
 	static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+	static double cpu() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 };
 thread_local Profile g_prof;                          // (the calling thread's: trainers may run side by side)
 thread_local long long g_em_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // candidates fitted on the device, of them handed back to the host, device iterations; growth steps' pairs (sum, max), longest transposed list
 struct Tick {
-	int k; double t0;
-	explicit Tick(int k_) : k(k_), t0(Profile::now()) {}
-	~Tick() { g_prof.t[k] += Profile::now() - t0; }
+	int k; double t0, c0;
+	explicit Tick(int k_) : k(k_), t0(Profile::now()), c0(Profile::cpu()) {}
+	~Tick() { g_prof.t[k] += Profile::now() - t0; g_prof.c[k] += Profile::cpu() - c0; }
 };
 
 void select(T &t, Sampling &s, int m_try)                               // RandomSelect, :949-962
@@ -762,6 +766,32 @@ int hibag_hip_trainer_set_em_mode(hibag_hip_trainer *t, int mode)
 	return 0;
 }
 
+int hibag_hip_trainer_set_shared(hibag_hip_trainer *t, int shared)
+{
+	if (!t) return hibag_fail(HIBAG_HIP_EINVAL, "trainer is NULL");
+	std::lock_guard<std::mutex> g(t->lock);
+	t->shared = shared != 0;
+	return 0;
+}
+
+int hibag_hip_train_set_thread_budget(int n_threads)
+{
+	hibag_combine_set_budget(n_threads);
+	return 0;
+}
+
+int hibag_hip_train_combine_stats(long long *launches, long long *ops, int reset)
+{
+	hibag_combine_stats(launches, ops, reset);
+	return 0;
+}
+
+int hibag_hip_train_combine_times(double *out12, int reset)
+{
+	hibag_combine_times(out12, reset);
+	return 0;
+}
+
 int hibag_hip_trainer_set_seed(hibag_hip_trainer *t, uint32_t seed)
 {
 	if (!t) return hibag_fail(HIBAG_HIP_EINVAL, "trainer is NULL");
@@ -788,6 +818,12 @@ int hibag_hip_trainer_new_classifiers(hibag_hip_trainer *t, int nclassifier, int
 	const size_t before = t->out.size();
 	if (hibag_hip_set_device(t->device)) return HIBAG_HIP_ENODEV;     // the build entries allocate on the selected device
 	if (hipSetDevice(t->device) != hipSuccess) return hibag_fail(HIBAG_HIP_ENODEV, "hipSetDevice(%d) failed", t->device);
+	// a trainer that runs beside others hands its device work to the device's combiners (one fused launch per kind of
+	// operation for all of them) and counts against the shared host-thread budget while it is runnable
+	struct Shared {
+		explicit Shared(bool on) { hibag_combine_set_shared(on); hibag_combine_enter(); }
+		~Shared() { hibag_combine_leave(); hibag_combine_set_shared(false); }
+	} shared_scope(t->shared);
 	try {
 		if (!t->pool && t->n_threads > 1) t->pool.reset(new Pool(t->n_threads - 1));
 		g_prof = Profile();
@@ -806,6 +842,9 @@ int hibag_hip_trainer_new_classifiers(hibag_hip_trainer *t, int nclassifier, int
 				"[pack %.3f (staging %.3f, allocation %.3f), copy+kernels %.3f, read-back %.3f, reductions %.3f], compare + accept %.3f, select %.3f; search() %.3f, %d growth steps\n",
 				Profile::now() - t0, g_prof.t[0], g_prof.t[1], g_prof.t[2], g_batch_prof[0], g_batch_prof[4], g_batch_prof[5], g_batch_prof[1], g_batch_prof[2], g_batch_prof[3],
 				g_prof.t[3], g_prof.t[4], g_prof.t[5], (int)g_prof.t[7]);
+		if (getenv("HIBAG_TRAIN_PROFILE"))
+			fprintf(stderr, "[hibag train] this thread's CPU time: pair lists %.3f, EM %.3f, scoring %.3f, compare %.3f, select %.3f; search() %.3f s = %.3f ms per growth step\n",
+				g_prof.c[0], g_prof.c[1], g_prof.c[2], g_prof.c[3], g_prof.c[4], g_prof.c[5], g_prof.t[7] > 0 ? 1e3 * g_prof.c[5] / g_prof.t[7] : 0.0);
 	} catch (const char *msg) {
 		t->out.resize(before);                         // a failed call adds nothing
 		return hibag_fail(hibag_hip_device_count() <= 0 ? HIBAG_HIP_ENODEV : HIBAG_HIP_EINVAL, "%s", msg);

@@ -171,6 +171,11 @@ class _Trainer:
         """Where the EM fits run: "auto" (the device where the trainer has two host threads or fewer), "host", "device"."""
         _lib.check(_lib.lib().hibag_hip_trainer_set_em_mode(self._h, {"auto": 0, "host": 1, "device": 2}[mode]))
 
+    def set_shared(self, shared: bool = True):
+        """The trainer runs beside others of this process: its device work goes through the device's combiners -- one fused
+        launch per kind of operation for all of them (``csrc/hibag_combine.h``).  Same classifiers, bit for bit."""
+        _lib.check(_lib.lib().hibag_hip_trainer_set_shared(self._h, int(bool(shared))))
+
     @property
     def threads(self) -> int:
         return int(_lib.lib().hibag_hip_trainer_threads(self._h))
@@ -375,14 +380,21 @@ def _usable_cpus() -> int:
 
 
 def grow_concurrently(genomat, h1, h2, n_hla: int, nclassifier: int, mtry: int, prune: bool, n_trainers: int,
-                      threads_per_trainer: int, seed: int, device: Optional[int] = None, em: str = "auto") -> List[Classifier]:
+                      threads_per_trainer: int, seed: int, device: Optional[int] = None, em: str = "auto",
+                      combine: bool = True, thread_budget: int = 0) -> List[Classifier]:
     """``n_trainers`` independent trainers of ONE process side by side on one device, each driven by its own host thread
     (the native calls release the interpreter lock; the library keeps its training state and its default stream per host
     thread) with ``threads_per_trainer`` host threads of its own for the EM fits: while one trainer's candidates are
     fitted on the host, another's are scored on the device.  Trainer r grows ``shard_bounds(nclassifier, n_trainers, r)``
     classifiers from R's Mersenne-Twister seeded with ``seed + r`` -- the streams of ``hlaParallelAttrBagging``'s workers
     (``R/HIBAG.R:329-390``: ``clusterSetRNGStream``-like, one stream per worker) -- and the shares are concatenated in
-    trainer order.  Every classifier equals what a serial trainer grows from the same stream."""
+    trainer order.  Every classifier equals what a serial trainer grows from the same stream.
+
+    ``combine`` (default): the trainers share the device through its combiners -- one fused launch per kind of operation
+    (pair lists, EM fits, scoring) for all of them instead of a stream each (``csrc/hibag_combine.h``).  ``thread_budget`` > 0:
+    at most that many of the trainers' host threads are runnable at a time -- a trainer waiting for the device gives its
+    slot up -- so ``n_trainers`` may be far larger than the host threads the process is allowed (sixteen trainers on the two
+    threads a rank of an eight-GPU node gets)."""
     import threading
     from .dist import shard_bounds
     k = max(1, min(int(n_trainers), max(int(nclassifier), 1)))
@@ -402,6 +414,7 @@ def grow_concurrently(genomat, h1, h2, n_hla: int, nclassifier: int, mtry: int, 
             try:
                 tr.set_em_mode(em)
                 tr.set_threads(int(threads_per_trainer))
+                tr.set_shared(bool(combine) and k > 1)
                 tr.set_seed(int(seed) + r)
                 tr.new_classifiers(hi - lo, mtry, prune, False, False)
                 parts[r] = tr.classifiers()
@@ -410,11 +423,16 @@ def grow_concurrently(genomat, h1, h2, n_hla: int, nclassifier: int, mtry: int, 
         except BaseException as e:                                             # noqa: BLE001 -- re-raised by the caller's thread
             errs[r] = e
 
+    _lib.lib().hibag_hip_train_set_thread_budget(int(thread_budget) if combine and k > 1 else 0)
     ths = [threading.Thread(target=work, args=(r,), name=f"hibag-trainer-{r}") for r in range(k)]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
+    try:
+        for t in ths:
+            t.start()
+    finally:
+        for t in ths:
+            if t.ident is not None:
+                t.join()
+        _lib.lib().hibag_hip_train_set_thread_budget(0)
     for e in errs:
         if e is not None:
             raise e

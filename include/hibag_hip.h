@@ -23,7 +23,7 @@ extern "C" {
 
 #define HIBAG_HIP_ABI_VERSION 7   /* 2: + PLINK BED entries, training driver; 3: + hibag_hip_predict_mapped[_device]; 4: + hibag_hip_model_stored_cells;
                                      5: + hibag_hip_model_status / _clear_status, hibag_hip_predict_multi, hibag_hip_model_replicate, hibag_hip_model_engine;
-                                     7: + hibag_hip_predict_snp_major[_device] */
+                                     7: + hibag_hip_predict_snp_major[_device], hibag_hip_trainer_set_shared, hibag_hip_train_set_thread_budget */
 
 /* error codes */
 #define HIBAG_HIP_OK          0
@@ -347,6 +347,25 @@ int hibag_hip_trainer_threads(const hibag_hip_trainer *t);
  * host's order; the stopping test decided with a margin for the device's log(), candidates it cannot decide handed back to the
  * host), 0 = automatic: the device where the trainer has two host threads or fewer.  Both give the same classifiers bit for bit. */
 int hibag_hip_trainer_set_em_mode(hibag_hip_trainer *t, int mode);
+
+/* Several trainers of ONE process on one device -- the decomposition of hlaParallelAttrBagging's workers (R/HIBAG.R:329-390:
+ * independent classifiers, one random stream per worker) without a process per worker.  A trainer flagged `shared` hands
+ * the device work of its growth steps -- the candidate pair lists (src/LibHLA.cpp:1569-1637), the EM fits (:1127-1255), the
+ * scoring (:1639-1767) -- to the device's combiners: whichever trainer thread finds a combiner idle launches ONE fused
+ * kernel per kind of operation for every trainer that has one pending (hibag_amd/csrc/hibag_combine.h), instead of each
+ * trainer queueing short kernels behind the others' on the runtime's few hardware queues.  Classifiers are bit-identical to
+ * a trainer that runs alone.  Each shared trainer is still driven by a host thread of its own (hibag_hip_trainer_new_classifiers
+ * blocks), but those threads mostly wait: hibag_hip_train_set_thread_budget(n) lets at most n of them be runnable at a
+ * time (0 = no limit; process-wide), so sixteen trainers fit the two host threads a rank of an eight-GPU node gets.
+ * hibag_hip_train_combine_stats: fused launches and the operations in them since the last reset, by kind
+ * (0 / 1 pair lists pass 0 / 1 as operations of their own, 2 scoring, 3 EM fits, 4 pair lists, both passes in one); out
+ * arrays of 8 (either may be NULL). */
+int hibag_hip_trainer_set_shared(hibag_hip_trainer *t, int shared);
+int hibag_hip_train_set_thread_budget(int n_threads);
+int hibag_hip_train_combine_stats(long long *launches, long long *ops, int reset);
+/* seconds the shared trainers' operations took from hand-over to results, summed by kind [0..7]; seconds spent in fused
+ * batches and their number, for the short operations' lane and the EM lane [8..9], [10..11] (measurement only) */
+int hibag_hip_train_combine_times(double *out12, int reset);
 
 /* Source of the uniform draws the reference takes from R's unif_rand()
  * (src/LibHLA.cpp:120-126; bootstrap :2236, SNP sampling :957).  An R binding
