@@ -816,45 +816,65 @@ def other_configs(K, faults=None):
                                           "one-GPU measurement at that thread count, no 8-GPU node was available to the build"}}
         from oracle import oracle as O
         O.build()
-        # Several trainers side by side on the one device (train.grow_concurrently: one host thread, default stream and
-        # training state each, R's stream seeded with seed + r like hlaParallelAttrBagging's workers) at the SAME budget of
-        # host threads: a single trainer leaves the device idle ~3/4 of a growth step (its candidates' EM fits run on the host).
+        # Several trainers side by side on the one device (train.grow_concurrently), their device work fused into one launch
+        # per kind of operation (csrc/hibag_combine.h) and their host threads under a BUDGET: sixteen trainers (one thread each,
+        # EM fits on the device, R's stream seeded with seed + r like hlaParallelAttrBagging's workers), of which at most
+        # `budget` are runnable at a time -- a trainer that waits for the device sleeps.  budget 4 = the headline; budget =
+        # cores / 8 = what a rank of an eight-GPU node gets; and for reference round 5's arrangement (4 trainers x 4 threads,
+        # EM fits on the host threads, a stream per trainer).
         try:
+            import resource
             import threading
             from hibag_amd.dist import shard_bounds
             conc = {}
-            best_k, best_rate, best_cls = 1, 1.0 / dt, None
-            for k in (2, 4, 8):
-                per = max(1, cores // k)
-                train.grow_concurrently(G, truth[:, 0], truth[:, 1], mdl.n_hla, k, mtry, True, k, per, 100)      # warm-up
-                t = time.perf_counter()
-                got = train.grow_concurrently(G, truth[:, 0], truth[:, 1], mdl.n_hla, ncl, mtry, True, k, per, 100)
+            best_rate, best_cls, best_k, best_key = 0.0, None, 1, None
+
+            def concurrent(key, k, per, em, budget, combine=True):
+                nonlocal best_rate, best_cls, best_k, best_key
+                kw = dict(em=em, combine=combine, thread_budget=budget)
+                train.grow_concurrently(G, truth[:, 0], truth[:, 1], mdl.n_hla, k, mtry, True, k, per, 100, **kw)      # warm-up
+                r0, t = resource.getrusage(resource.RUSAGE_SELF), time.perf_counter()
+                got = train.grow_concurrently(G, truth[:, 0], truth[:, 1], mdl.n_hla, ncl, mtry, True, k, per, 100, **kw)
                 dtk = time.perf_counter() - t
-                conc[str(k)] = {"trainers": k, "threads_per_trainer": per, "classifiers": ncl, "seconds": dtk,
-                                "classifiers_per_s": ncl / dtk}
-                if ncl / dtk > best_rate:
-                    best_k, best_rate, best_cls = k, ncl / dtk, got
+                r1 = resource.getrusage(resource.RUSAGE_SELF)
+                conc[key] = {"trainers": k, "threads_per_trainer": per, "em_fits": em, "host_thread_budget": budget or None,
+                             "launches": "fused across trainers" if combine else "a stream per trainer",
+                             "classifiers": ncl, "seconds": dtk, "classifiers_per_s": ncl / dtk,
+                             "host_cores_busy": round((r1.ru_utime + r1.ru_stime - r0.ru_utime - r0.ru_stime) / dtk, 2)}
+                return got
+            cls4 = concurrent("16_trainers_budget_4", 16, 1, "device", min(4, cores))
+            concurrent("16_trainers_budget_cores_over_8", 16, 1, "device", per_rank)
+            concurrent("4x4_host_em_own_streams", 4, max(1, cores // 4), "host", 0, combine=False)
+            best_k, best_cls, best_key = 16, cls4, "16_trainers_budget_4"
+            best_rate = conc[best_key]["classifiers_per_s"]
             res["cfg5_training"]["concurrent_trainers"] = conc
             res["cfg5_training"]["single_trainer_classifiers_per_s"] = 1.0 / dt
-            if best_cls is not None:
-                # checked against the oracle: the first two classifiers of EVERY trainer's stream (one oracle run per stream,
-                # the streams side by side on the host's threads)
-                chk = [None] * best_k
+            # checked against the oracle: the first two classifiers of EVERY trainer's stream (one oracle run per stream,
+            # the streams side by side on the host's threads)
+            chk = [None] * best_k
 
-                def check(r):
-                    lo, hi = shard_bounds(ncl, best_k, r)
-                    want = O.train(G, truth[:, 0], truth[:, 1], mdl.n_hla, min(2, hi - lo), mtry, True, 100 + r)
-                    chk[r] = all(np.array_equal(a.snpidx, b["snpidx"]) and np.array_equal(a.freq, b["freq"]) and a.haplo == b["haplo"]
-                                 and np.array_equal(a.samp_num, b["samp_num"]) for a, b in zip(best_cls[lo:lo + 2], want))
-                th = [threading.Thread(target=check, args=(r,)) for r in range(best_k)]
-                [x.start() for x in th]; [x.join() for x in th]
-                res["cfg5_training"].update({
-                    "classifiers_per_s": best_rate, "s_per_classifier": 1.0 / best_rate, "model_of_100_classifiers_s": ncl / best_rate,
-                    "trainers": best_k, "threads": cores,
-                    "what": f"{best_k} trainers side by side on one MI355X, {max(1, cores // best_k)} host threads each ({cores} in all), "
-                            f"stream r seeded with 100 + r; a single trainer with all {cores} threads: {1.0 / dt:.1f} classifiers/s",
-                    "oracle_check": {"classifiers_compared": 2 * best_k, "what": "the first two classifiers of every trainer's stream",
-                                     "identical": bool(all(chk))}})
+            def check(r):
+                lo, hi = shard_bounds(ncl, best_k, r)
+                want = O.train(G, truth[:, 0], truth[:, 1], mdl.n_hla, min(2, hi - lo), mtry, True, 100 + r)
+                chk[r] = all(np.array_equal(a.snpidx, b["snpidx"]) and np.array_equal(a.freq, b["freq"]) and a.haplo == b["haplo"]
+                             and np.array_equal(a.samp_num, b["samp_num"]) for a, b in zip(best_cls[lo:lo + 2], want))
+            th = [threading.Thread(target=check, args=(r,)) for r in range(best_k)]
+            [x.start() for x in th]; [x.join() for x in th]
+            one8 = conc["16_trainers_budget_cores_over_8"]
+            res["cfg5_training"].update({
+                "classifiers_per_s": best_rate, "s_per_classifier": 1.0 / best_rate, "model_of_100_classifiers_s": ncl / best_rate,
+                "trainers": best_k, "threads": min(4, cores), "host_cores_busy": conc[best_key]["host_cores_busy"],
+                "what": f"{best_k} trainers side by side on one MI355X, one fused launch per kind of device work for all of them, EM fits on "
+                        f"the device, at most {min(4, cores)} of their host threads runnable at a time; stream r seeded with 100 + r; a single "
+                        f"trainer with all {cores} threads: {1.0 / dt:.1f} classifiers/s",
+                "oracle_check": {"classifiers_compared": 2 * best_k, "what": "the first two classifiers of every trainer's stream",
+                                 "identical": bool(all(chk))}})
+            res["cfg5_training"]["at_one_eighth_of_the_host"].update({
+                "concurrent": one8, "classifiers_per_s": one8["classifiers_per_s"],
+                "slowdown_vs_budget_4": best_rate / one8["classifiers_per_s"],
+                "projected_8_ranks_concurrent": {"classifiers_per_s": 8 * one8["classifiers_per_s"],
+                                                 "what": f"eight ranks, each sixteen trainers on its own GPU under a budget of {per_rank} host threads "
+                                                         "(measured on one GPU at that budget; no 8-GPU node was available to the build)"}})
         except Exception as e:
             res["cfg5_training"]["concurrent_trainers"] = {"error": repr(e)}
         # the oracle's one-core restatement of the reference's training driver on the same data, same random stream
@@ -882,8 +902,8 @@ def other_configs(K, faults=None):
             "sample": f"{cores} oracle trainers side by side, one classifier each, seeds 200.. ({dtc:.1f} s)"}
         res["cfg5_training"]["speedup_vs_one_cpu_thread"] = dto * res["cfg5_training"]["classifiers_per_s"]
         res["cfg5_training"]["speedup_vs_cpu_baseline"] = res["cfg5_training"]["classifiers_per_s"] / (cores / dtc)
-        res["cfg5_training"]["speedup_note"] = ("speedup_vs_cpu_baseline: the GPU line (device + `threads` host threads) against the same "
-                                                "number of host threads running the CPU port; speedup_vs_one_cpu_thread: against one core")
+        res["cfg5_training"]["speedup_note"] = ("speedup_vs_cpu_baseline: the GPU line (device + a budget of `threads` host threads) against ALL "
+                                                f"{cores} usable cores running the CPU port; speedup_vs_one_cpu_thread: against one core")
     except Exception as e:
         res["cfg5_training"] = dict(res.get("cfg5_training", {}), error=repr(e))
     # A REAL model: the reference's bundled HLA-A model (inst/extdata/ModelList.RData: 100 classifiers, 14 alleles, 18-87

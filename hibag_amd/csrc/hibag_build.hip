@@ -919,128 +919,61 @@ void hibag_build_eval_launch(int slot, const PluginGenotype base_geno[], int n_s
 	size_t H = 0;
 	for (int c = 0; c < n_cand; c++) H += (size_t)cand[c].n_haplo;
 	const size_t Hs = std::max<size_t>(H, 1);
-	std::vector<uint32_t> hb((size_t)nw * Hs, 0), cw((size_t)n_cand * 2 * np);
-	std::vector<double> hf(Hs, 0.0);
-	std::vector<int> start((size_t)n_cand * (nh + 1), 0), cells, seg;
 	static const int wave_target = getenv("HIBAG_BATCH_WAVES") ? atoi(getenv("HIBAG_BATCH_WAVES")) : 8192;
 	const int n_seg = std::max(1, std::min(64, wave_target / std::max(1, (np / HIBAG_WAVE) * n_cand)));
+
+	// Pass 1 (small): per candidate the haplotypes per allele and the list of its non-empty cells, in posterior order.  The
+	// scratch lives with the thread: a growth step is a millisecond, and allocating (and page-faulting) a few hundred KB of
+	// vectors per step was a quarter of what the step cost the host.
+	struct Scratch {
+		std::vector<int> start, true_cell, at;
+		std::vector<std::vector<int>> cell_list;
+		std::vector<std::vector<uint64_t>> cell_work;
+		std::vector<uint32_t> base_w1, base_w2;
+	};
+	static thread_local Scratch S;
+	S.start.assign((size_t)n_cand * (nh + 1), 0);
+	if ((int)S.cell_list.size() < n_cand) { S.cell_list.resize(n_cand); S.cell_work.resize(n_cand); }
 	int max_cells = 1;
-	std::vector<uint32_t> base_w1(np), base_w2(np);            // word `word` of every sample's base genotype
-	for (int s = 0; s < n; s++) {
-		base_w1[s] = (uint32_t)((uint64_t)base_geno[s].snp1[word >> 1] >> (32 * (word & 1)));
-		base_w2[s] = (uint32_t)((uint64_t)base_geno[s].snp2[word >> 1] >> (32 * (word & 1)));
-	}
-	std::vector<std::vector<int>> cell_list(n_cand);
-	std::vector<std::vector<uint64_t>> cell_work(n_cand);
-	size_t off = 0;
-	for (int c = 0; c < n_cand; c++) {
-		const PluginHaplotype *hp = cand[c].haplo;
-		int *st = &start[(size_t)c * (nh + 1)];
-		for (int i = 0; i < cand[c].n_haplo; i++) {
-			for (int w = 0; w < nw; w++) {
-				uint32_t v = (uint32_t)((uint64_t)hp[i].packed[w >> 1] >> (32 * (w & 1)));
-				const int lo = 32 * w;
-				if (n_snp < lo + 32) v &= (n_snp <= lo) ? 0u : ((1u << (n_snp - lo)) - 1);
-				hb[(size_t)w * Hs + off + i] = v;
+	{
+		size_t off = 0;
+		for (int c = 0; c < n_cand; c++) {
+			const PluginHaplotype *hp = cand[c].haplo;
+			int *st = &S.start[(size_t)c * (nh + 1)];
+			for (int i = 0; i < cand[c].n_haplo; i++) {
+				const int a = hp[i].aux.hla_allele;
+				if (a < 0 || a >= nh) build_throw("haplotype with an invalid HLA allele index");
+				st[a + 1]++;
 			}
-			hf[off + i] = hp[i].freq;
-			const int a = hp[i].aux.hla_allele;
-			if (a < 0 || a >= nh) build_throw("haplotype with an invalid HLA allele index");
-			st[a + 1]++;
-		}
-		st[0] = (int)off;
-		for (int h = 0; h < nh; h++) st[h + 1] += st[h];
-		off += (size_t)cand[c].n_haplo;
-		for (int h1 = 0; h1 < nh; h1++) {
-			const uint64_t n1 = (uint64_t)(st[h1 + 1] - st[h1]);
-			if (!n1) continue;
-			for (int h2 = h1; h2 < nh; h2++) {
-				const uint64_t n2 = (uint64_t)(st[h2 + 1] - st[h2]);
-				if (!n2) continue;
-				cell_list[c].push_back((h1 << 16) | h2);
-				cell_work[c].push_back(h1 == h2 ? n1 * (n1 + 1) / 2 : n1 * n2);
+			st[0] = (int)off;
+			for (int h = 0; h < nh; h++) st[h + 1] += st[h];
+			off += (size_t)cand[c].n_haplo;
+			std::vector<int> &cl = S.cell_list[c];
+			std::vector<uint64_t> &cwk = S.cell_work[c];
+			cl.clear(); cwk.clear();
+			for (int h1 = 0; h1 < nh; h1++) {
+				const uint64_t n1 = (uint64_t)(st[h1 + 1] - st[h1]);
+				if (!n1) continue;
+				for (int h2 = h1; h2 < nh; h2++) {
+					const uint64_t n2 = (uint64_t)(st[h2 + 1] - st[h2]);
+					if (!n2) continue;
+					cl.push_back((h1 << 16) | h2);
+					cwk.push_back(h1 == h2 ? n1 * (n1 + 1) / 2 : n1 * n2);
+				}
 			}
-		}
-		max_cells = std::max(max_cells, (int)cell_list[c].size());
-		// the candidate SNP's bit in the two planes of its word (branch-free: the compiler vectorises it)
-		{
-			uint32_t *o1 = &cw[((size_t)c * 2) * np], *o2 = &cw[((size_t)c * 2 + 1) * np];
-			const int32_t *col = cand[c].column;
-			const uint32_t keep = ~(1u << bit);
-			for (int s = 0; s < n; s++) {
-				const uint32_t v = (uint32_t)col[s];
-				const uint32_t b1 = (uint32_t)(v == 1u) | (uint32_t)(v == 2u), b2 = (uint32_t)(v > 1u);   // TGenotype::_SetSNP, src/LibHLA.cpp:609-622
-				o1[s] = (base_w1[s] & keep) | (b1 << bit);
-				o2[s] = (base_w2[s] & keep) | (b2 << bit);
-			}
-			for (int s = n; s < np; s++) { o1[s] = 0u; o2[s] = 0xFFFFFFFFu; }      // padding lanes: all missing
+			max_cells = std::max(max_cells, (int)cl.size());
 		}
 	}
 	max_cells = (max_cells + SCAN_NB - 1) / SCAN_NB * SCAN_NB;
-	cells.assign((size_t)n_cand * max_cells, 0);
-	std::vector<int> cellb((size_t)n_cand * max_cells * 4, 0);
-	for (int c = 0; c < n_cand; c++) {
-		const int *st = &start[(size_t)c * (nh + 1)];
-		for (size_t i = 0; i < cell_list[c].size(); i++) {
-			const int h1 = cell_list[c][i] >> 16, h2 = cell_list[c][i] & 0xFFFF;
-			int *r = &cellb[((size_t)c * max_cells + i) * 4];
-			r[0] = st[h1]; r[1] = st[h1 + 1]; r[2] = st[h2]; r[3] = st[h2 + 1];
-		}
-	}
-	seg.assign((size_t)n_cand * (n_seg + 1), 0);
-	for (int c = 0; c < n_cand; c++) {
-		std::copy(cell_list[c].begin(), cell_list[c].end(), cells.begin() + (size_t)c * max_cells);
-		uint64_t total = 0;
-		for (uint64_t w : cell_work[c]) total += w + 4;
-		int *sg = &seg[(size_t)c * (n_seg + 1)];
-		uint64_t acc = 0;
-		int k = 1;
-		for (size_t i = 0; i < cell_list[c].size(); i++) {            // equal work per segment, contiguous cells
-			while (k < n_seg && acc * n_seg >= total * k) sg[k++] = (int)i;
-			acc += cell_work[c][i] + 4;
-		}
-		while (k <= n_seg) sg[k++] = (int)cell_list[c].size();
-	}
-
-	// genotype planes and true pairs of the cohort (what upload_geno does, but into the same transfer)
-	std::vector<uint32_t> planes((size_t)2 * NW * np);
-	std::vector<int> true_cell(np, -1);
-	g.true1.assign(n, 0); g.true2.assign(n, 0);
-	for (int w = 0; w < NW; w++)
-		for (int s = 0; s < np; s++) {
-			planes[(size_t)w * np + s] = s < n ? (uint32_t)((uint64_t)base_geno[s].snp1[w >> 1] >> (32 * (w & 1))) : 0u;
-			planes[(size_t)(NW + w) * np + s] = s < n ? (uint32_t)((uint64_t)base_geno[s].snp2[w >> 1] >> (32 * (w & 1))) : 0xFFFFFFFFu;
-		}
-	for (int s = 0; s < n; s++) {
-		int a1 = base_geno[s].hla1, a2 = base_geno[s].hla2;
-		if (a1 > a2) std::swap(a1, a2);
-		if (a1 < 0 || a2 >= nh) build_throw("genotype with an invalid true HLA pair");
-		g.true1[s] = a1; g.true2[s] = a2;
-		true_cell[s] = a2 + a1 * (2 * nh - a1 - 1) / 2;
-	}
-
-	// where each sample's true pair sits in each candidate's cell list
-	std::vector<int> wpos((size_t)n_cand * np, -1);
-	{
-		std::vector<int> at((size_t)nh * (nh + 1) / 2);
-		for (int c = 0; c < n_cand; c++) {
-			std::fill(at.begin(), at.end(), -1);
-			for (size_t i = 0; i < cell_list[c].size(); i++) {
-				const int h1 = cell_list[c][i] >> 16, h2 = cell_list[c][i] & 0xFFFF;
-				at[h2 + h1 * (2 * nh - h1 - 1) / 2] = (int)i;
-			}
-			for (int s = 0; s < n; s++) wpos[(size_t)c * np + s] = at[true_cell[s]];
-		}
-	}
 
 	// One device arena = [inputs | outputs | scratch]; the inputs travel in ONE copy from a pinned
 	// staging buffer and the outputs come back in one: a growth step is a handful of small arrays,
 	// and a dozen separate pageable copies cost more than the kernels.
 	size_t o = 0;
 	auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
-	const size_t o_hb = take(hb.size() * 4), o_cw = take(cw.size() * 4), o_start = take(start.size() * 4),
-		o_cells = take(cells.size() * 4), o_cellb = take(cellb.size() * 4), o_seg = take(seg.size() * 4), o_planes = take(planes.size() * 4),
-		o_true = take(true_cell.size() * 4), o_wpos = take(wpos.size() * 4), o_hf = take(hf.size() * 8), in_end = o;
+	const size_t o_hb = take((size_t)nw * Hs * 4), o_cw = take((size_t)n_cand * 2 * np * 4), o_start = take(S.start.size() * 4),
+		o_cells = take((size_t)n_cand * max_cells * 4), o_cellb = take((size_t)n_cand * max_cells * 16), o_seg = take((size_t)n_cand * (n_seg + 1) * 4),
+		o_planes = take((size_t)2 * NW * np * 4), o_true = take((size_t)np * 4), o_wpos = take((size_t)n_cand * np * 4), o_hf = take(Hs * 8), in_end = o;
 	const size_t b_best = (size_t)n_cand * 2 * np * 4, b_post = (size_t)n_cand * np * 8;
 	const size_t o_best = take(b_best), o_post = take(b_post), out_end = o;
 	const size_t o_cellv = take((size_t)n_cand * max_cells * np * 8);
@@ -1054,16 +987,102 @@ void hibag_build_eval_launch(int slot, const PluginGenotype base_geno[], int n_s
 	}
 	const double t_res1 = batch_now();
 	char *d = (char *)SL.d, *h = (char *)SL.h;
-	memcpy(h + o_hb, hb.data(), hb.size() * 4);
-	memcpy(h + o_cw, cw.data(), cw.size() * 4);
-	memcpy(h + o_start, start.data(), start.size() * 4);
-	memcpy(h + o_cells, cells.data(), cells.size() * 4);
-	memcpy(h + o_cellb, cellb.data(), cellb.size() * 4);
-	memcpy(h + o_seg, seg.data(), seg.size() * 4);
-	memcpy(h + o_planes, planes.data(), planes.size() * 4);
-	memcpy(h + o_true, true_cell.data(), true_cell.size() * 4);
-	memcpy(h + o_wpos, wpos.data(), wpos.size() * 4);
-	memcpy(h + o_hf, hf.data(), hf.size() * 8);
+
+	// Pass 2: every input array written where it travels from (the pinned staging area), once.
+	uint32_t *const hb = (uint32_t *)(h + o_hb), *const cw = (uint32_t *)(h + o_cw), *const planes = (uint32_t *)(h + o_planes);
+	double *const hf = (double *)(h + o_hf);
+	int *const cells = (int *)(h + o_cells), *const cellb = (int *)(h + o_cellb), *const seg = (int *)(h + o_seg),
+		*const true_cell = (int *)(h + o_true), *const wpos = (int *)(h + o_wpos);
+	memcpy(h + o_start, S.start.data(), S.start.size() * 4);
+	if (H == 0) { for (int w = 0; w < nw; w++) hb[w] = 0; hf[0] = 0.0; }
+	S.base_w1.resize(np); S.base_w2.resize(np);                      // word `word` of every sample's base genotype
+	for (int s = 0; s < n; s++) {
+		S.base_w1[s] = (uint32_t)((uint64_t)base_geno[s].snp1[word >> 1] >> (32 * (word & 1)));
+		S.base_w2[s] = (uint32_t)((uint64_t)base_geno[s].snp2[word >> 1] >> (32 * (word & 1)));
+	}
+	{
+		size_t off = 0;
+		for (int c = 0; c < n_cand; c++) {
+			const PluginHaplotype *hp = cand[c].haplo;
+			for (int i = 0; i < cand[c].n_haplo; i++) {
+				for (int w = 0; w < nw; w++) {
+					uint32_t v = (uint32_t)((uint64_t)hp[i].packed[w >> 1] >> (32 * (w & 1)));
+					const int lo = 32 * w;
+					if (n_snp < lo + 32) v &= (n_snp <= lo) ? 0u : ((1u << (n_snp - lo)) - 1);
+					hb[(size_t)w * Hs + off + i] = v;
+				}
+				hf[off + i] = hp[i].freq;
+			}
+			off += (size_t)cand[c].n_haplo;
+			// the candidate SNP's bit in the two planes of its word (branch-free: the compiler vectorises it)
+			uint32_t *o1 = &cw[((size_t)c * 2) * np], *o2 = &cw[((size_t)c * 2 + 1) * np];
+			const int32_t *col = cand[c].column;
+			const uint32_t keep = ~(1u << bit);
+			const uint32_t *b1p = S.base_w1.data(), *b2p = S.base_w2.data();
+			for (int s = 0; s < n; s++) {
+				const uint32_t v = (uint32_t)col[s];
+				const uint32_t b1 = (uint32_t)(v == 1u) | (uint32_t)(v == 2u), b2 = (uint32_t)(v > 1u);   // TGenotype::_SetSNP, src/LibHLA.cpp:609-622
+				o1[s] = (b1p[s] & keep) | (b1 << bit);
+				o2[s] = (b2p[s] & keep) | (b2 << bit);
+			}
+			for (int s = n; s < np; s++) { o1[s] = 0u; o2[s] = 0xFFFFFFFFu; }      // padding lanes: all missing
+			// the cell list, the cells' haplotype ranges, the segments of equal work
+			const int *st = &S.start[(size_t)c * (nh + 1)];
+			const std::vector<int> &cl = S.cell_list[c];
+			const std::vector<uint64_t> &cwk = S.cell_work[c];
+			int *cc = cells + (size_t)c * max_cells, *cbv = cellb + (size_t)c * max_cells * 4;
+			for (size_t i = 0; i < cl.size(); i++) {
+				const int h1 = cl[i] >> 16, h2 = cl[i] & 0xFFFF;
+				cc[i] = cl[i];
+				cbv[4 * i] = st[h1]; cbv[4 * i + 1] = st[h1 + 1]; cbv[4 * i + 2] = st[h2]; cbv[4 * i + 3] = st[h2 + 1];
+			}
+			for (size_t i = cl.size(); i < (size_t)max_cells; i++) { cc[i] = 0; cbv[4 * i] = cbv[4 * i + 1] = cbv[4 * i + 2] = cbv[4 * i + 3] = 0; }
+			uint64_t total = 0;
+			for (uint64_t w : cwk) total += w + 4;
+			int *sg = seg + (size_t)c * (n_seg + 1);
+			sg[0] = 0;
+			uint64_t acc = 0;
+			int k = 1;
+			for (size_t i = 0; i < cl.size(); i++) {                        // equal work per segment, contiguous cells
+				while (k < n_seg && acc * n_seg >= total * k) sg[k++] = (int)i;
+				acc += cwk[i] + 4;
+			}
+			while (k <= n_seg) sg[k++] = (int)cl.size();
+		}
+	}
+
+	// genotype planes and true pairs of the cohort (what upload_geno does, but into the same transfer)
+	g.true1.assign(n, 0); g.true2.assign(n, 0);
+	for (int w = 0; w < NW; w++) {
+		uint32_t *p1 = planes + (size_t)w * np, *p2 = planes + (size_t)(NW + w) * np;
+		for (int s = 0; s < n; s++) {
+			p1[s] = (uint32_t)((uint64_t)base_geno[s].snp1[w >> 1] >> (32 * (w & 1)));
+			p2[s] = (uint32_t)((uint64_t)base_geno[s].snp2[w >> 1] >> (32 * (w & 1)));
+		}
+		for (int s = n; s < np; s++) { p1[s] = 0u; p2[s] = 0xFFFFFFFFu; }
+	}
+	for (int s = 0; s < n; s++) {
+		int a1 = base_geno[s].hla1, a2 = base_geno[s].hla2;
+		if (a1 > a2) std::swap(a1, a2);
+		if (a1 < 0 || a2 >= nh) build_throw("genotype with an invalid true HLA pair");
+		g.true1[s] = a1; g.true2[s] = a2;
+		true_cell[s] = a2 + a1 * (2 * nh - a1 - 1) / 2;
+	}
+	for (int s = n; s < np; s++) true_cell[s] = -1;
+
+	// where each sample's true pair sits in each candidate's cell list
+	S.at.resize((size_t)nh * (nh + 1) / 2);
+	for (int c = 0; c < n_cand; c++) {
+		std::fill(S.at.begin(), S.at.end(), -1);
+		const std::vector<int> &cl = S.cell_list[c];
+		for (size_t i = 0; i < cl.size(); i++) {
+			const int h1 = cl[i] >> 16, h2 = cl[i] & 0xFFFF;
+			S.at[h2 + h1 * (2 * nh - h1 - 1) / 2] = (int)i;
+		}
+		int *wp = wpos + (size_t)c * np;
+		for (int s = 0; s < n; s++) wp[s] = S.at[true_cell[s]];
+		for (int s = n; s < np; s++) wp[s] = -1;
+	}
 	const double t1 = batch_now();
 	g_batch_prof[4] += t1 - t_res1; g_batch_prof[5] += t_res1 - t_res0;
 	BatchView B{nh, np, nw, n_cand, n_seg, word, (const uint32_t *)(d + o_hb), (const double *)(d + o_hf), (int)Hs,

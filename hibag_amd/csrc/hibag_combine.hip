@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <condition_variable>
 #include <cstdio>
 #include <ctime>
@@ -127,10 +128,18 @@ void launch_copies(const HibagCopy *c, int n, hipStream_t st)
 // (ROCm 7.2: a leader burnt a core for the length of every batch, profiles/r06_notes.txt), and the trainers' threads are
 // meant to cost the host next to nothing: poll the event between short sleeps instead (timer slack of the thread lowered
 // to a microsecond, so that a 25 us sleep is not rounded up to 75).
-hipError_t sleepy_wait(hipEvent_t ev)
+// `expect_s`: the shortest of the lane's recent batches -- the first sleep is half of that (a poll costs the host a few
+// microseconds, and an EM batch lasts forty naps), then 25 us naps.  (Sleeping most of the AVERAGE batch instead was measured:
+// batches differ too much, the overshoot cost 6 % of the throughput.)
+hipError_t sleepy_wait(hipEvent_t ev, double expect_s)
 {
 	static thread_local bool slack_set = false;
 	if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slack_set = true; }
+	if (expect_s > 200e-6) {
+		const long ns = (long)(0.5 * std::min(expect_s, 2e-3) * 1e9);
+		const timespec first{0, ns};
+		nanosleep(&first, nullptr);
+	}
 	const timespec nap{0, 25000};
 	for (;;) {
 		const hipError_t q = hipEventQuery(ev);
@@ -141,7 +150,7 @@ hipError_t sleepy_wait(hipEvent_t ev)
 
 // Everything of the batch is enqueued, then waited for once.  `done`: a blocking-sync event to sleep on (the leader of shared
 // trainers also gives up its host-thread slot meanwhile); nullptr: wait on the stream.
-hipError_t execute(HibagOp *const ops[], int n, hipStream_t st, hipEvent_t done)
+hipError_t execute(HibagOp *const ops[], int n, hipStream_t st, hipEvent_t done, double expect_s = 0)
 {
 	const bool give_up_slot = done != nullptr;
 	hipError_t err = hipSuccess;
@@ -173,7 +182,7 @@ hipError_t execute(HibagOp *const ops[], int n, hipStream_t st, hipEvent_t done)
 	}
 	if (give_up_slot) slot_release();
 	// (also after a failed enqueue: nothing of the batch may still be in flight)
-	if (done && err == hipSuccess && ok(hipEventRecord(done, st))) ok(sleepy_wait(done));
+	if (done && err == hipSuccess && ok(hipEventRecord(done, st))) ok(sleepy_wait(done, expect_s));
 	else ok(hipStreamSynchronize(st));
 	if (give_up_slot) slot_acquire();
 	{
@@ -184,11 +193,13 @@ hipError_t execute(HibagOp *const ops[], int n, hipStream_t st, hipEvent_t done)
 }
 
 // ---- the lanes ----------------------------------------------------------------------------------------------
-constexpr int LANE_SLOTS = 2;                     // batches of a lane in flight at a time (a stream and an event each)
+constexpr int LANE_SLOTS = 3;                     // batches of a lane in flight at a time (a stream and an event each)
 struct Lane {
 	std::mutex m;
 	std::vector<HibagOp *> pending;
 	bool busy[LANE_SLOTS] = {};
+	double recent[8] = {};                        // how long the lane's last batches took (seconds; 0 = none yet)
+	int recent_at = 0;
 	hipStream_t st[LANE_SLOTS] = {};
 	hipEvent_t ev[LANE_SLOTS] = {};
 };
@@ -265,19 +276,27 @@ void hibag_combine_run(HibagOp &op)
 		batch.swap(L.pending);
 		L.busy[slot] = true;
 		if (!L.st[slot]) {
-			if (hipStreamCreateWithFlags(&L.st[slot], hipStreamNonBlocking) != hipSuccess) L.st[slot] = nullptr;
+			// (the short operations' streams at the highest priority: streams of a priority class have hardware queues of their own
+			// -- an EM fit at the head of a queue never holds a pair list up -- and a short kernel goes ahead of a long one)
+			int pr_lo = 0, pr_hi = 0;
+			(void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
+			if (hipStreamCreateWithPriority(&L.st[slot], hipStreamNonBlocking, lane == 0 ? pr_hi : pr_lo) != hipSuccess) L.st[slot] = nullptr;
 			if (L.st[slot] && hipEventCreateWithFlags(&L.ev[slot], hipEventDisableTiming) != hipSuccess) L.ev[slot] = nullptr;
 		}
 		const hipStream_t st = L.st[slot];
 		const hipEvent_t ev = L.ev[slot];
-		lk.unlock();
+		double expect = 1e9;
+		for (double r : L.recent) expect = std::min(expect, r > 0 ? r : 0.0);      // (the shortest recent batch; 0 until eight are known)
 		const double t_b = now_s();
-		const hipError_t be = st && ev ? execute(batch.data(), (int)batch.size(), st, ev) : hipErrorOutOfMemory;
+		lk.unlock();
+		const hipError_t be = st && ev ? execute(batch.data(), (int)batch.size(), st, ev, expect) : hipErrorOutOfMemory;
+		const double took = now_s() - t_b;
 		{
 			std::lock_guard<std::mutex> sl(g_stat_m);
-			g_stat_time[8 + lane] += now_s() - t_b; g_stat_time[10 + lane] += 1;
+			g_stat_time[8 + lane] += took; g_stat_time[10 + lane] += 1;
 		}
 		lk.lock();
+		L.recent[L.recent_at++ & 7] = took;
 		// wake the batch's owners -- each on its own condition variable: nobody is woken for nothing -- and, if operations piled
 		// up meanwhile, ONE of their owners to lead them (whoever leads takes everything that is pending)
 		for (HibagOp *o : batch) { o->err = be; o->done = true; if (o != &op) o->cv.notify_one(); }

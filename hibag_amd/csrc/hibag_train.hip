@@ -466,12 +466,17 @@ int usable_threads()
 	int n = (int)std::thread::hardware_concurrency();
 	cpu_set_t set;
 	if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
-	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                     // cgroup v2
 		char quota[32];
 		long period = 0;
 		if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
 			n = std::min(n, std::max(1, (int)((atol(quota) + period / 2) / period)));
 		fclose(f);
+	} else {                                                                  // cgroup v1
+		long quota = -1, period = 0;
+		if (FILE *q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(q, "%ld", &quota) != 1) quota = -1; fclose(q); }
+		if (FILE *q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(q, "%ld", &period) != 1) period = 0; fclose(q); }
+		if (quota > 0 && period > 0) n = std::min(n, std::max(1, (int)((quota + period / 2) / period)));
 	}
 	int ranks = 1;
 	if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
@@ -497,8 +502,12 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 	int global_max_acc = 0;
 	double global_min_loss = 1e+30;
 
+	// (the candidate pair lists depend on the current haplotype list and the committed SNPs alone: a growth step that accepted
+	// no candidate leaves both as they were, and the step after it starts from the same lists -- half of all steps at config 5's
+	// shape; the reference recomputes them, src/LibHLA.cpp:2001, with the same result)
+	bool lists_current = false;
 	while (!vs.a.empty() && (int)o.snpidx.size() < MAX_SNP) {
-		{ Tick tk(0); prepare_haplotypes(t, out_haplo, next); }
+		if (!lists_current) { Tick tk(0); prepare_haplotypes(t, out_haplo, next); lists_current = true; }
 		int max_acc = global_max_acc, min_i = -1;
 		double min_loss = global_min_loss;
 		{ Tick tk(4); select(t, vs, mtry); }
@@ -645,6 +654,7 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 			global_max_acc = max_acc;
 			global_min_loss = min_loss;
 			out_haplo = minh;
+			lists_current = false;
 			o.snpidx.push_back(vs.at(min_i));
 			add_snp(t, vs.at(min_i));
 			if (prune) { vs.at(min_i) = -1; vs.remove_flag(); } else vs.remove(min_i);

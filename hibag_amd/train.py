@@ -371,11 +371,17 @@ def _usable_cpus() -> int:
     except AttributeError:
         n = os.cpu_count() or 1
     try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
         if quota != "max":
             n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
     except (OSError, ValueError):
-        pass
+        try:                                                                        # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
     return max(1, n)
 
 
@@ -386,8 +392,8 @@ def grow_concurrently(genomat, h1, h2, n_hla: int, nclassifier: int, mtry: int, 
     (the native calls release the interpreter lock; the library keeps its training state and its default stream per host
     thread) with ``threads_per_trainer`` host threads of its own for the EM fits: while one trainer's candidates are
     fitted on the host, another's are scored on the device.  Trainer r grows ``shard_bounds(nclassifier, n_trainers, r)``
-    classifiers from R's Mersenne-Twister seeded with ``seed + r`` -- the streams of ``hlaParallelAttrBagging``'s workers
-    (``R/HIBAG.R:329-390``: ``clusterSetRNGStream``-like, one stream per worker) -- and the shares are concatenated in
+    classifiers from R's Mersenne-Twister seeded with ``seed + r`` -- one stream per worker like ``hlaParallelAttrBagging``'s
+    (``R/HIBAG.R:329-390``), though not R's own cluster streams (L'Ecuyer-CMRG via ``clusterSetRNGStream``) -- and the shares are concatenated in
     trainer order.  Every classifier equals what a serial trainer grows from the same stream.
 
     ``combine`` (default): the trainers share the device through its combiners -- one fused launch per kind of operation
@@ -441,19 +447,29 @@ def grow_concurrently(genomat, h1, h2, n_hla: int, nclassifier: int, mtry: int, 
 
 def hlaConcurrentAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,
                              mtry: Union[str, float, int] = "sqrt", prune: bool = True, na_rm: bool = True,
-                             mono_rm: bool = True, maf: float = float("nan"), n_trainers: int = 4,
-                             nthread: Optional[int] = None, seed: int = 0, verbose: bool = True,
+                             mono_rm: bool = True, maf: float = float("nan"), n_trainers: int = 16,
+                             nthread: Optional[int] = None, seed: Optional[int] = None, verbose: bool = True,
                              device: Optional[int] = None) -> HlaAttrBagClass:
     """``hlaParallelAttrBagging``'s decomposition (``R/HIBAG.R:293-440``: independent workers, one random stream each, the
     classifiers combined in worker order) inside ONE process on ONE device: ``n_trainers`` trainers side by side
-    (:func:`grow_concurrently`), ``nthread`` host threads in all (default: the usable CPUs) shared out evenly.  A single
-    trainer leaves the device idle about three quarters of a growth step -- the EM fits of its candidates run on the host --
-    which the others' scoring passes fill."""
-    total = int(nthread) if nthread else _usable_cpus()
-    per = max(1, total // max(int(n_trainers), 1))
+    (:func:`grow_concurrently`), their device work fused into one launch per kind of operation, their EM fits on the device,
+    and at most ``nthread`` of their host threads runnable at a time (default: the usable CPUs, at most four -- more buys
+    nothing: a trainer's thread sleeps while the device works).  A single trainer leaves the device idle most of a growth
+    step; sixteen keep it busy on the host threads of four.
+
+    Random streams: trainer r draws from R's Mersenne-Twister seeded with ``seed + r``.  These are NOT the streams of R's
+    cluster workers -- ``hlaParallelAttrBagging`` sets those with ``parallel::clusterSetRNGStream`` (L'Ecuyer-CMRG,
+    ``R/HIBAG.R:338``) -- so the model differs from what R's workers would grow, as two runs of the reference with
+    different cluster sizes differ from each other.  ``seed=None`` (default): one integer drawn from the module's stream
+    (:func:`set_seed`), so that repeated calls give different models and ``set_seed(s)`` before the call makes it
+    reproducible -- like ``hlaAttrBagging``."""
+    total = int(nthread) if nthread else min(4, _usable_cpus())
+    if seed is None:
+        seed = int(_R.unif_rand() * 2147483647.0)
 
     def grow(genomat, h1, h2, n_hla, n, m, pr):
-        return grow_concurrently(genomat, h1, h2, n_hla, n, m, pr, n_trainers, per, seed, device)
+        return grow_concurrently(genomat, h1, h2, n_hla, n, m, pr, n_trainers, 1, seed, device, em="device",
+                                 combine=True, thread_budget=total)
 
     return hlaAttrBagging(hla, snp, nclassifier=nclassifier, mtry=mtry, prune=prune, na_rm=na_rm, mono_rm=mono_rm,
                           maf=maf, verbose=verbose, grow=grow, device=device)

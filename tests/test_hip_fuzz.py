@@ -189,7 +189,7 @@ def test_campaign_case_with_vector_engine_classifiers_last(oracle, monkeypatch):
 def test_entry_points_campaign(monkeypatch, tmp_path):
     """Time-boxed random campaign over the OTHER ways into the same kernels (HIBAG_FUZZ_SECONDS, default 15), each against
     hibag_hip_predict on the model-order matrix (which the campaign above pins to the oracle): the cohort's own matrix with a
-    column map and flips (hibag_hip_predict_mapped), a PLINK BED file in either storage mode (hibag_hip_predict_bed), the device
+    column map and flips (hibag_hip_predict_mapped; the same SNP-major through hibag_hip_predict_snp_major), a PLINK BED file in either storage mode (hibag_hip_predict_bed), the device
     entry on a caller's stream with device-resident data, replicas on the one device (hibag_hip_predict_multi), and classifier
     shards merged by the library's RCCL all-reduce (identical calls, posteriors to 1e-10: the summation order differs)."""
     import os
@@ -235,6 +235,13 @@ def test_entry_points_campaign(monkeypatch, tmp_path):
         got = m.predict_mapped(cohort, col, flip, vote, want_dosage=True, want_prob=True)
         if not same(got, want):
             bad.append((seed, "mapped"))
+        # -- the same cohort SNP-major ([SNP][sample], rows `ld` apart): hibag_hip_predict_snp_major gathers the model's rows
+        ld = n + int(rng.integers(0, 9))
+        wide = np.full((S + n_extra, ld), 9, np.int32)
+        wide[:, :n] = cohort.T
+        got = m.predict_snp_major(wide[:, :n], col, flip, vote, want_dosage=True, want_prob=True)
+        if not same(got, want):
+            bad.append((seed, "snp-major"))
         # -- the same cohort as a BED file (values outside 0..2 are missing there as here)
         if seed % 3 == 0:
             mode = int(rng.integers(0, 2))

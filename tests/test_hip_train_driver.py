@@ -131,19 +131,22 @@ def test_parallel_entry_single_rank(hib, oracle):
     del remap
 
 
+@pytest.mark.parametrize("combine,budget", [(True, 0), (True, 2), (False, 0)])
 @pytest.mark.parametrize("em", ["host", "device"])
-def test_concurrent_trainers_equal_a_serial_trainer_per_stream(hib, oracle, em):
+def test_concurrent_trainers_equal_a_serial_trainer_per_stream(hib, oracle, em, combine, budget):
     """Several trainers of one process side by side on one device (train.grow_concurrently: one host thread, one default
     stream and one training state each): trainer r draws from R's Mersenne-Twister seeded with seed + r, like the workers of
     hlaParallelAttrBagging (R/HIBAG.R:329-390), so its classifiers must equal the oracle's serial run from that seed --
-    field by field, with the EM fits on the trainers' host threads and on the device."""
+    field by field, with the EM fits on the trainers' host threads and on the device; with the trainers' device work fused
+    into one launch per kind of operation (csrc/hibag_combine.h), also under a budget of two runnable host threads, and with a
+    stream per trainer as in round 5."""
     from hibag_amd import synth, train
     from hibag_amd.dist import shard_bounds
     model, founders, af = synth.make_model("hla-a-small", seed=15, n_snp=70)
     G, truth = synth.make_samples(founders, af, 180, seed=16, miss=0.02)
     n_hla, ncl, k, mtry = model.n_hla, 10, 4, 9
     got = train.grow_concurrently(G, truth[:, 0], truth[:, 1], n_hla, ncl, mtry, True, n_trainers=k, threads_per_trainer=2,
-                                  seed=300, em=em)
+                                  seed=300, em=em, combine=combine, thread_budget=budget)
     assert len(got) == ncl
     at = 0
     for r in range(k):
@@ -165,6 +168,28 @@ def test_concurrent_trainers_equal_a_serial_trainer_per_stream(hib, oracle, em):
                                      mono_rm=False)
     assert len(m.obj.classifiers) == 6 and m.obj.matching is not None
     hib.hlaClose(m)
+
+
+def test_more_trainers_than_one_fused_launch_holds(hib, oracle):
+    """Twenty trainers, one classifier each: more operations pending at a time than one fused launch takes (sixteen views
+    travel as kernel arguments), so the combiner cuts a batch into several launches per kind.  Every classifier still equals
+    the oracle's serial run from its stream, and the fused launches did carry several operations."""
+    import ctypes as C
+    from hibag_amd import _lib, synth, train
+    model, founders, af = synth.make_model("hla-a-small", seed=25, n_snp=60)
+    G, truth = synth.make_samples(founders, af, 150, seed=26, miss=0.02)
+    k, mtry = 20, 8
+    _lib.lib().hibag_hip_train_combine_stats(None, None, 1)
+    got = train.grow_concurrently(G, truth[:, 0], truth[:, 1], model.n_hla, k, mtry, True, n_trainers=k, threads_per_trainer=1,
+                                  seed=700, em="device", combine=True, thread_budget=3)
+    assert len(got) == k
+    for r in range(k):
+        w = oracle.train(G, truth[:, 0], truth[:, 1], model.n_hla, nclassifier=1, mtry=mtry, prune=True, seed=700 + r)[0]
+        c = hib.Classifier(snpidx=w["snpidx"], freq=w["freq"], hla=w["hla"], haplo=w["haplo"], samp_num=w["samp_num"], outofbag_acc=w["acc"])
+        assert_same_classifier(_as_dict(got[r]), c, r)
+    nl, no = (C.c_longlong * 8)(), (C.c_longlong * 8)()
+    _lib.lib().hibag_hip_train_combine_stats(nl, no, 0)
+    assert sum(no) > sum(nl) > 0, (list(nl), list(no))        # some launches carried more than one trainer's operation
 
 
 @pytest.mark.parametrize("seed", range(8))
