@@ -285,6 +285,29 @@ __device__ __forceinline__ void block_own_sample(v16i &D0, v16i &D1, int n_valid
 	block_own_sample(D0, D1, [&](int g) { return 8 * g < n_valid; });
 }
 
+// A bank-interleaved table for classifiers of several K steps (33 .. 112 SNPs) -- BUILT, MEASURED SLOWER, NOT SHIPPED
+// (-DHIBAG_WIDE_TAB=true builds it).  Their distances spread over 0 .. 2 k, so the 64 lanes of a look-up hit 64 different
+// 8-byte entries of the plain table: k_total_wide counts more bank-conflict cycles than LDS-busy cycles
+// (profiles/r05_sq_counters.txt: SQ_LDS_BANK_CONFLICT 976,690 against SQ_ACTIVE_INST_LDS 837,640).  TAB[d] is exactly zero
+// from d = 65 on (exp(d log 1e-5) underflows: src/LibHLA.cpp:176-183; checked where a model is created), so the offset can be
+// clamped at 65 and the 66 entries laid out 32-way interleaved -- entry d of replica r at (32 d + r) * 8 bytes, lane l reads
+// replica l % 32: whatever d, the 32 lanes of a ds_read_b64 group are on 32 different bank pairs; 17 KB per workgroup.
+// It removes the conflicts and costs two vector instructions per pair (the clamp, the shift-and-add) where the plain table
+// costs none -- the matrix result IS its byte offset -- on a loop whose vector ALU work is two FP64 operations per pair:
+// pass 1 of the wide-classifier model 0.60 ms with the plain table, 0.92 ms with this one, same box, three runs each
+// (profiles/r06_notes.txt).  The conflicts are the cheaper evil.
+#ifndef HIBAG_WIDE_TAB
+#define HIBAG_WIDE_TAB false
+#endif
+#define HIBAG_WIDE_TAB_CLAMP 65
+#define HIBAG_WIDE_TAB_N ((HIBAG_WIDE_TAB_CLAMP + 1) * 32)
+__device__ __forceinline__ double table_value_wide(const double *tabw_s, int off)     // off = 8 d
+{
+	const uint32_t o = min((uint32_t)off, (uint32_t)(8 * HIBAG_WIDE_TAB_CLAMP));
+	const uint32_t lane8 = (__builtin_amdgcn_mbcnt_lo(~0u, 0u) & 31u) * 8u;        // (lane & 31) * 8: lanes l and l + 32 are in different groups
+	return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tabw_s) + (o << 5) + lane8);
+}
+
 // cell += prod_i * TAB[d_i] for the first n_valid records of a block, in order;
 // `fin(cell, stored, slot)` at every record that closes a cell (end mask, store mask; cells are padded to
 // an even number of records, so only odd positions can close one).
@@ -310,7 +333,8 @@ template <> struct FactorGroup<8> { typedef f64x8 type; };
 // record before closed one (a scalar register; the walk that ends on it materialises the zero).
 // `live(g)`: group g of the block has records worth evaluating (the groups before it then have too).
 // LINEAR: record i's distance is D0[i] (i < 16) / D1[i - 16] -- the layout of the walk without lane swaps (walk_blocks, OWN).
-template <int G, bool AHEAD = false, bool LINEAR = false, class Live, class Fin>
+// WIDE_TAB: `tab_s` is the bank-interleaved table of the classifiers with several K steps (table_value_wide below).
+template <int G, bool AHEAD = false, bool LINEAR = false, bool WIDE_TAB = false, class Live, class Fin>
 __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename FactorGroup<G>::type F, uint32_t endmask, uint32_t storemask, Live &&live,
 	const v16i &D0, const v16i &D1, double &cell, uint32_t fresh, const double *tab_s, Fin &&fin)
 {
@@ -324,7 +348,7 @@ __device__ __forceinline__ void block_accumulate(ConstPtr<double> fac, typename 
 		for (int q = 0; q < G; q++) {         // D = 8*d: already the byte offset into the table
 			const int i = G * g + q;          // record i = 8 m + r  ->  r < 4 ? D0[4 m + r] : D1[4 m + r - 4]
 			const int off = LINEAR ? (i < 16 ? D0[i] : D1[i - 16]) : (i & 7) < 4 ? D0[4 * (i >> 3) + (i & 3)] : D1[4 * (i >> 3) + (i & 3)];
-			t[q] = table_value(tab_s, off);
+			t[q] = WIDE_TAB ? table_value_wide(tab_s, off) : table_value(tab_s, off);
 		}
 	};
 	double tt[AHEAD ? 2 : 1][G];
@@ -549,7 +573,88 @@ __device__ __forceinline__ void walk_blocks(const HibagModelView &M, uint64_t at
 		if (fresh) cell = 0;
 		return;
 	}
-	// FP4W: an FP4 classifier of `wide.nstep` K steps; `k` = SNPs of its LAST step, the others have HIBAG_FP4_STEP_SNPS
+#ifndef HIBAG_WIDE_OLDWALK                   // (variant for A/B timing: round 5's walk, which fetches the further steps' operands where they are used)
+	if (ENG == HIBAG_ENGINE_FP4W) {
+		// An FP4 classifier of `wide.nstep` (2 .. 4) K steps; `k` = SNPs of its LAST step, the others have HIBAG_FP4_STEP_SNPS.
+		// Round 6: until now the further steps' images and B operands were fetched where they were used -- two dependent gathers
+		// and two operand loads per step, each waited for on the spot, three times per block -- and the kernel ran at a quarter
+		// of its issue floor.  Now the B operands of the further steps, which are the same for every block, live in registers,
+		// and a block's images of ALL steps are requested a block ahead, right behind the matrix instructions that read the
+		// current ones (as the prebuilt rows of the one-step walk are); `tab_s` is the bank-interleaved table.
+		const int ns = wide.nstep;
+		const uint32_t ES = 4u * (uint32_t)HIBAG_FP4_ENTRY_DWORDS(ns);
+		const int vo_i = (lane & 31) * 4;
+		const uint32_t BB = 4 * HIBAG_PLIST_DWORDS;
+		const uint64_t left = (M.plist_dwords - at) * 4;
+		const __amdgpu_buffer_rsrc_t pl = __builtin_amdgcn_make_buffer_rsrc((void *)(M.plist + at), 0,
+			left > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left, 0x00020000);
+		v4i wb[HIBAG_FP4_MAX_STEPS - 1][2];
+#pragma unroll
+		for (int j = 1; j < HIBAG_FP4_MAX_STEPS; j++) {
+			wb[j - 1][0] = wb[j - 1][1] = v4i{0, 0, 0, 0};
+			if (j < ns) {
+				const uint4 *row = wide.bt + ((size_t)(wide.bt_row + 2 * j) * wide.n_group + wide.group) * HIBAG_WAVE;
+				const uint4 u0 = row[lane], u1 = row[wide.n_group * HIBAG_WAVE + lane];
+				wb[j - 1][0] = v4i{(int)u0.x, (int)u0.y, (int)u0.z, (int)u0.w};
+				wb[j - 1][1] = v4i{(int)u1.x, (int)u1.y, (int)u1.z, (int)u1.w};
+			}
+		}
+		// the steps' constant nibbles: every step but the last has HIBAG_FP4_STEP_SNPS SNPs
+		const v4i c_mid = fp4_offset_term(HIBAG_FP4_STEP_SNPS, lane), c_last = fp4_offset_term(k, lane);
+		uint32_t soff = 0;
+		uint32_t idx_c = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff, 0), idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + BB, 0);
+		v4i im[HIBAG_FP4_MAX_STEPS][2];
+		auto request_images = [&](uint32_t word) {
+			const uint32_t o1 = (word & 0xFFFFu) * ES, o2 = ((word >> 16) & 0x3FFFu) * ES;
+			im[0][0] = load_hap_image(hp, o1); im[0][1] = load_hap_image(hp, o2);
+#pragma unroll
+			for (int j = 1; j < HIBAG_FP4_MAX_STEPS; j++)
+				if (j < ns) { im[j][0] = load_hap_image(hp, o1 + 16u + 16u * (uint32_t)j); im[j][1] = load_hap_image(hp, o2 + 16u + 16u * (uint32_t)j); }
+		};
+#pragma unroll
+		for (int j = 0; j < HIBAG_FP4_MAX_STEPS; j++) im[j][0] = im[j][1] = v4i{0, 0, 0, 0};
+		request_images(idx_c);
+		u32x4 H_n = hdr[0];
+		FG F_n = *(ConstPtr<FG>)fac;
+		for (int b = 0; b < nblk; b++) {
+			const u32x4 H = H_n;
+			const FG F = F_n;
+			const uint32_t endmask = abl_endmask(H[0]), storemask = abl_storemask(H[1]);
+			const int n_valid = (int)H[2];
+			asm volatile("" :: "s"(n_valid));             // (the header is waited for HERE, before the next scalar loads are issued)
+			__builtin_amdgcn_sched_barrier(0);
+			H_n = hdr[b + 1];
+			F_n = *(ConstPtr<FG>)(fac + (size_t)(b + 1) * HIBAG_PLIST_DWORDS);
+			idx_c = idx_n;
+			idx_n = __builtin_amdgcn_raw_buffer_load_b32(pl, vo_i, soff + 2 * BB, 0);
+			v16i D0, D1;
+			if (n_valid > 0) {
+				v16f d0, d1;
+#pragma unroll
+				for (int r = 0; r < 16; r++) { d0[r] = 0.0f; d1[r] = 0.0f; }
+				fp4_step(im[0][0], im[0][1], lane, c_mid, T.b[0][0], T.b[1][0], d0, d1);
+#pragma unroll
+				for (int j = 1; j < HIBAG_FP4_MAX_STEPS; j++)
+					if (j < ns) fp4_step(im[j][0], im[j][1], lane, j == ns - 1 ? c_last : c_mid, wb[j - 1][0], wb[j - 1][1], d0, d1);
+				asm volatile("" : "+v"(d0), "+v"(d1));    // (the matrix instructions stay HERE, in front of the next block's loads)
+				D0 = __builtin_bit_cast(v16i, d0);
+				D1 = __builtin_bit_cast(v16i, d1);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			request_images(idx_c);                        // block b + 1's, into the registers the matrix instructions have just read
+			__builtin_amdgcn_sched_barrier(0);
+			if (n_valid > 0) {
+				block_own_sample(D0, D1, n_valid);
+				block_accumulate<G, false, false, HIBAG_WIDE_TAB>(fac + (size_t)b * HIBAG_PLIST_DWORDS, F, endmask, storemask, [&](int g) { return G * g < n_valid; }, D0, D1, cell, fresh, tab_s, fin);
+				fresh = fresh_behind<G>(fresh, endmask, n_valid);
+			}
+			soff += BB;
+		}
+		if (fresh) cell = 0;
+		return;
+	}
+#endif
+	// (FP4W is handled above; the flag stays for the shared declarations below)
 	constexpr bool FP4W = ENG == HIBAG_ENGINE_FP4W;
 	const uint32_t ES = FP4W ? 4u * (uint32_t)HIBAG_FP4_ENTRY_DWORDS(wide.nstep)
 	                         : 4u * (uint32_t)HIBAG_ENGINE_HAP_DWORDS(ENG);   // bytes per table entry (one-step FP4 and int8: 48)
@@ -672,6 +777,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t hap_rsrc(const HibagModelView 
 	case 10: { CALL(10); } break;          \
 	default: { CALL(12); } break;          \
 	}
+
+__device__ __forceinline__ void stage_table_wide(const HibagModelView &M, double *tabw_s)
+{
+	for (int i = threadIdx.x; i < HIBAG_WIDE_TAB_N; i += blockDim.x) tabw_s[i] = M.tab[i >> 5];
+	__syncthreads();
+}
 
 __device__ __forceinline__ void stage_table(const HibagModelView &M, double *tab_s, int n = HIBAG_TAB_N)
 {

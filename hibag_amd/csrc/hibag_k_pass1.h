@@ -269,11 +269,20 @@ __global__ __launch_bounds__(BLOCK_THREADS, OCC) void k_total(HibagModelView M, 
 // stored (pass 2 reads them back whatever the model's other classifiers do) and k_total_scan adds them in order.
 // grid (group quads, segments).
 // WHOLE: every segment is a whole classifier (a model with many of them): the walk forms the in-order total itself.
+// (three workgroups per CU: the walk keeps the further steps' B operands and a block's images of every step in registers,
+// 24 + 32 of them -- at four per CU, 128 registers, it spilled)
 template <bool WHOLE>
-__global__ __launch_bounds__(BLOCK_THREADS, 4) void k_total_wide(HibagModelView M, HibagBatchView B)
+#ifndef HIBAG_WIDE_OCC
+#define HIBAG_WIDE_OCC 3
+#endif
+__global__ __launch_bounds__(BLOCK_THREADS, HIBAG_WIDE_OCC) void k_total_wide(HibagModelView M, HibagBatchView B)
 {
-	__shared__ double tab_s[HIBAG_TAB_N];
+	__shared__ double tab_s[HIBAG_WIDE_TAB ? HIBAG_WIDE_TAB_N : HIBAG_TAB_N];     // (HIBAG_WIDE_TAB: the bank-interleaved variant, hibag_k_engine.h)
+#if defined(HIBAG_WIDE_OLDWALK) || !HIBAG_WIDE_TAB
 	stage_table(M, tab_s);
+#else
+	stage_table_wide(M, tab_s);
+#endif
 	const int *__restrict__ seg = M.wide_seg + 4 * blockIdx.y;
 	const int c = seg[0];
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;

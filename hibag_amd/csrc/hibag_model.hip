@@ -921,6 +921,15 @@ hibag_hip_model *hibag_hip_model_new(int n_hla, int n_snp)
 	m->n_hla = n_hla;
 	m->n_snp = n_snp;
 	build_table(m->tab);
+	// k_total_wide clamps a distance at 65 (hibag_k_engine.h, table_value_wide): every entry from there on must be the exact
+	// zero IEEE arithmetic makes of exp(65 log 1e-5) = 1e-325 -- a libm that returned a denormal there would be a different
+	// table from the reference's, and the clamp would change results
+	for (int i = 65; i < HIBAG_TAB_N; i++)
+		if (m->tab[i] != 0.0) {
+			delete m;
+			hibag_fail(HIBAG_HIP_ESTATE, "this libm's exp() does not underflow to zero at exp(%d * log(1e-5)): the mutation table differs from the reference's", i);
+			return nullptr;
+		}
 	return m;
 }
 

@@ -11,5 +11,7 @@ KFLAGS=$([ -n "${NO_KFLAGS:-}" ] || make -s -C $src print-kflags)
 /opt/rocm/bin/hipcc $FLAGS $KFLAGS "$@" -c $src/hibag_kernels.hip -o /tmp/var_$name.o
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $src/hibag_model.hip -o /tmp/var_${name}_model.o
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $src/hibag_predict.hip -o /tmp/var_${name}_predict.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_var_$name.so /tmp/var_$name.o /tmp/var_${name}_model.o /tmp/var_${name}_predict.o $src/hibag_api.o $src/hibag_build.o $src/hibag_train.o $src/hibag_sample.o $src/hibag_shard.o $src/hibag_ubench.o $src/hibag_em.o -ldl
+# (every other object as the Makefile built it: the list is the Makefile's own)
+others=$(ls $src/*.o | grep -v -e hibag_kernels.o -e hibag_model.o -e hibag_predict.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_var_$name.so /tmp/var_$name.o /tmp/var_${name}_model.o /tmp/var_${name}_predict.o $others -ldl
 echo built gpurun_var_$name.so
