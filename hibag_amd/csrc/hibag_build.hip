@@ -395,14 +395,17 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_batch_scan(HibagMulti<BatchView>
 	double best = 0, total = 0, hit = 0;
 	int bi = -1;
 	const double *__restrict__ col = B.cellv + ((size_t)c * (B.n_pad / HIBAG_WAVE) + (s >> 6)) * B.max_cells * HIBAG_WAVE + (s & 63);
-	for (int i0 = 0; i0 < n; i0 += SCAN_NB, col += (size_t)SCAN_NB * HIBAG_WAVE) {
-		// SCAN_NB loads in flight, then the strictly ordered scan over them: one load per dependent iteration would make
-		// this kernel pure memory latency (hundreds of cells per candidate).  No condition anywhere near the loads -- with
-		// one branch per load (round 2's form) the compiler serialised them: 146 us per launch (profiles/r03_cfg5_*) -- the list
-		// is padded with +0.0 instead, which can neither become the maximum nor change the total.
-		double v[SCAN_NB];
+	// SCAN_NB loads in flight, then the strictly ordered scan over them: one load per dependent iteration would make
+	// this kernel pure memory latency (hundreds of cells per candidate).  No condition anywhere near the loads -- with
+	// one branch per load (round 2's form) the compiler serialised them: 146 us per launch (profiles/r03_cfg5_*) -- the list
+	// is padded with +0.0 instead, which can neither become the maximum nor change the total.
+	// Round 6: two such groups take turns -- the next group's loads are on their way while this one is scanned (the kernel was
+	// still twenty load latencies long, 66 us: as long as the evaluation of the cells itself).  Same operations, same order.
+	auto request = [&](double (&v)[SCAN_NB], const double *from) {
 #pragma unroll
-		for (int j = 0; j < SCAN_NB; j++) v[j] = __builtin_nontemporal_load(col + (size_t)j * HIBAG_WAVE);
+		for (int j = 0; j < SCAN_NB; j++) v[j] = __builtin_nontemporal_load(from + (size_t)j * HIBAG_WAVE);
+	};
+	auto scan = [&](const double (&v)[SCAN_NB], int i0) {
 #pragma unroll
 		for (int j = 0; j < SCAN_NB; j++) {
 			const double cell = v[j];
@@ -410,6 +413,16 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_batch_scan(HibagMulti<BatchView>
 			if (i0 + j == wpos) hit = cell;                         // the true pair's cell (_PostProb, :1706-1767)
 			total += cell;
 		}
+	};
+	double va[SCAN_NB], vb[SCAN_NB];
+	const size_t step = (size_t)SCAN_NB * HIBAG_WAVE;
+	if (n > 0) request(va, col);
+	for (int i0 = 0; i0 < n; i0 += 2 * SCAN_NB, col += 2 * step) {
+		if (i0 + SCAN_NB < n) request(vb, col + step);
+		scan(va, i0);
+		if (i0 + SCAN_NB >= n) break;
+		if (i0 + 2 * SCAN_NB < n) request(va, col + 2 * step);
+		scan(vb, i0 + SCAN_NB);
 	}
 	const int hh = bi >= 0 ? cl[bi] : 0;
 	B.best[((size_t)c * 2) * B.n_pad + s] = bi >= 0 ? hh >> 16 : -2147483647 - 1;

@@ -406,12 +406,16 @@ def grow_concurrently(genomat, h1, h2, n_hla: int, nclassifier: int, mtry: int, 
     k = max(1, min(int(n_trainers), max(int(nclassifier), 1)))
     if device is None:
         device = int(_lib.lib().hibag_hip_get_device())      # the caller's selection: the workers' threads start from the default
+    # a list of devices: trainer r on devices[r % len] -- the GPUs of a node from ONE process (each device has combiners of its own)
+    devices = [int(d) for d in device] if isinstance(device, (list, tuple)) else [int(device)]
+    if not devices:
+        raise ValueError("no device given")
     parts: List = [None] * k
     errs: List = [None] * k
 
     def work(r: int) -> None:
         try:
-            _lib.check(_lib.lib().hibag_hip_set_device(int(device)))          # (the selection is per host thread)
+            _lib.check(_lib.lib().hibag_hip_set_device(devices[r % len(devices)]))     # (the selection is per host thread)
             lo, hi = shard_bounds(int(nclassifier), k, r)
             if hi <= lo:
                 parts[r] = []
@@ -455,7 +459,10 @@ def hlaConcurrentAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: 
     (:func:`grow_concurrently`), their device work fused into one launch per kind of operation, their EM fits on the device,
     and at most ``nthread`` of their host threads runnable at a time (default: the usable CPUs, at most four -- more buys
     nothing: a trainer's thread sleeps while the device works).  A single trainer leaves the device idle most of a growth
-    step; sixteen keep it busy on the host threads of four.
+    step; sixteen keep it busy on the host threads of four.  ``device``: a device index, or a LIST of them -- trainer r then runs
+    on ``device[r % len(device)]``: the GPUs of a node from one process (BASELINE config 5's "in parallel across 8 GPUs" without a
+    process per GPU; give ``n_trainers`` a multiple of the list's length, sixteen per device, and ``nthread`` accordingly); the
+    model is kept on the first.
 
     Random streams: trainer r draws from R's Mersenne-Twister seeded with ``seed + r``.  These are NOT the streams of R's
     cluster workers -- ``hlaParallelAttrBagging`` sets those with ``parallel::clusterSetRNGStream`` (L'Ecuyer-CMRG,
@@ -471,8 +478,9 @@ def hlaConcurrentAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: 
         return grow_concurrently(genomat, h1, h2, n_hla, n, m, pr, n_trainers, 1, seed, device, em="device",
                                  combine=True, thread_budget=total)
 
+    first = device[0] if isinstance(device, (list, tuple)) and device else device
     return hlaAttrBagging(hla, snp, nclassifier=nclassifier, mtry=mtry, prune=prune, na_rm=na_rm, mono_rm=mono_rm,
-                          maf=maf, verbose=verbose, grow=grow, device=device)
+                          maf=maf, verbose=verbose, grow=grow, device=first)
 
 
 def hlaParallelAttrBagging(cl, hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,

@@ -7,7 +7,9 @@ shards / ranks on the one device.
     output must equal the one-device run bit for bit;
   * hibag_hip_shard_group_predict with one RCCL rank per device: the classifiers' terms are added in another order, so
     identical calls and 1e-10 relative on the posteriors (north_star's tolerance);
-  * `python bench.py --gpus 2` over real RCCL: the line's rccl_ranks must say 2."""
+  * `python bench.py --gpus 2` over real RCCL: the line's rccl_ranks must say 2;
+  * concurrent trainers of ONE process spread over the devices (train.grow_concurrently(device=[0, 1, ...]): a combiner per
+    device): every classifier equal to the oracle's serial run from its stream."""
 
 import json
 import os
@@ -132,3 +134,28 @@ def test_bench_over_two_real_ranks(extra):
         assert chk["calls_identical_to_unsharded"] and chk["max_rel_dev_posterior_vs_unsharded"] < chk["tolerance"]
     elif "--launcher" not in extra:
         assert "error" not in d.get("classifier_sharded", {}), d["classifier_sharded"]
+
+
+@needs_two
+def test_concurrent_trainers_over_the_devices_of_the_node(hib, oracle):
+    """hlaConcurrentAttrBagging's decomposition over a LIST of devices from one process: trainer r on device r % n, each device
+    with combiners of its own (csrc/hibag_combine.h); classifiers are independent given their streams, so every one must equal
+    the oracle's serial run from seed + r."""
+    from hibag_amd import synth, train
+    from hibag_amd.dist import shard_bounds
+    from test_hip_train_driver import _as_dict
+    from test_oracle_train import assert_same_classifier
+    model, founders, af = synth.make_model("hla-a-small", seed=35, n_snp=60)
+    G, truth = synth.make_samples(founders, af, 160, seed=36, miss=0.02)
+    nd = _n_devices()
+    k, ncl, mtry = 4 * nd, 8 * nd, 8
+    got = train.grow_concurrently(G, truth[:, 0], truth[:, 1], model.n_hla, ncl, mtry, True, n_trainers=k, threads_per_trainer=1,
+                                  seed=900, device=list(range(nd)), em="device", combine=True, thread_budget=4)
+    assert len(got) == ncl
+    at = 0
+    for r in range(k):
+        lo, hi = shard_bounds(ncl, k, r)
+        for w in oracle.train(G, truth[:, 0], truth[:, 1], model.n_hla, nclassifier=hi - lo, mtry=mtry, prune=True, seed=900 + r):
+            c = hib.Classifier(snpidx=w["snpidx"], freq=w["freq"], hla=w["hla"], haplo=w["haplo"], samp_num=w["samp_num"], outofbag_acc=w["acc"])
+            assert_same_classifier(_as_dict(got[at]), c, at)
+            at += 1

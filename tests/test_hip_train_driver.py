@@ -190,6 +190,11 @@ def test_more_trainers_than_one_fused_launch_holds(hib, oracle):
     nl, no = (C.c_longlong * 8)(), (C.c_longlong * 8)()
     _lib.lib().hibag_hip_train_combine_stats(nl, no, 0)
     assert sum(no) > sum(nl) > 0, (list(nl), list(no))        # some launches carried more than one trainer's operation
+    # the device-LIST form (trainer r on device[r % len]) rehearsed on the one device: tests/test_hip_multi_device.py runs it on two
+    again = train.grow_concurrently(G, truth[:, 0], truth[:, 1], model.n_hla, 6, mtry, True, n_trainers=6, threads_per_trainer=1,
+                                    seed=700, device=[0, 0, 0], em="device", combine=True, thread_budget=2)
+    for r in range(6):
+        assert_same_classifier(_as_dict(again[r]), got[r], r)
 
 
 @pytest.mark.parametrize("seed", range(8))
