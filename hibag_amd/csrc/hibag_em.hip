@@ -49,6 +49,7 @@
 namespace {
 
 #define EM_THREADS 1024
+#define HIBAG_WAVE_EM 64
 #define EM_MAX_ITER 500                     // src/LibHLA.cpp:98
 #define EM_INIT_VAL_FRAC 0.001              // :100
 #define EM_LDS_BYTES (156 * 1024)           // a growth step's pair set and a candidate's state live in LDS (a CU has 160 KB); larger steps go to the host
@@ -109,8 +110,15 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 	uint16_t *ps = (uint16_t *)(lds + L.ps);                          // the sample of each pair
 	double *rs = (double *)(lds + L.rs);                              // boot_i / psum_i
 	const int tid = threadIdx.x, c = (int)blockIdx.x - M.first[owner], n_ib = V.n_ib, n_pair = V.n_pair, n_hap = V.n_hap;
-	const bool summer = tid == EM_THREADS - 1;                        // the thread of the loglik chain (no other work)
-	const int nw = EM_THREADS - 1;                                    // worker threads
+	// The loglik chain has a WAVEFRONT of its own (round 6): its first lane adds, the other 63 do nothing.  Until then the chain's
+	// thread was the last lane of a wavefront whose other lanes were workers -- a wavefront runs both sides of a divergent branch
+	// one after the other, so every phase lasted that wavefront's worker share PLUS its piece of the chain instead of the longer
+	// of the two.  It also runs at raised priority: a chain of dependent FP64 additions that has to take turns with three busy
+	// wavefronts on its SIMD waited 28-34 cycles per addition against 12 alone (profiles/r04_cfg5_notes.txt).
+	const int nw = EM_THREADS - HIBAG_WAVE_EM;                        // worker threads
+	const bool summer = tid == nw;                                    // the thread of the loglik chain (no other work)
+	const bool worker = tid < nw;
+	if (tid >= nw) __builtin_amdgcn_s_setprio(3);
 	// the growth step's pair set (the same for every candidate) and this candidate's genotypes: once into LDS
 	for (int e = tid; e < V.n_ent; e += EM_THREADS) hent[e] = V.hent[e];
 	if (tid == 0) G[n_pair] = 0.0;                                   // what the lists' padding entries point at
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 		__syncthreads();
 		// ---- A
 		if (summer) { if (iter > 0) sum_part(t_prev, 0); }
-		else
+		else if (worker)
 			for (int j0 = tid; j0 < n_pair; j0 += 4 * nw) {            // four pairs per turn: their look-ups in flight together
 				uint32_t w[4];
 				double fa[4], fb[4];
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 		// ---- B: a sample's psum in list order (sixteen reads in flight), its term, its scaling factor
 		unsigned long long my_max = 0;
 		if (summer) { if (iter > 0) sum_part(t_prev, 1); }
-		else
+		else if (worker)
 			for (int i = tid; i < n_ib; i += nw) {
 				const int j0 = off[i], j1 = off[i + 1], b_i = bt[i];
 				double psum = 0;
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 		__syncthreads();
 		// ---- B': thread = pair again: the compatible G *= boot / psum (an incompatible pair stays +0.0 whatever the factor is)
 		if (summer) { if (iter > 0) sum_part(t_prev, 2); }
-		else
+		else if (worker)
 			for (int j0 = tid; j0 < n_pair; j0 += 4 * nw) {
 				uint32_t w[4];
 				double r[4], x[4];
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 				loglik_prev = loglik; bound_prev = bound;
 				verdict_s = verdict;
 			}
-		} else
+		} else if (worker)
 			for (int h = tid; h < n_hap; h += nw) {
 				const int e0 = hoff[h], e1 = hoff[h + 1];                 // (multiples of 4: the lists are padded with a +0.0 slot)
 				const char *Gb = (const char *)G;
