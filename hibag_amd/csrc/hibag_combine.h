@@ -12,9 +12,12 @@
 // all their uploads, launches ONE fused kernel per kind (grid = the operations' workgroups back to back, each workgroup
 // looks up whose it is), queues all downloads, waits once and wakes the owners.  While it waits the next operations pile up
 // for the next leader.  Two combiners per device -- the long EM fits on one, the short operations on the other, so a pair
-// list never queues behind an EM fit -- with two streams each: a second leader may start its batch while the first one's
-// runs.  The leader sleeps on a blocking event while the device works (no spinning: the trainers' threads are meant to
-// cost the host next to nothing).  Results are bit-identical: the kernels' per-workgroup work is unchanged.
+// list never queues behind an EM fit (the short operations' streams at the highest priority: hardware queues of their own) --
+// with three streams each: another leader may start its batch while the first one's runs.  A batch's copies are ONE kernel
+// each way (pinned host memory is device-addressable; per-operation hipMemcpyAsync calls were what saturated first), and the
+// leader SLEEPS between event queries while the device works (hipEventSynchronize spins, also for a blocking-sync event: the
+// trainers' threads are meant to cost the host next to nothing).  Results are bit-identical: the kernels' per-workgroup work
+// is unchanged.  Measurements of every step of that: profiles/r06_notes.txt item 4.
 //
 // A trainer that runs alone (the default, and the plugin-table entries an unmodified HIBAG drives) uses the same code with a
 // batch of one on its own thread's stream: hibag_combine_run() is the only way this library launches training work.

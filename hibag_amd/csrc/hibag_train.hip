@@ -169,6 +169,9 @@ struct hibag_hip_trainer {
 	int device = 0;                             // HIP device of this trainer (hibag_hip_set_device at creation)
 	int n_snp = 0, n_samp = 0, n_hla = 0;
 	std::vector<int32_t> geno, h1, h2;          // geno [n_samp][n_snp]
+	std::vector<int32_t> geno_t;                // the same SNP-major, [n_snp][n_samp]: a candidate SNP's genotypes are one contiguous row
+	                                            // (the search reads 18 such columns per growth step, twice: out of the sample-major
+	                                            // matrix every read was a cache miss)
 	RMersenne rng;
 	double (*unif_fn)(void *) = nullptr;
 	void *unif_ctx = nullptr;
@@ -274,7 +277,7 @@ void set_aux(HapList &h)                                                // SetHa
 
 void add_snp(T &t, int snp)                                             // CGenotypeList::AddSNP, :860-874
 {
-	for (int i = 0; i < t.n_samp; i++) geno_set(t.g[i], t.g_nsnp, t.geno[(size_t)i * t.n_snp + snp]);
+	for (int i = 0; i < t.n_samp; i++) geno_set(t.g[i], t.g_nsnp, t.geno_t[(size_t)snp * t.n_samp + i]);
 	t.g_nsnp++;
 }
 
@@ -355,9 +358,10 @@ struct FitScratch {
 bool fit_new_snp(const T &t, int snp, const HapList &cur, HapList &next, FitScratch &S)
 {
 	int allele_cnt = 0, valid_cnt = 0;
+	const int32_t *const gcol = &t.geno_t[(size_t)snp * t.n_samp];        // the SNP's genotypes, contiguous
 	for (int i : t.inbag) {
 		const int dup = t.g[i].bootstrap_count;
-		const int g = t.geno[(size_t)i * t.n_snp + snp];
+		const int g = gcol[i];
 		if (0 <= g && g <= 2) { allele_cnt += g * dup; valid_cnt += 2 * dup; }
 	}
 	if (allele_cnt == 0 || allele_cnt == valid_cnt) return false;
@@ -376,7 +380,7 @@ bool fit_new_snp(const T &t, int snp, const HapList &cur, HapList &next, FitScra
 	S.h1.clear(); S.h2.clear();
 	for (size_t i = 0; i < num; i++) {
 		S.off[i] = (int)S.h1.size();
-		const int geno = t.geno[(size_t)pls.samp[i] * t.n_snp + snp];
+		const int geno = gcol[pls.samp[i]];
 		const bool typed = 0 <= geno && geno <= 2;
 		for (int j = pls.off[i]; j < pls.off[i + 1]; j++) {
 			const HapPair &p = pls.p[j];
@@ -527,7 +531,7 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 		// fitted while helper threads fit the last two was measured too: no gain, the second launch and read-back cost what the
 		// overlap saves; profiles/r03_cfg5_notes.txt.)
 		const int half = m;
-		struct Part { std::vector<HibagBuildCandidate> bc; std::vector<std::vector<int32_t>> cols; std::vector<int> which; } part[2];
+		struct Part { std::vector<HibagBuildCandidate> bc; std::vector<int> which; } part[2];
 		// The fits: on the device (hibag_em.hip, workgroup = candidate), except the candidates whose stopping test the device's
 		// log() cannot decide the way the host's would -- a handful per model -- and where the rank has host threads to spare all of them:
 		// those go to the host threads below, as every fit did until round 4.
@@ -561,8 +565,9 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 				const int snp = vs.at(i);
 				int allele_cnt = 0, valid_cnt = 0;
 				std::vector<int8_t> col(n_ib);
+				const int32_t *const gc = &t.geno_t[(size_t)snp * t.n_samp];
 				for (int k = 0; k < n_ib; k++) {
-					const int g = t.geno[(size_t)pls.samp[k] * t.n_snp + snp];
+					const int g = gc[pls.samp[k]];
 					const bool typed = 0 <= g && g <= 2;
 					col[k] = typed ? (int8_t)g : (int8_t)3;
 					if (typed) { allele_cnt += g * pls.boot[k]; valid_cnt += 2 * pls.boot[k]; }
@@ -610,14 +615,11 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 		auto launch = [&](int slot, int lo, int hi) {
 			Tick tk(2);
 			Part &P = part[slot];
-			for (int i = lo; i < hi; i++) {
-				if (!valid[i]) continue;
-				P.cols.emplace_back(t.n_samp);
-				for (int k = 0; k < t.n_samp; k++) P.cols.back()[k] = t.geno[(size_t)k * t.n_snp + vs.at(i)];
-				P.which.push_back(i);
-			}
+			for (int i = lo; i < hi; i++) if (valid[i]) P.which.push_back(i);
+			// (a candidate's genotype column is a row of the SNP-major copy: nothing to gather)
 			for (size_t j = 0; j < P.which.size(); j++)
-				P.bc.push_back(HibagBuildCandidate{cand[P.which[j]].list.data(), (int)cand[P.which[j]].list.size(), P.cols[j].data()});
+				P.bc.push_back(HibagBuildCandidate{cand[P.which[j]].list.data(), (int)cand[P.which[j]].list.size(),
+					&t.geno_t[(size_t)vs.at(P.which[j]) * t.n_samp]});
 			hibag_build_eval_launch(slot, t.g.data(), t.g_nsnp + 1, P.bc.data(), (int)P.bc.size());
 		};
 		int acc_floor = global_max_acc;
@@ -748,6 +750,9 @@ hibag_hip_trainer *hibag_hip_trainer_new(int n_snp, int n_samp, const int32_t *s
 	t->device = hibag_selected_device();
 	t->n_snp = n_snp; t->n_samp = n_samp; t->n_hla = n_hla;
 	t->geno.assign(snp_geno, snp_geno + (size_t)n_samp * n_snp);
+	t->geno_t.resize((size_t)n_samp * n_snp);
+	for (int i = 0; i < n_samp; i++)
+		for (int j = 0; j < n_snp; j++) t->geno_t[(size_t)j * n_samp + i] = snp_geno[(size_t)i * n_snp + j];
 	t->h1.assign(H1, H1 + n_samp); t->h2.assign(H2, H2 + n_samp);
 	t->g.assign(n_samp, PluginGenotype{});
 	t->n_threads = usable_threads();

@@ -353,3 +353,77 @@ def test_classifier_shard_bounds_cover_the_model_in_order():
         assert at == n
     assert L.hibag_hip_shard_bounds(10, 0, 0, None, None) != 0 and L.hibag_hip_shard_bounds(10, 2, 2, None, None) != 0
     assert L.hibag_hip_shard_group_new(None, 0) is None          # (no GPU needed to be refused)
+
+
+def test_hlaPredict_host_side_routes_by_memory_order_and_copies_nothing():
+    """The host side of hlaPredict (R/HIBAG.R:481-818) without a device: a stub model records which entry of the C ABI would
+    be called and with what.  int32 genotypes reach it as VIEWS of the caller's array in either memory order (R's column-major:
+    the sample-major entry; numpy's row-major: hibag_hip_predict_snp_major), doubles are converted once (NaN -> NA), the SNP
+    selection / flips are handed on instead of being applied on the host, dosage / postprob come back as [row, sample] views,
+    allele names are made when first read, NA calls are counted and warned about."""
+    import warnings
+    import hibag_amd
+    from hibag_amd import hibag, synth
+    model, founders, af = synth.make_model("hla-a-small", seed=5)
+    G, _ = synth.make_samples(founders, af, 37, seed=6)
+    calls = []
+
+    class Stub(hibag.HlaAttrBagClass):
+        def __init__(self, obj):
+            self.obj, self._h = obj, None
+
+        def _out(self, n, want_dosage, want_prob):
+            o = self._outputs(n, want_dosage, want_prob)
+            o["h1"][:] = 1; o["h2"][:] = 2; o["h1"][0] = o["h2"][0] = hibag.NA_INTEGER
+            o["prob"][:] = 0.5; o["matching"][:] = 0.25
+            for k in ("dosage", "postprob"):
+                if k in o:
+                    o[k][:] = np.arange(o[k].size, dtype=np.float64).reshape(o[k].shape)
+            return o
+
+        def predict_raw(self, g, vote_method=1, want_dosage=True, want_prob=False):
+            calls.append(("raw", g, None, None)); return self._out(g.shape[0], want_dosage, want_prob)
+
+        def predict_mapped(self, g, col, flip, vote_method=1, want_dosage=True, want_prob=False):
+            calls.append(("mapped", g, col, flip)); return self._out(g.shape[0], want_dosage, want_prob)
+
+        def predict_snp_major(self, g, col=None, flip=None, vote_method=1, want_dosage=True, want_prob=False):
+            calls.append(("snp_major", g, col, flip)); return self._out(g.shape[1], want_dosage, want_prob)
+
+    m = Stub(model)
+    for order, entry in (("F", "raw"), ("C", "snp_major")):
+        snp = synth.as_snp_geno(model, G, order=order)
+        calls.clear()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            res = hibag_amd.hlaPredict(m, snp, type="response+prob", verbose=False)
+        assert [c[0] for c in calls] == [entry]
+        assert np.shares_memory(calls[0][1], snp.genotype)                  # the caller's own array went down, not a copy
+        assert any("No prediction output for 1 individual" in str(x.message) for x in w)
+        assert res.dosage.shape == (model.n_hla, 37) and res.postprob.shape == (model.n_cell, 37)
+        assert res.dosage.base is not None and res.dosage.flags.f_contiguous          # views of the sample-major outputs
+        assert res._allele1 is None                                         # not made yet ...
+        assert res.allele1[:3] == [None, model.hla_allele[1], model.hla_allele[1]] and res.allele2[1] == model.hla_allele[2]
+        assert res.pair_names[1] == f"{model.hla_allele[1]}/{model.hla_allele[0]}" and len(res.pair_names) == model.n_cell
+    # doubles with NaN: one conversion, NaN -> NA_integer_, layout kept
+    D = np.ascontiguousarray(np.where(G.T == hibag.NA_INTEGER, np.nan, G.T.astype(np.float64)))      # row-major [SNP, sample]
+    calls.clear()
+    hibag_amd.hlaPredict(m, D, type="response", verbose=False)
+    assert calls[0][0] == "snp_major" and calls[0][1].dtype == np.int32
+    assert np.array_equal(calls[0][1], np.where(np.isnan(D), hibag.NA_INTEGER, D).astype(np.int32))
+    # a cohort whose SNPs differ from the model's: the selection and the flips are passed on, not applied on the host
+    keep = np.ones(model.n_snp, bool); keep[[3, 11]] = False
+    alle = ["G/A" if k % 5 == 0 else "A/G" for k in range(model.n_snp)]
+    sub = hibag_amd.HlaSNPGeno(genotype=np.ascontiguousarray(G.T[keep]), sample_id=[f"s{i}" for i in range(37)],
+                               snp_id=[i for i, k in zip(model.snp_id, keep) if k], snp_position=np.asarray(model.snp_position)[keep],
+                               snp_allele=[a for a, k in zip(alle, keep) if k], assembly="hg19")
+    calls.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hibag_amd.hlaPredict(m, sub, type="response", verbose=False)
+    kind, g, col, flip = calls[0]
+    assert kind == "snp_major" and np.shares_memory(g, sub.genotype)
+    assert list(np.where(np.asarray(col) < 0)[0]) == [3, 11] and np.asarray(col)[4] == 3
+    assert [bool(f) for f in flip] == [k % 5 == 0 and k not in (3, 11) for k in range(model.n_snp)]
+    with pytest.raises(TypeError):
+        hibag_amd.hlaPredict(m, np.array([["a"] * 3] * model.n_snp), verbose=False)
