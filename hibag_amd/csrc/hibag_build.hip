@@ -773,7 +773,7 @@ uint32_t *hibag_build_haplomatch(const PluginHaplotype haplo[], const size_t n_h
 		const int nw = std::max(1, (n_snp + 31) / 32);
 		std::vector<int> start(nh + 1, 0);
 		for (int h = 0; h < nh; h++) start[h + 1] = start[h] + (int)n_haplo[h];
-		g.n_haplo = (int)H; g.n_snp = n_snp;
+		// (g.n_haplo / g.n_snp / g.d_hb describe what build_set_haplo_geno uploaded for evaluate(): this path has an arena of its own and leaves them alone)
 		g.true1.assign(n, 0); g.true2.assign(n, 0);
 		for (int s = 0; s < n; s++) {
 			int a1 = geno[s].hla1, a2 = geno[s].hla2;

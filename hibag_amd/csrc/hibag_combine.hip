@@ -1,5 +1,6 @@
-// hibag_combine.hip -- the combiner of hibag_combine.h: per device two lanes (short operations, EM fits), each a stream,
-// a list of pending operations and a leader-takes-all protocol; the host-thread budget of shared trainers.
+// hibag_combine.hip -- the combiner of hibag_combine.h: per device two lanes (short operations, EM fits), each a list of
+// pending operations, three streams (batches in flight) and a leader-takes-all protocol; the batch's copies as one kernel
+// each way; the leader's sleeping wait; the host-thread budget of shared trainers.
 // Compiled with -fgpu-default-stream=per-thread like the files whose work it launches: stream 0 below is the CALLING
 // THREAD's own stream.
 
