@@ -352,3 +352,69 @@ def test_training_campaign(hib, oracle):
         with open(os.environ["HIBAG_FUZZ_REPORT"], "a") as f:
             f.write(f"training, seeds {seed0}..{seed - 1}: {done} cohorts x 2 classifiers, mismatches: {bad}\n")
     assert not bad, bad
+
+
+def test_combined_trainers_on_different_cohorts_campaign(hib, oracle):
+    """Time-boxed random campaign of the combiner (HIBAG_FUZZ_SECONDS, default 15) with what the other tests never give it:
+    trainers that share the device but work on DIFFERENT problems -- cohorts of different sizes (other sample paddings, grids,
+    LDS layouts of the EM kernel, 1..4 genotype words), allele counts, mtry -- so that one fused launch carries views that
+    have nothing in common.  Each of 3..8 trainers is a thread with its own hibag_hip_trainer in shared mode, EM on the device,
+    under a budget of 2..4 runnable threads; every classifier must equal the oracle's serial run on that trainer's cohort."""
+    import os
+    import threading
+    import time
+    from hibag_amd import _lib, train
+    budget_s = float(os.environ.get("HIBAG_FUZZ_SECONDS", "15"))
+    seed0 = int(os.environ.get("HIBAG_FUZZ_SEED", "90000"))
+    t_end = time.time() + budget_s
+    seed, done, bad = seed0, 0, []
+    while time.time() < t_end:
+        rng = np.random.default_rng(seed)
+        k = int(rng.integers(3, 9))
+        probs = []
+        for r in range(k):
+            n_hla = int(rng.integers(2, 16))
+            n_snp = int(rng.integers(6, 100))
+            n_samp = int(rng.choice([rng.integers(12, 60), rng.integers(60, 200), rng.integers(200, 500)]))
+            founders = (rng.random((n_hla, n_snp)) < rng.uniform(0.1, 0.9, n_snp)).astype(np.int32)
+            a = rng.integers(0, n_hla, (n_samp, 2))
+            G = (founders[a[:, 0]] + founders[a[:, 1]]).astype(np.int32)
+            G = np.where(rng.random(G.shape) < rng.uniform(0, 0.06), (G + 1) % 3, G).astype(np.int32)
+            G[rng.random(G.shape) < rng.uniform(0, 0.2)] = hib.NA_INTEGER
+            probs.append(dict(G=G, a=a, n_hla=n_hla, mtry=int(rng.integers(1, n_snp + 1)), prune=bool(rng.integers(0, 2)), seed=seed * 16 + r))
+        got, errs = [None] * k, [None] * k
+
+        def work(r):
+            try:
+                p = probs[r]
+                tr = train._Trainer(p["G"], p["a"][:, 0], p["a"][:, 1], p["n_hla"])
+                try:
+                    tr.set_em_mode("device"); tr.set_threads(1); tr.set_shared(True); tr.set_seed(p["seed"])
+                    tr.new_classifiers(2, p["mtry"], p["prune"], False, False)
+                    got[r] = tr.classifiers()
+                finally:
+                    tr.close()
+            except BaseException as e:              # noqa: BLE001 -- reported below
+                errs[r] = e
+        _lib.lib().hibag_hip_train_set_thread_budget(int(rng.integers(2, 5)))
+        ths = [threading.Thread(target=work, args=(r,)) for r in range(k)]
+        [t.start() for t in ths]; [t.join() for t in ths]
+        _lib.lib().hibag_hip_train_set_thread_budget(0)
+        for r in range(k):
+            p = probs[r]
+            try:
+                assert errs[r] is None, repr(errs[r])
+                want = oracle.train(p["G"], p["a"][:, 0], p["a"][:, 1], p["n_hla"], nclassifier=2, mtry=p["mtry"], prune=p["prune"], seed=p["seed"])
+                assert len(got[r]) == len(want)
+                for i, (g, w) in enumerate(zip(got[r], want)):
+                    c = hib.Classifier(snpidx=w["snpidx"], freq=w["freq"], hla=w["hla"], haplo=w["haplo"], samp_num=w["samp_num"], outofbag_acc=w["acc"])
+                    assert_same_classifier(_as_dict(g), c, i)
+            except AssertionError as e:
+                bad.append((seed, r, str(e)[:120]))
+        done += k
+        seed += 1
+    print(f"combined-trainers campaign: {done} trainers in {seed - seed0} rounds (seeds {seed0}..{seed - 1}), {len(bad)} mismatches")
+    if os.environ.get("HIBAG_FUZZ_REPORT"):
+        with open(os.environ["HIBAG_FUZZ_REPORT"], "a") as f:
+            f.write(f"combined trainers on different cohorts, seeds {seed0}..{seed - 1}: {done} trainers x 2 classifiers, mismatches: {bad}\n")
+    assert not bad, bad

@@ -408,7 +408,9 @@ def test_hlaPredict_host_side_routes_by_memory_order_and_copies_nothing():
     # doubles with NaN: one conversion, NaN -> NA_integer_, layout kept
     D = np.ascontiguousarray(np.where(G.T == hibag.NA_INTEGER, np.nan, G.T.astype(np.float64)))      # row-major [SNP, sample]
     calls.clear()
-    hibag_amd.hlaPredict(m, D, type="response", verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hibag_amd.hlaPredict(m, D, type="response", verbose=False)
     assert calls[0][0] == "snp_major" and calls[0][1].dtype == np.int32
     assert np.array_equal(calls[0][1], np.where(np.isnan(D), hibag.NA_INTEGER, D).astype(np.int32))
     # a cohort whose SNPs differ from the model's: the selection and the flips are passed on, not applied on the host
