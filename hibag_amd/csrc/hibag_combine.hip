@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <ctime>
 #include <mutex>
 #include <sys/prctl.h>
@@ -194,7 +195,16 @@ hipError_t execute(HibagOp *const ops[], int n, hipStream_t st, hipEvent_t done,
 }
 
 // ---- the lanes ----------------------------------------------------------------------------------------------
-constexpr int LANE_SLOTS = 3;                     // batches of a lane in flight at a time (a stream and an event each)
+constexpr int LANE_SLOTS = 6;                     // at most (the arrays' size); in use: lane_slots() below
+// batches of a lane in flight at a time (a stream and an event each): three (measured: profiles/r06_notes.txt item 4);
+// HIBAG_COMBINE_SLOTS_SHORT / _EM override for measurements
+int lane_slots(int lane)
+{
+	static const int n[2] = {
+		getenv("HIBAG_COMBINE_SLOTS_SHORT") ? std::max(1, std::min(LANE_SLOTS, atoi(getenv("HIBAG_COMBINE_SLOTS_SHORT")))) : 3,
+		getenv("HIBAG_COMBINE_SLOTS_EM") ? std::max(1, std::min(LANE_SLOTS, atoi(getenv("HIBAG_COMBINE_SLOTS_EM")))) : 3};
+	return n[lane];
+}
 struct Lane {
 	std::mutex m;
 	std::vector<HibagOp *> pending;
@@ -260,7 +270,7 @@ void hibag_combine_run(HibagOp &op)
 	L.pending.push_back(&op);
 	while (!op.done) {
 		int slot = -1;
-		for (int i = 0; i < LANE_SLOTS; i++) if (!L.busy[i]) { slot = i; break; }
+		for (int i = 0; i < lane_slots(lane); i++) if (!L.busy[i]) { slot = i; break; }
 		// (this operation may already be part of a batch another leader took: then it is no longer pending and all there is to do is wait)
 		bool mine_pending = false;
 		for (HibagOp *o : L.pending) if (o == &op) { mine_pending = true; break; }
