@@ -124,6 +124,16 @@ def test_snp_major_device_entry_and_errors(hib, oracle):
     assert rc == -1 and b"smaller than n_samp" in _lib.lib().hibag_hip_last_error()
     # zero samples: nothing to do, no error
     assert len(m.predict_snp_major(np.zeros((model.n_snp, 0), np.int32))["h1"]) == 0
+    # a cohort that has NONE of the model's SNPs: no row travels at all, every genotype is missing, every call NA -- as the
+    # plain entry says for an all-missing matrix
+    none = m.predict_snp_major(np.ones((5, 9), np.int32), np.full(model.n_snp, -1, np.int32), None, 1, want_dosage=True, want_prob=True)
+    ref = m.predict_raw(np.full((9, model.n_snp), NA, np.int32), 1, want_dosage=True, want_prob=True)
+    same(none, ref)
+    assert np.all(none["h1"] == NA)
+    # narrow integer types are widened once (uint8 genotypes with 255 = missing)
+    g8 = np.where((G.T >= 0) & (G.T <= 2), G.T, 255).astype(np.uint8)
+    r8 = hib.hlaPredict(m, np.ascontiguousarray(g8), type="response+prob", verbose=False)
+    assert np.array_equal(r8.h1, want["h1"]) and np.array_equal(r8.postprob, want["postprob"].T, equal_nan=True)
 
 
 def test_hlaPredict_takes_either_memory_order_without_copies(hib, oracle, hapmap_geno, model_a):
