@@ -939,7 +939,7 @@ void hibag_build_eval_launch(int slot, const PluginGenotype base_geno[], int n_s
 	// scratch lives with the thread: a growth step is a millisecond, and allocating (and page-faulting) a few hundred KB of
 	// vectors per step was a quarter of what the step cost the host.
 	struct Scratch {
-		std::vector<int> start, true_cell, at;
+		std::vector<int> start, true_cell, at, present;
 		std::vector<std::vector<int>> cell_list;
 		std::vector<std::vector<uint64_t>> cell_work;
 		std::vector<uint32_t> base_w1, base_w2;
@@ -964,12 +964,15 @@ void hibag_build_eval_launch(int slot, const PluginGenotype base_geno[], int n_s
 			std::vector<int> &cl = S.cell_list[c];
 			std::vector<uint64_t> &cwk = S.cell_work[c];
 			cl.clear(); cwk.clear();
-			for (int h1 = 0; h1 < nh; h1++) {
+			// (posterior order = h1 ascending, h2 >= h1 ascending, over the alleles that have haplotypes: src/LibHLA.cpp:1653-1691)
+			S.present.clear();
+			for (int h = 0; h < nh; h++) if (st[h + 1] > st[h]) S.present.push_back(h);
+			for (size_t i1 = 0; i1 < S.present.size(); i1++) {
+				const int h1 = S.present[i1];
 				const uint64_t n1 = (uint64_t)(st[h1 + 1] - st[h1]);
-				if (!n1) continue;
-				for (int h2 = h1; h2 < nh; h2++) {
+				for (size_t i2 = i1; i2 < S.present.size(); i2++) {
+					const int h2 = S.present[i2];
 					const uint64_t n2 = (uint64_t)(st[h2 + 1] - st[h2]);
-					if (!n2) continue;
 					cl.push_back((h1 << 16) | h2);
 					cwk.push_back(h1 == h2 ? n1 * (n1 + 1) / 2 : n1 * n2);
 				}

@@ -510,6 +510,18 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 	// no candidate leaves both as they were, and the step after it starts from the same lists -- half of all steps at config 5's
 	// shape; the reference recomputes them, src/LibHLA.cpp:2001, with the same result)
 	bool lists_current = false;
+	// (the step's containers live across steps: their capacity is reused, a growth step does no allocation in steady state)
+	std::vector<HapList> cand;
+	std::vector<char> valid, on_host;
+	std::vector<int> accv;
+	std::vector<double> lossv;
+	struct EmScratch {
+		std::vector<int> ph1, ph2, hoff, hent, at, which, status, iters;
+		std::vector<double> curf, af, freq;
+		std::vector<int8_t> gcol;                                       // [candidates][n_ib]
+		std::vector<const int8_t *> gp;
+		HapList nx;
+	} E;
 	while (!vs.a.empty() && (int)o.snpidx.size() < MAX_SNP) {
 		if (!lists_current) { Tick tk(0); prepare_haplotypes(t, out_haplo, next); lists_current = true; }
 		int max_acc = global_max_acc, min_i = -1;
@@ -521,10 +533,10 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 		// pass, then apply the reference's sequential comparison to the results.
 		const int m = vs.m_try;
 		g_prof.t[7] += 1;                                               // growth steps
-		std::vector<HapList> cand(m);
-		std::vector<char> valid(m, 0);
-		std::vector<int> accv(m, 0);
-		std::vector<double> lossv(m, 0.0);
+		cand.resize(m);
+		valid.assign(m, 0);
+		accv.assign(m, 0);
+		lossv.assign(m, 0.0);
 		// (Fitting in two halves, the first being scored while the second is fitted -- hibag_build_eval_launch / _collect have
 		// two slots for that -- was measured and dropped: the fits of a step differ so much in length that each half lasts
 		// about as long as the whole, 0.58 ms against 0.37 per step.  Sending the first 16 candidates off as soon as they are
@@ -540,31 +552,34 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 		static const int em_env = !getenv("HIBAG_TRAIN_EM") ? 0 : !strcmp(getenv("HIBAG_TRAIN_EM"), "host") ? 1 : !strcmp(getenv("HIBAG_TRAIN_EM"), "device") ? 2 : 0;
 		const int em_mode = t.em_mode ? t.em_mode : em_env;
 		const bool em_host = em_mode == 1 || (em_mode == 0 && t.n_threads > 2);
-		std::vector<char> on_host(m, 1);
+		on_host.assign(m, 1);
 		if (!em_host && hibag_em_fits((int)t.pl.size(), (int)t.pl.p.size(), (int)next.list.size())) {
 			Tick tk(1);
 			const PairSet &pls = t.pl;
 			const int n_ib = (int)pls.size(), n_pair = (int)pls.p.size(), n_hap = (int)next.list.size();
-			std::vector<int> ph1(n_pair), ph2(n_pair), hoff(n_hap + 1, 0), hent(2 * (size_t)n_pair);
+			std::vector<int> &ph1 = E.ph1, &ph2 = E.ph2, &hoff = E.hoff, &hent = E.hent;
+			ph1.resize(n_pair); ph2.resize(n_pair); hoff.assign(n_hap + 1, 0); hent.resize(2 * (size_t)n_pair);
 			for (int j = 0; j < n_pair; j++) { ph1[j] = pls.p[j].h1; ph2[j] = pls.p[j].h2; hoff[ph1[j] + 1]++; hoff[ph2[j] + 1]++; }
 			for (int h = 0; h < n_hap; h++) hoff[h + 1] += hoff[h];
 			{
-				std::vector<int> at(hoff.begin(), hoff.end() - 1);
-				for (int j = 0; j < n_pair; j++) { hent[at[ph1[j]]++] = j; hent[at[ph2[j]]++] = j; }      // (pair order; (h, h) twice)
+				E.at.assign(hoff.begin(), hoff.end() - 1);
+				for (int j = 0; j < n_pair; j++) { hent[E.at[ph1[j]]++] = j; hent[E.at[ph2[j]]++] = j; }      // (pair order; (h, h) twice)
 			}
 			g_em_stats[3] += n_pair; g_em_stats[4] = std::max<long long>(g_em_stats[4], n_pair);
 			for (int h = 0; h < n_hap; h++) g_em_stats[5] = std::max<long long>(g_em_stats[5], hoff[h + 1] - hoff[h]);
 			for (int k = 0; k < n_ib; k++) g_em_stats[7] = std::max<long long>(g_em_stats[7], pls.off[k + 1] - pls.off[k]);
-			std::vector<double> curf(out_haplo.list.size());
+			std::vector<double> &curf = E.curf;
+			curf.resize(out_haplo.list.size());
 			for (size_t i = 0; i < curf.size(); i++) curf[i] = out_haplo.list[i].freq;
 			// the reference skips a SNP that is monomorphic in the bag (:1140-1143)
-			std::vector<int> which;
-			std::vector<double> af;
-			std::vector<std::vector<int8_t>> gcol;
+			std::vector<int> &which = E.which;
+			std::vector<double> &af = E.af;
+			which.clear(); af.clear();
+			E.gcol.resize((size_t)m * n_ib);
 			for (int i = 0; i < m; i++) {
 				const int snp = vs.at(i);
 				int allele_cnt = 0, valid_cnt = 0;
-				std::vector<int8_t> col(n_ib);
+				int8_t *col = E.gcol.data() + which.size() * (size_t)n_ib;
 				const int32_t *const gc = &t.geno_t[(size_t)snp * t.n_samp];
 				for (int k = 0; k < n_ib; k++) {
 					const int g = gc[pls.samp[k]];
@@ -573,21 +588,24 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 					if (typed) { allele_cnt += g * pls.boot[k]; valid_cnt += 2 * pls.boot[k]; }
 				}
 				if (allele_cnt == 0 || allele_cnt == valid_cnt) { on_host[i] = 0; continue; }       // (not fitted at all: valid stays 0)
-				which.push_back(i); af.push_back((double)allele_cnt / valid_cnt); gcol.push_back(std::move(col));
+				which.push_back(i); af.push_back((double)allele_cnt / valid_cnt);
 			}
 			if (!which.empty()) {
 				HibagEmPairs P{n_ib, n_pair, n_hap, t.n_samp, ph1.data(), ph2.data(), pls.off.data(), pls.boot.data(), hoff.data(), hent.data(), curf.data()};
-				std::vector<const int8_t *> gp;
-				for (auto &c : gcol) gp.push_back(c.data());
-				std::vector<double> freq((size_t)which.size() * n_hap);
-				std::vector<int> status(which.size()), iters(which.size());
-				hibag_em_fit_batch(P, gp.data(), af.data(), (int)which.size(), freq.data(), status.data(), iters.data());
+				E.gp.clear();
+				for (size_t w = 0; w < which.size(); w++) E.gp.push_back(E.gcol.data() + w * (size_t)n_ib);
+				E.freq.resize((size_t)which.size() * n_hap);
+				E.status.resize(which.size()); E.iters.resize(which.size());
+				std::vector<double> &freq = E.freq;
+				std::vector<int> &status = E.status, &iters = E.iters;
+				hibag_em_fit_batch(P, E.gp.data(), af.data(), (int)which.size(), freq.data(), status.data(), iters.data());
 				g_em_stats[6] += *std::max_element(iters.begin(), iters.end());
 				for (size_t w = 0; w < which.size(); w++) {
 					const int i = which[w];
 					g_em_stats[0]++; g_em_stats[2] += iters[w];
 					if (status[w] != 1) { g_em_stats[1]++; continue; }                                  // (stays on_host)
-					HapList nx = next;
+					HapList &nx = E.nx;
+					nx = next;
 					for (int h = 0; h < n_hap; h++) nx.list[h].freq = freq[w * n_hap + h];
 					erase_double_haplos(nx, rare_prob, cand[i]);
 					set_aux(cand[i]);                                   // _Init_EvalAcc, :1913-1929
