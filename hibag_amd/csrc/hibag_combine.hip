@@ -150,8 +150,8 @@ hipError_t sleepy_wait(hipEvent_t ev, double expect_s)
 	}
 }
 
-// Everything of the batch is enqueued, then waited for once.  `done`: a blocking-sync event to sleep on (the leader of shared
-// trainers also gives up its host-thread slot meanwhile); nullptr: wait on the stream.
+// Everything of the batch is enqueued, then waited for once.  `done`: the event the leader of shared trainers sleeps on
+// (sleepy_wait; it gives up its host-thread slot meanwhile); nullptr: a trainer that runs alone waits on its own stream.
 hipError_t execute(HibagOp *const ops[], int n, hipStream_t st, hipEvent_t done, double expect_s = 0)
 {
 	const bool give_up_slot = done != nullptr;
@@ -300,7 +300,14 @@ void hibag_combine_run(HibagOp &op)
 		for (double r : L.recent) expect = std::min(expect, r > 0 ? r : 0.0);      // (the shortest recent batch; 0 until eight are known)
 		const double t_b = now_s();
 		lk.unlock();
-		const hipError_t be = st && ev ? execute(batch.data(), (int)batch.size(), st, ev, expect) : hipErrorOutOfMemory;
+		// (nothing may leave this block by exception: the batch's owners sleep until they are told, and the slot stays taken)
+		hipError_t be = hipErrorOutOfMemory;
+		try {
+			if (st && ev) be = execute(batch.data(), (int)batch.size(), st, ev, expect);
+		} catch (...) {
+			if (st) (void)hipStreamSynchronize(st);
+			slot_acquire();
+		}
 		const double took = now_s() - t_b;
 		{
 			std::lock_guard<std::mutex> sl(g_stat_m);
