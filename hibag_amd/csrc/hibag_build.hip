@@ -64,6 +64,7 @@ struct BuildState {
 	void *h_up = nullptr; size_t cap_up = 0, up_at = 0;
 	std::vector<void *> h_retired;          // staging areas outgrown while an operation was being put together (freed at the next rewind)
 	void *h_dn = nullptr; size_t cap_dn = 0; // pinned landing area of the pair-list step's read-backs
+	void *d_geno8 = nullptr; int geno8_snps = 0;   // the cohort's genotype codes [n_snp][n_pad] (hibag_build_set_genotypes), or null
 	void *d_pairs = nullptr; size_t cap_pairs = 0;
 };
 // One state per HOST THREAD (thread_local), and every copy / launch of this file on the calling thread's own default
@@ -259,6 +260,16 @@ struct BatchView {
 	double *cellv;             // [n_cand][n_pad / 64][max_cells][64]: a sample group's cell sums of a candidate are one contiguous stream
 	int *best;                 // [n_cand][2][n_pad]
 	double *post;              // [n_cand][n_pad]
+	// Round 6 (the driver's trainers): what the host used to expand per growth step stays on the device or is derived there --
+	// the cohort's genotype matrix is uploaded once per training call (hibag_build_set_genotypes), so a candidate travels as
+	// its SNP index instead of two bit planes per sample (`cand_w` is then null); a cell's haplotype ranges come from `cells`
+	// and `start` (`cellb` null); the true pair's place in a candidate's cell list is found by the scan itself, comparing the
+	// cells' packed allele pairs with the sample's (`wpos` null).  A growth step's upload shrinks from 520 KB to 125 KB and
+	// its packing on the host by half (profiles/r06_notes.txt item 4).
+	const int8_t *gdev;        // [n_snp_total][n_pad] genotype codes 0 / 1 / 2 / 3 = missing (padding lanes: 3), or null
+	const int *cand_snp;       // [n_cand] row of `gdev` of each candidate
+	int bit;                   // the candidate SNP's bit inside word `word`
+	const int *true_pair;      // [n_pad] (a1 << 16) | a2 of the sample's true alleles, -1 on padding lanes
 };
 
 #define SCAN_NB 32          // cells k_batch_scan has in flight; BatchView::max_cells is a multiple of it
@@ -326,17 +337,33 @@ __device__ __forceinline__ void batch_cells(const BatchView &B, int c, int sg, i
 #pragma unroll
 	for (int w = 0; w < W; w++) {
 		uint32_t s1 = B.planes[(size_t)w * B.n_pad + s], s2 = B.planes[(size_t)(NW + w) * B.n_pad + s];
-		if (w == B.word) { s1 = B.cand_w[((size_t)c * 2) * B.n_pad + s]; s2 = B.cand_w[((size_t)c * 2 + 1) * B.n_pad + s]; }
+		if (w == B.word) {
+			if (B.gdev) {
+				// TGenotype::_SetSNP (src/LibHLA.cpp:609-622) on the base genotype's word: g = 0 -> (0, 0), 1 -> (1, 0), 2 -> (1, 1), missing -> (0, 1)
+				const uint32_t v = (uint32_t)(uint8_t)B.gdev[(size_t)B.cand_snp[c] * B.n_pad + s];
+				const uint32_t b1 = (uint32_t)(v == 1u) | (uint32_t)(v == 2u), b2 = (uint32_t)(v > 1u), keep = ~(1u << B.bit);
+				s1 = (s1 & keep) | (b1 << B.bit);
+				s2 = (s2 & keep) | (b2 << B.bit);
+			} else { s1 = B.cand_w[((size_t)c * 2) * B.n_pad + s]; s2 = B.cand_w[((size_t)c * 2 + 1) * B.n_pad + s]; }
+		}
 		G.zt[w] = ~(s1 ^ s2); G.t[w] = s1 & s2; G.e[w] = s1 & ~s2;
 		G.n_het += __popc(G.e[w]);
 	}
-	const int4 *__restrict__ cb = B.cellb + (size_t)c * B.max_cells;
 	const int i0 = B.seg[c * (B.n_seg + 1) + sg], i1 = B.seg[c * (B.n_seg + 1) + sg + 1];
 	double *__restrict__ out = B.cellv + ((size_t)c * (B.n_pad / HIBAG_WAVE) + (s >> 6)) * B.max_cells * HIBAG_WAVE + (s & 63);
-	int4 nb = cb[i0 < i1 ? i0 : 0];
+	// a cell's haplotype ranges {a0, a1, b0, b1}: one 16-byte load from `cellb`, or -- where the host no longer writes that
+	// table -- from the cell's packed allele pair and the candidate's allele starts (all wave-uniform: scalar loads)
+	const int *__restrict__ st = B.start + (size_t)c * (B.n_hla + 1);
+	const int *__restrict__ cl = B.cells + (size_t)c * B.max_cells;
+	auto ranges = [&](int i) {
+		if (B.cellb) return B.cellb[(size_t)c * B.max_cells + i];
+		const int hh = cl[i], h1 = hh >> 16, h2 = hh & 0xFFFF;
+		return int4{st[h1], st[h1 + 1], st[h2], st[h2 + 1]};
+	};
+	int4 nb = ranges(i0 < i1 ? i0 : 0);
 	for (int i = i0; i < i1; i++) {
 		const int4 r = nb;
-		nb = cb[i + 1 < i1 ? i + 1 : i];         // the next cell's ranges travel while this cell is summed
+		nb = ranges(i + 1 < i1 ? i + 1 : i);       // the next cell's ranges travel while this cell is summed
 		double cell;
 		if (hb_s)      // the candidate's list sits in LDS, indices relative to its first haplotype
 			cell = batch_cell<W>(hb_s, hf_s, n_h, r.x - h_lo, r.y - h_lo, r.z - h_lo, r.w - h_lo, r.x == r.z, G, tab_s);
@@ -391,7 +418,8 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_batch_scan(HibagMulti<BatchView>
 	const int s = (local % ng) * HIBAG_WAVE + (int)threadIdx.x;
 	const int *cl = B.cells + (size_t)c * B.max_cells;
 	const int n = B.seg[c * (B.n_seg + 1) + B.n_seg];
-	const int wpos = B.wpos[(size_t)c * B.n_pad + s];
+	const int wpos = B.wpos ? B.wpos[(size_t)c * B.n_pad + s] : -2;
+	const int tp = B.true_pair ? B.true_pair[s] : -1;                 // (the cells' packed pairs are >= 0; the list's padding holds -1 ... and so do padding lanes)
 	double best = 0, total = 0, hit = 0;
 	int bi = -1;
 	const double *__restrict__ col = B.cellv + ((size_t)c * (B.n_pad / HIBAG_WAVE) + (s >> 6)) * B.max_cells * HIBAG_WAVE + (s & 63);
@@ -410,7 +438,8 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_batch_scan(HibagMulti<BatchView>
 		for (int j = 0; j < SCAN_NB; j++) {
 			const double cell = v[j];
 			if (best < cell) { best = cell; bi = i0 + j; }          // first strict maximum (_BestGuess, src/LibHLA.cpp:1639-1704)
-			if (i0 + j == wpos) hit = cell;                         // the true pair's cell (_PostProb, :1706-1767)
+			// the true pair's cell (_PostProb, :1706-1767): by its place in the list, or by comparing the cell's alleles with the sample's
+			if (B.wpos ? i0 + j == wpos : (cl[i0 + j] == tp && tp >= 0)) hit = cell;
 			total += cell;
 		}
 	};
@@ -704,6 +733,7 @@ void hibag_build_done()
 	if (g.h_dn) (void)hipHostFree(g.h_dn);
 	g.h_dn = nullptr; g.cap_dn = 0;
 	dev_free(g.d_pairs);
+	dev_free(g.d_geno8); g.geno8_snps = 0;
 	g.cap_h = g.cap_s = g.cap_match = g.cap_batch = g.cap_stage = g.cap_up = g.up_at = g.cap_pairs = 0;
 	g.active = false; g.evaluated = false;
 }
@@ -716,6 +746,26 @@ void hibag_build_set_bootstrap(const int oob_cnt[])
 	g.inbag.clear(); g.oob.clear();
 	for (int i = 0; i < g.n_sample; i++) (g.boot[i] > 0 ? g.inbag : g.oob).push_back(i);
 	g.evaluated = false;
+}
+
+// The library's own driver: the cohort's genotype matrix, SNP-major int32 [n_snp][n_sample] (values outside 0..2 = missing), kept
+// on the device as byte codes for the whole training call -- a growth step's candidates then travel as SNP indices
+// (HibagBuildCandidate::snp) instead of two bit planes per candidate and sample.  After build_init.
+void hibag_build_set_genotypes(const int32_t *geno_snp_major, int n_snp)
+{
+	if (!g.active) build_throw("build_set_genotypes before build_init");
+	dev_free(g.d_geno8); g.geno8_snps = 0;
+	if (!geno_snp_major || n_snp <= 0) return;
+	const size_t np = (size_t)g.n_pad, n = (size_t)g.n_sample;
+	std::vector<int8_t> codes((size_t)n_snp * np, (int8_t)3);
+	for (int j = 0; j < n_snp; j++)
+		for (size_t s = 0; s < n; s++) {
+			const int32_t v = geno_snp_major[(size_t)j * n + s];
+			codes[(size_t)j * np + s] = (0 <= v && v <= 2) ? (int8_t)v : (int8_t)3;
+		}
+	HIP_OK(hipMalloc(&g.d_geno8, codes.size()), "hipMalloc(genotype codes)");
+	HIP_OK(hipMemcpy(g.d_geno8, codes.data(), codes.size(), hipMemcpyHostToDevice), "copy genotype codes");
+	g.geno8_snps = n_snp;
 }
 
 // build_set_haplo_geno(haplo, n_haplo, geno, n_snp): src/LibHLA.cpp:1916-1920
@@ -987,9 +1037,13 @@ void hibag_build_eval_launch(int slot, const PluginGenotype base_geno[], int n_s
 	// and a dozen separate pageable copies cost more than the kernels.
 	size_t o = 0;
 	auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
-	const size_t o_hb = take((size_t)nw * Hs * 4), o_cw = take((size_t)n_cand * 2 * np * 4), o_start = take(S.start.size() * 4),
-		o_cells = take((size_t)n_cand * max_cells * 4), o_cellb = take((size_t)n_cand * max_cells * 16), o_seg = take((size_t)n_cand * (n_seg + 1) * 4),
-		o_planes = take((size_t)2 * NW * np * 4), o_true = take((size_t)np * 4), o_wpos = take((size_t)n_cand * np * 4), o_hf = take(Hs * 8), in_end = o;
+	// (the driver's trainers keep the cohort's genotypes on the device: no bit planes per candidate, no range table per cell,
+	// no per-sample position table -- BatchView "Round 6")
+	bool use_dev = g.d_geno8 != nullptr;
+	for (int c = 0; c < n_cand && use_dev; c++) use_dev = cand[c].snp >= 0 && cand[c].snp < g.geno8_snps;
+	const size_t o_hb = take((size_t)nw * Hs * 4), o_cw = take(use_dev ? (size_t)n_cand * 4 : (size_t)n_cand * 2 * np * 4), o_start = take(S.start.size() * 4),
+		o_cells = take((size_t)n_cand * max_cells * 4), o_cellb = take(use_dev ? 0 : (size_t)n_cand * max_cells * 16), o_seg = take((size_t)n_cand * (n_seg + 1) * 4),
+		o_planes = take((size_t)2 * NW * np * 4), o_true = take((size_t)np * 4), o_wpos = take(use_dev ? (size_t)np * 4 : (size_t)n_cand * np * 4), o_hf = take(Hs * 8), in_end = o;
 	const size_t b_best = (size_t)n_cand * 2 * np * 4, b_post = (size_t)n_cand * np * 8;
 	const size_t o_best = take(b_best), o_post = take(b_post), out_end = o;
 	const size_t o_cellv = take((size_t)n_cand * max_cells * np * 8);
@@ -1030,6 +1084,8 @@ void hibag_build_eval_launch(int slot, const PluginGenotype base_geno[], int n_s
 				hf[off + i] = hp[i].freq;
 			}
 			off += (size_t)cand[c].n_haplo;
+			if (use_dev) cw[c] = (uint32_t)cand[c].snp;                      // (the slot holds the candidates' SNP indices instead)
+			else {
 			// the candidate SNP's bit in the two planes of its word (branch-free: the compiler vectorises it)
 			uint32_t *o1 = &cw[((size_t)c * 2) * np], *o2 = &cw[((size_t)c * 2 + 1) * np];
 			const int32_t *col = cand[c].column;
@@ -1042,17 +1098,23 @@ void hibag_build_eval_launch(int slot, const PluginGenotype base_geno[], int n_s
 				o2[s] = (b2p[s] & keep) | (b2 << bit);
 			}
 			for (int s = n; s < np; s++) { o1[s] = 0u; o2[s] = 0xFFFFFFFFu; }      // padding lanes: all missing
+			}
 			// the cell list, the cells' haplotype ranges, the segments of equal work
 			const int *st = &S.start[(size_t)c * (nh + 1)];
 			const std::vector<int> &cl = S.cell_list[c];
 			const std::vector<uint64_t> &cwk = S.cell_work[c];
 			int *cc = cells + (size_t)c * max_cells, *cbv = cellb + (size_t)c * max_cells * 4;
-			for (size_t i = 0; i < cl.size(); i++) {
-				const int h1 = cl[i] >> 16, h2 = cl[i] & 0xFFFF;
-				cc[i] = cl[i];
-				cbv[4 * i] = st[h1]; cbv[4 * i + 1] = st[h1 + 1]; cbv[4 * i + 2] = st[h2]; cbv[4 * i + 3] = st[h2 + 1];
+			if (use_dev) {
+				memcpy(cc, cl.data(), cl.size() * sizeof(int));
+				for (size_t i = cl.size(); i < (size_t)max_cells; i++) cc[i] = -1;     // (never equal to a sample's packed true pair)
+			} else {
+				for (size_t i = 0; i < cl.size(); i++) {
+					const int h1 = cl[i] >> 16, h2 = cl[i] & 0xFFFF;
+					cc[i] = cl[i];
+					cbv[4 * i] = st[h1]; cbv[4 * i + 1] = st[h1 + 1]; cbv[4 * i + 2] = st[h2]; cbv[4 * i + 3] = st[h2 + 1];
+				}
+				for (size_t i = cl.size(); i < (size_t)max_cells; i++) { cc[i] = 0; cbv[4 * i] = cbv[4 * i + 1] = cbv[4 * i + 2] = cbv[4 * i + 3] = 0; }
 			}
-			for (size_t i = cl.size(); i < (size_t)max_cells; i++) { cc[i] = 0; cbv[4 * i] = cbv[4 * i + 1] = cbv[4 * i + 2] = cbv[4 * i + 3] = 0; }
 			uint64_t total = 0;
 			for (uint64_t w : cwk) total += w + 4;
 			int *sg = seg + (size_t)c * (n_seg + 1);
@@ -1086,9 +1148,13 @@ void hibag_build_eval_launch(int slot, const PluginGenotype base_geno[], int n_s
 	}
 	for (int s = n; s < np; s++) true_cell[s] = -1;
 
-	// where each sample's true pair sits in each candidate's cell list
+	// where each sample's true pair sits in each candidate's cell list -- or just the packed pair, which the scan compares itself
+	if (use_dev) {
+		for (int s = 0; s < n; s++) wpos[s] = (g.true1[s] << 16) | g.true2[s];
+		for (int s = n; s < np; s++) wpos[s] = -1;
+	}
 	S.at.resize((size_t)nh * (nh + 1) / 2);
-	for (int c = 0; c < n_cand; c++) {
+	for (int c = 0; c < n_cand && !use_dev; c++) {
 		std::fill(S.at.begin(), S.at.end(), -1);
 		const std::vector<int> &cl = S.cell_list[c];
 		for (size_t i = 0; i < cl.size(); i++) {
@@ -1104,7 +1170,11 @@ void hibag_build_eval_launch(int slot, const PluginGenotype base_geno[], int n_s
 	BatchView B{nh, np, nw, n_cand, n_seg, word, (const uint32_t *)(d + o_hb), (const double *)(d + o_hf), (int)Hs,
 		(const int *)(d + o_start), (const uint32_t *)(d + o_planes), (const uint32_t *)(d + o_cw), (const int *)(d + o_cells),
 		(const int4 *)(d + o_cellb), (const int *)(d + o_seg), max_cells, (const int *)(d + o_true), (const int *)(d + o_wpos), (const double *)g.d_tab, (double *)(d + o_cellv),
-		(int *)(d + o_best), (double *)(d + o_post)};
+		(int *)(d + o_best), (double *)(d + o_post), nullptr, nullptr, bit, nullptr};
+	if (use_dev) {
+		B.gdev = (const int8_t *)g.d_geno8; B.cand_snp = (const int *)(d + o_cw); B.true_pair = (const int *)(d + o_wpos);
+		B.cand_w = nullptr; B.cellb = nullptr; B.wpos = nullptr;
+	}
 	// one operation (hibag_combine.h): the step's inputs in one copy, the two kernels -- alone, or fused with the scoring of
 	// the other trainers' steps of the moment --, the results back in one; returns when they are in the staging area
 	HibagOp op;

@@ -55,7 +55,10 @@ struct HibagBuildCandidate {
 	const PluginHaplotype *haplo;   // aux.hla_allele filled (SetHaploAux_GPU)
 	int n_haplo;
 	const int32_t *column;          // [n_sample] raw genotype of the candidate SNP
+	int snp = -1;                   // its row in the matrix given to hibag_build_set_genotypes (-1: none was given; `column` is used)
 };
+// the cohort's genotypes, SNP-major int32 [n_snp][n_sample], kept on the device for the training call (after hibag_build_init)
+void hibag_build_set_genotypes(const int32_t *geno_snp_major, int n_snp);
 // acc_floor: the search's best out-of-bag count so far.  The reference looks at a candidate's in-bag loss only when its
 // out-of-bag count reaches the running maximum of the comparison (src/LibHLA.cpp:2033-2034); the same rule decides here
 // which candidates' losses are computed at all (the others get 0 -- they are never read).

@@ -637,7 +637,7 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 			// (a candidate's genotype column is a row of the SNP-major copy: nothing to gather)
 			for (size_t j = 0; j < P.which.size(); j++)
 				P.bc.push_back(HibagBuildCandidate{cand[P.which[j]].list.data(), (int)cand[P.which[j]].list.size(),
-					&t.geno_t[(size_t)vs.at(P.which[j]) * t.n_samp]});
+					&t.geno_t[(size_t)vs.at(P.which[j]) * t.n_samp], vs.at(P.which[j])});
 			hibag_build_eval_launch(slot, t.g.data(), t.g_nsnp + 1, P.bc.data(), (int)P.bc.size());
 		};
 		int acc_floor = global_max_acc;
@@ -709,6 +709,7 @@ void build_classifiers(T &t, int nclassifier, int mtry, bool prune, bool verbose
 		Scope(int nh, int ns) { hibag_build_init(nh, ns); }
 		~Scope() { hibag_build_done(); hibag_em_release(); }      // (both states are the calling thread's own: nothing of them outlives the call)
 	} scope(t.n_hla, t.n_samp);
+	hibag_build_set_genotypes(t.geno_t.data(), t.n_snp);             // (the candidates of a growth step then travel as SNP indices)
 	Sampling vs;
 	const int n = t.n_samp;
 	for (int k = 0; k < nclassifier; k++) {
