@@ -498,7 +498,8 @@ def main():
             "host_inclusive_samples_per_s": round(out["host_inclusive"]["value"], 1), "host_inclusive_ms_per_step": round(out["host_inclusive"]["ms_per_step"], 4),
             "api_inclusive_samples_per_s": round(out["api_inclusive"]["value"], 1), "api_inclusive_ms_per_step": round(out["api_inclusive"]["ms_per_step"], 4),
             "api_inclusive_frac_of_host_inclusive": round(out["api_inclusive"]["frac_of_host_inclusive"], 4),
-            "api_inclusive_numpy_order_samples_per_s": round(out["api_inclusive"]["numpy_order"]["value"], 1)})
+            "api_inclusive_numpy_order_samples_per_s": round(out["api_inclusive"]["numpy_order"]["value"], 1),
+            "api_inclusive_plink_bed_samples_per_s": round(out["api_inclusive"]["plink_bed"]["value"], 1)})
         faults["host_inclusive"] = int(model.handover_faults()) - faults["timed_model"]
         if args.shape == SHAPE and n == SAMPLES_PER_GPU:
             out["host_inclusive_100k"] = host_inclusive_cohort(model, model_obj, founders, afreq, dev, 100_000)
@@ -602,8 +603,22 @@ def api_inclusive(model, model_obj, geno, n, calls, reps=12):
         res[key] = {"value": n / ms * 1e3, "ms_per_step": ms,
                     "calls_identical_to_timed_step": bool(np.array_equal(r.h1, calls[0]) and np.array_equal(r.h2, calls[1])),
                     "result": f"hlaAlleleClass: {len(r.sample_id)} samples, dosage {tuple(r.dosage.shape)}"}
+    # the cohort in a PLINK BED file (two bits per genotype: a sixteenth of the int32 upload), decoded on the device
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        bed = synth.as_bed_geno(model_obj, geno, os.path.join(tmp, "cohort.bed"))
+        last = [None]
+
+        def call_bed():
+            last[0] = hibag_amd.hlaPredict(model, bed, type="response+dosage", verbose=False)
+        ms = median_ms(call_bed, reps)
+        r = last[0]
+        res["plink_bed"] = {"value": n / ms * 1e3, "ms_per_step": ms,
+                            "calls_identical_to_timed_step": bool(np.array_equal(r.h1, calls[0]) and np.array_equal(r.h2, calls[1])),
+                            "what": "hlaPredict(model, hlaBED2Geno(..., lazy=TRUE)): the file read (page cache), H2D of the packed bytes, "
+                                    "decode + kernels (hibag_hip_predict_bed), D2H, the result object"}
     out = dict(res["r_order"])
-    out.update({"unit": "samples/s", "repetitions": reps, "numpy_order": res["numpy_order"],
+    out.update({"unit": "samples/s", "repetitions": reps, "numpy_order": res["numpy_order"], "plink_bed": res["plink_bed"],
                 "what": "hibag_amd.hlaPredict(model, hlaSNPGenoClass, type='response+dosage', verbose=False): annotation matching + "
                         "H2D of the int32 genotypes (pageable, the caller's own array) + kernels + D2H + the result object, median; "
                         "`value`: genotype matrix in R's memory order, `numpy_order`: row-major [SNP, sample] through "

@@ -202,12 +202,7 @@ class HlaAttrBagClass:
         if g.ndim != 2 or g.shape[1] != self.obj.n_snp:
             raise ValueError("genomat must be [n_samp, n.snp] int32")
         n = g.shape[0]
-        out = dict(h1=np.zeros(n, np.int32), h2=np.zeros(n, np.int32),
-                   prob=np.zeros(n, np.float64), matching=np.zeros(n, np.float64))
-        if want_dosage:
-            out["dosage"] = np.zeros((n, self.obj.n_hla), np.float64)
-        if want_prob:
-            out["postprob"] = np.zeros((n, self.obj.n_cell), np.float64)
+        out = self._outputs(n, want_dosage, want_prob)
         _lib.check(_lib.lib().hibag_hip_predict(
             self.handle, _as_ptr(g), n, int(vote_method), _as_ptr(out["h1"]), _as_ptr(out["h2"]),
             _as_ptr(out["prob"]), _as_ptr(out["matching"]), _as_ptr(out.get("dosage")), _as_ptr(out.get("postprob"))))
@@ -223,12 +218,7 @@ class HlaAttrBagClass:
             raise ValueError("snp_col must have one entry per model SNP")
         fl = None if flip is None else np.ascontiguousarray(np.asarray(flip) != 0, np.int32)
         n = int(n_samp)
-        out = dict(h1=np.zeros(n, np.int32), h2=np.zeros(n, np.int32),
-                   prob=np.zeros(n, np.float64), matching=np.zeros(n, np.float64))
-        if want_dosage:
-            out["dosage"] = np.zeros((n, self.obj.n_hla), np.float64)
-        if want_prob:
-            out["postprob"] = np.zeros((n, self.obj.n_cell), np.float64)
+        out = self._outputs(n, want_dosage, want_prob)
         _lib.check(_lib.lib().hibag_hip_predict_bed(
             self.handle, os.fsencode(bed_fn), n, int(n_snp), _as_ptr(col), _as_ptr(fl), int(vote_method),
             _as_ptr(out["h1"]), _as_ptr(out["h2"]), _as_ptr(out["prob"]), _as_ptr(out["matching"]),
@@ -248,12 +238,7 @@ class HlaAttrBagClass:
             raise ValueError("snp_col must have one entry per model SNP")
         fl = None if flip is None else np.ascontiguousarray(np.asarray(flip) != 0, np.int32)
         n = g.shape[0]
-        out = dict(h1=np.zeros(n, np.int32), h2=np.zeros(n, np.int32),
-                   prob=np.zeros(n, np.float64), matching=np.zeros(n, np.float64))
-        if want_dosage:
-            out["dosage"] = np.zeros((n, self.obj.n_hla), np.float64)
-        if want_prob:
-            out["postprob"] = np.zeros((n, self.obj.n_cell), np.float64)
+        out = self._outputs(n, want_dosage, want_prob)
         _lib.check(_lib.lib().hibag_hip_predict_mapped(
             self.handle, _as_ptr(g), n, g.shape[1], _as_ptr(col), _as_ptr(fl), int(vote_method),
             _as_ptr(out["h1"]), _as_ptr(out["h2"]), _as_ptr(out["prob"]), _as_ptr(out["matching"]),

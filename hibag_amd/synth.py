@@ -107,3 +107,31 @@ def as_snp_geno(model: HlaAttrBagObj, genomat: np.ndarray, order: str = "C") -> 
     return HlaSNPGeno(genotype=(np.ascontiguousarray(genomat.T) if order == "C" else np.ascontiguousarray(genomat).T), sample_id=[f"S{i + 1}" for i in range(n)],
                       snp_id=list(model.snp_id), snp_position=model.snp_position,
                       snp_allele=list(model.snp_allele), assembly=model.assembly)
+
+
+def write_bed(path: str, genomat: np.ndarray) -> str:
+    """The sample-major matrix ``genomat`` [n_samp, n_snp] as a SNP-major PLINK BED file (two bits per genotype: 2 -> 00,
+    missing -> 01, 1 -> 10, 0 -> 11, four samples per byte from the low bits up: the format ``HIBAG_ConvBED`` reads,
+    ``src/HIBAG.cpp:1094-1191``)."""
+    g = np.asarray(genomat).T
+    code = np.full(g.shape, 1, np.uint8)
+    code[g == 2] = 0
+    code[g == 1] = 2
+    code[g == 0] = 3
+    pad = np.zeros((g.shape[0], (g.shape[1] + 3) // 4 * 4), np.uint8)
+    pad[:, :g.shape[1]] = code
+    q = pad.reshape(g.shape[0], -1, 4)
+    with open(path, "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 1]))
+        f.write((q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).astype(np.uint8).tobytes())
+    return path
+
+
+def as_bed_geno(model: HlaAttrBagObj, genomat: np.ndarray, path: str):
+    """The same cohort as :func:`as_snp_geno`, kept in a PLINK BED file: what ``hlaBED2Geno(..., lazy=True)`` returns."""
+    from .bed import HlaBEDGeno
+    n, s = genomat.shape
+    write_bed(path, genomat)
+    return HlaBEDGeno(bed_fn=path, mode=1, n_bed_samp=n, n_bed_snp=s, bed_index=np.arange(s, dtype=np.int64),
+                      sample_id=[f"S{i + 1}" for i in range(n)], snp_id=list(model.snp_id), snp_position=model.snp_position,
+                      snp_allele=list(model.snp_allele), assembly=model.assembly)

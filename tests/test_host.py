@@ -429,3 +429,16 @@ def test_hlaPredict_host_side_routes_by_memory_order_and_copies_nothing():
     assert [bool(f) for f in flip] == [k % 5 == 0 and k not in (3, 11) for k in range(model.n_snp)]
     with pytest.raises(TypeError):
         hibag_amd.hlaPredict(m, np.array([["a"] * 3] * model.n_snp), verbose=False)
+
+
+def test_synth_bed_writer_matches_the_test_writer(tmp_path):
+    """``synth.write_bed`` (bench.py's PLINK leg) writes the same bytes as the tests' own writer, which the reference's
+    BED <-> .rdata fixture pair pins (tests/test_hip_bed.py)."""
+    from conftest import write_bed
+    from hibag_amd import synth
+    rng = np.random.default_rng(5)
+    for n, s in ((1, 1), (7, 3), (64, 10), (101, 5)):
+        g = rng.integers(-1, 4, (n, s)).astype(np.int32)
+        a = synth.write_bed(str(tmp_path / "a.bed"), g)
+        b = write_bed(str(tmp_path / "b.bed"), g.T, 1)
+        assert open(a, "rb").read() == open(b, "rb").read()
