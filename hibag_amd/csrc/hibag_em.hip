@@ -101,7 +101,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 	const EmView V = M.v[owner];
 	extern __shared__ __attribute__((aligned(16))) char lds[];
 	__shared__ int verdict_s;                                         // of the iteration before: 0 = go on, 1 = converged, 2 = cannot tell (host)
-	__shared__ unsigned long long tmax_s[2];                          // largest |term| of an iteration (bits of a non-negative double), by parity
+	__shared__ double tabs_s[2][EM_THREADS / HIBAG_WAVE_EM];         // sum of |term| of an iteration, by parity and wavefront (only ever a BOUND: its own order of summation is free)
 	const EmLayout L(V.n_ib, V.n_pair, V.n_hap);
 	double *oldf = (double *)(lds + L.oldf), *newf = (double *)(lds + L.newf), *G = (double *)(lds + L.G), *lterm = (double *)(lds + L.lterm);
 	uint32_t *pw = (uint32_t *)(lds + L.pw);                          // h1 | h2 << 14 | genotype of the pair's sample << 28
@@ -159,7 +159,6 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 		const double *t_prev = lterm + (size_t)((iter + 1) & 1) * n_ib;   // the terms of iteration iter - 1
 		double *t_cur = lterm + (size_t)(iter & 1) * n_ib;
 		if (summer) chain = 0;
-		if (tid == 0) tmax_s[iter & 1] = 0;
 		__syncthreads();
 		// ---- A
 		if (summer) { if (iter > 0) sum_part(t_prev, 0); }
@@ -183,7 +182,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 			}
 		__syncthreads();
 		// ---- B: a sample's psum in list order (sixteen reads in flight), its term, its scaling factor
-		unsigned long long my_max = 0;
+		double my_abs = 0;
 		if (summer) { if (iter > 0) sum_part(t_prev, 1); }
 		else if (worker)
 			for (int i = tid; i < n_ib; i += nw) {
@@ -201,10 +200,10 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 				const double term = b_i * log(psum);
 				t_cur[i] = term;
 				rs[i] = b_i / psum;
-				my_max = max(my_max, (unsigned long long)__double_as_longlong(fabs(term)));     // (bits of a non-negative double: NaN / inf sort above every number)
+				my_abs += fabs(term);                                  // (NaN / inf stay what they are: the verdict below then is "cannot tell")
 			}
-		for (int d = 32; d > 0; d >>= 1) my_max = max(my_max, (unsigned long long)__shfl_xor((long long)my_max, d));
-		if ((tid & 63) == 0 && my_max) atomicMax(&tmax_s[iter & 1], my_max);
+		for (int d = 32; d > 0; d >>= 1) my_abs += __shfl_xor(my_abs, d);
+		if ((tid & 63) == 0) tabs_s[iter & 1][tid >> 6] = worker ? my_abs : 0.0;
 		__syncthreads();
 		// ---- B': thread = pair again: the compatible G *= boot / psum (an incompatible pair stays +0.0 whatever the factor is)
 		if (summer) { if (iter > 0) sum_part(t_prev, 2); }
@@ -227,11 +226,16 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 		if (summer) {
 			if (iter > 0) {
 				sum_part(t_prev, 3);
-				// the stopping test of iteration iter - 1 (:1247-1254), with a margin for the device's log():
-				// |loglik here - loglik on the host| <= (n + 4) 2^-52 (sum of the terms' magnitudes) for logs within 2 ulp of each
-				// other; the sum bounded by n times the largest, and the whole taken eight times as wide
-				const double tmax = __longlong_as_double((long long)tmax_s[(iter + 1) & 1]);
-				const double loglik = chain, bound = 16.0 * 1.1102230246251565e-16 * (double)(n_ib + 4) * ((double)n_ib * tmax);
+				// the stopping test of iteration iter - 1 (:1247-1254), with a margin for the device's log().  With logs within
+				// 2 ulp of each other a term differs by at most 3 ulp (the product with the count rounds again), and two in-order
+				// sums of n such terms by at most (2 (n - 1) u + 7 u) T, u = 2^-53, T = the sum of the terms' magnitudes
+				// (Higham, Accuracy and Stability of Numerical Algorithms, 4.2): (2 n + 6) u T.  Taken four times as wide:
+				// 8 (n + 4) u T.  (Until round 6 T was bounded by n times the largest term and the whole taken eight times as
+				// wide: a band 6 times wider than this one, in which 1 % of all fits landed and went back to the host, a third of a
+				// millisecond of its time each -- profiles/r06_notes.txt item 4g.)
+				double tsum = 0;
+				for (int w = 0; w < EM_THREADS / HIBAG_WAVE_EM; w++) tsum += tabs_s[(iter + 1) & 1][w];
+				const double loglik = chain, bound = 8.0 * 1.1102230246251565e-16 * (double)(n_ib + 4) * tsum;
 				int verdict = 0;
 				if (iter > 1) {
 					const double d = fabs(loglik - loglik_prev), slack = bound + bound_prev + tol_bound;

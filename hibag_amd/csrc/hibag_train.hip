@@ -614,7 +614,7 @@ void search(T &t, Sampling &vs, OutClassifier &o, int mtry, bool prune, bool ver
 			}
 		}
 		auto fit = [&](int lo, int hi) {
-			Tick tk(1);
+			Tick tk(1), tk_host(6);
 			std::atomic<int> next_i(lo);
 			auto work = [&]() {
 				HapList nx;
@@ -877,8 +877,8 @@ int hibag_hip_trainer_new_classifiers(hibag_hip_trainer *t, int nclassifier, int
 				Profile::now() - t0, g_prof.t[0], g_prof.t[1], g_prof.t[2], g_batch_prof[0], g_batch_prof[4], g_batch_prof[5], g_batch_prof[1], g_batch_prof[2], g_batch_prof[3],
 				g_prof.t[3], g_prof.t[4], g_prof.t[5], (int)g_prof.t[7]);
 		if (getenv("HIBAG_TRAIN_PROFILE"))
-			fprintf(stderr, "[hibag train] this thread's CPU time: pair lists %.3f, EM %.3f, scoring %.3f, compare %.3f, select %.3f; search() %.3f s = %.3f ms per growth step\n",
-				g_prof.c[0], g_prof.c[1], g_prof.c[2], g_prof.c[3], g_prof.c[4], g_prof.c[5], g_prof.t[7] > 0 ? 1e3 * g_prof.c[5] / g_prof.t[7] : 0.0);
+			fprintf(stderr, "[hibag train] this thread's CPU time: pair lists %.3f, EM %.3f, scoring %.3f, compare %.3f, select %.3f; search() %.3f s = %.3f ms per growth step; of EM: fits on this thread %.3f\n",
+				g_prof.c[0], g_prof.c[1], g_prof.c[2], g_prof.c[3], g_prof.c[4], g_prof.c[5], g_prof.t[7] > 0 ? 1e3 * g_prof.c[5] / g_prof.t[7] : 0.0, g_prof.c[6]);
 	} catch (const char *msg) {
 		t->out.resize(before);                         // a failed call adds nothing
 		return hibag_fail(hibag_hip_device_count() <= 0 ? HIBAG_HIP_ENODEV : HIBAG_HIP_EINVAL, "%s", msg);
