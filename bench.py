@@ -867,22 +867,28 @@ def other_configs(K, faults=None):
             conc = {}
             best_rate, best_cls, best_k, best_key = 0.0, None, 1, None
 
-            def concurrent(key, k, per, em, budget, combine=True):
+            def concurrent(key, k, per, em, budget, combine=True, n=None):
                 nonlocal best_rate, best_cls, best_k, best_key
+                n = n or ncl
                 kw = dict(em=em, combine=combine, thread_budget=budget)
                 train.grow_concurrently(G, truth[:, 0], truth[:, 1], mdl.n_hla, k, mtry, True, k, per, 100, **kw)      # warm-up
                 r0, t = resource.getrusage(resource.RUSAGE_SELF), time.perf_counter()
-                got = train.grow_concurrently(G, truth[:, 0], truth[:, 1], mdl.n_hla, ncl, mtry, True, k, per, 100, **kw)
+                got = train.grow_concurrently(G, truth[:, 0], truth[:, 1], mdl.n_hla, n, mtry, True, k, per, 100, **kw)
                 dtk = time.perf_counter() - t
                 r1 = resource.getrusage(resource.RUSAGE_SELF)
                 conc[key] = {"trainers": k, "threads_per_trainer": per, "em_fits": em, "host_thread_budget": budget or None,
                              "launches": "fused across trainers" if combine else "a stream per trainer",
-                             "classifiers": ncl, "seconds": dtk, "classifiers_per_s": ncl / dtk,
+                             "classifiers": n, "seconds": dtk, "classifiers_per_s": n / dtk,
                              "host_cores_busy": round((r1.ru_utime + r1.ru_stime - r0.ru_utime - r0.ru_stime) / dtk, 2)}
                 return got
             cls4 = concurrent("16_trainers_budget_4", 16, 1, "device", min(4, cores))
             concurrent("16_trainers_budget_cores_over_8", 16, 1, "device", per_rank)
             concurrent("4x4_host_em_own_streams", 4, max(1, cores // 4), "host", 0, combine=False)
+            # the same two budgets on a job several models long (40 classifiers per trainer): with the configuration's 100
+            # classifiers a trainer grows six or seven, and the trainers that finish first leave the device to the last ones
+            concurrent("steady_16_trainers_budget_4", 16, 1, "device", min(4, cores), n=640)
+            concurrent("steady_16_trainers_budget_cores_over_8", 16, 1, "device", per_rank, n=640)
+            concurrent("steady_32_trainers_no_budget", 32, 1, "device", 0, n=960)
             best_k, best_cls, best_key = 16, cls4, "16_trainers_budget_4"
             best_rate = conc[best_key]["classifiers_per_s"]
             res["cfg5_training"]["concurrent_trainers"] = conc
@@ -910,6 +916,7 @@ def other_configs(K, faults=None):
             res["cfg5_training"]["at_one_eighth_of_the_host"].update({
                 "concurrent": one8, "classifiers_per_s": one8["classifiers_per_s"],
                 "slowdown_vs_budget_4": best_rate / one8["classifiers_per_s"],
+                "steady_state_slowdown_vs_budget_4": conc["steady_16_trainers_budget_4"]["classifiers_per_s"] / conc["steady_16_trainers_budget_cores_over_8"]["classifiers_per_s"],
                 "projected_8_ranks_concurrent": {"classifiers_per_s": 8 * one8["classifiers_per_s"],
                                                  "what": f"eight ranks, each sixteen trainers on its own GPU under a budget of {per_rank} host threads "
                                                          "(measured on one GPU at that budget; no 8-GPU node was available to the build)"}})

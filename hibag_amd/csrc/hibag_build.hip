@@ -328,11 +328,10 @@ __device__ __forceinline__ double batch_cell(const uint32_t *hb, const double *h
 	return cell;
 }
 
+// the lane's genotype with the candidate SNP of candidate c set (TGenotype::_SetSNP on the base genotype)
 template <int W>
-__device__ __forceinline__ void batch_cells(const BatchView &B, int c, int sg, int s, const double *tab_s,
-	const uint32_t *hb_s, const double *hf_s, int h_lo, int n_h)
+__device__ __forceinline__ void batch_lane_genotype(const BatchView &B, int c, int s, LaneG<W> &G)
 {
-	LaneG<W> G;
 	G.n_het = 0;
 #pragma unroll
 	for (int w = 0; w < W; w++) {
@@ -349,17 +348,27 @@ __device__ __forceinline__ void batch_cells(const BatchView &B, int c, int sg, i
 		G.zt[w] = ~(s1 ^ s2); G.t[w] = s1 & s2; G.e[w] = s1 & ~s2;
 		G.n_het += __popc(G.e[w]);
 	}
+}
+
+// a cell's haplotype ranges {a0, a1, b0, b1}: one 16-byte load from `cellb`, or -- where the host no longer writes that
+// table -- from the cell's packed allele pair and the candidate's allele starts (all wave-uniform: scalar loads)
+__device__ __forceinline__ int4 batch_cell_ranges(const BatchView &B, int c, int i)
+{
+	if (B.cellb) return B.cellb[(size_t)c * B.max_cells + i];
+	const int *__restrict__ st = B.start + (size_t)c * (B.n_hla + 1);
+	const int hh = B.cells[(size_t)c * B.max_cells + i], h1 = hh >> 16, h2 = hh & 0xFFFF;
+	return int4{st[h1], st[h1 + 1], st[h2], st[h2 + 1]};
+}
+
+template <int W>
+__device__ __forceinline__ void batch_cells(const BatchView &B, int c, int sg, int s, const double *tab_s,
+	const uint32_t *hb_s, const double *hf_s, int h_lo, int n_h)
+{
+	LaneG<W> G;
+	batch_lane_genotype<W>(B, c, s, G);
 	const int i0 = B.seg[c * (B.n_seg + 1) + sg], i1 = B.seg[c * (B.n_seg + 1) + sg + 1];
 	double *__restrict__ out = B.cellv + ((size_t)c * (B.n_pad / HIBAG_WAVE) + (s >> 6)) * B.max_cells * HIBAG_WAVE + (s & 63);
-	// a cell's haplotype ranges {a0, a1, b0, b1}: one 16-byte load from `cellb`, or -- where the host no longer writes that
-	// table -- from the cell's packed allele pair and the candidate's allele starts (all wave-uniform: scalar loads)
-	const int *__restrict__ st = B.start + (size_t)c * (B.n_hla + 1);
-	const int *__restrict__ cl = B.cells + (size_t)c * B.max_cells;
-	auto ranges = [&](int i) {
-		if (B.cellb) return B.cellb[(size_t)c * B.max_cells + i];
-		const int hh = cl[i], h1 = hh >> 16, h2 = hh & 0xFFFF;
-		return int4{st[h1], st[h1 + 1], st[h2], st[h2 + 1]};
-	};
+	auto ranges = [&](int i) { return batch_cell_ranges(B, c, i); };
 	int4 nb = ranges(i0 < i1 ? i0 : 0);
 	for (int i = i0; i < i1; i++) {
 		const int4 r = nb;
@@ -452,6 +461,144 @@ __global__ __launch_bounds__(HIBAG_WAVE) void k_batch_scan(HibagMulti<BatchView>
 		if (i0 + SCAN_NB >= n) break;
 		if (i0 + 2 * SCAN_NB < n) request(va, col + 2 * step);
 		scan(vb, i0 + SCAN_NB);
+	}
+	const int hh = bi >= 0 ? cl[bi] : 0;
+	B.best[((size_t)c * 2) * B.n_pad + s] = bi >= 0 ? hh >> 16 : -2147483647 - 1;
+	B.best[((size_t)c * 2 + 1) * B.n_pad + s] = bi >= 0 ? hh & 0xFFFF : -2147483647 - 1;
+	B.post[(size_t)c * B.n_pad + s] = hit / total;
+}
+
+// Round 6, a VARIANT (HIBAG_BATCH_FUSED=1; the default stays the two kernels above -- the measurement is at the end of this
+// comment): both steps in ONE kernel, the cell sums never leave the CU.  The two kernels above exchange every cell sum of
+// every sample and candidate through HBM -- 190 MB written and read again per growth step of config 5's shape -- and the scan,
+// 288 wavefronts each waiting for its own loads forty times over, took as long as the evaluation itself (116 of 228 us per
+// growth step in a trace of sixteen trainers, profiles/r06_notes.txt item 4h).  Here one workgroup = (candidate, sample
+// group): eleven PRODUCER wavefronts take the candidate's cells one at a time from a counter, in posterior order, evaluate
+// them for the group's 64 samples (lane = sample, batch_cell as above) and put the sums into a ring in LDS; ONE wavefront scans
+// the ring in cell order -- first strict maximum, in-order total, the true pair's cell: k_batch_scan's operations in its
+// order.  Same bits; no cell segments, no cellv.  Measured (16 trainers, config 5's shape): 352 us per launch against
+// 180 + 185 for the two kernels, 170 against 173 classifiers/s -- the cells of one (candidate, sample group) are now evaluated
+// on ONE CU (eleven wavefronts) instead of spread over the device in 28 segments, and a workgroup's 70 KB of LDS keeps it off
+// the CUs that hold an EM fit; a trainer alone: 31.1 against 30.2.  Not a gain: not the default.
+#define SCORE_WAVES 12
+#define SCORE_RING 64       // slots of 64 doubles; a producer is at most this far ahead of the scan
+#define SCORE_STEP 8        // cells the scan takes at a time (SCORE_RING is a multiple)
+#define SCORE_CELLS_LDS 2048 // the candidate's cell list sits in LDS for the scan if it has at most this many cells (50 alleles: 1,275)
+struct ScoreShared {
+	double ring[SCORE_RING][HIBAG_WAVE];
+	int ready[SCORE_RING];      // cell index + 1 of what the slot holds
+	int next_cell, scan_pos;    // the next cell to hand out; cells the scan has consumed
+	int sink[SCORE_WAVES][HIBAG_WAVE];   // where the lanes that have nothing to publish store (see score_publish)
+};
+
+// One lane of the wavefront publishes `value` at `word`.  Written WITHOUT a branch on the lane -- every lane stores, all but
+// lane 0 into a word of their own that nobody reads: with `if (lane == 0)` around the store and around the counter's fetch-add
+// the compiler threaded the two branches through the loop's back edge into separate loops for lane 0 and for the other lanes,
+// whose readfirstlane then read a lane that had never fetched anything (ISA of the first build; the kernel never ended).
+__device__ __forceinline__ void score_publish(ScoreShared &S, int *word, int value)
+{
+	const int lane = (int)threadIdx.x & (HIBAG_WAVE - 1), wave = (int)threadIdx.x >> 6;
+	int *to = lane == 0 ? word : &S.sink[wave][lane];
+	__hip_atomic_store(to, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int score_peek(const int *word)          // the same value in every lane, and the compiler knows it
+{
+	return __builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+
+template <int W>
+__device__ __forceinline__ void batch_produce(const BatchView &B, int c, int s, int n, ScoreShared &S, const double *tab_s,
+	const uint32_t *hb_s, const double *hf_s, int h_lo, int n_h)
+{
+	LaneG<W> G;
+	batch_lane_genotype<W>(B, c, s, G);
+	const int lane = (int)threadIdx.x & (HIBAG_WAVE - 1);
+	for (;;) {
+		// (every lane adds one -- the compiler makes that ONE add of 64 by one lane -- so the counter runs in units of 64: no
+		// branch on the lane in the source)
+		const int k = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add(&S.next_cell, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 6;
+		if (k >= n) break;
+		const int4 r = batch_cell_ranges(B, c, k);
+		double cell;
+		if (hb_s) cell = batch_cell<W>(hb_s, hf_s, n_h, r.x - h_lo, r.y - h_lo, r.z - h_lo, r.w - h_lo, r.x == r.z, G, tab_s);
+		else      cell = batch_cell<W>(B.hb, B.hf, B.n_haplo_total, r.x, r.y, r.z, r.w, r.x == r.z, G, tab_s);
+		const int slot = k & (SCORE_RING - 1);
+		// (the slot's previous cell, k - SCORE_RING, must have been scanned)
+		while (k - score_peek(&S.scan_pos) >= SCORE_RING) __builtin_amdgcn_s_sleep(2);
+		S.ring[slot][lane] = cell;
+		score_publish(S, &S.ready[slot], k + 1);                       // (release: behind the wavefront's ring store)
+	}
+}
+
+__global__ __launch_bounds__(SCORE_WAVES * HIBAG_WAVE) void k_batch_score(HibagMulti<BatchView> M)
+{
+	__shared__ double tab_s[HIBAG_TAB_N];
+	__shared__ double hf_s[BATCH_LDS_HAPLO];
+	__shared__ uint32_t hb_s[NW * BATCH_LDS_HAPLO];
+	__shared__ ScoreShared S;
+	__shared__ int cells_s[SCORE_CELLS_LDS];
+	const int owner = hibag_multi_owner(M, (int)blockIdx.x);
+	const BatchView B = M.v[owner];
+	const int local = (int)blockIdx.x - M.first[owner];
+	const int ng = B.n_pad / HIBAG_WAVE;
+	const int c = local / ng, grp = local % ng;
+	const int n = B.seg[c * (B.n_seg + 1) + B.n_seg];                 // the candidate's cells
+	const int *cl = B.cells + (size_t)c * B.max_cells;
+	if (n <= SCORE_CELLS_LDS)                                         // (the scan compares every cell's allele pair with the sample's: not from global memory, cell by cell)
+		for (int i = threadIdx.x; i < n; i += blockDim.x) cells_s[i] = cl[i];
+	const int *st = B.start + (size_t)c * (B.n_hla + 1);
+	const int h_lo = st[0], n_h = st[B.n_hla] - st[0];
+	const bool staged = n_h <= BATCH_LDS_HAPLO;
+	for (int i = threadIdx.x; i < HIBAG_TAB_N; i += blockDim.x) tab_s[i] = B.tab[i];
+	if (staged) {
+		for (int i = threadIdx.x; i < n_h; i += blockDim.x) hf_s[i] = B.hf[h_lo + i];
+		for (int w = 0; w < B.nw; w++)
+			for (int i = threadIdx.x; i < n_h; i += blockDim.x) hb_s[w * n_h + i] = B.hb[(size_t)w * B.n_haplo_total + h_lo + i];
+	}
+	if (threadIdx.x < SCORE_RING) S.ready[threadIdx.x] = 0;
+	if (threadIdx.x == 0) { S.next_cell = 0; S.scan_pos = 0; }
+	__syncthreads();
+	const int lane = (int)threadIdx.x & (HIBAG_WAVE - 1), wave = (int)threadIdx.x >> 6;
+	const int s = grp * HIBAG_WAVE + lane;
+	if (wave > 0) {
+		const uint32_t *hbp = staged ? hb_s : nullptr;
+		switch (B.nw) {
+		case 1:  batch_produce<1>(B, c, s, n, S, tab_s, hbp, hf_s, h_lo, n_h); break;
+		case 2:  batch_produce<2>(B, c, s, n, S, tab_s, hbp, hf_s, h_lo, n_h); break;
+		case 3:  batch_produce<3>(B, c, s, n, S, tab_s, hbp, hf_s, h_lo, n_h); break;
+		default: batch_produce<4>(B, c, s, n, S, tab_s, hbp, hf_s, h_lo, n_h); break;
+		}
+		return;
+	}
+	// ---- the scan (k_batch_scan's, fed from the ring)
+	const int *clp = n <= SCORE_CELLS_LDS ? cells_s : cl;
+	const int wpos = B.wpos ? B.wpos[(size_t)c * B.n_pad + s] : -2;
+	const int tp = B.true_pair ? B.true_pair[s] : -1;
+	double best = 0, total = 0, hit = 0;
+	int bi = -1;
+	// SCORE_STEP cells at a time: their flags in one look (lane j of every eight reads flag j), their sums requested
+	// together -- cell by cell the scan was two dependent LDS round trips per cell, a chain as long as the producers' work
+	for (int k0 = 0; k0 < n; k0 += SCORE_STEP) {
+		const int m = min(SCORE_STEP, n - k0), s0 = k0 & (SCORE_RING - 1), j8 = lane & (SCORE_STEP - 1);
+		for (;;) {
+			const int seen = __hip_atomic_load(&S.ready[s0 + j8], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (__ballot(j8 >= m || seen == k0 + j8 + 1) == ~0ull) break;
+			__builtin_amdgcn_s_sleep(1);
+		}
+		double v[SCORE_STEP];
+#pragma unroll
+		for (int j = 0; j < SCORE_STEP; j++) v[j] = S.ring[s0 + j][lane];
+#pragma unroll
+		for (int j = 0; j < SCORE_STEP; j++) {
+			if (j >= m) break;
+			const double cell = v[j];
+			const int k = k0 + j;
+			if (best < cell) { best = cell; bi = k; }                    // first strict maximum (_BestGuess, src/LibHLA.cpp:1639-1704)
+			if (B.wpos ? k == wpos : (clp[k] == tp && tp >= 0)) hit = cell;   // the true pair's cell (_PostProb, :1706-1767)
+			total += cell;
+		}
+		// (the slots are free once their values are in registers: LDS serves a wavefront's accesses in order, the release keeps the compiler to it)
+		score_publish(S, &S.scan_pos, k0 + m);
 	}
 	const int hh = bi >= 0 ? cl[bi] : 0;
 	B.best[((size_t)c * 2) * B.n_pad + s] = bi >= 0 ? hh >> 16 : -2147483647 - 1;
@@ -675,6 +822,14 @@ void match_launch(const HibagOp *const ops[], int n, hipStream_t st)
 void eval_launch(const HibagOp *const ops[], int n, hipStream_t st)
 {
 	int total = 0;
+	// HIBAG_BATCH_FUSED=1: the one-kernel form (k_batch_score) -- bit-identical, measured equal to the two kernels beside other
+	// trainers and 3 % faster for a trainer alone (profiles/r06_notes.txt item 4h): kept as a variant, not the default
+	const char *fused = getenv("HIBAG_BATCH_FUSED");
+	if (fused && *fused == '1') {
+		const HibagMulti<BatchView> M1 = multi_of<BatchView>(ops, n, [](const BatchView &b) { return (b.n_pad / HIBAG_WAVE) * b.n_cand; }, total);
+		if (total > 0) hipLaunchKernelGGL(k_batch_score, dim3(total), dim3(SCORE_WAVES * HIBAG_WAVE), 0, st, M1);
+		return;
+	}
 	const HibagMulti<BatchView> Mc = multi_of<BatchView>(ops, n, [](const BatchView &b) {
 		return ((b.n_pad / HIBAG_WAVE + BATCH_WAVES - 1) / BATCH_WAVES) * b.n_seg * b.n_cand; }, total);
 	if (total > 0) hipLaunchKernelGGL(k_batch_cells, dim3(total), dim3(BATCH_WAVES * HIBAG_WAVE), 0, st, Mc);

@@ -63,6 +63,8 @@ struct EmView {
 	const int *boot;                        // [n_ib]
 	const int *hoff;                        // [n_hap + 1] transposed lists: the pairs that contain haplotype h ...
 	const uint32_t *hent;                   // ... in pair order, a homozygous pair twice: BYTE offsets into G, every list padded to a multiple of 4 entries with n_pair * 8 (a slot that holds +0.0); hoff counts entries incl. padding
+	const uint16_t *pos;                    // or (round 6, where LDS has room: EmLayout::staged) the INVERSE of those lists: [2 n_pair] the two entries pair j has in them -- its scaled G is
+	                                        // written there (phase B'), so a haplotype's G are contiguous and phase C reads them in order instead of gathering; null: hent is used
 	const double *cur_freq;                 // [n_hap / 2]
 	// per candidate
 	const int8_t *geno;                     // [n_cand][n_ib] genotype of the in-bag samples at the candidate SNP: 0, 1, 2, 3 = missing
@@ -73,14 +75,17 @@ struct EmView {
 
 // LDS layout of k_em_fit (bytes), shared by the kernel and the host's size check
 struct EmLayout {
-	size_t oldf, newf, G, lterm, rs, pw, off, bt, hoff, hent, ps, total;
-	__host__ __device__ EmLayout(int n_ib, int n_pair, int n_hap)
+	size_t oldf, newf, G, lterm, rs, pw, off, bt, hoff, hent, ps, gt, total;
+	// staged: the lists' G values have a (transposed) copy of their own, `gt`, and `hent` holds 16-bit positions instead of offsets
+	__host__ __device__ EmLayout(int n_ib, int n_pair, int n_hap, bool staged)
 	{
 		size_t o = 0;
 		auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 7) & ~(size_t)7; return at; };
 		oldf = take((size_t)n_hap * 8); newf = take((size_t)n_hap * 8); G = take((size_t)(n_pair + 1) * 8 + 8); lterm = take((size_t)n_ib * 16); rs = take((size_t)n_ib * 8);
 		pw = take((size_t)n_pair * 4); off = take((size_t)(n_ib + 1) * 4); bt = take((size_t)n_ib * 4); hoff = take((size_t)(n_hap + 1) * 4);
-		hent = take(((size_t)2 * n_pair + 4 * (size_t)n_hap) * 4 + 16); ps = take((size_t)n_pair * 2);
+		const size_t n_ent_max = (size_t)2 * n_pair + 4 * (size_t)n_hap;
+		hent = take(staged ? (size_t)4 * n_pair + 16 : n_ent_max * 4 + 16); ps = take((size_t)n_pair * 2);
+		gt = take(staged ? n_ent_max * 8 + 16 : 0);
 		total = o;
 	}
 };
@@ -102,11 +107,14 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 	extern __shared__ __attribute__((aligned(16))) char lds[];
 	__shared__ int verdict_s;                                         // of the iteration before: 0 = go on, 1 = converged, 2 = cannot tell (host)
 	__shared__ double tabs_s[2][EM_THREADS / HIBAG_WAVE_EM];         // sum of |term| of an iteration, by parity and wavefront (only ever a BOUND: its own order of summation is free)
-	const EmLayout L(V.n_ib, V.n_pair, V.n_hap);
+	const bool staged = V.pos != nullptr;
+	const EmLayout L(V.n_ib, V.n_pair, V.n_hap, staged);
 	double *oldf = (double *)(lds + L.oldf), *newf = (double *)(lds + L.newf), *G = (double *)(lds + L.G), *lterm = (double *)(lds + L.lterm);
 	uint32_t *pw = (uint32_t *)(lds + L.pw);                          // h1 | h2 << 14 | genotype of the pair's sample << 28
 	int *off = (int *)(lds + L.off), *bt = (int *)(lds + L.bt), *hoff = (int *)(lds + L.hoff);
 	uint32_t *hent = (uint32_t *)((((uintptr_t)(lds + L.hent)) + 15) & ~(uintptr_t)15);
+	uint16_t *pos = (uint16_t *)hent;                                 // (staged: the same bytes hold the pairs' positions)
+	double *Gt = (double *)((((uintptr_t)(lds + L.gt)) + 15) & ~(uintptr_t)15);
 	uint16_t *ps = (uint16_t *)(lds + L.ps);                          // the sample of each pair
 	double *rs = (double *)(lds + L.rs);                              // boot_i / psum_i
 	const int tid = threadIdx.x, c = (int)blockIdx.x - M.first[owner], n_ib = V.n_ib, n_pair = V.n_pair, n_hap = V.n_hap;
@@ -120,7 +128,11 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 	const bool worker = tid < nw;
 	if (tid >= nw) __builtin_amdgcn_s_setprio(3);
 	// the growth step's pair set (the same for every candidate) and this candidate's genotypes: once into LDS
-	for (int e = tid; e < V.n_ent; e += EM_THREADS) hent[e] = V.hent[e];
+	if (staged) {
+		for (int e = tid; e < 2 * V.n_pair; e += EM_THREADS) pos[e] = V.pos[e];
+		for (int e = tid; e < V.n_ent; e += EM_THREADS) Gt[e] = 0.0;      // (the lists' padding entries stay +0.0: s + (+0.0) is s)
+	} else
+		for (int e = tid; e < V.n_ent; e += EM_THREADS) hent[e] = V.hent[e];
 	if (tid == 0) G[n_pair] = 0.0;                                   // what the lists' padding entries point at
 	for (int i = tid; i <= n_ib; i += EM_THREADS) off[i] = V.off[i];
 	for (int i = tid; i < n_ib; i += EM_THREADS) bt[i] = V.boot[i];
@@ -137,7 +149,8 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 	// the summer's state: the chain of iteration (iter - 1)'s terms, its loglik history, the tolerance.  The chain is cut in
 	// four pieces, one per phase of the next iteration, about as long as the phases are (A 12 %, B 22 %, B' 6 %, C 60 %).
 	double chain = 0, conv_tol = 0, tol_bound = 0, loglik_prev = -1e+30, bound_prev = 0;
-	const int cut[5] = {0, (n_ib * 12 + 99) / 100, (n_ib * 34 + 99) / 100, (n_ib * 40 + 99) / 100, n_ib};
+	// (staged lists: phase C is a third of an iteration instead of three fifths)
+	const int cut[5] = {0, (n_ib * (staged ? 19 : 12) + 99) / 100, (n_ib * (staged ? 54 : 34) + 99) / 100, (n_ib * (staged ? 67 : 40) + 99) / 100, n_ib};
 	auto sum_part = [&](const double *t, int part) {                  // terms [cut[part], cut[part + 1]) in order, sixteen reads in flight
 		const int hi = min(n_ib, cut[part + 1]);
 		int i = min(n_ib, cut[part]);
@@ -218,7 +231,11 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 					const int j = j0 + u * nw;
 					if (j >= n_pair) break;
 					const int g = (int)(w[u] >> 28);
-					if (g > 2 || (int)((w[u] & 1u) + ((w[u] >> 14) & 1u)) == g) G[j] = x[u] * r[u];
+					const bool compatible = g > 2 || (int)((w[u] & 1u) + ((w[u] >> 14) & 1u)) == g;
+					if (staged) {
+						const double y = compatible ? x[u] * r[u] : x[u];     // (an incompatible pair's G is the +0.0 phase A wrote)
+						Gt[pos[2 * j]] = y; Gt[pos[2 * j + 1]] = y;
+					} else if (compatible) G[j] = x[u] * r[u];
 				}
 			}
 		__syncthreads();
@@ -250,7 +267,29 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 				loglik_prev = loglik; bound_prev = bound;
 				verdict_s = verdict;
 			}
-		} else if (worker)
+		} else if (worker && staged)
+			for (int h = tid; h < n_hap; h += nw) {
+				// the haplotype's G in pair order are Gt[e0 .. e1): sixteen reads in flight, the additions in order
+				const int e0 = hoff[h], e1 = hoff[h + 1];                 // (multiples of 4)
+				double s = 0;
+				int e = e0;
+				for (; e + 16 <= e1; e += 16) {
+					double v[16];
+#pragma unroll
+					for (int u = 0; u < 16; u++) v[u] = Gt[e + u];
+#pragma unroll
+					for (int u = 0; u < 16; u++) s += v[u];
+				}
+				for (; e < e1; e += 4) {
+					double v[4];
+#pragma unroll
+					for (int u = 0; u < 4; u++) v[u] = Gt[e + u];
+#pragma unroll
+					for (int u = 0; u < 4; u++) s += v[u];
+				}
+				newf[h] = s * scale;
+			}
+		else if (worker)
 			for (int h = tid; h < n_hap; h += nw) {
 				const int e0 = hoff[h], e1 = hoff[h + 1];                 // (multiples of 4: the lists are padded with a +0.0 slot)
 				const char *Gb = (const char *)G;
@@ -336,7 +375,7 @@ void em_launch(const HibagOp *const ops[], int n, hipStream_t st)
 		M.v[j] = V;
 		M.first[j] = at;
 		at += V.n_cand;
-		lds = std::max(lds, EmLayout(V.n_ib, V.n_pair, V.n_hap).total);
+		lds = std::max(lds, EmLayout(V.n_ib, V.n_pair, V.n_hap, V.pos != nullptr).total);
 	}
 	for (int j = n; j <= HIBAG_COMBINE_MAX; j++) M.first[j] = at;
 	hipLaunchKernelGGL(k_em_fit, dim3(at), dim3(EM_THREADS), lds, st, M);
@@ -363,7 +402,8 @@ void hibag_em_fit_batch(const HibagEmPairs &P, const int8_t *const geno[], const
 	EM_OK(hipGetDevice(&dev), "hipGetDevice");
 	if (g_em.device != dev) { hibag_em_release(); g_em.device = dev; }
 	const size_t np = (size_t)P.n_pair, nib = (size_t)P.n_ib, nh = (size_t)P.n_hap, nc = (size_t)n_cand;
-	const EmLayout L(P.n_ib, P.n_pair, P.n_hap);
+	// (the lists' own copy of G where the step leaves LDS room for it, else the gather through offsets)
+	const bool staged = 2 * np + 4 * nh <= 65535 && EmLayout(P.n_ib, P.n_pair, P.n_hap, true).total + 64 <= EM_LDS_BYTES;
 	// upload area (one copy), then the results (one copy back)
 	size_t o = 0;
 	auto take = [&](size_t bytes) { const size_t at = o; o = (o + std::max<size_t>(bytes, 8) + 63) & ~(size_t)63; return at; };
@@ -389,14 +429,23 @@ void hibag_em_fit_batch(const HibagEmPairs &P, const int8_t *const geno[], const
 	{
 		uint32_t *pw = (uint32_t *)(h + o_pw);
 		for (size_t j = 0; j < np; j++) pw[j] = (uint32_t)P.h1[j] | ((uint32_t)P.h2[j] << 14);
-		// the transposed lists as byte offsets into G, each padded to a multiple of four entries with the +0.0 slot behind G
+		// the transposed lists as byte offsets into G, each padded to a multiple of four entries with the +0.0 slot behind G --
+		// or, staged, their inverse: the two entries of every pair (a homozygous pair's are neighbours in one list)
 		uint32_t *he = (uint32_t *)(h + o_hent);
+		uint16_t *ps16 = (uint16_t *)(h + o_hent);
 		int *ho = (int *)(h + o_hoff);
 		size_t e = 0;
+		static thread_local std::vector<uint8_t> seen;
+		if (staged) seen.assign(np, 0);
 		for (size_t q = 0; q < nh; q++) {
 			ho[q] = (int)e;
-			for (int k = P.hoff[q]; k < P.hoff[q + 1]; k++) he[e++] = (uint32_t)P.hent[k] * 8u;
-			while (e & 3) he[e++] = (uint32_t)np * 8u;
+			if (staged)
+				for (int k = P.hoff[q]; k < P.hoff[q + 1]; k++) { const int j = P.hent[k]; ps16[2 * (size_t)j + seen[j]++] = (uint16_t)e++; }
+			else {
+				for (int k = P.hoff[q]; k < P.hoff[q + 1]; k++) he[e++] = (uint32_t)P.hent[k] * 8u;
+				while (e & 3) he[e++] = (uint32_t)np * 8u;
+			}
+			e = (e + 3) & ~(size_t)3;
 		}
 		ho[nh] = (int)e;
 		n_ent = e;
@@ -410,7 +459,7 @@ void hibag_em_fit_batch(const HibagEmPairs &P, const int8_t *const geno[], const
 	V.n_cand = n_cand;
 	V.n_ib = P.n_ib; V.n_pair = P.n_pair; V.n_hap = P.n_hap; V.n_samp_total = P.n_samp_total;
 	V.pw = (const uint32_t *)(d + o_pw); V.off = (const int *)(d + o_off); V.boot = (const int *)(d + o_boot);
-	V.hoff = (const int *)(d + o_hoff); V.hent = (const uint32_t *)(d + o_hent); V.n_ent = (int)n_ent; V.cur_freq = (const double *)(d + o_cur);
+	V.hoff = (const int *)(d + o_hoff); V.hent = staged ? nullptr : (const uint32_t *)(d + o_hent); V.pos = staged ? (const uint16_t *)(d + o_hent) : nullptr; V.n_ent = (int)n_ent; V.cur_freq = (const double *)(d + o_cur);
 	V.geno = (const int8_t *)(d + o_geno); V.afreq = (const double *)(d + o_af);
 	V.out_freq = (double *)(d + o_out); V.status = (int *)(d + o_stat);
 	// one operation: the step's upload, its candidates' workgroups (alone, or fused with the other trainers' of the moment:
@@ -431,6 +480,6 @@ void hibag_em_fit_batch(const HibagEmPairs &P, const int8_t *const geno[], const
 // does a growth step of these dimensions fit the device kernel (its LDS, 16-bit indices)?
 bool hibag_em_fits(int n_ib, int n_pair, int n_hap)
 {
-	return n_hap <= 16384 && n_pair <= 65535 && n_ib > 0 && n_ib <= 65535 && EmLayout(n_ib, n_pair, n_hap).total + 64 <= EM_LDS_BYTES;
+	return n_hap <= 16384 && n_pair <= 65535 && n_ib > 0 && n_ib <= 65535 && EmLayout(n_ib, n_pair, n_hap, false).total + 64 <= EM_LDS_BYTES;
 }
 

@@ -88,6 +88,32 @@ def test_driver_equals_oracle_with_missing_genotypes(hib, oracle, prune):
             assert len(g.snpidx) > 0
 
 
+@pytest.mark.timeout(300)
+def test_fused_scoring_variant_equals_the_oracle(hib, oracle, monkeypatch):
+    """``HIBAG_BATCH_FUSED=1``: a growth step's scoring as ONE kernel (``k_batch_score``: producer wavefronts hand the cell sums
+    to a scanning wavefront through a ring in LDS) instead of two -- the same classifiers, alone and with shared trainers."""
+    from hibag_amd import synth, train
+    monkeypatch.setenv("HIBAG_BATCH_FUSED", "1")
+    model, founders, af = synth.make_model("hla-a-small", seed=15, n_snp=70)
+    G, truth = synth.make_samples(founders, af, 200, seed=16, miss=0.02)
+    want = oracle.train(G, truth[:, 0], truth[:, 1], model.n_hla, nclassifier=3, mtry=9, prune=True, seed=77)
+    tr = train._Trainer(G, truth[:, 0], truth[:, 1], model.n_hla)
+    tr.set_seed(77)
+    tr.new_classifiers(3, 9, True, False, False)
+    got = tr.classifiers()
+    tr.close()
+    for i, (g, w) in enumerate(zip(got, want)):
+        c = hib.Classifier(snpidx=w["snpidx"], freq=w["freq"], hla=w["hla"], haplo=w["haplo"], samp_num=w["samp_num"], outofbag_acc=w["acc"])
+        assert_same_classifier(_as_dict(g), c, i)
+    # four shared trainers (fused launches carrying several growth steps), stream r seeded with 300 + r
+    both = train.grow_concurrently(G, truth[:, 0], truth[:, 1], model.n_hla, 8, 9, True, 4, 1, 300, em="device", combine=True)
+    for r in range(4):
+        w = oracle.train(G, truth[:, 0], truth[:, 1], model.n_hla, nclassifier=2, mtry=9, prune=True, seed=300 + r)
+        for j in range(2):
+            g = both[2 * r + j]
+            assert np.array_equal(g.snpidx, w[j]["snpidx"]) and np.array_equal(g.freq, w[j]["freq"]) and g.haplo == w[j]["haplo"], (r, j)
+
+
 def test_trainer_argument_errors(hib):
     import ctypes as C
     from hibag_amd import _lib
