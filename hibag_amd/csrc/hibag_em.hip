@@ -71,6 +71,7 @@ struct EmView {
 	const double *afreq;                    // [n_cand] allele frequency in the bag (DoubleHaplosInitFreq, :444-459)
 	double *out_freq;                       // [n_cand][n_hap]
 	int *status;                            // [n_cand] 1 = fitted, 2 = the host must fit it; [n_cand + c]: iterations
+	long long *stamps;                      // measurement only (HIBAG_EM_STAMPS=1, else null): [n_cand][6] ticks of the 100 MHz clock candidate c spent in set-up, phases A, B, B', C and in all
 };
 
 // LDS layout of k_em_fit (bytes), shared by the kernel and the host's size check
@@ -123,10 +124,27 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 	// one after the other, so every phase lasted that wavefront's worker share PLUS its piece of the chain instead of the longer
 	// of the two.  It also runs at raised priority: a chain of dependent FP64 additions that has to take turns with three busy
 	// wavefronts on its SIMD waited 28-34 cycles per addition against 12 alone (profiles/r04_cfg5_notes.txt).
-	const int nw = EM_THREADS - HIBAG_WAVE_EM;                        // worker threads
-	const bool summer = tid == nw;                                    // the thread of the loglik chain (no other work)
-	const bool worker = tid < nw;
-	if (tid >= nw) __builtin_amdgcn_s_setprio(3);
+	// ... and (later in round 6) a SIMD of its own: raised priority did not get the chain more than its turn -- in-kernel stamps
+	// (HIBAG_EM_STAMPS) showed every phase lasting exactly its piece of the chain at 29 cycles per addition, the rate of one
+	// wavefront among four -- so the wavefronts that share the chain's SIMD (read from HW_ID; a workgroup's sixteen wavefronts
+	// sit four to a SIMD) do no work at all.  The twelve others are the workers; no phase has more than one turn per thread
+	// for them either (632 samples, ~600 haplotypes, 2,600 pairs four at a time).
+	__shared__ int simd_s[EM_THREADS / HIBAG_WAVE_EM];
+	const int wave = tid >> 6, last = EM_THREADS / HIBAG_WAVE_EM - 1;
+	{
+		uint32_t hw_id;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+		if ((tid & 63) == 0) simd_s[wave] = (int)((hw_id >> 4) & 3u);  // SIMD_ID
+	}
+	__syncthreads();
+	int n_apart = 0, rank_apart = 0;
+	for (int w = 0; w < last; w++) { const int apart = simd_s[w] != simd_s[last]; n_apart += apart; rank_apart += apart && w < wave; }
+	const bool spread = n_apart > 0;                                  // (else: every wavefront on one SIMD -- all of them work, as before)
+	const bool summer = tid == last * HIBAG_WAVE_EM;                  // the thread of the loglik chain (no other work)
+	const bool worker = wave != last && (!spread || simd_s[wave] != simd_s[last]);
+	const int nw = (spread ? n_apart : last) * HIBAG_WAVE_EM;         // worker threads
+	const int wid = (spread ? rank_apart : wave) * HIBAG_WAVE_EM + (tid & 63);    // a worker's index among them
+	if (wave == last) __builtin_amdgcn_s_setprio(3);
 	// the growth step's pair set (the same for every candidate) and this candidate's genotypes: once into LDS
 	if (staged) {
 		for (int e = tid; e < 2 * V.n_pair; e += EM_THREADS) pos[e] = V.pos[e];
@@ -151,38 +169,58 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 	double chain = 0, conv_tol = 0, tol_bound = 0, loglik_prev = -1e+30, bound_prev = 0;
 	// (staged lists: phase C is a third of an iteration instead of three fifths)
 	const int cut[5] = {0, (n_ib * (staged ? 19 : 12) + 99) / 100, (n_ib * (staged ? 54 : 34) + 99) / 100, (n_ib * (staged ? 67 : 40) + 99) / 100, n_ib};
-	auto sum_part = [&](const double *t, int part) {                  // terms [cut[part], cut[part + 1]) in order, sixteen reads in flight
+	// terms [cut[part], cut[part + 1]) in order.  The additions are one dependent chain -- the longest thing in an iteration
+	// (in-kernel stamps, HIBAG_EM_STAMPS: every phase lasted as long as its piece of the chain, 28 cycles per term) -- so
+	// nothing else may sit in it: the NEXT eight terms are requested before the current eight are added (round 6; until then
+	// each group of sixteen waited for its own loads first).
+	auto sum_part = [&](const double *t, int part) {
 		const int hi = min(n_ib, cut[part + 1]);
 		int i = min(n_ib, cut[part]);
-		for (; i + 16 <= hi; i += 16) {
-			double v[16];
+		if (i + 8 <= hi) {
+			double a[8], b[8];
 #pragma unroll
-			for (int u = 0; u < 16; u++) v[u] = t[i + u];
+			for (int u = 0; u < 8; u++) a[u] = t[i + u];
+			for (; i + 16 <= hi; i += 8) {
 #pragma unroll
-			for (int u = 0; u < 16; u++) chain += v[u];
+				for (int u = 0; u < 8; u++) b[u] = t[i + 8 + u];
+#pragma unroll
+				for (int u = 0; u < 8; u++) chain += a[u];
+#pragma unroll
+				for (int u = 0; u < 8; u++) a[u] = b[u];
+			}
+#pragma unroll
+			for (int u = 0; u < 8; u++) chain += a[u];
+			i += 8;
 		}
 		for (; i < hi; i++) chain += t[i];
 	};
 	int iter = 0, stopped = 0;
 	if (tid == 0) verdict_s = 0;
+	long long tk[6] = {0, 0, 0, 0, 0, 0}, t_last = V.stamps ? (long long)wall_clock64() : 0;
+	const long long t_first = t_last;
+	auto stamp = [&](int k) { if (V.stamps) { const long long t = (long long)wall_clock64(); tk[k] += t - t_last; t_last = t; } };
+	// The frequencies alternate between two buffers (round 6: no copy, and four barriers per iteration instead of six): iteration
+	// `iter` READS `cur` and phase C writes `nxt`; the first reads the initial values, which the set-up put into `newf`.
+	const double *cur = newf;
+	double *nxt = oldf;
+	__syncthreads();
+	stamp(0);
 
 	for (; iter <= EM_MAX_ITER; iter++) {
-		__syncthreads();
-		for (int h = tid; h < n_hap; h += EM_THREADS) oldf[h] = newf[h];
+		cur = (iter & 1) ? oldf : newf; nxt = (iter & 1) ? newf : oldf;
 		const double *t_prev = lterm + (size_t)((iter + 1) & 1) * n_ib;   // the terms of iteration iter - 1
 		double *t_cur = lterm + (size_t)(iter & 1) * n_ib;
 		if (summer) chain = 0;
-		__syncthreads();
 		// ---- A
 		if (summer) { if (iter > 0) sum_part(t_prev, 0); }
 		else if (worker)
-			for (int j0 = tid; j0 < n_pair; j0 += 4 * nw) {            // four pairs per turn: their look-ups in flight together
+			for (int j0 = wid; j0 < n_pair; j0 += 4 * nw) {            // four pairs per turn: their look-ups in flight together
 				uint32_t w[4];
 				double fa[4], fb[4];
 #pragma unroll
 				for (int u = 0; u < 4; u++) w[u] = pw[min(j0 + u * nw, n_pair - 1)];
 #pragma unroll
-				for (int u = 0; u < 4; u++) { fa[u] = oldf[w[u] & 0x3FFFu]; fb[u] = oldf[(w[u] >> 14) & 0x3FFFu]; }
+				for (int u = 0; u < 4; u++) { fa[u] = cur[w[u] & 0x3FFFu]; fb[u] = cur[(w[u] >> 14) & 0x3FFFu]; }
 #pragma unroll
 				for (int u = 0; u < 4; u++) {
 					const int j = j0 + u * nw;
@@ -194,11 +232,12 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 				}
 			}
 		__syncthreads();
+		stamp(1);
 		// ---- B: a sample's psum in list order (sixteen reads in flight), its term, its scaling factor
 		double my_abs = 0;
 		if (summer) { if (iter > 0) sum_part(t_prev, 1); }
 		else if (worker)
-			for (int i = tid; i < n_ib; i += nw) {
+			for (int i = wid; i < n_ib; i += nw) {
 				const int j0 = off[i], j1 = off[i + 1], b_i = bt[i];
 				double psum = 0;
 				int j = j0;
@@ -218,10 +257,11 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 		for (int d = 32; d > 0; d >>= 1) my_abs += __shfl_xor(my_abs, d);
 		if ((tid & 63) == 0) tabs_s[iter & 1][tid >> 6] = worker ? my_abs : 0.0;
 		__syncthreads();
+		stamp(2);
 		// ---- B': thread = pair again: the compatible G *= boot / psum (an incompatible pair stays +0.0 whatever the factor is)
 		if (summer) { if (iter > 0) sum_part(t_prev, 2); }
 		else if (worker)
-			for (int j0 = tid; j0 < n_pair; j0 += 4 * nw) {
+			for (int j0 = wid; j0 < n_pair; j0 += 4 * nw) {
 				uint32_t w[4];
 				double r[4], x[4];
 #pragma unroll
@@ -239,6 +279,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 				}
 			}
 		__syncthreads();
+		stamp(3);
 		// ---- C
 		if (summer) {
 			if (iter > 0) {
@@ -268,9 +309,12 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 				verdict_s = verdict;
 			}
 		} else if (worker && staged)
-			for (int h = tid; h < n_hap; h += nw) {
+			for (int h = wid; h < n_hap; h += nw) {
 				// the haplotype's G in pair order are Gt[e0 .. e1): sixteen reads in flight, the additions in order
 				const int e0 = hoff[h], e1 = hoff[h + 1];                 // (multiples of 4)
+				// (requesting the next values before the current ones are added, as the chain above does, was measured here: 4.4 us
+				// per iteration instead of 2.9 -- every worker is busy in this phase, and the copies between the two register sets cost
+				// more than the exposed look-ups)
 				double s = 0;
 				int e = e0;
 				for (; e + 16 <= e1; e += 16) {
@@ -287,10 +331,10 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 #pragma unroll
 					for (int u = 0; u < 4; u++) s += v[u];
 				}
-				newf[h] = s * scale;
+				nxt[h] = s * scale;
 			}
 		else if (worker)
-			for (int h = tid; h < n_hap; h += nw) {
+			for (int h = wid; h < n_hap; h += nw) {
 				const int e0 = hoff[h], e1 = hoff[h + 1];                 // (multiples of 4: the lists are padded with a +0.0 slot)
 				const char *Gb = (const char *)G;
 				const uint32_t pad_off = (uint32_t)n_pair * 8u;
@@ -320,14 +364,19 @@ __global__ __launch_bounds__(EM_THREADS) void k_em_fit(HibagMulti<EmView> M)
 #pragma unroll
 					for (int u = 0; u < 8; u++) s += tb[u];
 				}
-				newf[h] = s * scale;
+				nxt[h] = s * scale;
 			}
 		__syncthreads();
-		if (verdict_s) { stopped = 1; break; }                        // iteration iter - 1 was the last: its frequencies are in oldf
+		stamp(4);
+		if (verdict_s) { stopped = 1; break; }                        // iteration iter - 1 was the last: its frequencies are what this one read
 	}
 	__syncthreads();
-	const double *res = stopped ? oldf : newf;
+	const double *res = stopped ? cur : nxt;
 	for (int h = tid; h < n_hap; h += EM_THREADS) V.out_freq[(size_t)c * n_hap + h] = res[h];
+	if (tid == 0 && V.stamps) {
+		tk[5] = (long long)wall_clock64() - t_first;
+		for (int k = 0; k < 6; k++) V.stamps[(size_t)c * 6 + k] = tk[k];
+	}
 	if (tid == 0) {
 		V.status[c] = verdict_s == 2 ? 2 : 1;                         // (500 iterations without convergence end the host's loop too)
 		V.status[V.n_cand + c] = stopped ? iter - 1 : iter;
@@ -410,7 +459,8 @@ void hibag_em_fit_batch(const HibagEmPairs &P, const int8_t *const geno[], const
 	const size_t o_pw = take(np * 4), o_off = take((nib + 1) * 4), o_boot = take(nib * 4), o_hoff = take((nh + 1) * 4),
 		o_hent = take((2 * np + 4 * nh) * 4), o_cur = take(nh / 2 * 8), o_geno = take(nc * nib), o_af = take(nc * 8);
 	const size_t up_bytes = o;
-	const size_t o_out = take(nc * nh * 8), o_stat = take(2 * nc * 4);
+	static const bool stamps = getenv("HIBAG_EM_STAMPS") != nullptr;
+	const size_t o_out = take(nc * nh * 8), o_stat = take(2 * nc * 4), o_stamp = take(stamps ? nc * 6 * 8 : 0);
 	const size_t down_bytes = o - o_out;
 	if (o > g_em.cap_d) {
 		if (g_em.d) (void)hipFree(g_em.d);            // (nothing of this thread's is in flight: every operation is waited for)
@@ -462,6 +512,7 @@ void hibag_em_fit_batch(const HibagEmPairs &P, const int8_t *const geno[], const
 	V.hoff = (const int *)(d + o_hoff); V.hent = staged ? nullptr : (const uint32_t *)(d + o_hent); V.pos = staged ? (const uint16_t *)(d + o_hent) : nullptr; V.n_ent = (int)n_ent; V.cur_freq = (const double *)(d + o_cur);
 	V.geno = (const int8_t *)(d + o_geno); V.afreq = (const double *)(d + o_af);
 	V.out_freq = (double *)(d + o_out); V.status = (int *)(d + o_stat);
+	V.stamps = stamps ? (long long *)(d + o_stamp) : nullptr;
 	// one operation: the step's upload, its candidates' workgroups (alone, or fused with the other trainers' of the moment:
 	// hibag_combine.h), the results back -- returns when they are in the staging area
 	HibagOp op;
@@ -474,6 +525,20 @@ void hibag_em_fit_batch(const HibagEmPairs &P, const int8_t *const geno[], const
 	memcpy(out_freq, h + o_out, nc * nh * 8);
 	const int *st = (const int *)(h + o_stat);
 	for (size_t c = 0; c < nc; c++) { status[c] = st[c]; if (iters) iters[c] = st[nc + c]; }
+	if (stamps) {
+		// per iteration of the step's slowest candidate: microseconds in the phases (100 MHz ticks)
+		static thread_local double acc[7];
+		static thread_local long n_steps;
+		size_t w = 0;
+		for (size_t c = 1; c < nc; c++) if (st[nc + c] > st[nc + w]) w = c;
+		const long long *tk = (const long long *)(h + o_stamp) + w * 6;
+		const double it = std::max(1, st[nc + w] + 1);
+		for (int k = 0; k < 6; k++) acc[k] += 0.01 * tk[k] / (k == 0 || k == 5 ? 1.0 : it);
+		acc[6] += it;
+		if (++n_steps % 200 == 0)
+			fprintf(stderr, "[hibag em stamps] slowest candidate of a step, mean of %ld steps: set-up %.2f us, per iteration A %.2f B %.2f B' %.2f C %.2f us, %.1f iterations, whole %.1f us\n",
+				n_steps, acc[0] / n_steps, acc[1] / n_steps, acc[2] / n_steps, acc[3] / n_steps, acc[4] / n_steps, acc[6] / n_steps, acc[5] / n_steps);
+	}
 	g_em_prof[0] += t_up - t_in; g_em_prof[1] += t_done - t_up; g_em_prof[2] += em_now() - t_in;
 }
 
