@@ -509,8 +509,18 @@ int load_bed(const char *fn, int n_samp, int n_snp, const int32_t *want, int n_w
 		for (int j = 0; j < n_want; j++) img.index[j] = want[j];
 	} else {
 		img.stride = ((size_t)n_samp + 3) / 4;
-		int n_row = 0;
-		for (int j = 0; j < n_want; j++) if (want[j] >= 0) n_row++;
+		int n_row = 0, lo = n_snp, hi = -1;
+		for (int j = 0; j < n_want; j++) if (want[j] >= 0) { n_row++; lo = std::min(lo, want[j]); hi = std::max(hi, want[j]); }
+		if (n_row > 0 && (size_t)(hi - lo + 1) <= 2 * (size_t)n_row) {
+			// the wanted rows lie close together (a model's SNPs are one region of the chromosome): ONE read of the range they
+			// span instead of a seek and a read per row -- 150 system calls were a tenth of a 10,000-sample call
+			img.rows.resize(img.stride * (size_t)(hi - lo + 1));
+			if (fseeko(f, (off_t)3 + (off_t)img.stride * lo, SEEK_SET) != 0 ||
+				(!img.rows.empty() && fread(img.rows.data(), 1, img.rows.size(), f) != img.rows.size()))
+				return hibag_fail(HIBAG_HIP_EINVAL, short_msg, n_samp, n_snp);
+			for (int j = 0; j < n_want; j++) img.index[j] = want[j] >= 0 ? want[j] - lo : -1;
+			return 0;
+		}
 		img.rows.resize(img.stride * (size_t)n_row);
 		int r = 0;
 		for (int j = 0; j < n_want; j++) {
