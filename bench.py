@@ -888,6 +888,7 @@ def other_configs(K, faults=None):
             # classifiers a trainer grows six or seven, and the trainers that finish first leave the device to the last ones
             concurrent("steady_16_trainers_budget_4", 16, 1, "device", min(4, cores), n=640)
             concurrent("steady_16_trainers_budget_cores_over_8", 16, 1, "device", per_rank, n=640)
+            concurrent("steady_32_trainers_budget_4", 32, 1, "device", min(4, cores), n=960)
             concurrent("steady_32_trainers_no_budget", 32, 1, "device", 0, n=960)
             best_k, best_cls, best_key = 16, cls4, "16_trainers_budget_4"
             best_rate = conc[best_key]["classifiers_per_s"]

@@ -451,7 +451,7 @@ def grow_concurrently(genomat, h1, h2, n_hla: int, nclassifier: int, mtry: int, 
 
 def hlaConcurrentAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: int = 100,
                              mtry: Union[str, float, int] = "sqrt", prune: bool = True, na_rm: bool = True,
-                             mono_rm: bool = True, maf: float = float("nan"), n_trainers: int = 16,
+                             mono_rm: bool = True, maf: float = float("nan"), n_trainers: Optional[int] = None,
                              nthread: Optional[int] = None, seed: Optional[int] = None, verbose: bool = True,
                              device: Optional[int] = None) -> HlaAttrBagClass:
     """``hlaParallelAttrBagging``'s decomposition (``R/HIBAG.R:293-440``: independent workers, one random stream each, the
@@ -459,7 +459,10 @@ def hlaConcurrentAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: 
     (:func:`grow_concurrently`), their device work fused into one launch per kind of operation, their EM fits on the device,
     and at most ``nthread`` of their host threads runnable at a time (default: the usable CPUs, at most four -- more buys
     nothing: a trainer's thread sleeps while the device works).  A single trainer leaves the device idle most of a growth
-    step; sixteen keep it busy on the host threads of four.  ``device``: a device index, or a LIST of them -- trainer r then runs
+    step; sixteen keep it busy on the host threads of four.  ``n_trainers=None``: per device one trainer for every six
+    classifiers, at most 32 -- sixteen for a model of 100 (with fewer classifiers each, the trainers that finish first leave the
+    device to the last ones: 16 trainers 178-199 classifiers/s, 32 trainers 155), 32 for jobs of 192 classifiers or more (250
+    against 216; ``profiles/r06_notes.txt`` item 4k).  The model depends on the number of trainers (stream r grows share r).  ``device``: a device index, or a LIST of them -- trainer r then runs
     on ``device[r % len(device)]``: the GPUs of a node from one process (BASELINE config 5's "in parallel across 8 GPUs" without a
     process per GPU; give ``n_trainers`` a multiple of the list's length, sixteen per device, and ``nthread`` accordingly); the
     model is kept on the first.
@@ -473,6 +476,9 @@ def hlaConcurrentAttrBagging(hla: HlaAlleleClass, snp: HlaSNPGeno, nclassifier: 
     total = int(nthread) if nthread else min(4, _usable_cpus())
     if seed is None:
         seed = int(_R.unif_rand() * 2147483647.0)
+    if n_trainers is None:
+        n_dev = len(device) if isinstance(device, (list, tuple)) and device else 1
+        n_trainers = n_dev * min(32, max(1, int(nclassifier) // (6 * n_dev)))
 
     def grow(genomat, h1, h2, n_hla, n, m, pr):
         return grow_concurrently(genomat, h1, h2, n_hla, n, m, pr, n_trainers, 1, seed, device, em="device",
