@@ -191,7 +191,7 @@ def test_entry_points_campaign(monkeypatch, tmp_path):
     hibag_hip_predict on the model-order matrix (which the campaign above pins to the oracle): the cohort's own matrix with a
     column map and flips (hibag_hip_predict_mapped; the same SNP-major through hibag_hip_predict_snp_major), a PLINK BED file in either storage mode (hibag_hip_predict_bed), the device
     entry on a caller's stream with device-resident data, replicas on the one device (hibag_hip_predict_multi), and classifier
-    shards merged by the library's RCCL all-reduce (identical calls, posteriors to 1e-10: the summation order differs)."""
+    shards merged by the library's RCCL all-reduce (posteriors to 1e-10 and identical calls up to rounding-level ties: the summation order differs)."""
     import os
     import time
     import torch
@@ -277,7 +277,11 @@ def test_entry_points_campaign(monkeypatch, tmp_path):
             grp = hib.hibag.ShardGroup(m, [0] * int(rng.integers(2, min(len(model.classifiers), 6) + 1)))
             got = grp.predict_raw(G, want_dosage=True, want_prob=True)
             grp.close()
-            ok = np.array_equal(got["h1"], want1["h1"]) and np.array_equal(got["h2"], want1["h2"])
+            # identical calls -- except where the two best cells of a sample tie to within rounding: the shards add the
+            # classifiers' terms in another order, and a call is the FIRST strict maximum (seed 950299: two cells one ulp apart
+            # in the one-model sums, equal in the shards'; tools/fuzz_repro_shards.py).  There the calls' probabilities must agree.
+            differ = (got["h1"] != want1["h1"]) | (got["h2"] != want1["h2"])
+            ok = bool(np.all(np.abs(got["prob"][differ] - want1["prob"][differ]) <= 1e-12 * np.abs(want1["prob"][differ])))
             with np.errstate(invalid="ignore", divide="ignore"):
                 fin = np.isfinite(want1["postprob"]) & (want1["postprob"] > 1e-200)
                 rel = np.abs(got["postprob"] - want1["postprob"])[fin] / want1["postprob"][fin]
