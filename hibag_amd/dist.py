@@ -11,7 +11,8 @@ Two ways to spread `hlaPredict()` over ranks:
   the un-normalised partial ensemble sums, ONE sum all-reduce merges them, then
   every rank finishes (arg-max, dosage, ...).  Changes the order in which
   classifier contributions are added, so it is held to 1e-10 relative with
-  identical calls, not to bit equality.
+  identical calls (wherever the two best cells of a sample do not tie to within
+  rounding: a call is the first strict maximum), not to bit equality.
 
 The compute is injected as callables so that the orchestration can be tested
 with gloo on CPU; on a GPU box the callables are the HIP entry points of
