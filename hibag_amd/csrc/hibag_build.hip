@@ -270,7 +270,6 @@ struct BatchView {
 	const int *cand_snp;       // [n_cand] row of `gdev` of each candidate
 	int bit;                   // the candidate SNP's bit inside word `word`
 	const int *true_pair;      // [n_pad] (a1 << 16) | a2 of the sample's true alleles, -1 on padding lanes
-	int max_h;                 // the most haplotypes any candidate has (sizes k_batch_cells_mfma's LDS)
 };
 
 #define SCAN_NB 32          // cells k_batch_scan has in flight; BatchView::max_cells is a multiple of it
@@ -416,178 +415,6 @@ __global__ __launch_bounds__(BATCH_WAVES * HIBAG_WAVE) void k_batch_cells(HibagM
 	case 3:  batch_cells<3>(B, c, by, s, tab_s, hbp, hf_s, h_lo, n_h); break;
 	default: batch_cells<4>(B, c, by, s, tab_s, hbp, hf_s, h_lo, n_h); break;
 	}
-}
-
-// ---- the cell sums through the matrix cores (round 6, a variant: HIBAG_BATCH_MFMA=1) ---------------------------------------
-// k_batch_cells evaluates a pair in 10.5 vector instructions (two popcount terms, the table address, three FP64 operations) and
-// is what saturates the device when many trainers run side by side (profiles/r06_notes.txt item 4).  The predict path's form
-// of the distance (hibag_device.h, "I8"): 8 d = A . B with A = the pair's haplotype bytes (h1 + h2 per SNP, h1 & h2 per SNP, the
-// constant 8) and B = the sample's (+8 / -8 / 0 per SNP, 16 [g = 1] per SNP, the offset 2 #[g = 2] + #[g = 1]) -- one
-// v_mfma_i32_32x32x32_i8 per K block and sample half gives 32 pairs x 64 samples, the result IS the table's byte offset.
-// Here for classifiers of at most 31 SNPs (one 32-bit word) and the cells that have enough pairs to fill a block; the
-// candidate's haplotypes as byte images in LDS, a block's 32 pairs enumerated in the reference's order (a outer, b inner), their
-// frequency factors (2 f_a) f_b -- the reference's rounding -- parked in LDS by the lanes that formed the rows and read back as
-// broadcasts, the additions in pair order.  Diagonal cells, small cells and wider classifiers take batch_cell as before.
-typedef int bc_v4i __attribute__((ext_vector_type(4)));
-typedef int bc_v16i __attribute__((ext_vector_type(16)));
-#ifndef MFMA_MIN_PAIRS
-#define MFMA_MIN_PAIRS 12
-#endif
-#ifndef MFMA_OCC
-#define MFMA_OCC 3
-#endif
-
-// 16 bits -> 16 bytes (bit i -> byte i = 0 / 1)
-__device__ __forceinline__ bc_v4i bc_bytes16(uint32_t x)
-{
-	bc_v4i r;
-#pragma unroll
-	for (int q = 0; q < 4; q++) r[q] = (int)((((x >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u);
-	return r;
-}
-
-struct MfmaShared {                      // offsets into the kernel's dynamic LDS
-	double *tab, *facs, *hf;
-	uint32_t *hb;
-	char *img;                           // [n_h][32] byte images; before they are staged: the waves' operand exchange
-};
-
-__device__ __forceinline__ double batch_cell_mfma(int a0, int a1, int b0, int b1, const char *img, const double *hf, double *facs,
-	const bc_v4i (&Bop)[2][2], const double *tab_s, int lane)
-{
-	const int nb = b1 - b0, np = (a1 - a0) * nb;
-	const float rnb = 1.0f / (float)nb;
-	const bool upper = lane >= 32;
-	double cell = 0;
-	for (int base = 0; base < np; base += 32) {
-		const int idx = min(base + (lane & 31), np - 1);          // (a partly filled last block repeats its last pair: never added)
-		int ia = (int)(((float)idx + 0.5f) * rnb);
-		int ib = idx - ia * nb;
-		if (ib < 0) { ia--; ib += nb; } else if (ib >= nb) { ia++; ib -= nb; }
-		const int a = a0 + ia, b = b0 + ib;
-		const bc_v4i e1 = *(const bc_v4i *)(img + a * 32 + (upper ? 16 : 0)), e2 = *(const bc_v4i *)(img + b * 32 + (upper ? 16 : 0));
-		facs[lane & 31] = (2 * hf[a]) * hf[b];                    // src/LibHLA.cpp:1680-1691: ff = 2 f1, then ff * f2
-		bc_v16i D0, D1;
-#pragma unroll
-		for (int r = 0; r < 16; r++) { D0[r] = 0; D1[r] = 0; }
-		bc_v4i sum = e1 + e2;                                      // bytes 0 / 1 / 2: no carry between bytes
-		const bc_v4i both = e1 & e2;
-		if (upper) sum[3] |= 8 << 24;                             // K position 31 meets the sample's offset
-		D0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(sum, Bop[0][0], D0, 0, 0, 0);
-		D1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(sum, Bop[1][0], D1, 0, 0, 0);
-		D0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(both, Bop[0][1], D0, 0, 0, 0);
-		D1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(both, Bop[1][1], D1, 0, 0, 0);
-		const int n_valid = min(32, np - base);
-		// every lane its OWN sample: the upper lanes of sample half 0 swap with the lower lanes of half 1; then
-		// pair i = 8 g + q of the block is q < 4 ? D0[4 g + q] : D1[4 g + q - 4]
-#pragma unroll
-		for (int g = 0; g < 4; g++) {
-			if (8 * g >= n_valid) break;
-#pragma unroll
-			for (int r = 4 * g; r < 4 * g + 4; r++) {
-				const auto sw = __builtin_amdgcn_permlane32_swap(D0[r], D1[r], false, false);
-				D0[r] = sw[0]; D1[r] = sw[1];
-			}
-		}
-#pragma unroll
-		for (int i = 0; i < 32; i++) {
-			if (i >= n_valid) break;
-			const int off = (i & 7) < 4 ? D0[4 * (i >> 3) + (i & 3)] : D1[4 * (i >> 3) + (i & 3)];       // = 8 d
-			cell += facs[i] * *(const double *)((const char *)tab_s + off);
-		}
-	}
-	return cell;
-}
-
-__global__ __launch_bounds__(BATCH_WAVES * HIBAG_WAVE, MFMA_OCC) void k_batch_cells_mfma(HibagMulti<BatchView> M)
-{
-	extern __shared__ __attribute__((aligned(16))) char lds[];
-	const int owner = hibag_multi_owner(M, (int)blockIdx.x);
-	const BatchView B = M.v[owner];
-	const int local = (int)blockIdx.x - M.first[owner];
-	const int gx = (B.n_pad / HIBAG_WAVE + BATCH_WAVES - 1) / BATCH_WAVES;
-	const int bx = local % gx, by = (local / gx) % B.n_seg, c = local / (gx * B.n_seg);
-	const int *st = B.start + (size_t)c * (B.n_hla + 1);
-	const int h_lo = st[0], n_h = st[B.n_hla] - st[0];
-	const bool staged = n_h <= BATCH_LDS_HAPLO;
-	const int n_hs = staged ? n_h : 0;
-	// layout: table | factors (32 per wavefront) | frequencies | bit words | images (the operand exchange first)
-	double *tab_s = (double *)lds;
-	double *facs_all = tab_s + 264;
-	double *hf_s = facs_all + 32 * BATCH_WAVES;
-	uint32_t *hb_s = (uint32_t *)(hf_s + n_hs);
-	char *img_s = (char *)(((uintptr_t)(hb_s + (size_t)B.nw * n_hs) + 15) & ~(uintptr_t)15);
-	const int k = B.word == 0 ? B.bit + 1 : 99;                        // SNPs of the candidate classifier
-	const bool mfma = staged && B.nw == 1 && k <= 31;
-	for (int i = threadIdx.x; i < HIBAG_TAB_N; i += blockDim.x) tab_s[i] = B.tab[i];
-	if (staged) {
-		for (int i = threadIdx.x; i < n_h; i += blockDim.x) hf_s[i] = B.hf[h_lo + i];
-		for (int w = 0; w < B.nw; w++)
-			for (int i = threadIdx.x; i < n_h; i += blockDim.x) hb_s[w * n_h + i] = B.hb[(size_t)w * B.n_haplo_total + h_lo + i];
-	}
-	const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-	const int s = bx * (int)blockDim.x + (int)threadIdx.x;
-	const bool live = s < B.n_pad;                                     // (whole wavefronts: n_pad is a multiple of 64)
-	LaneG<1> G;
-	bc_v4i Bop[2][2];
-	if (mfma) {
-		if (live) {
-			batch_lane_genotype<1>(B, c, s, G);
-			// the sample's B operand: K block 0 = +8 (g = 0) / -8 (g = 1, 2) / 0 (missing) per SNP and the offset at K position 31,
-			// K block 1 = 16 [g = 1] per SNP
-			const uint32_t m1 = G.e[0], m2 = G.t[0], m0 = G.zt[0] & ~G.t[0], neg = m1 | m2;
-			const int offset = 2 * __popc(m2) + __popc(m1);
-			bc_v4i *mine = (bc_v4i *)(img_s + ((size_t)wave * 64 + lane) * 64);
-			bc_v4i lo = bc_bytes16(m0 & 0xFFFFu) * 0x08 + bc_bytes16(neg & 0xFFFFu) * 0xF8;
-			bc_v4i hi = bc_bytes16((m0 >> 16) & 0x7FFFu) * 0x08 + bc_bytes16((neg >> 16) & 0x7FFFu) * 0xF8;
-			hi[3] |= offset << 24;
-			mine[0] = lo; mine[1] = hi;
-			mine[2] = bc_bytes16(m1 & 0xFFFFu) * 16; mine[3] = bc_bytes16((m1 >> 16) & 0x7FFFu) * 16;
-		}
-		__syncthreads();
-		if (live) {
-#pragma unroll
-			for (int n = 0; n < 2; n++)
-#pragma unroll
-				for (int kb = 0; kb < 2; kb++)
-					Bop[n][kb] = *(const bc_v4i *)(img_s + ((size_t)wave * 64 + 32 * n + (lane & 31)) * 64 + kb * 32 + 16 * (lane >> 5));
-		}
-		__syncthreads();
-		// the haplotypes' byte images (bit s -> byte s) over the exchange area
-		for (int i = threadIdx.x; i < 2 * n_h; i += blockDim.x) {
-			const uint32_t w = hb_s[i >> 1];
-			*(bc_v4i *)(img_s + (size_t)i * 16) = bc_bytes16((i & 1) ? (w >> 16) & 0x7FFFu : w & 0xFFFFu);
-		}
-	}
-	__syncthreads();
-	if (!live) return;
-	if (!mfma) {
-		const uint32_t *hbp = staged ? hb_s : nullptr;
-		switch (B.nw) {
-		case 1:  batch_cells<1>(B, c, by, s, tab_s, hbp, hf_s, h_lo, n_h); break;
-		case 2:  batch_cells<2>(B, c, by, s, tab_s, hbp, hf_s, h_lo, n_h); break;
-		case 3:  batch_cells<3>(B, c, by, s, tab_s, hbp, hf_s, h_lo, n_h); break;
-		default: batch_cells<4>(B, c, by, s, tab_s, hbp, hf_s, h_lo, n_h); break;
-		}
-		return;
-	}
-	double *facs = facs_all + 32 * wave;
-	const int i0 = B.seg[c * (B.n_seg + 1) + by], i1 = B.seg[c * (B.n_seg + 1) + by + 1];
-	double *__restrict__ out = B.cellv + ((size_t)c * (B.n_pad / HIBAG_WAVE) + (s >> 6)) * B.max_cells * HIBAG_WAVE + (s & 63);
-	int4 nb = batch_cell_ranges(B, c, i0 < i1 ? i0 : 0);
-	for (int i = i0; i < i1; i++) {
-		const int4 r = nb;
-		nb = batch_cell_ranges(B, c, i + 1 < i1 ? i + 1 : i);
-		const bool diagonal = r.x == r.z;
-		double cell;
-		if (!diagonal && (r.y - r.x) * (r.w - r.z) >= MFMA_MIN_PAIRS)
-			cell = batch_cell_mfma(r.x - h_lo, r.y - h_lo, r.z - h_lo, r.w - h_lo, img_s, hf_s, facs, Bop, tab_s, lane);
-		else
-			cell = batch_cell<1>(hb_s, hf_s, n_h, r.x - h_lo, r.y - h_lo, r.z - h_lo, r.w - h_lo, diagonal, G, tab_s);
-		out[(size_t)i * HIBAG_WAVE] = cell;
-	}
-	if (by == B.n_seg - 1)
-		for (int i = i1; i < (i1 + SCAN_NB - 1) / SCAN_NB * SCAN_NB; i++) out[(size_t)i * HIBAG_WAVE] = 0.0;
 }
 
 __global__ __launch_bounds__(HIBAG_WAVE) void k_batch_scan(HibagMulti<BatchView> M)
@@ -1005,29 +832,6 @@ void eval_launch(const HibagOp *const ops[], int n, hipStream_t st)
 	}
 	const HibagMulti<BatchView> Mc = multi_of<BatchView>(ops, n, [](const BatchView &b) {
 		return ((b.n_pad / HIBAG_WAVE + BATCH_WAVES - 1) / BATCH_WAVES) * b.n_seg * b.n_cand; }, total);
-	const char *mf = getenv("HIBAG_BATCH_MFMA");
-	if (total > 0 && mf && *mf == '1') {
-		// dynamic LDS: the largest candidate of the launch (host-side bound: every candidate's haplotype count is in its view's starts,
-		// which live on the device -- the views carry the total instead)
-		size_t lds = 0;
-		for (int j = 0; j < n; j++) {
-			const BatchView &V = *(const BatchView *)ops[j]->view;
-			const size_t nh = (size_t)std::min(V.max_h > 0 ? V.max_h : V.n_haplo_total, BATCH_LDS_HAPLO);
-			lds = std::max(lds, (size_t)264 * 8 + 32 * BATCH_WAVES * 8 + nh * 8 + (size_t)V.nw * nh * 4 + 16 + std::max<size_t>(nh * 32, (size_t)BATCH_WAVES * 64 * 64));
-		}
-		static std::mutex lds_m;
-		static bool lds_set[64] = {};
-		int dev = 0;
-		(void)hipGetDevice(&dev);
-		{
-			std::lock_guard<std::mutex> lk(lds_m);
-			if (dev >= 0 && dev < 64 && !lds_set[dev]) {
-				(void)hipFuncSetAttribute((const void *)k_batch_cells_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-				lds_set[dev] = true;
-			}
-		}
-		hipLaunchKernelGGL(k_batch_cells_mfma, dim3(total), dim3(BATCH_WAVES * HIBAG_WAVE), lds, st, Mc);
-	} else
 	if (total > 0) hipLaunchKernelGGL(k_batch_cells, dim3(total), dim3(BATCH_WAVES * HIBAG_WAVE), 0, st, Mc);
 	const HibagMulti<BatchView> Ms = multi_of<BatchView>(ops, n, [](const BatchView &b) { return (b.n_pad / HIBAG_WAVE) * b.n_cand; }, total);
 	if (total > 0) hipLaunchKernelGGL(k_batch_scan, dim3(total), dim3(HIBAG_WAVE), 0, st, Ms);
@@ -1521,8 +1325,7 @@ void hibag_build_eval_launch(int slot, const PluginGenotype base_geno[], int n_s
 	BatchView B{nh, np, nw, n_cand, n_seg, word, (const uint32_t *)(d + o_hb), (const double *)(d + o_hf), (int)Hs,
 		(const int *)(d + o_start), (const uint32_t *)(d + o_planes), (const uint32_t *)(d + o_cw), (const int *)(d + o_cells),
 		(const int4 *)(d + o_cellb), (const int *)(d + o_seg), max_cells, (const int *)(d + o_true), (const int *)(d + o_wpos), (const double *)g.d_tab, (double *)(d + o_cellv),
-		(int *)(d + o_best), (double *)(d + o_post), nullptr, nullptr, bit, nullptr, 0};
-	for (int c = 0; c < n_cand; c++) B.max_h = std::max(B.max_h, cand[c].n_haplo);
+		(int *)(d + o_best), (double *)(d + o_post), nullptr, nullptr, bit, nullptr};
 	if (use_dev) {
 		B.gdev = (const int8_t *)g.d_geno8; B.cand_snp = (const int *)(d + o_cw); B.true_pair = (const int *)(d + o_wpos);
 		B.cand_w = nullptr; B.cellb = nullptr; B.wpos = nullptr;
